@@ -1,0 +1,76 @@
+"""The oracle (oracle/ref_cpu.py) against the golden vectors minted from the imported reference
+(oracle/make_golden.py).  CPU only.  Bit-exact for token ids; <=2e-5 abs on fp32 hiddens / mels."""
+import numpy as np
+import pytest
+import torch
+
+from chatttsplus_amd import synth
+from oracle import ref_cpu
+from tests.helpers import gen_case_inputs, load_golden
+
+
+def _run_oracle(name, cfg):
+    z, meta = load_golden(name)
+    sd, ids, mask, spk = gen_case_inputs(meta, cfg)
+    o = ref_cpu.OracleGPT(sd, cfg["num_attention_heads"])
+    emb = o.embed(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
+    if spk is not None:
+        emb = o.apply_spk_emb(emb, torch.from_numpy(spk), torch.from_numpy(ids), int(meta["spk_id"]))
+    temp = float(meta["temperature"]) if "temperature" in meta else 0.3
+    sp = ref_cpu.SamplerParams(temperature=[temp] * 4, min_new_token=int(meta["min_new"]))
+    torch.manual_seed(int(meta["torch_seed"]))
+    out = o.generate(emb, torch.from_numpy(ids), sp, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]))
+    return z, meta, emb, out
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("gpt_tiny_b2_pad", synth.GPT_TINY),
+    ("gpt_tiny_regen", synth.GPT_TINY),
+    ("gpt_real_b1", synth.GPT_REAL),
+    ("gpt_real_b2_pad", synth.GPT_REAL),
+    ("gpt_real_greedy", synth.GPT_REAL),
+])
+def test_generate_matches_reference(name, cfg):
+    z, meta, emb, out = _run_oracle(name, cfg)
+    lens = z["lens"]
+    assert [int(i.shape[0]) for i in out.ids] == lens.tolist()
+    np.testing.assert_allclose(emb[:, -1].numpy(), z["emb_last"], atol=0, rtol=0)
+    np.testing.assert_allclose(emb[:, 1].numpy(), z["emb_row1"], atol=1e-7, rtol=0)
+    for b, n in enumerate(lens):
+        assert np.array_equal(out.ids[b].numpy(), z["ids"][b, :n].astype(np.int64)), f"row {b} token ids differ"
+        err = np.abs(out.hiddens[b].numpy() - z["hiddens"][b, :n]).max()
+        assert err <= 2e-5, f"row {b} hidden err {err}"
+
+
+def test_sampler_cases_match_reference():
+    z = np.load(__import__("os").path.join(__import__("tests.helpers", fromlist=["GOLDEN"]).GOLDEN, "sampler_cases.npz"))
+    for c in range(int(z["n"])):
+        temp, top_p, top_k, rep, step, min_new = z[f"c{c}_params"]
+        rows = z[f"c{c}_logits"].shape[0]
+        sp = ref_cpu.SamplerParams(temperature=[temp] * 4, top_p=float(top_p), top_k=int(top_k), repetition_penalty=float(rep),
+                                   min_new_token=int(min_new))
+        idx = ref_cpu.sample_step(torch.from_numpy(z[f"c{c}_logits"]), torch.from_numpy(z[f"c{c}_history"]),
+                                  torch.from_numpy(z[f"c{c}_q"]), int(step), sp,
+                                  torch.full((rows, 1), float(temp), dtype=torch.float32))
+        assert np.array_equal(idx.numpy(), z[f"c{c}_idx"].astype(np.int64)), f"case {c}"
+
+
+def test_dvae_decode_matches_reference():
+    z = np.load(__import__("os").path.join(__import__("tests.helpers", fromlist=["GOLDEN"]).GOLDEN, "dvae_real.npz"))
+    sd = synth.dvae_state_dict(synth.DVAE_REAL, int(z["weight_seed"]))
+    hid = np.random.Generator(np.random.Philox(key=int(z["hidden_seed"]))).standard_normal((int(z["n"]), 768)).astype(np.float32)
+    mel = ref_cpu.dvae_decode(sd, torch.from_numpy(hid)).numpy()
+    assert mel.shape == z["mel"].shape
+    assert np.abs(mel - z["mel"]).max() <= 2e-5
+
+
+def test_vocos_istft_self_consistency():
+    """Vocos is parity-unpinned (third-party, absent): check the restatement's ISTFT against the direct definition."""
+    sd = {k: torch.from_numpy(v) for k, v in synth.vocos_state_dict(synth.VOCOS_REAL, 1234).items()}
+    mel = torch.from_numpy(np.random.Generator(np.random.Philox(key=9)).standard_normal((100, 24)).astype(np.float32))
+    wav = ref_cpu.vocos_decode(sd, mel)
+    assert wav.shape[0] == 256 * (24 - 1)
+    re, im = ref_cpu.vocos_head_spec(sd, ref_cpu.vocos_backbone(sd, mel))
+    wav2 = ref_cpu.istft_direct(re, im, sd["head.istft.window"])
+    scale = wav.abs().max().item()
+    assert (wav - wav2).abs().max().item() <= 1e-4 * max(scale, 1.0)
