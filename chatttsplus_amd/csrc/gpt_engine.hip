@@ -1,0 +1,519 @@
+// Host side of the GPT path: C ABI (include/ctts_hip.h), weight packing, launch sequencing, hipGraph.
+//
+// Layout in HBM (all owned by the handle unless noted):
+//   packed weights   per layer  Wqkv [144 tiles][K=768]  Wo [48][768]  Wgu [384][768]  Wd [48][3072]
+//                    + heads [157 tiles][768], each tile = 16 rows x KT cols stored [k-tile][lane][16 B]
+//   KV cache         [layers][2][max_batch][heads][max_seq][64]   (caller-owned, bound with ctts_gpt_bind_kv)
+//   residual stream  x_dec [B][768] fp32 (decode), x_pre [<=2048 rows][768] (prompt pass)
+//   act              fragment-major SwiGLU output for the down projection
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ctts_hip.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+void ctts_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* ctts_last_error(void) { return g_err; }
+extern "C" int ctts_version(void) { return 1; }
+
+#define PASS_ROWS 2048
+#define SMAX 16
+
+struct LayerW {
+    void *qkv, *o, *gu, *d;
+    float *ln1, *ln2;
+};
+
+struct ctts_gpt {
+    ctts_gpt_cfg cfg;
+    int H, I, NH, L, V, NVQ;
+    int esz;                                     // element size of weights / KV
+    std::map<std::string, std::vector<float>> host;   // staged fp32 weights until finalize
+    bool finalized = false;
+    // device
+    char* wblob = nullptr;
+    std::vector<LayerW> lw;
+    void* whead = nullptr;
+    float* lnf = nullptr;
+    float* emb_code = nullptr;
+    float* rope = nullptr;
+    int rope_n = 0;
+    char* kv = nullptr;
+    size_t kv_bytes = 0;
+    float *x_dec = nullptr, *x_last = nullptr, *x_pre = nullptr, *q_buf = nullptr, *part_ml = nullptr, *part_o = nullptr, *logits = nullptr;
+    void* act = nullptr;
+    RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
+    DevState* st = nullptr;
+    int* last_rows = nullptr;
+    int* host_pin = nullptr;
+    // per generate()
+    int B = 0, T = 0;
+    SamplerCfgDev sc;
+    ctts_gen_io io = {};
+    hipStream_t cap_stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    std::string graph_sig;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static int dev_alloc(void** p, size_t bytes) {
+    CTTS_HIP_CHECK(hipMalloc(p, bytes));
+    CTTS_HIP_CHECK(hipMemset(*p, 0, bytes));
+    return 0;
+}
+
+extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
+    if (!c || !out) { ctts_set_error("null argument"); return 1; }
+    if (c->hidden != 768 || c->inter != 3072 || c->heads * CTTS_HEAD_DIM != c->hidden) {
+        ctts_set_error("this build is specialised to hidden=768, inter=3072, head_dim=64 (got %d/%d/%d heads)", c->hidden, c->inter, c->heads);
+        return 1;
+    }
+    if (c->num_vq != CTTS_NUM_VQ || c->vocab_code > 640 || c->max_batch < 1 || c->max_batch > CTTS_MAX_B || c->max_seq < 2 ||
+        (c->dtype != CTTS_DTYPE_F32 && c->dtype != CTTS_DTYPE_F16)) {
+        ctts_set_error("unsupported configuration (num_vq=%d vocab=%d max_batch=%d dtype=%d)", c->num_vq, c->vocab_code, c->max_batch, c->dtype);
+        return 1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { ctts_set_error("no HIP device visible"); return 1; }
+    ctts_gpt* h = new ctts_gpt();
+    h->cfg = *c;
+    h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
+    h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
+    if (gemm_configure()) { delete h; return 1; }
+    if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        ctts_set_error("stream/event creation failed"); delete h; return 1;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
+    if (!h) return;
+    if (h->gexec) hipGraphExecDestroy(h->gexec);
+    if (h->graph) hipGraphDestroy(h->graph);
+    void* bufs[] = {h->wblob, h->lnf, h->emb_code, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
+                    h->act, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
+    for (void* b : bufs) if (b) hipFree(b);
+    for (auto& l : h->lw) { if (l.ln1) hipFree(l.ln1); if (l.ln2) hipFree(l.ln2); }
+    if (h->host_pin) hipHostFree(h->host_pin);
+    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    delete h;
+}
+
+extern "C" int ctts_gpt_set_weight(ctts_gpt* h, const char* name, const float* data, size_t numel) {
+    if (!h || !name || !data) { ctts_set_error("null argument"); return 1; }
+    if (h->finalized) { ctts_set_error("weights already finalized"); return 1; }
+    std::string n(name);
+    if (n.rfind("emb_text", 0) == 0 || n.rfind("head_text", 0) == 0) return 0;   // text path: host side / next round
+    h->host[n].assign(data, data + numel);
+    return 0;
+}
+
+extern "C" int ctts_gpt_merge_lora(ctts_gpt* h, int layer, const char* target, const float* A, const float* B, int r, float scale) {
+    if (!h || h->finalized) { ctts_set_error("merge_lora must precede finalize"); return 1; }
+    char key[128];
+    snprintf(key, sizeof(key), "gpt.layers.%d.self_attn.%s.weight", layer, target);
+    auto it = h->host.find(key);
+    if (it == h->host.end()) { ctts_set_error("merge_lora: %s not loaded", key); return 1; }
+    const int out = h->H, in = h->H;
+    std::vector<float>& W = it->second;
+    // peft merge_and_unload: W' = W + scale * B @ A   (pipeline:420-432; scale = lora_alpha / r)
+    for (int o = 0; o < out; ++o)
+        for (int i = 0; i < in; ++i) {
+            float acc = 0.f;
+            for (int k = 0; k < r; ++k) acc += B[(size_t)o * r + k] * A[(size_t)k * in + i];
+            W[(size_t)o * in + i] += scale * acc;
+        }
+    return 0;
+}
+
+// ---- packing ---------------------------------------------------------------------------------
+template <typename WT> static inline WT cvt(float v);
+template <> inline float cvt<float>(float v) { return v; }
+template <> inline half_t cvt<half_t>(float v) { return (half_t)v; }
+
+// rows(pr) -> pointer to the source row (K floats) or nullptr for zero padding
+template <typename WT, typename RowFn>
+static void pack_tiles(WT* dst, int n_row_tiles, int K, RowFn rows) {
+    constexpr int KT = WTraits<WT>::KT, EPL = WTraits<WT>::EPL;
+    const int ktiles = K / KT;
+    for (int rt = 0; rt < n_row_tiles; ++rt)
+        for (int i = 0; i < 16; ++i) {
+            const float* src = rows(rt * 16 + i);
+            for (int kt = 0; kt < ktiles; ++kt)
+                for (int kq = 0; kq < 4; ++kq) {
+                    WT* d = dst + (((size_t)rt * ktiles + kt) * 64 + i + 16 * kq) * EPL;
+                    const int k0 = kt * KT + kq * EPL;
+                    for (int j = 0; j < EPL; ++j) d[j] = src ? cvt<WT>(src[k0 + j]) : cvt<WT>(0.f);
+                }
+        }
+}
+
+static const std::vector<float>* need(ctts_gpt* h, const std::string& k, size_t numel) {
+    auto it = h->host.find(k);
+    if (it == h->host.end()) { ctts_set_error("missing weight %s", k.c_str()); return nullptr; }
+    if (it->second.size() != numel) { ctts_set_error("weight %s has %zu elements, expected %zu", k.c_str(), it->second.size(), numel); return nullptr; }
+    return &it->second;
+}
+
+template <typename WT>
+static int finalize_t(ctts_gpt* h) {
+    const int H = h->H, I = h->I, L = h->L, V = h->V;
+    const size_t n_qkv = (size_t)3 * H * H, n_o = (size_t)H * H, n_gu = (size_t)2 * I * H, n_d = (size_t)H * I;
+    const int head_tiles = (h->NVQ * V + 15) / 16;
+    const size_t n_head = (size_t)head_tiles * 16 * H;
+    const size_t per_layer = n_qkv + n_o + n_gu + n_d;
+    const size_t total = per_layer * L + n_head;
+    std::vector<WT> blob(total);
+    h->lw.resize(L);
+    if (dev_alloc((void**)&h->wblob, total * sizeof(WT))) return 1;
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "gpt.layers." + std::to_string(l) + ".";
+        const std::vector<float>*q = need(h, p + "self_attn.q_proj.weight", n_o), *k = need(h, p + "self_attn.k_proj.weight", n_o),
+                                *v = need(h, p + "self_attn.v_proj.weight", n_o), *o = need(h, p + "self_attn.o_proj.weight", n_o),
+                                *g = need(h, p + "mlp.gate_proj.weight", (size_t)I * H), *u = need(h, p + "mlp.up_proj.weight", (size_t)I * H),
+                                *d = need(h, p + "mlp.down_proj.weight", n_d), *l1 = need(h, p + "input_layernorm.weight", H),
+                                *l2 = need(h, p + "post_attention_layernorm.weight", H);
+        if (!q || !k || !v || !o || !g || !u || !d || !l1 || !l2) return 1;
+        WT* base = blob.data() + per_layer * l;
+        const int HT = H / 16;
+        // QKV: tile rows = dims [8t..8t+7 | 8t+32..8t+39] of one head, so RoPE's (d, d+32) pair sits in one tile
+        pack_tiles<WT>(base, 3 * HT, H, [&](int pr) -> const float* {
+            const int rt = pr / 16, i = pr % 16;
+            const int which = rt / HT, within = rt % HT, hh = within / 4, tq = within % 4;
+            const int dd = (i < 8) ? 8 * tq + i : 8 * tq + (i - 8) + 32;
+            const std::vector<float>* src = which == 0 ? q : (which == 1 ? k : v);
+            return src->data() + (size_t)(hh * CTTS_HEAD_DIM + dd) * H;
+        });
+        pack_tiles<WT>(base + n_qkv, HT, H, [&](int pr) { return o->data() + (size_t)pr * H; });
+        // gate|up: tile rows = [8 gate rows | the matching 8 up rows]
+        pack_tiles<WT>(base + n_qkv + n_o, 2 * I / 16, H, [&](int pr) -> const float* {
+            const int rt = pr / 16, i = pr % 16;
+            return (i < 8) ? g->data() + (size_t)(rt * 8 + i) * H : u->data() + (size_t)(rt * 8 + i - 8) * H;
+        });
+        pack_tiles<WT>(base + n_qkv + n_o + n_gu, HT, I, [&](int pr) { return d->data() + (size_t)pr * I; });
+        char* dv = h->wblob + per_layer * l * sizeof(WT);
+        h->lw[l].qkv = dv;
+        h->lw[l].o = dv + n_qkv * sizeof(WT);
+        h->lw[l].gu = dv + (n_qkv + n_o) * sizeof(WT);
+        h->lw[l].d = dv + (n_qkv + n_o + n_gu) * sizeof(WT);
+        if (dev_alloc((void**)&h->lw[l].ln1, H * 4) || dev_alloc((void**)&h->lw[l].ln2, H * 4)) return 1;
+        CTTS_HIP_CHECK(hipMemcpy(h->lw[l].ln1, l1->data(), H * 4, hipMemcpyHostToDevice));
+        CTTS_HIP_CHECK(hipMemcpy(h->lw[l].ln2, l2->data(), H * 4, hipMemcpyHostToDevice));
+    }
+    // heads: fold weight norm, W = v * (g / ||v||_row)  (gpt.py:57-77; torch._weight_norm dim=0)
+    std::vector<float> folded((size_t)h->NVQ * V * H);
+    for (int i = 0; i < h->NVQ; ++i) {
+        const std::string p = "head_code." + std::to_string(i) + ".parametrizations.weight.original";
+        const std::vector<float>*g0 = need(h, p + "0", V), *v1 = need(h, p + "1", (size_t)V * H);
+        if (!g0 || !v1) return 1;
+        for (int r = 0; r < V; ++r) {
+            double ss = 0.0;
+            const float* vr = v1->data() + (size_t)r * H;
+            for (int c = 0; c < H; ++c) ss += (double)vr[c] * vr[c];
+            const float a = (*g0)[r] / (float)sqrt(ss);
+            float* dst = folded.data() + ((size_t)i * V + r) * H;
+            for (int c = 0; c < H; ++c) dst[c] = vr[c] * a;
+        }
+    }
+    const int nvalid = h->NVQ * V;
+    pack_tiles<WT>(blob.data() + per_layer * L, head_tiles, H, [&](int pr) -> const float* {
+        return pr < nvalid ? folded.data() + (size_t)pr * H : nullptr;
+    });
+    h->whead = h->wblob + per_layer * L * sizeof(WT);
+    CTTS_HIP_CHECK(hipMemcpy(h->wblob, blob.data(), total * sizeof(WT), hipMemcpyHostToDevice));
+    const std::vector<float>* nf = need(h, "gpt.norm.weight", H);
+    if (!nf) return 1;
+    if (dev_alloc((void**)&h->lnf, H * 4)) return 1;
+    CTTS_HIP_CHECK(hipMemcpy(h->lnf, nf->data(), H * 4, hipMemcpyHostToDevice));
+    if (dev_alloc((void**)&h->emb_code, (size_t)h->NVQ * V * H * 4)) return 1;
+    for (int i = 0; i < h->NVQ; ++i) {
+        const std::vector<float>* e = need(h, "emb_code." + std::to_string(i) + ".weight", (size_t)V * H);
+        if (!e) return 1;
+        CTTS_HIP_CHECK(hipMemcpy(h->emb_code + (size_t)i * V * H, e->data(), (size_t)V * H * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
+    if (!h) { ctts_set_error("null handle"); return 1; }
+    if (h->finalized) return 0;
+    int rc = (h->cfg.dtype == CTTS_DTYPE_F16) ? finalize_t<half_t>(h) : finalize_t<float>(h);
+    if (rc) return rc;
+    const int H = h->H, NH = h->NH, MB = h->cfg.max_batch;
+    const size_t act_bytes = (size_t)(PASS_ROWS / 16) * (h->I / (h->esz == 2 ? 32 : 16)) * 1024;
+    if (dev_alloc((void**)&h->x_dec, (size_t)CTTS_MAX_B * H * 4) || dev_alloc((void**)&h->x_last, (size_t)CTTS_MAX_B * H * 4) ||
+        dev_alloc((void**)&h->x_pre, (size_t)PASS_ROWS * H * 4) ||
+        dev_alloc((void**)&h->q_buf, (size_t)PASS_ROWS * H * 4) ||
+        dev_alloc((void**)&h->part_ml, (size_t)PASS_ROWS * NH * SMAX * 2 * 4) ||
+        dev_alloc((void**)&h->part_o, (size_t)PASS_ROWS * NH * SMAX * CTTS_HEAD_DIM * 4) ||
+        dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * h->NVQ * h->V * 4) || dev_alloc(&h->act, act_bytes) ||
+        dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
+        dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
+        dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4))
+        return 1;
+    CTTS_HIP_CHECK(hipHostMalloc((void**)&h->host_pin, 64));
+    h->host.clear();
+    h->finalized = true;
+    return 0;
+}
+
+extern "C" size_t ctts_gpt_kv_bytes(const ctts_gpt* h) {
+    return (size_t)h->L * 2 * h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM * h->esz;
+}
+extern "C" int ctts_gpt_bind_kv(ctts_gpt* h, void* kv, size_t bytes) {
+    if (!h || !kv || bytes < ctts_gpt_kv_bytes(h)) { ctts_set_error("bind_kv: need %zu bytes", h ? ctts_gpt_kv_bytes(h) : 0); return 1; }
+    h->kv = (char*)kv; h->kv_bytes = bytes;
+    h->graph_sig.clear();
+    return 0;
+}
+extern "C" int ctts_gpt_set_rope(ctts_gpt* h, const float* rope_host, int n_pos) {
+    if (!h || !rope_host || n_pos < h->cfg.max_seq) { ctts_set_error("set_rope: need at least max_seq=%d positions", h ? h->cfg.max_seq : 0); return 1; }
+    if (h->rope) hipFree(h->rope);
+    if (dev_alloc((void**)&h->rope, (size_t)n_pos * 64 * 4)) return 1;
+    CTTS_HIP_CHECK(hipMemcpy(h->rope, rope_host, (size_t)n_pos * 64 * 4, hipMemcpyHostToDevice));
+    h->rope_n = n_pos;
+    return 0;
+}
+
+// ---- launch sequencing -----------------------------------------------------------------------
+static inline void* kv_layer(ctts_gpt* h, int l, int which) {
+    const size_t per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM * h->esz;
+    return h->kv + ((size_t)l * 2 + which) * per;
+}
+static inline int decode_splits(const ctts_gpt* h, int B) {
+    int s = 256 / (B * h->NH);
+    return s < 1 ? 1 : (s > SMAX ? SMAX : s);
+}
+
+// 20 decoder layers on R rows starting at row `r0` of residual stream x (llama.py:719-749 per layer)
+static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, int R, int S, const DevState* st, hipStream_t s) {
+    const int dt = h->cfg.dtype;
+    const int nbg = (R <= 16) ? 1 : 2;
+    const int NB = 16 * nbg;
+    const int chunks = (R + NB - 1) / NB;
+    for (int l = 0; l < h->L; ++l) {
+        GemmArgs a = {};
+        a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq;
+        // RMSNorm + QKV + RoPE + KV append
+        GemmArgs g1 = a;
+        g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x; g1.lnw = h->lw[l].ln1;
+        g1.q_out = h->q_buf; g1.k_cache = kv_layer(h, l, 0); g1.v_cache = kv_layer(h, l, 1); g1.rope = h->rope;
+        if (launch_gemm(dt, nbg, PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
+        AttnArgs at = {};
+        at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
+        at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
+        if (launch_attention(dt, at, s)) return 1;
+        // softmax combine + o_proj + residual
+        GemmArgs g2 = a;
+        g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = S; g2.x_out = x;
+        if (launch_gemm(dt, nbg, PRO_ATTN, EPI_RESID, g2, chunks, s)) return 1;
+        // RMSNorm + gate|up + SiLU*up
+        GemmArgs g3 = a;
+        g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.lnw = h->lw[l].ln2; g3.act_out = h->act;
+        if (launch_gemm(dt, nbg, PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
+        // down + residual
+        GemmArgs g4 = a;
+        g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x;
+        if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID, g4, chunks, s)) return 1;
+    }
+    return 0;
+}
+
+static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
+    const int nbg = (h->B <= 16) ? 1 : 2;
+    GemmArgs a = {};
+    a.st = h->st; a.R = h->B; a.eps = 1e-6f; a.meta = h->meta_dec;
+    a.W = h->whead; a.n_row_tiles = (h->NVQ * h->V + 15) / 16; a.K = h->H; a.x = h->x_dec; a.lnw = h->lnf;
+    a.logits = h->logits; a.n_valid = h->NVQ * h->V;
+    if (write_hidden && h->io.hiddens) { a.hidden_out = h->io.hiddens; a.hidden_stride = h->sc.max_new * h->H; }
+    return launch_gemm(h->cfg.dtype, nbg, PRO_NORM, EPI_LOGITS, a, 1, s);
+}
+
+static int run_sample_phase(ctts_gpt* h, hipStream_t s) {
+    if (run_heads(h, true, s)) return 1;
+    SamplerArgs sa = {};
+    sa.cfg = h->sc; sa.logits = h->logits; sa.V = h->V; sa.B = h->B; sa.st = h->st;
+    sa.ids = h->io.ids; sa.finish = h->io.finish; sa.end_idx = h->io.end_idx;
+    sa.noise = h->io.noise; sa.n_draws = h->io.n_draws; sa.seed = h->io.seed;
+    sa.emb_code = h->emb_code; sa.H = h->H; sa.x_next = h->x_dec; sa.meta = h->meta_dec;
+    return launch_sampler(sa, h->B, s);
+}
+
+static int reset_state(ctts_gpt* h, bool keep_draw, hipStream_t s) {
+    // step/all_done/ticket <- 0; decode rows back to (slot T-1, pos cum-1); finish/end_idx <- 0
+    CTTS_HIP_CHECK(hipMemsetAsync(&h->st->step, 0, 4, s));
+    if (!keep_draw) CTTS_HIP_CHECK(hipMemsetAsync(&h->st->draw, 0, 4, s));
+    CTTS_HIP_CHECK(hipMemsetAsync(&h->st->all_done, 0, 8, s));          // all_done + ticket
+    CTTS_HIP_CHECK(hipMemcpyAsync(h->meta_dec, h->meta_dec0, h->B * sizeof(RowMeta), hipMemcpyDeviceToDevice, s));
+    CTTS_HIP_CHECK(hipMemsetAsync(h->io.finish, 0, h->B * 4, s));
+    CTTS_HIP_CHECK(hipMemsetAsync(h->io.end_idx, 0, h->B * 4, s));
+    return 0;
+}
+
+extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, const ctts_sampler_cfg* sc, const ctts_gen_io* io, void* stream) {
+    if (!h || !h->finalized || !h->kv || !h->rope) { ctts_set_error("begin: handle not ready (finalize / bind_kv / set_rope)"); return 1; }
+    if (!mask || !sc || !io || !io->ids || !io->finish || !io->end_idx) { ctts_set_error("begin: null argument"); return 1; }
+    if (B < 1 || B > h->cfg.max_batch || T < 1 || T + sc->max_new_token > h->cfg.max_seq) {
+        ctts_set_error("begin: B=%d T=%d max_new=%d exceed max_batch=%d / max_seq=%d", B, T, sc->max_new_token, h->cfg.max_batch, h->cfg.max_seq);
+        return 1;
+    }
+    if (sc->past_window > 16 || sc->eos_token >= h->V) { ctts_set_error("begin: past_window>16 or eos out of range"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    h->B = B; h->T = T; h->io = *io;
+    memcpy(h->sc.temperature, sc->temperature, sizeof(sc->temperature));
+    h->sc.top_p_threshold = sc->top_p_threshold; h->sc.top_k = sc->top_k; h->sc.min_keep = sc->min_tokens_to_keep;
+    h->sc.use_penalty = sc->use_penalty; memcpy(h->sc.penalty_table, sc->penalty_table, sizeof(sc->penalty_table));
+    h->sc.past_window = sc->past_window; h->sc.max_input_ids = sc->max_input_ids; h->sc.eos = sc->eos_token;
+    h->sc.min_new = sc->min_new_token; h->sc.max_new = sc->max_new_token;
+    if (launch_fill_meta(h->meta_pre, h->meta_dec0, h->st, mask, B, T, s)) return 1;
+    return reset_state(h, false, s);
+}
+
+extern "C" int ctts_gpt_prefill(ctts_gpt* h, const float* emb, void* stream) {
+    if (!h || !emb || h->B == 0) { ctts_set_error("prefill: call begin first"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const int R = h->B * h->T;
+    std::vector<int> last(h->B);
+    for (int r0 = 0; r0 < R; r0 += PASS_ROWS) {
+        const int n = (R - r0 < PASS_ROWS) ? R - r0 : PASS_ROWS;
+        CTTS_HIP_CHECK(hipMemcpyAsync(h->x_pre, emb + (size_t)r0 * h->H, (size_t)n * h->H * 4, hipMemcpyDeviceToDevice, s));
+        if (run_layers(h, h->x_pre, h->meta_pre + r0, n, 1, nullptr, s)) return 1;
+        // rows (b, T-1) that live in this pass -> x_dec[b]
+        bool any = false;
+        for (int b = 0; b < h->B; ++b) {
+            const int lr = b * h->T + h->T - 1;
+            last[b] = (lr >= r0 && lr < r0 + n) ? lr - r0 : -1;
+            any = any || last[b] >= 0;
+        }
+        if (any) {
+            CTTS_HIP_CHECK(hipMemcpyAsync(h->last_rows, last.data(), h->B * 4, hipMemcpyHostToDevice, s));
+            CTTS_HIP_CHECK(hipStreamSynchronize(s));     // `last` is a pageable host buffer reused next pass
+            if (launch_gather_rows(h->x_pre, h->x_dec, h->last_rows, h->B, h->H, s)) return 1;
+        }
+    }
+    // keep a copy of the prompt's last residual rows for ensure_non_empty restarts
+    CTTS_HIP_CHECK(hipMemcpyAsync(h->x_last, h->x_dec, (size_t)h->B * h->H * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int ctts_gpt_sample(ctts_gpt* h, void* stream) {
+    if (!h || h->B == 0) { ctts_set_error("sample: call begin first"); return 1; }
+    return run_sample_phase(h, (hipStream_t)stream);
+}
+
+extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
+    if (!h || h->B == 0) { ctts_set_error("restart: call begin first"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    CTTS_HIP_CHECK(hipMemcpyAsync(h->x_dec, h->x_last, (size_t)h->B * h->H * 4, hipMemcpyDeviceToDevice, s));
+    return reset_state(h, true, s);
+}
+
+static int run_decode_step(ctts_gpt* h, hipStream_t s) {
+    if (run_layers(h, h->x_dec, h->meta_dec, h->B, decode_splits(h, h->B), h->st, s)) return 1;
+    return run_sample_phase(h, s);
+}
+
+static int ensure_graph(ctts_gpt* h) {
+    char sig[256];
+    snprintf(sig, sizeof(sig), "%d|%p|%p|%p|%p|%p|%d|%llu|%p|%d|%f|%f|%d|%d|%d|%d", h->B, (void*)h->io.ids, (void*)h->io.hiddens,
+             (void*)h->io.finish, (void*)h->io.end_idx, (void*)h->io.noise, h->io.n_draws, (unsigned long long)h->io.seed, (void*)h->kv,
+             h->sc.max_new, h->sc.temperature[0], h->sc.top_p_threshold, h->sc.top_k, h->sc.min_new, h->sc.use_penalty, h->sc.eos);
+    std::string key(sig);
+    for (int i = 0; i < 4; ++i) key += "|" + std::to_string(h->sc.temperature[i]);
+    key += "|" + std::to_string(h->sc.penalty_table[1]);
+    if (h->gexec && key == h->graph_sig) return 0;
+    if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+    CTTS_HIP_CHECK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = run_decode_step(h, h->cap_stream);
+    hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
+    if (rc) return 1;
+    if (e != hipSuccess) { ctts_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return 1; }
+    CTTS_HIP_CHECK(hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0));
+    h->graph_sig = key;
+    return 0;
+}
+
+extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* stream) {
+    if (!h || h->B == 0) { ctts_set_error("decode: call begin first"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (use_graph) {
+        if (ensure_graph(h)) return 1;
+        for (int i = 0; i < n_steps; ++i) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+    } else {
+        for (int i = 0; i < n_steps; ++i) if (run_decode_step(h, s)) return 1;
+    }
+    return 0;
+}
+
+extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_finished, void* stream) {
+    if (!h) { ctts_set_error("null handle"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    CTTS_HIP_CHECK(hipMemcpyAsync(h->host_pin, h->st, 16, hipMemcpyDeviceToHost, s));
+    CTTS_HIP_CHECK(hipStreamSynchronize(s));
+    if (steps_done) *steps_done = h->host_pin[0];
+    if (all_finished) *all_finished = h->host_pin[2];
+    return 0;
+}
+
+extern "C" int ctts_gpt_logits(ctts_gpt* h, float* out, void* stream) {
+    if (!h || !out || h->B == 0) { ctts_set_error("logits: call begin first"); return 1; }
+    CTTS_HIP_CHECK(hipMemcpyAsync(out, h->logits, (size_t)h->B * h->NVQ * h->V * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int ctts_gpt_force_ids(ctts_gpt* h, const int32_t* ids, void* stream) {
+    if (!h || !ids || h->B == 0) { ctts_set_error("force_ids: call begin first"); return 1; }
+    return launch_embed_ids(ids, h->emb_code, h->x_dec, h->B, h->V, h->H, (hipStream_t)stream);
+}
+
+extern "C" int ctts_sampler_run(const ctts_sampler_cfg* sc, const float* logits, const int32_t* history, int hist_len, const float* q,
+                                int rows, int vocab, int step, int32_t* idx, void* stream) {
+    if (!sc || !logits || !q || !idx || (hist_len > 0 && !history)) { ctts_set_error("sampler_run: null argument"); return 1; }
+    SamplerArgs sa = {};
+    memcpy(sa.cfg.temperature, sc->temperature, sizeof(sc->temperature));
+    sa.cfg.top_p_threshold = sc->top_p_threshold; sa.cfg.top_k = sc->top_k; sa.cfg.min_keep = sc->min_tokens_to_keep;
+    sa.cfg.use_penalty = sc->use_penalty; memcpy(sa.cfg.penalty_table, sc->penalty_table, sizeof(sc->penalty_table));
+    sa.cfg.past_window = sc->past_window; sa.cfg.max_input_ids = sc->max_input_ids; sa.cfg.eos = sc->eos_token;
+    sa.cfg.min_new = sc->min_new_token; sa.cfg.max_new = sc->max_new_token;
+    sa.logits = logits; sa.V = vocab; sa.B = rows; sa.st = nullptr; sa.noise = q; sa.history = history; sa.hist_len = hist_len;
+    sa.step_override = step; sa.idx_out = idx;
+    return launch_sampler(sa, (rows + 3) / 4, (hipStream_t)stream);
+}
+
+extern "C" int ctts_gpt_time_decode(ctts_gpt* h, int n_steps, float* ms_per_step, void* stream) {
+    if (!h || h->B == 0 || n_steps < 1 || !ms_per_step) { ctts_set_error("time_decode: bad argument"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (ensure_graph(h)) return 1;
+    CTTS_HIP_CHECK(hipEventRecord(h->ev0, s));
+    for (int i = 0; i < n_steps; ++i) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+    CTTS_HIP_CHECK(hipEventRecord(h->ev1, s));
+    CTTS_HIP_CHECK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    CTTS_HIP_CHECK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_per_step = ms / n_steps;
+    return 0;
+}
+
+extern "C" double ctts_gpt_step_bytes(const ctts_gpt* h, int B, double mean_ctx) {
+    // s * [ W + B*(L+1)*KV_tok ],  W = layers*(4H^2 + 3HI) + 4*V*H + (2*layers+1)*H
+    const double W = (double)h->L * (4.0 * h->H * h->H + 3.0 * h->H * h->I) + (double)h->NVQ * h->V * h->H + (2.0 * h->L + 1) * h->H;
+    const double kv_tok = (double)h->L * 2 * h->H;
+    return h->esz * (W + B * (mean_ctx + 1.0) * kv_tok);
+}

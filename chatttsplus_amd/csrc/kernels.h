@@ -1,0 +1,97 @@
+// Kernel argument blocks and host launchers of libctts_hip's GPT path.
+#pragma once
+#include "common.h"
+
+enum { PRO_NORM = 0, PRO_ATTN = 1, PRO_PACKED = 2 };
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
+
+// out[R rows][N] = prologue(x)[R][K] . W[N][K]^T  followed by a fused epilogue.
+// W is pre-packed in 16-row x KT-col MFMA-A tiles, [row tile][k tile][lane][16 B] (gpt_engine.cpp).
+struct GemmArgs {
+    const void* W;
+    int n_row_tiles;        // N / 16 (grid.x)
+    int K;
+    int R;                  // valid rows
+    const DevState* st;     // may be null (prefill / tests)
+    // prologues
+    const float* x;         // PRO_NORM: residual stream [R][K] fp32
+    const float* lnw;       // PRO_NORM: RMSNorm weight [K]
+    float eps;
+    float* hidden_out;      // PRO_NORM (heads only): normalised rows -> hiddens[seq][step][K]; may be null
+    int hidden_stride;      //   = max_new_token * K
+    const float* part_ml;   // PRO_ATTN: [R][NH][S][2]  (running max, running sum)
+    const float* part_o;    // PRO_ATTN: [R][NH][S][64] unnormalised
+    int S;
+    const void* xpacked;    // PRO_PACKED: fragment-major activations [chunk][g][kt][lane][16 B]
+    // epilogues
+    float* x_out;           // EPI_RESID: residual stream [R][N] (+=)
+    float* q_out;           // EPI_QKV : [R][H] fp32 after RoPE
+    void* k_cache;          // EPI_QKV : this layer's K  [maxB][NH][Lmax][64]
+    void* v_cache;
+    int Lmax;
+    const RowMeta* meta;
+    const float* rope;      // [max_seq][64] = cos[32] | sin[32]
+    void* act_out;          // EPI_SWIGLU: fragment-major [chunk][g][kt'][lane][16 B], K' = N/2
+    float* logits;          // EPI_LOGITS: [R][n_valid]
+    int n_valid;            // valid output rows (2504)
+};
+
+struct AttnArgs {
+    const float* q;         // [R][NH][64]
+    const void* k_cache;    // this layer
+    const void* v_cache;
+    int Lmax;
+    int NH;
+    int R;
+    int S;                  // key splits (grid.y)
+    const RowMeta* meta;
+    const DevState* st;
+    float* part_ml;         // [R][NH][S][2]
+    float* part_o;          // [R][NH][S][64]
+};
+
+struct SamplerCfgDev {      // mirrors ctts_sampler_cfg
+    float temperature[CTTS_NUM_VQ];
+    float top_p_threshold;
+    int top_k;
+    int min_keep;
+    int use_penalty;
+    float penalty_table[17];
+    int past_window;
+    int max_input_ids;
+    int eos;
+    int min_new;
+    int max_new;
+};
+
+struct SamplerArgs {
+    SamplerCfgDev cfg;
+    const float* logits;    // [rows][V]
+    int V;
+    int B;
+    DevState* st;           // null in stand-alone mode
+    // generate mode
+    int* ids;               // [B][max_new][4]
+    int* finish;
+    int* end_idx;
+    const float* noise;     // [n_draws][B*4][V] or null
+    int n_draws;
+    unsigned long long seed;
+    const float* emb_code;  // [4][V][H] fp32
+    int H;
+    float* x_next;          // [B][H]
+    RowMeta* meta;          // decode rows [B]
+    // stand-alone mode (ctts_sampler_run)
+    const int* history;     // [rows][hist_len]
+    int hist_len;
+    int step_override;
+    int* idx_out;           // [rows]
+};
+
+int launch_gemm(int dtype, int nbg, int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s);
+int launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
+int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s);
+int launch_gather_rows(const float* src, float* dst, const int* src_rows, int n, int H, hipStream_t s);
+int launch_embed_ids(const int* ids, const float* emb_code, float* x, int B, int V, int H, hipStream_t s);
+int launch_fill_meta(RowMeta* prefill_meta, RowMeta* decode_meta, DevState* st, const int* mask, int B, int T, hipStream_t s);
+int gemm_configure();

@@ -1,0 +1,304 @@
+// Fused sampler: one wavefront per (sequence, codebook) row of 626 logits (10 per lane).
+//
+// Restates, in order (chattts_plus/models/gpt.py:469-494,527-532):
+//   logits /= temperature                                              gpt.py:469
+//   CustomRepetitionPenaltyLogitsProcessorRepeat (window 16)            models/processors.py:18-34
+//   TopPLogitsWarper(top_p, min_tokens_to_keep=3)   (transformers; built at processors.py:45)
+//   TopKLogitsWarper(top_k, min_tokens_to_keep=3)   (transformers; built at processors.py:47)
+//   i < min_new_token -> logits[eos] = -inf                              gpt.py:477-478
+//   softmax ; multinomial(1) == argmax(p / q), q ~ Exp(1)               gpt.py:480-481
+//   finish |= any(idx == eos); ids_buf[progress] = idx; end_idx += ~finish     gpt.py:483-488,530-531
+//   next-token embedding = sum of the 4 code embeddings                  gpt.py:403-407
+//
+// Top-p needs the *ascending* cumulative softmax.  Because the removed set is a prefix of the ascending
+// order, and top-k follows, only the largest <= top_k (+ties) candidates are ever kept: they are pulled
+// out one by one with a wave-wide arg-max (6 shuffle steps), and the ascending cumsum at rank r is
+// total - (sum of the r larger probabilities), accumulated in fp64 exactly like torch's CPU cumsum
+// (acc_type<float> = double) and rounded to fp32 before the `<= 1 - top_p` compare.
+#include "kernels.h"
+
+#define VPL 10   // values per lane (64 * 10 = 640 >= 626)
+
+__device__ inline uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+struct RowIn {
+    const float* logits;     // [V]
+    const float* q;          // [V] or null -> Philox
+    const int* hist;         // first id of the penalty window
+    int hist_stride;
+    int nh;                  // ids in the window (<= past_window <= 16)
+    float T;
+    bool penalize;
+    int step;
+    unsigned long long seed;
+    unsigned draw, row;
+};
+
+// returns the sampled index (identical in every lane)
+__device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn& in, int V, int lane) {
+    float x[VPL];
+    unsigned valid = 0;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int j = lane + 64 * i;
+        if (j < V) { x[i] = __fdiv_rn(in.logits[j], in.T); valid |= 1u << i; }
+        else x[i] = -INFINITY;
+    }
+    if (in.penalize && in.nh > 0) {
+        int cnt[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) cnt[i] = 0;
+        for (int hh = 0; hh < in.nh; ++hh) {
+            const int id = in.hist[(size_t)hh * in.hist_stride];
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) cnt[i] += (id == lane + 64 * i) ? 1 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float alpha = tab[cnt[i]];
+            x[i] = (x[i] < 0.f) ? __fmul_rn(x[i], alpha) : __fdiv_rn(x[i], alpha);   // processors.py:29-33
+        }
+    }
+    // softmax over the whole row (TopPLogitsWarper: sorted_logits.softmax(-1))
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) mx = fmaxf(mx, x[i]);
+    mx = wave_max(mx);
+    float pr[VPL], se = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { pr[i] = (valid >> i & 1u) ? expf(x[i] - mx) : 0.f; se += pr[i]; }
+    se = wave_sum(se);
+    const float inv = 1.0f / se;
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { pr[i] *= inv; tot += (double)pr[i]; }
+    tot = wave_sum_d(tot);
+
+    unsigned taken = ~valid, kept = 0;
+    double cum_before = 0.0;
+    float vk = 0.f;
+    const int topk = (c.top_k > 0) ? c.top_k : V;
+    for (int r = 0; r < V; ++r) {
+        float bv = -INFINITY, bp = 0.f;
+        int bi = -1;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            if (!((taken >> i) & 1u)) {
+                const int j = lane + 64 * i;
+                if (x[i] > bv || (x[i] == bv && j > bi)) { bv = x[i]; bi = j; bp = pr[i]; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off), op = __shfl_xor(bp, off);
+            const int oi = __shfl_xor(bi, off);
+            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; bp = op; }
+        }
+        if (bi < 0) break;                                        // nothing left
+        if (r >= topk && bv != vk) break;                          // beyond top-k and not tied with the k-th value
+        const float cr = (float)(tot - cum_before);               // ascending cumsum at this element
+        if (cr <= c.top_p_threshold && r >= c.min_keep) break;     // removed by top-p (and so is every smaller one)
+        if (lane == (bi & 63)) { taken |= 1u << (bi >> 6); kept |= 1u << (bi >> 6); }
+        if (r == topk - 1) vk = bv;
+        cum_before += (double)bp;
+    }
+    if (in.step < c.min_new) {                                     // gpt.py:477-478
+        if (lane == (c.eos & 63)) kept &= ~(1u << (c.eos >> 6));
+    }
+    // final softmax over the kept set and the exponential race
+    float m2 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) if ((kept >> i) & 1u) m2 = fmaxf(m2, x[i]);
+    m2 = wave_max(m2);
+    float e2[VPL], s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { e2[i] = ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f; s2 += e2[i]; }
+    s2 = wave_sum(s2);
+    const float inv2 = 1.0f / s2;
+    float best = -1.f;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int j = lane + 64 * i;
+        if (j < V) {
+            float q;
+            if (in.q != nullptr) q = in.q[j];
+            else {
+                const uint4 rnd = philox4x32_10(make_uint4((unsigned)j, in.row, in.draw, 0x43545453u),
+                                                make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
+                const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                q = -logf(u);
+            }
+            const float ratio = __fdiv_rn(e2[i] * inv2, q);
+            if (ratio > best || (ratio == best && j < besti)) { best = ratio; besti = j; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(besti, off);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    return besti;
+}
+
+// generate mode: grid = B blocks, block = 4 waves (one per codebook)
+__global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs a) {
+    __shared__ float tab[17];
+    __shared__ int idx_s[CTTS_NUM_VQ];
+    DevState* st = a.st;
+    if (st->all_done) return;
+    const int tid = threadIdx.x, lane = tid & 63, vq = tid >> 6;
+    const int b = blockIdx.x;
+    const int step = st->step, draw = st->draw;
+    if (tid < 17) tab[tid] = a.cfg.penalty_table[tid];
+    __syncthreads();
+    const int row = b * CTTS_NUM_VQ + vq;
+    RowIn in;
+    in.logits = a.logits + (size_t)row * a.V;
+    in.q = (a.noise != nullptr) ? a.noise + ((size_t)min(draw, a.n_draws - 1) * a.B * CTTS_NUM_VQ + row) * a.V : nullptr;
+    const int nh = min(step, a.cfg.past_window);
+    in.hist = a.ids + ((size_t)b * a.cfg.max_new + (step - nh)) * CTTS_NUM_VQ + vq;
+    in.hist_stride = CTTS_NUM_VQ;
+    in.nh = nh;
+    in.T = a.cfg.temperature[vq];
+    in.penalize = a.cfg.use_penalty && (row < a.cfg.max_input_ids);      // quirk SURVEY F8
+    in.step = step;
+    in.seed = a.seed; in.draw = (unsigned)draw; in.row = (unsigned)row;
+    const int idx = sample_row(a.cfg, tab, in, a.V, lane);
+    if (lane == 0) {
+        idx_s[vq] = idx;
+        a.ids[((size_t)b * a.cfg.max_new + step) * CTTS_NUM_VQ + vq] = idx;
+    }
+    __syncthreads();
+    // next-token embedding: ((e0 + e1) + e2) + e3   (torch.stack(..., 3).sum(3), gpt.py:403-407)
+    for (int k = tid; k < a.H; k += 256) {
+        float s = a.emb_code[((size_t)0 * a.V + idx_s[0]) * a.H + k];
+#pragma unroll
+        for (int v = 1; v < CTTS_NUM_VQ; ++v) s += a.emb_code[((size_t)v * a.V + idx_s[v]) * a.H + k];
+        a.x_next[(size_t)b * a.H + k] = s;
+    }
+    if (tid == 0) {
+        const bool was = a.finish[b] != 0;
+        bool fin = was;
+        for (int v = 0; v < CTTS_NUM_VQ; ++v) fin = fin || (idx_s[v] == a.cfg.eos);   // gpt.py:486-487
+        a.finish[b] = fin ? 1 : 0;
+        if (!fin) a.end_idx[b] += 1;                                                // gpt.py:530-531
+        RowMeta m = a.meta[b];                                                     // next decode row
+        m.pos += 1; m.slot += 1;
+        a.meta[b] = m;
+        // One agent-scope atomic carries both the arrival ticket (low 16 bits) and the number of finished
+        // sequences (high 16 bits, persistent over the steps): no fences, no cross-block plain loads.
+        const int add = 1 + ((fin && !was) ? 0x10000 : 0);
+        const int tot = __hip_atomic_fetch_add(&st->ticket, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        if ((tot & 0xFFFF) == a.B) {                           // last block of this step: advance the step state
+            const int nfin = tot >> 16;
+            st->ticket = nfin << 16;
+            st->step = step + 1;
+            st->draw = draw + 1;
+            if (nfin == a.B || step + 1 >= a.cfg.max_new) st->all_done = 1;         // gpt.py:545 / loop bound :389
+        }
+    }
+}
+
+// stand-alone mode (ctts_sampler_run): block = 4 rows
+__global__ __launch_bounds__(256) void sampler_rows_kernel(const SamplerArgs a) {
+    const int rows = a.B;
+    __shared__ float tab[17];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 17) tab[tid] = a.cfg.penalty_table[tid];
+    __syncthreads();
+    const int row = blockIdx.x * 4 + w;
+    if (row >= rows) return;
+    RowIn in;
+    in.logits = a.logits + (size_t)row * a.V;
+    in.q = a.noise + (size_t)row * a.V;
+    const int nh = min(a.hist_len, a.cfg.past_window);
+    in.hist = a.history + (size_t)row * a.hist_len + (a.hist_len - nh);
+    in.hist_stride = 1;
+    in.nh = nh;
+    in.T = a.cfg.temperature[row % CTTS_NUM_VQ];
+    in.penalize = a.cfg.use_penalty && (row < a.cfg.max_input_ids);
+    in.step = a.step_override;
+    in.seed = 0; in.draw = 0; in.row = (unsigned)row;
+    const int idx = sample_row(a.cfg, tab, in, a.V, lane);
+    if (lane == 0) a.idx_out[row] = idx;
+}
+
+int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s) {
+    if (a.V > 64 * VPL) { ctts_set_error("sampler: vocab %d > %d", a.V, 64 * VPL); return 1; }
+    if (a.st != nullptr) hipLaunchKernelGGL(sampler_generate_kernel, dim3(a.B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(sampler_rows_kernel, dim3(blocks), dim3(256), 0, s, a);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- small helper kernels --------------------------------------------------------------------
+
+__global__ void gather_rows_kernel(const float* src, float* dst, const int* src_rows, int n, int H) {
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const int sr = src_rows[r];
+    if (sr < 0) return;                        // row not part of this prefill pass
+    for (int k = threadIdx.x; k < H; k += blockDim.x) dst[(size_t)r * H + k] = src[(size_t)sr * H + k];
+}
+int launch_gather_rows(const float* src, float* dst, const int* src_rows, int n, int H, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, s, src, dst, src_rows, n, H);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// teacher forcing: x[b] = sum_vq emb_code[vq][ids[b][vq]]  (gpt.py:403-407)
+__global__ void embed_ids_kernel(const int* ids, const float* emb_code, float* x, int V, int H) {
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        float s = emb_code[((size_t)0 * V + ids[b * CTTS_NUM_VQ]) * H + k];
+        for (int v = 1; v < CTTS_NUM_VQ; ++v) s += emb_code[((size_t)v * V + ids[b * CTTS_NUM_VQ + v]) * H + k];
+        x[(size_t)b * H + k] = s;
+    }
+}
+int launch_embed_ids(const int* ids, const float* emb_code, float* x, int B, int V, int H, hipStream_t s) {
+    hipLaunchKernelGGL(embed_ids_kernel, dim3(B), dim3(256), 0, s, ids, emb_code, x, V, H);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// position ids / cache slots from the left-padded attention mask (gpt.py:238-245):
+//   pos = cumsum(mask) - 1, pad -> 1;   decode rows start at slot T with pos = (#valid tokens)
+__global__ void fill_meta_kernel(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int cum = 0, pad = 0;
+    bool seen = false;
+    for (int t = 0; t < T; ++t) {
+        const int mk = mask[b * T + t];
+        cum += mk ? 1 : 0;
+        if (!mk && !seen) pad = t + 1;     // left padding: leading zeros
+        if (mk) seen = true;
+        RowMeta m;
+        m.seq = b;
+        m.pos = mk ? cum - 1 : 1;
+        m.slot = t;
+        m.kv_start = mk ? pad : t;          // pad query rows attend to themselves only (their output is never used)
+        pm[b * T + t] = m;
+    }
+    RowMeta d;
+    d.seq = b; d.pos = cum - 1; d.slot = T - 1; d.kv_start = pad;   // every sample phase advances pos/slot by one
+    dm[b] = d;
+    st->pad[b] = pad;
+    if (b == 0) { st->step = 0; st->all_done = 0; st->ticket = 0; st->B = B; st->T = T; }
+}
+int launch_fill_meta(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(fill_meta_kernel, dim3(B), dim3(64), 0, s, pm, dm, st, mask, B, T);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}

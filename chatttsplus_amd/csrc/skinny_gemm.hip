@@ -1,0 +1,296 @@
+// Decode-time projections of the Llama-style decoder as MFMA "skinny GEMMs" (gfx950).
+//
+//   out[R][N] = prologue(x)[R][K] . W[N][K]^T  + fused epilogue,   R <= 16*NBG rows per chunk
+//
+// The weight matrix is the MFMA *A* operand (M dimension = output features) and the activations are
+// the *B* operand (N dimension = batch rows), so one 1-KiB weight tile = one coalesced 16-byte load per
+// lane = one v_mfma_f32_16x16x32_f16 (fp16) or four v_mfma_f32_16x16x4_f32 (fp32 parity mode).  Weights
+// are streamed from HBM exactly once per step with non-temporal loads issued *before* the prologue; a
+// block owns one 16-row tile, its waves split K and combine through LDS in a fixed order (deterministic).
+//
+// Reference arithmetic restated by the fused pieces:
+//   PRO_NORM   LlamaRMSNorm.forward                       chattts_plus/models/llama.py:82-87
+//   PRO_ATTN   softmax normalisation of the split-K attention partials (attention.hip)
+//   EPI_QKV    q/k/v proj + apply_rotary_pos_emb + cache append   llama.py:619-633,151-182
+//   EPI_RESID  o_proj / down_proj + residual add                  llama.py:666,731,737-739
+//   EPI_SWIGLU act_fn(gate_proj(x)) * up_proj(x)                  llama.py:214
+//   EPI_LOGITS head_code[i](hidden) for the 4 folded heads        gpt.py:437-447
+#include "kernels.h"
+
+template <typename WT> struct Mma;
+template <> struct Mma<half_t> {
+    __device__ static inline f32x4 run(half8 a, half8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static inline f32x4 run(f32x4 a, f32x4 b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename WT> struct FragOf;
+template <> struct FragOf<half_t> { typedef half8 type; };
+template <> struct FragOf<float> { typedef f32x4 type; };
+
+// store 4 consecutive-k activations of row n into the fragment-major LDS/global image
+template <typename WT>
+__device__ inline void store_x4(void* base, int n, int k, int ktiles, float y0, float y1, float y2, float y3);
+template <>
+__device__ inline void store_x4<half_t>(void* base, int n, int k, int ktiles, float y0, float y1, float y2, float y3) {
+    half4 h = {(half_t)y0, (half_t)y1, (half_t)y2, (half_t)y3};
+    *(half4*)((half_t*)base + xfrag_index<half_t>(n, k, ktiles)) = h;
+}
+template <>
+__device__ inline void store_x4<float>(void* base, int n, int k, int ktiles, float y0, float y1, float y2, float y3) {
+    f32x4 v = {y0, y1, y2, y3};
+    *(f32x4*)((float*)base + xfrag_index<float>(n, k, ktiles)) = v;
+}
+
+template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI>
+__global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs a) {
+    typedef typename FragOf<WT>::type frag;
+    constexpr int KT = WTraits<WT>::KT;
+    constexpr int KTILES = WAVES * KPW;
+    constexpr int K = KTILES * KT;
+    constexpr int NB = 16 * NBG;
+    constexpr int XS_BYTES = (PRO == PRO_PACKED) ? 0 : NBG * KTILES * 1024;
+    constexpr int PER = K / 256;                      // float4 per lane per row in the prologues
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    if (a.st != nullptr && a.st->all_done) return;    // every sequence finished (gpt.py:545): skip on device
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rt = blockIdx.x, chunk = blockIdx.y;
+    const int row0 = chunk * NB;
+
+    // 1. this wave's weight fragments: KPW x 1 KiB, coalesced, streamed once -> non-temporal
+    const frag* Wp = (const frag*)a.W + ((size_t)rt * KTILES + (size_t)wave * KPW) * 64 + lane;
+    frag wf[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) wf[i] = __builtin_nontemporal_load(Wp + i * 64);
+
+    // 2. prologue: build the B operand (activations) in LDS, fragment-major
+    if (PRO == PRO_NORM) {
+        for (int n = wave; n < NB; n += WAVES) {
+            const int r = row0 + n;
+            f32x4 v[PER];
+            if (r < a.R) {
+                const f32x4* xr = (const f32x4*)(a.x + (size_t)r * K);
+#pragma unroll
+                for (int i = 0; i < PER; ++i) v[i] = xr[lane + 64 * i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < PER; ++i) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            ss = wave_sum(ss);
+            const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);          // torch.rsqrt(mean(x^2) + eps)
+            const bool write_hidden = (a.hidden_out != nullptr) && (rt == 0) && (r < a.R);
+            float* hrow = nullptr;
+            if (write_hidden) hrow = a.hidden_out + (size_t)a.meta[r].seq * a.hidden_stride + (size_t)a.st->step * K;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = 4 * (lane + 64 * i);
+                const f32x4 w = *(const f32x4*)(a.lnw + k);
+                const float y0 = w[0] * (v[i][0] * rs), y1 = w[1] * (v[i][1] * rs);
+                const float y2 = w[2] * (v[i][2] * rs), y3 = w[3] * (v[i][3] * rs);
+                store_x4<WT>(smem, n, k, KTILES, y0, y1, y2, y3);
+                if (write_hidden) *(f32x4*)(hrow + k) = (f32x4){y0, y1, y2, y3};
+            }
+        }
+        __syncthreads();
+    } else if (PRO == PRO_ATTN) {
+        constexpr int NH = K / CTTS_HEAD_DIM;
+        const int S = a.S;
+        for (int n = wave; n < NB; n += WAVES) {
+            const int r = row0 + n;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = 4 * (lane + 64 * i);
+                float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+                if (r < a.R) {
+                    const int h = k >> 6, d = k & 63;
+                    const float* ml = a.part_ml + ((size_t)(r * NH + h) * S) * 2;
+                    const float* po = a.part_o + ((size_t)(r * NH + h) * S) * CTTS_HEAD_DIM + d;
+                    float mx = -INFINITY;
+                    for (int s = 0; s < S; ++s) mx = fmaxf(mx, ml[2 * s]);
+                    float L = 0.f;
+                    for (int s = 0; s < S; ++s) {
+                        const float ms = ml[2 * s];
+                        const float w = (ms == -INFINITY) ? 0.f : expf(ms - mx);
+                        L += ml[2 * s + 1] * w;
+                        const f32x4 o = *(const f32x4*)(po + (size_t)s * CTTS_HEAD_DIM);
+                        y0 += o[0] * w; y1 += o[1] * w; y2 += o[2] * w; y3 += o[3] * w;
+                    }
+                    const float inv = 1.0f / L;
+                    y0 *= inv; y1 *= inv; y2 *= inv; y3 *= inv;
+                }
+                store_x4<WT>(smem, n, k, KTILES, y0, y1, y2, y3);
+            }
+        }
+        __syncthreads();
+    }
+
+    // 3. MFMA over this wave's K slice
+    f32x4 acc[NBG];
+#pragma unroll
+    for (int g = 0; g < NBG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const frag* xs = (const frag*)smem;
+    const frag* xg = (const frag*)a.xpacked + (size_t)chunk * NBG * KTILES * 64;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int kt = wave * KPW + i;
+#pragma unroll
+        for (int g = 0; g < NBG; ++g) {
+            frag b;
+            if (PRO == PRO_PACKED) b = xg[(size_t)(g * KTILES + kt) * 64 + lane];
+            else b = xs[(g * KTILES + kt) * 64 + lane];
+            acc[g] = Mma<WT>::run(wf[i], b, acc[g]);
+        }
+    }
+
+    // 4. deterministic cross-wave reduction through LDS
+    float* red = (float*)(smem + XS_BYTES);                 // [WAVES][NBG][64][4]
+    float* outt = red + WAVES * NBG * 256;                  // [16][NB]
+#pragma unroll
+    for (int g = 0; g < NBG; ++g) *(f32x4*)(red + ((wave * NBG + g) * 64 + lane) * 4) = acc[g];
+    __syncthreads();
+    if (tid < 64 * NBG) {
+        const int g = tid >> 6, l = tid & 63;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += *(const f32x4*)(red + ((w * NBG + g) * 64 + l) * 4);
+        const int n = 16 * g + (l & 15);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) outt[((l >> 4) * 4 + r4) * NB + n] = s[r4];   // C: row=(lane>>4)*4+reg, col=lane&15
+    }
+    __syncthreads();
+
+    // 5. fused epilogue
+    if (EPI == EPI_RESID || EPI == EPI_LOGITS) {
+        for (int t = tid; t < 16 * NB; t += WAVES * 64) {
+            const int n = t >> 4, i = t & 15;
+            const int r = row0 + n;
+            if (r >= a.R) continue;
+            const int col = rt * 16 + i;
+            const float v = outt[i * NB + n];
+            if (EPI == EPI_RESID) {
+                float* p = a.x_out + (size_t)r * (a.n_row_tiles * 16) + col;
+                *p = *p + v;                                               // residual + proj (llama.py:731,739)
+            } else if (col < a.n_valid) {
+                a.logits[(size_t)r * a.n_valid + col] = v;
+            }
+        }
+    } else {
+        for (int t = tid; t < 8 * NB; t += WAVES * 64) {
+            const int n = t >> 3, p = t & 7;
+            const int r = row0 + n;
+            const float va = outt[p * NB + n], vb = outt[(p + 8) * NB + n];
+            if (EPI == EPI_SWIGLU) {
+                // packed rows: [8 gate | 8 up] per tile -> act[rt*8+p] = silu(g) * u
+                float y = 0.f;
+                if (r < a.R) y = (va / (1.0f + expf(-va))) * vb;
+                const int ktiles_out = (a.n_row_tiles * 8) / KT;
+                WT* dst = (WT*)a.act_out + (size_t)chunk * NBG * ktiles_out * 64 * WTraits<WT>::EPL;
+                dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = (WT)y;
+            } else {  // EPI_QKV: packed rows per tile = dims [8t..8t+7 | 8t+32..8t+39] of one head
+                if (r >= a.R) continue;
+                constexpr int HT = K / 16;                   // tiles per projection (H == K for q/k/v)
+                constexpr int NH = K / CTTS_HEAD_DIM;
+                const int which = rt / HT, within = rt % HT;
+                const int h = within >> 2, d = ((within & 3) << 3) + p;
+                const RowMeta m = a.meta[r];
+                float ya = va, yb = vb;
+                if (which < 2) {
+                    const float c = a.rope[(size_t)m.pos * 64 + d], s = a.rope[(size_t)m.pos * 64 + 32 + d];
+                    // q*cos + rotate_half(q)*sin, products rounded separately like the reference (llama.py:180-181)
+                    ya = __fadd_rn(__fmul_rn(va, c), __fmul_rn(-vb, s));
+                    yb = __fadd_rn(__fmul_rn(vb, c), __fmul_rn(va, s));
+                }
+                if (which == 0) {
+                    float* q = a.q_out + ((size_t)r * NH + h) * CTTS_HEAD_DIM;
+                    q[d] = ya; q[d + 32] = yb;
+                } else {
+                    WT* c = (WT*)(which == 1 ? a.k_cache : a.v_cache) +
+                            (((size_t)m.seq * NH + h) * a.Lmax + m.slot) * CTTS_HEAD_DIM;
+                    c[d] = (WT)ya; c[d + 32] = (WT)yb;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI>
+static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configure_only) {
+    constexpr int KTILES = WAVES * KPW;
+    constexpr int XS = (PRO == PRO_PACKED) ? 0 : NBG * KTILES * 1024;
+    constexpr int LDS = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4;
+    auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI>;
+    if (configure_only) {
+        CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        return 0;
+    }
+    if (a.K != KTILES * WTraits<WT>::KT) {
+        ctts_set_error("skinny_gemm: K=%d does not match the compiled tiling %d", a.K, KTILES * WTraits<WT>::KT);
+        return 1;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles, chunks), dim3(WAVES * 64), LDS, s, a);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Tilings (real ChatTTS shapes: H=768, I=3072):
+//   K=768  fp16: 24 k-tiles = 4 waves x 6      fp32: 48 = 8 x 6
+//   K=3072 fp16: 96 k-tiles = 16 waves x 6     fp32: 192 = 16 x 12
+template <typename WT, int NBG>
+static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s, bool cfg) {
+    constexpr bool F16 = sizeof(WT) == 2;
+    constexpr int W768 = F16 ? 4 : 8, P768 = 6;
+    constexpr int W3072 = 16, P3072 = F16 ? 6 : 12;
+    if (cfg) {
+        int rc = 0;
+        rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV>(a, chunks, s, true);
+        rc |= launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID>(a, chunks, s, true);
+        rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU>(a, chunks, s, true);
+        rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
+        rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, true);
+        return rc;
+    }
+    if (pro == PRO_NORM && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV>(a, chunks, s, false);
+    if (pro == PRO_ATTN && epi == EPI_RESID) return launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID>(a, chunks, s, false);
+    if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU>(a, chunks, s, false);
+    if (pro == PRO_PACKED && epi == EPI_RESID) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
+    if (pro == PRO_NORM && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, false);
+    ctts_set_error("skinny_gemm: unsupported prologue/epilogue %d/%d", pro, epi);
+    return 1;
+}
+
+int launch_gemm(int dtype, int nbg, int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s) {
+    if (dtype == 1) {
+        if (nbg == 1) return dispatch<half_t, 1>(pro, epi, a, chunks, s, false);
+        if (nbg == 2) return dispatch<half_t, 2>(pro, epi, a, chunks, s, false);
+    } else {
+        if (nbg == 1) return dispatch<float, 1>(pro, epi, a, chunks, s, false);
+        if (nbg == 2) return dispatch<float, 2>(pro, epi, a, chunks, s, false);
+    }
+    ctts_set_error("skinny_gemm: unsupported dtype/nbg %d/%d", dtype, nbg);
+    return 1;
+}
+
+int gemm_configure() {
+    GemmArgs a = {};
+    int rc = 0;
+    rc |= dispatch<half_t, 1>(0, 0, a, 1, nullptr, true);
+    rc |= dispatch<half_t, 2>(0, 0, a, 1, nullptr, true);
+    rc |= dispatch<float, 1>(0, 0, a, 1, nullptr, true);
+    rc |= dispatch<float, 2>(0, 0, a, 1, nullptr, true);
+    return rc;
+}

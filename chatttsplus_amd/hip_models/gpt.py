@@ -1,0 +1,317 @@
+"""hip_models.GPT -- drop-in for chattts_plus.models.GPT (reference chattts_plus/models/gpt.py) whose
+decoder, heads, sampler and generate-loop bookkeeping run in libctts_hip.so on an MI355X.
+
+Same constructor kwargs, `__call__(input_ids, text_mask) -> emb`, `generate(...)` generator of
+GenerationOutputs, `num_vq`, `emb_code[i].num_embeddings`, `.eval()`, `.to()`, `from_pretrained`.
+torch is used for device memory, the current stream and the (negligible) embedding gather only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+
+RMS_EPS = 1e-6
+ROPE_BASE = 10000.0
+
+
+def rope_table(n_pos: int) -> np.ndarray:
+    """[n_pos][64] = cos[32] | sin[32] with the reference's fp32 arithmetic (llama.py:100,106-119)."""
+    inv_freq = 1.0 / (ROPE_BASE ** (torch.arange(0, 64, 2, dtype=torch.int64).float() / 64))
+    freqs = torch.arange(n_pos, dtype=torch.int64)[:, None].float() * inv_freq[None, :]
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).contiguous().numpy()
+
+
+class _EmbShim:
+    def __init__(self, n):
+        self.num_embeddings = n
+
+
+@dataclass(repr=False, eq=False)
+class GenerationOutputs:          # gpt.py:280-284
+    ids: List[torch.Tensor]
+    attentions: list
+    hiddens: List[torch.Tensor]
+
+
+class Context:                    # gpt.py:87-95
+    def __init__(self):
+        self._interrupt = False
+
+    def set(self, v: bool):
+        self._interrupt = v
+
+    def get(self) -> bool:
+        return self._interrupt
+
+
+def sampler_cfg_from_objects(temperature, eos_token, max_new_token, min_new_token, logits_warpers, logits_processors,
+                             num_vq=4) -> _lib.SamplerCfg:
+    """Reads the scalars off the HF warpers / reference processor objects that processors.gen_logits builds
+    (models/processors.py:37-57).  Unknown object types are rejected (no silent host fallback)."""
+    sc = _lib.SamplerCfg()
+    t = torch.as_tensor(temperature, dtype=torch.float32).flatten().tolist()
+    if len(t) == 1:
+        t = t * num_vq
+    for i in range(num_vq):
+        sc.temperature[i] = t[i]
+    sc.top_p_threshold = -1.0
+    sc.top_k = 0
+    sc.min_tokens_to_keep = 1
+    for w in logits_warpers or []:
+        if hasattr(w, "top_p"):
+            # torch compares the fp32 cumsum with the python double (1 - top_p) cast to fp32
+            sc.top_p_threshold = float(np.float32(1 - float(w.top_p)))
+            sc.min_tokens_to_keep = int(w.min_tokens_to_keep)
+        elif hasattr(w, "top_k"):
+            sc.top_k = int(w.top_k)          # already max(top_k, min_tokens_to_keep)
+        else:
+            raise _lib.HipBackendError(f"unsupported logits warper for the hip backend: {type(w).__name__}")
+    sc.use_penalty = 0
+    sc.past_window = 16
+    sc.max_input_ids = 1 << 30
+    tab = torch.ones(17)
+    for p in logits_processors or []:
+        if hasattr(p, "penalty") and hasattr(p, "past_window"):
+            sc.use_penalty = 1
+            sc.past_window = int(p.past_window)
+            sc.max_input_ids = int(p.max_input_ids)
+            tab = torch.pow(float(p.penalty), torch.arange(0, 17, dtype=torch.int64))     # processors.py:28
+        else:
+            raise _lib.HipBackendError(f"unsupported logits processor for the hip backend: {type(p).__name__}")
+    for i in range(17):
+        sc.penalty_table[i] = float(tab[i])
+    sc.eos_token = int(eos_token)
+    sc.min_new_token = int(min_new_token)
+    sc.max_new_token = int(max_new_token)
+    return sc
+
+
+class GPT:
+    """See module docstring.  Extra kwargs (ride in the YAML `kwargs`):
+    max_batch (<=32), max_seq_len, weight_dtype "fp16" | "fp32", chunk_steps."""
+
+    Context = Context
+    GenerationOutputs = GenerationOutputs
+
+    def __init__(self, gpt_config: dict, num_audio_tokens: int = 626, num_text_tokens: int = 21178, num_vq=4,
+                 use_flash_attn=False, **kwargs):
+        self.num_vq = num_vq
+        self.num_audio_tokens = num_audio_tokens
+        self.num_text_tokens = num_text_tokens
+        self.gpt_config = dict(gpt_config)
+        self.model_dim = int(gpt_config["hidden_size"])
+        self.emb_code = [_EmbShim(num_audio_tokens) for _ in range(num_vq)]
+        self.max_batch = int(kwargs.get("max_batch", 4))
+        self.max_seq = int(kwargs.get("max_seq_len", 4096))
+        wd = kwargs.get("weight_dtype", "fp16")
+        self.dtype_code = {"fp16": _lib.DTYPE_F16, "float16": _lib.DTYPE_F16, "fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32}[str(wd)]
+        self.chunk_steps = int(kwargs.get("chunk_steps", 32))
+        self.use_graph = bool(kwargs.get("use_graph", True))
+        self.device = torch.device(kwargs.get("device", "cuda"))
+        self.gpt = None              # attribute the pipeline swaps for LoRA (pipeline:420-432); unused here
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.HipBackendError("infer_type='hip' needs a visible MI355X (torch.cuda.is_available() is False); no CPU fallback")
+        self._h = C.c_void_p()
+        cfg = _lib.GptCfg(hidden=self.model_dim, inter=int(gpt_config["intermediate_size"]),
+                          heads=int(gpt_config["num_attention_heads"]), layers=int(gpt_config["num_hidden_layers"]),
+                          vocab_code=num_audio_tokens, num_vq=num_vq, max_batch=self.max_batch, max_seq=self.max_seq,
+                          dtype=self.dtype_code)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_gpt_create(C.byref(cfg), C.byref(self._h)), "ctts_gpt_create")
+        self._finalized = False
+        self._emb_text = None
+        self._emb_code_t = None
+        self._kv = None
+        self._lora = []
+        self.model_path = kwargs.get("model_path", None)
+        if self.model_path:
+            self.from_pretrained(self.model_path)
+
+    # -- nn.Module-like surface ------------------------------------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, device=None, dtype=None):
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._lib.ctts_gpt_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def from_pretrained(self, file_path: str):
+        self.load_state_dict(torch.load(file_path, weights_only=True, mmap=True))      # gpt.py:84-85
+
+    def add_lora(self, layer: int, target: str, A, B, scale: float):
+        """peft merge rule W += scale * B @ A (pipeline:420-432) applied before finalize."""
+        self._lora.append((layer, target, np.ascontiguousarray(A, dtype=np.float32), np.ascontiguousarray(B, dtype=np.float32), float(scale)))
+
+    def load_state_dict(self, sd, strict: bool = True):
+        if self._finalized:
+            raise _lib.HipBackendError("weights already loaded")
+        keep = []
+        for k, v in sd.items():
+            a = v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, dtype=np.float32)
+            a = np.ascontiguousarray(a)
+            keep.append(a)
+            _lib.check(self._lib.ctts_gpt_set_weight(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), f"set_weight({k})")
+            if k == "emb_text.weight":
+                self._emb_text = torch.from_numpy(a).to(self.device)
+        for (layer, target, A, B, scale) in self._lora:
+            _lib.check(self._lib.ctts_gpt_merge_lora(self._h, layer, target.encode(), A.ctypes.data_as(C.c_void_p),
+                                                     B.ctypes.data_as(C.c_void_p), A.shape[0], scale), "merge_lora")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_gpt_finalize(self._h), "ctts_gpt_finalize")
+            self._emb_code_t = torch.stack([torch.as_tensor(np.asarray(sd[f"emb_code.{i}.weight"], dtype=np.float32) if not isinstance(sd[f"emb_code.{i}.weight"], torch.Tensor)
+                                                            else sd[f"emb_code.{i}.weight"].float()) for i in range(self.num_vq)]).to(self.device)
+            rope = rope_table(self.max_seq)
+            _lib.check(self._lib.ctts_gpt_set_rope(self._h, rope.ctypes.data_as(C.c_void_p), self.max_seq), "set_rope")
+            nbytes = self._lib.ctts_gpt_kv_bytes(self._h)
+            self._kv = torch.empty(nbytes, dtype=torch.uint8, device=self.device)       # torch owns the KV cache
+            _lib.check(self._lib.ctts_gpt_bind_kv(self._h, self._kv.data_ptr(), nbytes), "bind_kv")
+        self._finalized = True
+        return self
+
+    # -- get_emb (gpt.py:125-149) ----------------------------------------------------------------
+    def __call__(self, input_ids: torch.Tensor, text_mask: torch.Tensor) -> torch.Tensor:
+        input_ids = input_ids.to(self.device)
+        text_mask = text_mask.to(self.device).bool()
+        emb = torch.zeros(input_ids.shape[:-1] + (self.model_dim,), device=self.device, dtype=torch.float32)
+        if text_mask.any():
+            if self._emb_text is None:
+                raise _lib.HipBackendError("emb_text.weight was not loaded")
+            emb[text_mask] = F.embedding(input_ids[text_mask][:, 0], self._emb_text)
+        inv = ~text_mask
+        if inv.any():
+            mids = input_ids[inv]
+            emb[inv] = torch.stack([F.embedding(mids[:, i], self._emb_code_t[i]) for i in range(self.num_vq)], 2).sum(2)
+        return emb
+
+    forward = __call__
+
+    # -- generate (gpt.py:313-569, infer_text=False) ----------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @torch.no_grad()
+    def generate(self, emb: torch.Tensor, inputs_ids: torch.Tensor, temperature: torch.Tensor,
+                 eos_token: Union[int, torch.Tensor], attention_mask: Optional[torch.Tensor] = None, max_new_token=2048,
+                 min_new_token=0, logits_warpers=[], logits_processors=[], infer_text=False, return_attn=False,
+                 return_hidden=False, stream=False, show_tqdm=True, ensure_non_empty=True, stream_batch=24,
+                 context=None, noise="torch", seed: int = 0, max_restarts: int = 64):
+        """`noise`: "torch" draws q = empty(B*4,V).exponential_() per step from torch's CPU generator -- the
+        very numbers torch.multinomial consumes in the reference, so TorchSeedContext(seed) reproduces the CPU
+        path's tokens; "device" uses the on-device Philox generator (`seed`); or an array [n_draws, B*4, V]."""
+        if infer_text:
+            raise _lib.HipBackendError("infer_text=True (refine-text path) is not served by the hip backend yet (SURVEY 8f N1)")
+        if return_attn:
+            raise _lib.HipBackendError("return_attn=True is unsupported (the reference's eager attention path is broken, SURVEY F2)")
+        if not self._finalized:
+            raise _lib.HipBackendError("weights not loaded")
+        context = context or Context()
+        lib, h = self._lib, self._h
+        B, T = int(inputs_ids.shape[0]), int(inputs_ids.shape[1])
+        V, H, NVQ = self.num_audio_tokens, self.model_dim, self.num_vq
+        dev = self.device
+        max_new_token = int(max_new_token)
+        sc = sampler_cfg_from_objects(temperature, int(eos_token), max_new_token, min_new_token, logits_warpers, logits_processors, NVQ)
+        mask = torch.ones(B, T, dtype=torch.int32, device=dev) if attention_mask is None else attention_mask.to(dev).to(torch.int32).contiguous()
+        emb = emb.to(dev, dtype=torch.float32).contiguous()
+        ids = torch.zeros(B, max_new_token, NVQ, dtype=torch.int32, device=dev)
+        hid = torch.zeros(B, max_new_token, H, dtype=torch.float32, device=dev) if return_hidden else None
+        finish = torch.zeros(B, dtype=torch.int32, device=dev)
+        end_idx = torch.zeros(B, dtype=torch.int32, device=dev)
+        n_draws = max_new_token + max_restarts
+        qbuf = None
+        rng_states = []
+        host_q = None
+        if isinstance(noise, str) and noise == "torch":
+            qbuf = torch.empty(n_draws, B * NVQ, V, dtype=torch.float32, device=dev)
+        elif isinstance(noise, str) and noise == "device":
+            qbuf = None
+        else:
+            host_q = torch.as_tensor(noise, dtype=torch.float32)
+            n_draws = int(host_q.shape[0])
+            qbuf = host_q.to(dev).contiguous()
+        io = _lib.GenIO(ids=ids.data_ptr(), hiddens=hid.data_ptr() if hid is not None else None, finish=finish.data_ptr(),
+                        end_idx=end_idx.data_ptr(), noise=qbuf.data_ptr() if qbuf is not None else None, n_draws=n_draws,
+                        seed=int(seed))
+        drawn = 0
+
+        def draw_to(n):
+            nonlocal drawn
+            if not (isinstance(noise, str) and noise == "torch"):
+                return
+            n = min(n, n_draws)
+            if n <= drawn:
+                return
+            chunk = []
+            for _ in range(n - drawn):
+                rng_states.append(torch.random.get_rng_state())
+                chunk.append(torch.empty(B * NVQ, V, dtype=torch.float32).exponential_(1))
+            qbuf[drawn:n].copy_(torch.stack(chunk), non_blocking=False)
+            drawn = n
+
+        with torch.cuda.device(dev):
+            st = self._stream()
+            _lib.check(lib.ctts_gpt_begin(h, B, T, mask.data_ptr(), C.byref(sc), C.byref(io), st), "begin")
+            _lib.check(lib.ctts_gpt_prefill(h, emb.data_ptr(), st), "prefill")
+            steps, alld = C.c_int32(0), C.c_int32(0)
+            used_draws = 0
+            # step 0 (+ ensure_non_empty regenerate, gpt.py:496-525)
+            while True:
+                draw_to(used_draws + 1)
+                _lib.check(lib.ctts_gpt_sample(h, st), "sample")
+                used_draws += 1
+                _lib.check(lib.ctts_gpt_progress(h, C.byref(steps), C.byref(alld), st), "progress")
+                if bool(finish.any().item()):
+                    if ensure_non_empty and used_draws < max_restarts:
+                        _lib.check(lib.ctts_gpt_restart(h, st), "restart")
+                        continue
+                    self._restore_rng(rng_states, used_draws)
+                    return                                   # gpt.py:525 bare return
+                break
+            chunk = int(stream_batch) if stream else self.chunk_steps
+            while not alld.value and steps.value < max_new_token and not context.get():
+                n = min(chunk, max_new_token - steps.value)
+                draw_to(used_draws + n)
+                _lib.check(lib.ctts_gpt_decode(h, n, 1 if self.use_graph else 0, st), "decode")
+                prev = steps.value
+                _lib.check(lib.ctts_gpt_progress(h, C.byref(steps), C.byref(alld), st), "progress")
+                used_draws += steps.value - prev
+                if stream and not alld.value and steps.value < max_new_token:
+                    yield self._outputs(ids, hid, end_idx)
+            self._restore_rng(rng_states, used_draws)
+            yield self._outputs(ids, hid, end_idx)
+
+    @staticmethod
+    def _restore_rng(states, used):
+        """Leave torch's CPU generator where the reference would have left it: after `used` multinomial draws."""
+        if states and used < len(states):
+            torch.random.set_rng_state(states[used])
+
+    def _outputs(self, ids, hid, end_idx) -> GenerationOutputs:
+        n = end_idx.cpu().tolist()
+        out_ids = [ids[b, :n[b]].to(torch.long) for b in range(len(n))]                # gpt.py:295-297
+        out_h = [hid[b, :n[b]] for b in range(len(n))] if hid is not None else []     # gpt.py:301-305
+        return GenerationOutputs(ids=out_ids, attentions=[], hiddens=out_h)
+
+    # -- test hooks ------------------------------------------------------------------------------
+    def last_logits(self, B: int) -> torch.Tensor:
+        out = torch.empty(B, self.num_vq, self.num_audio_tokens, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ctts_gpt_logits(self._h, out.data_ptr(), self._stream()), "logits")
+        return out
+
+    def step_bytes(self, B: int, mean_ctx: float) -> float:
+        return float(self._lib.ctts_gpt_step_bytes(self._h, B, float(mean_ctx)))

@@ -1,0 +1,201 @@
+/*
+ * ctts_hip.h -- C ABI of libctts_hip.so: the MI355X (gfx950) backend for the ChatTTS hot path.
+ *
+ * This is the drop-in boundary.  The reference selects a backend per model
+ * through the YAML field `infer_type` (chattts_plus/pipelines/chattts_plus_pipeline.py:113-129);
+ * its accelerated backend (chattts_plus/trt_models/) drives an opaque engine through
+ *   create_kv_cache / predict / get_cur_kv_caches   (trt_models/llama_trt_model.py:25-35,77-81)
+ *   TensorRTPredictor.predict(feed_dict, stream)     (trt_models/predictor.py:141-169)
+ * with torch owning every user-visible buffer and the engine seeing raw data_ptr()s and a stream.
+ * The functions below are what an `infer_type: "hip"` binding needs for the same path; each entry
+ * cites the reference interface it replaces.  Python binding: chatttsplus_amd/_lib.py (ctypes);
+ * see INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; ctts_last_error() gives the text
+ *     (reference: predictor.py:165-167 raises ValueError("ERROR: inference failed.")).
+ *   - no C++ exceptions, no abort(), no torch types cross the ABI: plain pointers and sizes.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - device pointers are borrowed; the caller keeps them alive (predictor.py:91-115,162).
+ *   - a handle is bound to the device that was current at create() and is not thread-safe.
+ */
+#ifndef CTTS_HIP_H
+#define CTTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTTS_DTYPE_F32 0 /* parity mode: fp32 weights / KV / MFMA (v_mfma_f32_16x16x4_f32) */
+#define CTTS_DTYPE_F16 1 /* performance mode: fp16 weights / KV, fp32 accumulate (reference GPU dtype, pipeline:37-41) */
+
+#define CTTS_MAX_BATCH 32   /* rows per decode chunk (reference caps at 4: pipeline:391-397) */
+#define CTTS_NUM_VQ 4
+
+const char* ctts_last_error(void);
+int ctts_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* GPT: Llama-style code-token decoder + sampler (models/gpt.py, models/llama.py, processors.py) */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct ctts_gpt ctts_gpt;
+
+typedef struct {
+    int32_t hidden;        /* 768   gpt_config.hidden_size        (configs/infer/chattts_plus.yaml:73) */
+    int32_t inter;         /* 3072  gpt_config.intermediate_size  (:74) */
+    int32_t heads;         /* 12    num_attention_heads           (:75)  head_dim must be 64 */
+    int32_t layers;        /* 20    num_hidden_layers             (:76) */
+    int32_t vocab_code;    /* 626   num_audio_tokens              (:81) */
+    int32_t num_vq;        /* 4                                   (:82) */
+    int32_t max_batch;     /* <= CTTS_MAX_BATCH sequences decoded together */
+    int32_t max_seq;       /* KV capacity per sequence: prompt + max_new_token */
+    int32_t dtype;         /* CTTS_DTYPE_* */
+} ctts_gpt_cfg;
+
+/* replaces models.GPT.__init__ / trt_models.GPT.__init__ (gpt.py:25-82) */
+int ctts_gpt_create(const ctts_gpt_cfg* cfg, ctts_gpt** out);
+void ctts_gpt_destroy(ctts_gpt* h);
+
+/* replaces GPT.from_pretrained -> load_state_dict (gpt.py:84-85).  `name` is the reference
+ * state-dict key; `data` is HOST fp32, row-major, `numel` elements.
+ * Accepted keys: gpt.layers.N.{self_attn.{q,k,v,o}_proj,mlp.{gate,up,down}_proj,input_layernorm,
+ * post_attention_layernorm}.weight, gpt.norm.weight, emb_code.N.weight,
+ * head_code.N.parametrizations.weight.original{0,1}.  Other keys (emb_text, head_text) are ignored
+ * with return code 0 (text path is host-side / next round). */
+int ctts_gpt_set_weight(ctts_gpt* h, const char* name, const float* data, size_t numel);
+
+/* LoRA merge rule of peft merge_and_unload (pipeline:420-432): W += scale * B @ A for one target
+ * ("q_proj","k_proj","v_proj","o_proj") of one layer; A [r, in], B [out, r], host fp32.  Call before finalize. */
+int ctts_gpt_merge_lora(ctts_gpt* h, int layer, const char* target, const float* A, const float* B, int r, float scale);
+
+/* folds weight-norm heads (W = g*v/||v||_row, gpt.py:57-77), packs QKV / gate|up, converts to the
+ * engine dtype, uploads.  After this the host copies are released. */
+int ctts_gpt_finalize(ctts_gpt* h);
+
+/* bytes of KV cache the caller must provide: [layers][2][max_batch][heads][max_seq][64] of dtype.
+ * replaces LlamaTRTModel.create_kv_cache (llama_trt_model.py:25-29). */
+size_t ctts_gpt_kv_bytes(const ctts_gpt* h);
+int ctts_gpt_bind_kv(ctts_gpt* h, void* kv_dev, size_t bytes);
+
+/* RoPE table [max_seq][64] fp32 = (cos[32], sin[32]) of pos*inv_freq, computed by the caller with the
+ * reference's fp32 arithmetic (llama.py:100,106-119) so that the values are bit-identical to the CPU path. */
+int ctts_gpt_set_rope(ctts_gpt* h, const float* rope_host, int n_pos);
+
+typedef struct {
+    float temperature[CTTS_NUM_VQ];   /* per-codebook temperature (gpt.py:346-351) */
+    float top_p_threshold;            /* (float)(1 - top_P) as torch compares it (TopPLogitsWarper); <0 disables top-p */
+    int32_t top_k;                    /* max(top_K, min_tokens_to_keep) (TopKLogitsWarper); <=0 disables */
+    int32_t min_tokens_to_keep;       /* 3 (processors.py:45,47) */
+    int32_t use_penalty;              /* repetition_penalty != 1 (processors.py:50) */
+    float penalty_table[17];          /* penalty**n, n=0..16, as torch.pow(float, int64) gives (processors.py:28) */
+    int32_t past_window;              /* 16 (processors.py:53) */
+    int32_t max_input_ids;            /* row-count quirk threshold (processors.py:23-27) */
+    int32_t eos_token;                /* num_embeddings-1 = 625 (pipeline:209) */
+    int32_t min_new_token;            /* (gpt.py:477-478) */
+    int32_t max_new_token;
+} ctts_sampler_cfg;
+
+/* Outputs of one generate() call, all device memory provided by the caller:
+ *   ids      int32 [B][max_new_token][4]     (gpt.py:368-376 inputs_ids_buf, generated part)
+ *   hiddens  fp32  [B][max_new_token][hidden] (gpt.py:422-423, post final norm)
+ *   finish   int32 [B], end_idx int32 [B]    (gpt.py:339-342,486-487,530-531)
+ * noise: fp32 [n_draws][B*4][vocab_code] Exp(1) draws consumed one per sample step (argmax(p/q) ==
+ * torch.multinomial), or NULL for the on-device Philox generator seeded with `seed`. */
+typedef struct {
+    int32_t* ids;
+    float* hiddens;
+    int32_t* finish;
+    int32_t* end_idx;
+    const float* noise;
+    int32_t n_draws;
+    uint64_t seed;
+} ctts_gen_io;
+
+/* Start a generate() call for B sequences with a T-token (left padded) prompt.
+ * attention_mask int32 [B][T] device (1 = token, 0 = pad; tokenizer.py:96-115).
+ * replaces the set-up part of GPT.generate (gpt.py:335-387). */
+int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* attention_mask_dev, const ctts_sampler_cfg* sc,
+                   const ctts_gen_io* io, void* stream);
+
+/* Prompt pass: emb fp32 [B][T][hidden] device (GPT.forward output after apply_spk_emb, gpt.py:125-149,
+ * tokenizer.py:150-178).  Fills the KV cache and leaves the last position's residual row per sequence.
+ * replaces the i == 0 iteration's LlamaModel.forward (gpt.py:410-418; llama.py:905-1019). */
+int ctts_gpt_prefill(ctts_gpt* h, const float* emb_dev, void* stream);
+
+/* Sample phase for the current hidden rows: final RMSNorm + 4 folded heads + sampler chain +
+ * EOS/finish bookkeeping + next-token embedding (gpt.py:422-494,527-532).  Used once after prefill
+ * (step 0) and again after an ensure_non_empty restart (gpt.py:496-525). */
+int ctts_gpt_sample(ctts_gpt* h, void* stream);
+
+/* Reset step/finish state and re-gather the prompt's last hidden rows (ensure_non_empty regenerate);
+ * the noise draw counter keeps running like torch's generator does in the reference. */
+int ctts_gpt_restart(ctts_gpt* h, void* stream);
+
+/* n_steps x { 20 decoder layers on the last sampled token ; sample phase } (gpt.py:389-546, i > 0).
+ * Uses a captured hipGraph of one step (use_graph != 0).  Steps after every sequence has finished are
+ * skipped on the device.  Asynchronous w.r.t. the host. */
+int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* stream);
+
+/* Host-visible progress: number of sample steps executed and whether every row has finished.
+ * Synchronises the stream. */
+int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_finished, void* stream);
+
+/* Test hooks (parity tests call the stages one by one through the same ABI):
+ * logits of the current hidden rows fp32 [B][4][vocab_code] into `logits_dev` without sampling. */
+int ctts_gpt_logits(ctts_gpt* h, float* logits_dev, void* stream);
+/* force the next input token ids (teacher forcing): int32 [B][4] device; replaces the sampled ids and
+ * re-embeds them (gpt.py:403-407). */
+int ctts_gpt_force_ids(ctts_gpt* h, const int32_t* ids_dev, void* stream);
+/* stand-alone sampler on caller-provided logits (fp32 [rows][vocab], rows = B*4; history int32
+ * [rows][hist_len]; q fp32 [rows][vocab]) -> idx int32 [rows]; A15-A19 of SURVEY 8(a). */
+int ctts_sampler_run(const ctts_sampler_cfg* sc, const float* logits_dev, const int32_t* history_dev, int hist_len,
+                     const float* q_dev, int rows, int vocab, int step, int32_t* idx_dev, void* stream);
+
+/* last measured average duration (ms) of one captured decode step, measured with hipEvents on the launch
+ * stream around `n` graph replays; used by bench.py for the roofline object. */
+int ctts_gpt_time_decode(ctts_gpt* h, int n_steps, float* ms_per_step, void* stream);
+
+/* algorithmic bytes of one decode step at mean context L: s*(W + B*(L+1)*KV_tok). */
+double ctts_gpt_step_bytes(const ctts_gpt* h, int B, double mean_ctx);
+
+/* ------------------------------------------------------------------------------------------ */
+/* DVAE decoder + Vocos (models/dvae.py decode branch; third-party vocos)                     */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct ctts_voc ctts_voc;
+
+typedef struct {
+    int32_t dvae_idim;      /* 384 */
+    int32_t dvae_hidden;    /* 512 */
+    int32_t dvae_bn;        /* 128 */
+    int32_t dvae_layers;    /* 12 */
+    int32_t n_mels;         /* 100 */
+    int32_t vocos_dim;      /* 512 */
+    int32_t vocos_inter;    /* 1536 */
+    int32_t vocos_layers;   /* 8 */
+    int32_t n_fft;          /* 1024 */
+    int32_t hop;            /* 256 */
+    int32_t max_frames;     /* capacity in mel frames (2 per generated token) */
+} ctts_voc_cfg;
+
+/* replaces DVAE.__init__ (dvae.py:203-239) + vocos.Vocos construction (pipeline:93-111) */
+int ctts_voc_create(const ctts_voc_cfg* cfg, ctts_voc** out);
+void ctts_voc_destroy(ctts_voc* h);
+/* `name` = "dvae." + DVAE state-dict key  or  "vocos." + Vocos state-dict key; host fp32 */
+int ctts_voc_set_weight(ctts_voc* h, const char* name, const float* data, size_t numel);
+int ctts_voc_finalize(ctts_voc* h);
+
+/* DVAE.forward(mode="decode") (dvae.py:272-291): hidden fp32 [n][768] device (one utterance) ->
+ * mel fp32 [100][2n] device. */
+int ctts_dvae_decode(ctts_voc* h, const float* hidden_dev, int n_tokens, float* mel_dev, void* stream);
+/* vocos.Vocos.decode (pipeline:303): mel fp32 [100][F] device -> wav fp32 [hop*(F-1)] device */
+int ctts_vocos_decode(ctts_voc* h, const float* mel_dev, int frames, float* wav_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTTS_HIP_H */

@@ -174,7 +174,7 @@ class OracleGPT:
         self.H = self.sd["gpt.norm.weight"].numel()
         self.nh = num_heads
         assert self.H // self.nh == HEAD_DIM
-        self.L = 1 + max(int(k.split(".")[2]) for k in self.sd if k.startswith("gpt.layers."))
+        self.L = 1 + max([int(k.split(".")[2]) for k in self.sd if k.startswith("gpt.layers.")] + [-1])
         self.num_vq = num_vq
         self.V = self.sd["emb_code.0.weight"].shape[0]
         # fold weight-norm once: W = g * v / ||v||_row  (gpt.py:57-77; torch weight_norm dim=0);

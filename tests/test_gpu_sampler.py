@@ -1,0 +1,75 @@
+"""GPU parity of the fused sampler kernel (ctts_sampler_run through the C ABI) -- bit-exact token ids
+against (a) the golden cases minted from the reference's own objects and (b) the oracle on random rows."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from chatttsplus_amd import _lib
+from oracle import ref_cpu
+from tests.helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(temp, top_p, top_k, rep, min_new, min_keep=3):
+    sc = _lib.SamplerCfg()
+    for i in range(4):
+        sc.temperature[i] = temp
+    sc.top_p_threshold = float(np.float32(1 - top_p)) if top_p is not None else -1.0
+    sc.top_k = max(int(top_k), min_keep) if top_k else 0
+    sc.min_tokens_to_keep = min_keep
+    sc.use_penalty = 1 if rep != 1 else 0
+    tab = torch.pow(float(rep), torch.arange(0, 17, dtype=torch.int64))
+    for i in range(17):
+        sc.penalty_table[i] = float(tab[i])
+    sc.past_window = 16
+    sc.max_input_ids = 625
+    sc.eos_token = 625
+    sc.min_new_token = int(min_new)
+    sc.max_new_token = 4096
+    return sc
+
+
+def _run(sc, logits, history, q, step):
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    rows, V = logits.shape
+    lg = torch.from_numpy(logits).to(dev)
+    hs = torch.from_numpy(history.astype(np.int32)).to(dev).contiguous()
+    qq = torch.from_numpy(q).to(dev)
+    idx = torch.zeros(rows, dtype=torch.int32, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ctts_sampler_run(C.byref(sc), lg.data_ptr(), hs.data_ptr() if history.shape[1] else None, history.shape[1],
+                                    qq.data_ptr(), rows, V, int(step), idx.data_ptr(), st), "sampler_run")
+    torch.cuda.synchronize()
+    return idx.cpu().numpy()
+
+
+def test_sampler_golden_cases_bit_exact():
+    z = np.load(os.path.join(GOLDEN, "sampler_cases.npz"))
+    for c in range(int(z["n"])):
+        temp, top_p, top_k, rep, step, min_new = z[f"c{c}_params"]
+        sc = _cfg(np.float32(temp), top_p, int(top_k), rep, min_new)
+        idx = _run(sc, z[f"c{c}_logits"], z[f"c{c}_history"], z[f"c{c}_q"], step)
+        assert np.array_equal(idx, z[f"c{c}_idx"].astype(np.int32)), f"case {c}: {idx} vs {z[f'c{c}_idx']}"
+
+
+@pytest.mark.parametrize("temp,top_p,top_k,rep,scale", [(0.3, 0.7, 20, 1.05, 0.55), (0.0003, 0.7, 20, 1.05, 0.55),
+                                                        (1.0, 0.9, 50, 1.3, 2.0), (0.7, 0.3, 3, 1.0, 4.0)])
+def test_sampler_random_rows_vs_oracle(temp, top_p, top_k, rep, scale):
+    rng = np.random.Generator(np.random.Philox(key=99))
+    rows = 128
+    logits = (rng.standard_normal((rows, 626)) * scale).astype(np.float32)
+    history = rng.integers(0, 626, size=(rows, 23), dtype=np.int64)
+    history[:, -4:] = history[:, -5:-4]
+    for r in range(rows):
+        logits[r, history[r, -1]] += 2.0 * scale
+    q = (-np.log1p(-rng.random((rows, 626)))).astype(np.float32).clip(min=1e-30)
+    sp = ref_cpu.SamplerParams(temperature=[temp] * 4, top_p=top_p, top_k=top_k, repetition_penalty=rep, min_new_token=0)
+    ref = ref_cpu.sample_step(torch.from_numpy(logits), torch.from_numpy(history), torch.from_numpy(q), 23, sp,
+                              torch.full((rows, 1), temp, dtype=torch.float32)).numpy()
+    idx = _run(_cfg(np.float32(temp), top_p, top_k, rep, 0), logits, history, q, 23)
+    assert np.array_equal(idx, ref.astype(np.int32)), f"{(idx != ref).sum()} of {rows} rows differ"
