@@ -76,9 +76,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
             float dot = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) dot += q[j] * kf[u][j];
-            dot += __shfl_xor(dot, 1);
-            dot += __shfl_xor(dot, 2);
-            dot += __shfl_xor(dot, 4);
+            dot += dpp_f<DPP_XOR1>(dot);                    // 8-lane group sum on DPP (quad xor1, xor2, half-mirror)
+            dot += dpp_f<DPP_XOR2>(dot);
+            dot += dpp_f<DPP_HALF_MIRROR>(dot);
             if (ok[u]) {
                 const float mn = fmaxf(mrun, dot);
                 const float sc = safe_exp_diff(mrun, mn);

@@ -59,20 +59,55 @@ __host__ __device__ inline size_t xfrag_index(int n, int k, int ktiles) {
     return ((size_t)(g * ktiles + k / KT) * 64 + (n & 15) + 16 * ((k / EPL) & 3)) * EPL + (k % EPL);
 }
 
+// ---- wave64 reductions on DPP (no LDS crossbar): 4 intra-row steps (quad xor1, quad xor2, half-mirror, mirror)
+// leave the 16-lane row result in every lane; the 4 rows are combined through v_readlane.  ~10x cheaper than a
+// 6-step ds_bpermute butterfly (the sampler's 20+ dependent arg-max rounds were 30 us with __shfl_xor).
+template <int CTRL> __device__ inline int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ inline float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+template <int CTRL> __device__ inline unsigned long long dpp_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)dpp_i<CTRL>((int)(unsigned)v), hi = (unsigned)dpp_i<CTRL>((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int CTRL> __device__ inline double dpp_d(double v) {
+    return __builtin_bit_cast(double, dpp_u64<CTRL>(__builtin_bit_cast(unsigned long long, v)));
+}
+#define DPP_XOR1 0xB1
+#define DPP_XOR2 0x4E
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+__device__ inline float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ inline unsigned long long readlane_u64(unsigned long long v, int l) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HALF_MIRROR>(v); v += dpp_f<DPP_MIRROR>(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
 __device__ inline double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_d<DPP_XOR1>(v); v += dpp_d<DPP_XOR2>(v); v += dpp_d<DPP_HALF_MIRROR>(v); v += dpp_d<DPP_MIRROR>(v);
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    return (__builtin_bit_cast(double, readlane_u64(b, 0)) + __builtin_bit_cast(double, readlane_u64(b, 16))) +
+           (__builtin_bit_cast(double, readlane_u64(b, 32)) + __builtin_bit_cast(double, readlane_u64(b, 48)));
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v)); v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+__device__ inline unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
+    v = umax64(v, dpp_u64<DPP_XOR1>(v)); v = umax64(v, dpp_u64<DPP_XOR2>(v));
+    v = umax64(v, dpp_u64<DPP_HALF_MIRROR>(v)); v = umax64(v, dpp_u64<DPP_MIRROR>(v));
+    return umax64(umax64(readlane_u64(v, 0), readlane_u64(v, 16)), umax64(readlane_u64(v, 32), readlane_u64(v, 48)));
+}
+// total order on floats as unsigned keys (larger float -> larger key; -inf -> small but non-zero key)
+__device__ inline unsigned f32_key(float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float key_f32(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __builtin_bit_cast(float, u);
 }
 
 // host-side error plumbing (gpt_engine.cpp)

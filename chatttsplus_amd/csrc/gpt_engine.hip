@@ -8,6 +8,7 @@
 //   act              fragment-major SwiGLU output for the down projection
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -28,7 +29,7 @@ extern "C" const char* ctts_last_error(void) { return g_err; }
 extern "C" int ctts_version(void) { return 1; }
 
 #define PASS_ROWS 2048
-#define SMAX 16
+#define SMAX 8        // == ATT_SMAX in skinny_gemm.hip
 
 struct LayerW {
     void *qkv, *o, *gu, *d;
@@ -65,6 +66,7 @@ struct ctts_gpt {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     std::string graph_sig;
+    int graph_steps = 1;                         // decode steps captured per graph (env CTTS_GRAPH_STEPS)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -91,6 +93,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->cfg = *c;
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
+    if (const char* gs = getenv("CTTS_GRAPH_STEPS")) { h->graph_steps = atoi(gs); if (h->graph_steps < 1) h->graph_steps = 1; }
     if (gemm_configure()) { delete h; return 1; }
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -102,16 +105,16 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
 
 extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
-    if (h->gexec) hipGraphExecDestroy(h->gexec);
-    if (h->graph) hipGraphDestroy(h->graph);
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
     void* bufs[] = {h->wblob, h->lnf, h->emb_code, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
-    for (void* b : bufs) if (b) hipFree(b);
-    for (auto& l : h->lw) { if (l.ln1) hipFree(l.ln1); if (l.ln2) hipFree(l.ln2); }
-    if (h->host_pin) hipHostFree(h->host_pin);
-    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-    if (h->ev0) hipEventDestroy(h->ev0);
-    if (h->ev1) hipEventDestroy(h->ev1);
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    for (auto& l : h->lw) { if (l.ln1) (void)hipFree(l.ln1); if (l.ln2) (void)hipFree(l.ln2); }
+    if (h->host_pin) (void)hipHostFree(h->host_pin);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
 }
 
@@ -284,7 +287,7 @@ extern "C" int ctts_gpt_bind_kv(ctts_gpt* h, void* kv, size_t bytes) {
 }
 extern "C" int ctts_gpt_set_rope(ctts_gpt* h, const float* rope_host, int n_pos) {
     if (!h || !rope_host || n_pos < h->cfg.max_seq) { ctts_set_error("set_rope: need at least max_seq=%d positions", h ? h->cfg.max_seq : 0); return 1; }
-    if (h->rope) hipFree(h->rope);
+    if (h->rope) (void)hipFree(h->rope);
     if (dev_alloc((void**)&h->rope, (size_t)n_pos * 64 * 4)) return 1;
     CTTS_HIP_CHECK(hipMemcpy(h->rope, rope_host, (size_t)n_pos * 64 * 4, hipMemcpyHostToDevice));
     h->rope_n = n_pos;
@@ -438,10 +441,11 @@ static int ensure_graph(ctts_gpt* h) {
     for (int i = 0; i < 4; ++i) key += "|" + std::to_string(h->sc.temperature[i]);
     key += "|" + std::to_string(h->sc.penalty_table[1]);
     if (h->gexec && key == h->graph_sig) return 0;
-    if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-    if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
     CTTS_HIP_CHECK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = run_decode_step(h, h->cap_stream);
+    int rc = 0;
+    for (int i = 0; i < h->graph_steps && !rc; ++i) rc = run_decode_step(h, h->cap_stream);
     hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
     if (rc) return 1;
     if (e != hipSuccess) { ctts_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return 1; }
@@ -455,7 +459,9 @@ extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* st
     hipStream_t s = (hipStream_t)stream;
     if (use_graph) {
         if (ensure_graph(h)) return 1;
-        for (int i = 0; i < n_steps; ++i) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+        int left = n_steps;
+        for (; left >= h->graph_steps; left -= h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+        for (; left > 0; --left) if (run_decode_step(h, s)) return 1;
     } else {
         for (int i = 0; i < n_steps; ++i) if (run_decode_step(h, s)) return 1;
     }
@@ -502,7 +508,8 @@ extern "C" int ctts_gpt_time_decode(ctts_gpt* h, int n_steps, float* ms_per_step
     hipStream_t s = (hipStream_t)stream;
     if (ensure_graph(h)) return 1;
     CTTS_HIP_CHECK(hipEventRecord(h->ev0, s));
-    for (int i = 0; i < n_steps; ++i) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+    n_steps = (n_steps + h->graph_steps - 1) / h->graph_steps * h->graph_steps;
+    for (int i = 0; i < n_steps; i += h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
     CTTS_HIP_CHECK(hipEventRecord(h->ev1, s));
     CTTS_HIP_CHECK(hipEventSynchronize(h->ev1));
     float ms = 0.f;

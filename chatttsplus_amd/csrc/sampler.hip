@@ -88,26 +88,26 @@ __device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn&
     float vk = 0.f;
     const int topk = (c.top_k > 0) ? c.top_k : V;
     for (int r = 0; r < V; ++r) {
-        float bv = -INFINITY, bp = 0.f;
-        int bi = -1;
+        // wave-wide arg-max of (value, index): one 64-bit key per lane, larger index wins ties (== reversed stable ascending sort)
+        unsigned long long key = 0ull;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            if (!((taken >> i) & 1u)) {
-                const int j = lane + 64 * i;
-                if (x[i] > bv || (x[i] == bv && j > bi)) { bv = x[i]; bi = j; bp = pr[i]; }
-            }
+            const unsigned long long k = ((unsigned long long)f32_key(x[i]) << 32) | (unsigned)(lane + 64 * i);
+            if (!((taken >> i) & 1u)) key = umax64(key, k);
         }
+        key = wave_max_u64(key);
+        if (key == 0ull) break;                                    // nothing left
+        const float bv = key_f32((unsigned)(key >> 32));
+        const int bi = (int)(unsigned)key;
+        const int owner = bi & 63, slot = bi >> 6;
+        float cand = 0.f;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off), op = __shfl_xor(bp, off);
-            const int oi = __shfl_xor(bi, off);
-            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; bp = op; }
-        }
-        if (bi < 0) break;                                        // nothing left
+        for (int i = 0; i < VPL; ++i) cand = (i == slot) ? pr[i] : cand;
+        const float bp = readlane_f(cand, owner);
         if (r >= topk && bv != vk) break;                          // beyond top-k and not tied with the k-th value
         const float cr = (float)(tot - cum_before);               // ascending cumsum at this element
         if (cr <= c.top_p_threshold && r >= c.min_keep) break;     // removed by top-p (and so is every smaller one)
-        if (lane == (bi & 63)) { taken |= 1u << (bi >> 6); kept |= 1u << (bi >> 6); }
+        if (lane == owner) { taken |= 1u << slot; kept |= 1u << slot; }
         if (r == topk - 1) vk = bv;
         cum_before += (double)bp;
     }
@@ -124,8 +124,7 @@ __device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn&
     for (int i = 0; i < VPL; ++i) { e2[i] = ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f; s2 += e2[i]; }
     s2 = wave_sum(s2);
     const float inv2 = 1.0f / s2;
-    float best = -1.f;
-    int besti = 0x7fffffff;
+    unsigned long long bkey = 0ull;                                // (ratio, first index wins ties) as one 64-bit key
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int j = lane + 64 * i;
@@ -139,15 +138,11 @@ __device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn&
                 q = -logf(u);
             }
             const float ratio = __fdiv_rn(e2[i] * inv2, q);
-            if (ratio > best || (ratio == best && j < besti)) { best = ratio; besti = j; }
+            bkey = umax64(bkey, ((unsigned long long)f32_key(ratio) << 32) | (unsigned)(0x7FFFFFFF - j));
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best, off);
-        const int oi = __shfl_xor(besti, off);
-        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-    }
+    bkey = wave_max_u64(bkey);
+    const int besti = 0x7FFFFFFF - (int)(unsigned)bkey;
     return besti;
 }
 

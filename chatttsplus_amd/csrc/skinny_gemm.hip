@@ -17,6 +17,8 @@
 //   EPI_LOGITS head_code[i](hidden) for the 4 folded heads        gpt.py:437-447
 #include "kernels.h"
 
+#define ATT_SMAX 8     // max key splits combined by PRO_ATTN (gpt_engine.hip decode_splits)
+
 template <typename WT> struct Mma;
 template <> struct Mma<half_t> {
     __device__ static inline f32x4 run(half8 a, half8 b, f32x4 c) {
@@ -74,65 +76,131 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
 #pragma unroll
     for (int i = 0; i < KPW; ++i) wf[i] = __builtin_nontemporal_load(Wp + i * 64);
 
+    // 1b. epilogue operands that do not depend on the GEMM are requested now and consumed at the very end, so
+    //     their L2/HBM round trips overlap the weight stream instead of forming a dependent tail
+    constexpr int RITEMS = (16 * NB + WAVES * 64 - 1) / (WAVES * 64);
+    float resid_pf[RITEMS];
+    if (EPI == EPI_RESID) {
+#pragma unroll
+        for (int u = 0; u < RITEMS; ++u) {
+            const int t = tid + u * WAVES * 64;
+            const int r = row0 + (t >> 4);
+            resid_pf[u] = (t < 16 * NB && r < a.R) ? a.x_out[(size_t)r * (a.n_row_tiles * 16) + rt * 16 + (t & 15)] : 0.f;
+        }
+    }
+    RowMeta meta_pf = {0, 0, 0, 0};
+    float rope_c = 1.f, rope_s = 0.f;
+    if (EPI == EPI_QKV) {
+        const int r = row0 + (tid >> 3);
+        if (tid < 8 * NB && r < a.R) {
+            meta_pf = a.meta[r];
+            const int d = (((rt % (K / 16)) & 3) << 3) + (tid & 7);
+            rope_c = a.rope[(size_t)meta_pf.pos * 64 + d];
+            rope_s = a.rope[(size_t)meta_pf.pos * 64 + 32 + d];
+        }
+    }
+
     // 2. prologue: build the B operand (activations) in LDS, fragment-major
     if (PRO == PRO_NORM) {
-        for (int n = wave; n < NB; n += WAVES) {
-            const int r = row0 + n;
-            f32x4 v[PER];
-            if (r < a.R) {
-                const f32x4* xr = (const f32x4*)(a.x + (size_t)r * K);
+        // rows beyond R are left unwritten: an MFMA output column depends only on its own B column, and the
+        // epilogues never read columns >= R.  A wave owns rows wave, wave+WAVES, ...; the loads of RB rows are
+        // issued together (one L2 round trip per batch instead of one per row: 8 serial trips at batch 32).
+        constexpr int RB = 4;
+        const int rows = min(NB, a.R - row0);
+        for (int nb = wave; nb < rows; nb += WAVES * RB) {
+            f32x4 v[RB][PER];
 #pragma unroll
-                for (int i = 0; i < PER; ++i) v[i] = xr[lane + 64 * i];
-            } else {
+            for (int u = 0; u < RB; ++u) {
+                const int n = nb + u * WAVES;
+                const f32x4* xr = (const f32x4*)(a.x + (size_t)(row0 + (n < rows ? n : nb)) * K);
 #pragma unroll
-                for (int i = 0; i < PER; ++i) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < PER; ++i) v[u][i] = xr[lane + 64 * i];
             }
-            float ss = 0.f;
+            f32x4 w[PER];
 #pragma unroll
-            for (int i = 0; i < PER; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-            ss = wave_sum(ss);
-            const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);          // torch.rsqrt(mean(x^2) + eps)
-            const bool write_hidden = (a.hidden_out != nullptr) && (rt == 0) && (r < a.R);
-            float* hrow = nullptr;
-            if (write_hidden) hrow = a.hidden_out + (size_t)a.meta[r].seq * a.hidden_stride + (size_t)a.st->step * K;
+            for (int i = 0; i < PER; ++i) w[i] = *(const f32x4*)(a.lnw + 4 * (lane + 64 * i));
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int k = 4 * (lane + 64 * i);
-                const f32x4 w = *(const f32x4*)(a.lnw + k);
-                const float y0 = w[0] * (v[i][0] * rs), y1 = w[1] * (v[i][1] * rs);
-                const float y2 = w[2] * (v[i][2] * rs), y3 = w[3] * (v[i][3] * rs);
-                store_x4<WT>(smem, n, k, KTILES, y0, y1, y2, y3);
-                if (write_hidden) *(f32x4*)(hrow + k) = (f32x4){y0, y1, y2, y3};
+            for (int u = 0; u < RB; ++u) {
+                const int n = nb + u * WAVES;
+                if (n >= rows) break;
+                const int r = row0 + n;
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) ss += v[u][i][0] * v[u][i][0] + v[u][i][1] * v[u][i][1] + v[u][i][2] * v[u][i][2] + v[u][i][3] * v[u][i][3];
+                ss = wave_sum(ss);
+                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);          // torch.rsqrt(mean(x^2) + eps)
+                const bool write_hidden = (a.hidden_out != nullptr) && (rt == 0);
+                float* hrow = nullptr;
+                if (write_hidden) hrow = a.hidden_out + (size_t)a.meta[r].seq * a.hidden_stride + (size_t)a.st->step * K;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int k = 4 * (lane + 64 * i);
+                    const float y0 = w[i][0] * (v[u][i][0] * rs), y1 = w[i][1] * (v[u][i][1] * rs);
+                    const float y2 = w[i][2] * (v[u][i][2] * rs), y3 = w[i][3] * (v[u][i][3] * rs);
+                    store_x4<WT>(smem, n, k, KTILES, y0, y1, y2, y3);
+                    if (write_hidden) *(f32x4*)(hrow + k) = (f32x4){y0, y1, y2, y3};
+                }
             }
         }
         __syncthreads();
     } else if (PRO == PRO_ATTN) {
+        // softmax-normalise the flash-decoding partials of attention.hip.  Items (row, 4 dims) are spread over the
+        // whole block and all loads of an item batch are issued together (they were a chain of dependent L2 round
+        // trips: 21 us per launch at batch 1 with 16 splits, 22 us at batch 32 with 24 serial items per thread).
         constexpr int NH = K / CTTS_HEAD_DIM;
+        constexpr int K4 = K / 4;
         const int S = a.S;
-        for (int n = wave; n < NB; n += WAVES) {
-            const int r = row0 + n;
+        const int rows = min(NB, a.R - row0);
+        if (S == 1) {
+            constexpr int IB = 8;
+            for (int it0 = tid; it0 < rows * K4; it0 += WAVES * 64 * IB) {
+                float ls[IB];
+                f32x4 os[IB];
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int k = 4 * (lane + 64 * i);
-                float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
-                if (r < a.R) {
-                    const int h = k >> 6, d = k & 63;
-                    const float* ml = a.part_ml + ((size_t)(r * NH + h) * S) * 2;
-                    const float* po = a.part_o + ((size_t)(r * NH + h) * S) * CTTS_HEAD_DIM + d;
-                    float mx = -INFINITY;
-                    for (int s = 0; s < S; ++s) mx = fmaxf(mx, ml[2 * s]);
-                    float L = 0.f;
-                    for (int s = 0; s < S; ++s) {
-                        const float ms = ml[2 * s];
-                        const float w = (ms == -INFINITY) ? 0.f : expf(ms - mx);
-                        L += ml[2 * s + 1] * w;
-                        const f32x4 o = *(const f32x4*)(po + (size_t)s * CTTS_HEAD_DIM);
-                        y0 += o[0] * w; y1 += o[1] * w; y2 += o[2] * w; y3 += o[3] * w;
-                    }
-                    const float inv = 1.0f / L;
-                    y0 *= inv; y1 *= inv; y2 *= inv; y3 *= inv;
+                for (int u = 0; u < IB; ++u) {
+                    const int it = it0 + u * WAVES * 64;
+                    const int itc = (it < rows * K4) ? it : it0;
+                    const int n = itc / K4, k = 4 * (itc % K4);
+                    const size_t ph = (size_t)(row0 + n) * NH + (k >> 6);
+                    ls[u] = a.part_ml[ph * 2 + 1];
+                    os[u] = *(const f32x4*)(a.part_o + ph * CTTS_HEAD_DIM + (k & 63));
                 }
-                store_x4<WT>(smem, n, k, KTILES, y0, y1, y2, y3);
+#pragma unroll
+                for (int u = 0; u < IB; ++u) {
+                    const int it = it0 + u * WAVES * 64;
+                    if (it >= rows * K4) break;
+                    const float inv = 1.0f / ls[u];
+                    store_x4<WT>(smem, it / K4, 4 * (it % K4), KTILES, os[u][0] * inv, os[u][1] * inv, os[u][2] * inv, os[u][3] * inv);
+                }
+            }
+        } else {
+            for (int it = tid; it < rows * K4; it += WAVES * 64) {
+                const int n = it / K4, k = 4 * (it % K4);
+                const int r = row0 + n, h = k >> 6, d = k & 63;
+                const float* ml = a.part_ml + ((size_t)(r * NH + h) * S) * 2;
+                const float* po = a.part_o + ((size_t)(r * NH + h) * S) * CTTS_HEAD_DIM + d;
+                float ms[ATT_SMAX], ls[ATT_SMAX];
+                f32x4 os[ATT_SMAX];
+#pragma unroll
+                for (int s = 0; s < ATT_SMAX; ++s) {
+                    const int sc = (s < S) ? s : 0;
+                    const float2 t = *(const float2*)(ml + 2 * sc);
+                    ms[s] = (s < S) ? t.x : -INFINITY;
+                    ls[s] = t.y;
+                    os[s] = *(const f32x4*)(po + (size_t)sc * CTTS_HEAD_DIM);
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int s = 0; s < ATT_SMAX; ++s) mx = fmaxf(mx, ms[s]);
+                float L = 0.f, y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+#pragma unroll
+                for (int s = 0; s < ATT_SMAX; ++s) {
+                    const float w = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - mx);
+                    L += ls[s] * w;
+                    y0 += os[s][0] * w; y1 += os[s][1] * w; y2 += os[s][2] * w; y3 += os[s][3] * w;
+                }
+                const float inv = 1.0f / L;
+                store_x4<WT>(smem, n, k, KTILES, y0 * inv, y1 * inv, y2 * inv, y3 * inv);
             }
         }
         __syncthreads();
@@ -175,53 +243,50 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
 
     // 5. fused epilogue
     if (EPI == EPI_RESID || EPI == EPI_LOGITS) {
-        for (int t = tid; t < 16 * NB; t += WAVES * 64) {
+#pragma unroll
+        for (int u = 0; u < RITEMS; ++u) {
+            const int t = tid + u * WAVES * 64;
+            if (t >= 16 * NB) continue;
             const int n = t >> 4, i = t & 15;
             const int r = row0 + n;
             if (r >= a.R) continue;
             const int col = rt * 16 + i;
             const float v = outt[i * NB + n];
             if (EPI == EPI_RESID) {
-                float* p = a.x_out + (size_t)r * (a.n_row_tiles * 16) + col;
-                *p = *p + v;                                               // residual + proj (llama.py:731,739)
+                a.x_out[(size_t)r * (a.n_row_tiles * 16) + col] = resid_pf[u] + v;   // residual + proj (llama.py:731,739)
             } else if (col < a.n_valid) {
                 a.logits[(size_t)r * a.n_valid + col] = v;
             }
         }
-    } else {
-        for (int t = tid; t < 8 * NB; t += WAVES * 64) {
-            const int n = t >> 3, p = t & 7;
-            const int r = row0 + n;
-            const float va = outt[p * NB + n], vb = outt[(p + 8) * NB + n];
-            if (EPI == EPI_SWIGLU) {
-                // packed rows: [8 gate | 8 up] per tile -> act[rt*8+p] = silu(g) * u
-                float y = 0.f;
-                if (r < a.R) y = (va / (1.0f + expf(-va))) * vb;
-                const int ktiles_out = (a.n_row_tiles * 8) / KT;
-                WT* dst = (WT*)a.act_out + (size_t)chunk * NBG * ktiles_out * 64 * WTraits<WT>::EPL;
-                dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = (WT)y;
-            } else {  // EPI_QKV: packed rows per tile = dims [8t..8t+7 | 8t+32..8t+39] of one head
-                if (r >= a.R) continue;
-                constexpr int HT = K / 16;                   // tiles per projection (H == K for q/k/v)
-                constexpr int NH = K / CTTS_HEAD_DIM;
-                const int which = rt / HT, within = rt % HT;
-                const int h = within >> 2, d = ((within & 3) << 3) + p;
-                const RowMeta m = a.meta[r];
-                float ya = va, yb = vb;
-                if (which < 2) {
-                    const float c = a.rope[(size_t)m.pos * 64 + d], s = a.rope[(size_t)m.pos * 64 + 32 + d];
-                    // q*cos + rotate_half(q)*sin, products rounded separately like the reference (llama.py:180-181)
-                    ya = __fadd_rn(__fmul_rn(va, c), __fmul_rn(-vb, s));
-                    yb = __fadd_rn(__fmul_rn(vb, c), __fmul_rn(va, s));
-                }
-                if (which == 0) {
-                    float* q = a.q_out + ((size_t)r * NH + h) * CTTS_HEAD_DIM;
-                    q[d] = ya; q[d + 32] = yb;
-                } else {
-                    WT* c = (WT*)(which == 1 ? a.k_cache : a.v_cache) +
-                            (((size_t)m.seq * NH + h) * a.Lmax + m.slot) * CTTS_HEAD_DIM;
-                    c[d] = (WT)ya; c[d + 32] = (WT)yb;
-                }
+    } else if (tid < 8 * NB) {
+        const int n = tid >> 3, p = tid & 7;
+        const int r = row0 + n;
+        const float va = outt[p * NB + n], vb = outt[(p + 8) * NB + n];
+        if (EPI == EPI_SWIGLU) {
+            // packed rows: [8 gate | 8 up] per tile -> act[rt*8+p] = silu(g) * u
+            float y = 0.f;
+            if (r < a.R) y = (va / (1.0f + expf(-va))) * vb;
+            const int ktiles_out = (a.n_row_tiles * 8) / KT;
+            WT* dst = (WT*)a.act_out + (size_t)chunk * NBG * ktiles_out * 64 * WTraits<WT>::EPL;
+            dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = (WT)y;
+        } else if (r < a.R) {  // EPI_QKV: packed rows per tile = dims [8t..8t+7 | 8t+32..8t+39] of one head
+            constexpr int HT = K / 16;                   // tiles per projection (H == K for q/k/v)
+            constexpr int NH = K / CTTS_HEAD_DIM;
+            const int which = rt / HT, within = rt % HT;
+            const int h = within >> 2, d = ((within & 3) << 3) + p;
+            float ya = va, yb = vb;
+            if (which < 2) {
+                // q*cos + rotate_half(q)*sin, products rounded separately like the reference (llama.py:180-181)
+                ya = __fadd_rn(__fmul_rn(va, rope_c), __fmul_rn(-vb, rope_s));
+                yb = __fadd_rn(__fmul_rn(vb, rope_c), __fmul_rn(va, rope_s));
+            }
+            if (which == 0) {
+                float* q = a.q_out + ((size_t)r * NH + h) * CTTS_HEAD_DIM;
+                q[d] = ya; q[d + 32] = yb;
+            } else {
+                WT* c = (WT*)(which == 1 ? a.k_cache : a.v_cache) +
+                        (((size_t)meta_pf.seq * NH + h) * a.Lmax + meta_pf.slot) * CTTS_HEAD_DIM;
+                c[d] = (WT)ya; c[d + 32] = (WT)yb;
             }
         }
     }

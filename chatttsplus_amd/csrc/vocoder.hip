@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
     for (int k0 = 0; k0 < a.K; k0 += 16) {
         const f32x4 a0 = *(const f32x4*)(Ap + k0), a1 = *(const f32x4*)(Ap + a16 + k0);
         const f32x4 b0 = *(const f32x4*)(Wp + k0), b1 = *(const f32x4*)(Wp + w16 + k0);

@@ -1,0 +1,148 @@
+"""hip_models.DVAE / hip_models.Vocos -- drop-ins for chattts_plus.models.DVAE (decode branch,
+reference chattts_plus/models/dvae.py:203-291) and vocos.Vocos.decode (third-party, constructed at
+pipelines/chattts_plus_pipeline.py:93-111, called at :303) running in libctts_hip.so.
+
+Both classes share one native handle per process-wide (dvae, vocos) pair: the C ABI keeps the two in one
+object (ctts_voc) because they share workspaces; `Synth` owns it, `DVAE` / `Vocos` are thin views with
+the reference's call surface."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _np(v) -> np.ndarray:
+    a = v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, dtype=np.float32)
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Synth:
+    """Owner of the native DVAE-decoder + Vocos handle."""
+
+    def __init__(self, dvae_cfg: dict, vocos_cfg: dict, max_frames: int = 4096, device="cuda"):
+        self.device = torch.device(device)
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.HipBackendError("infer_type='hip' needs a visible MI355X; no CPU fallback")
+        self.cfg = _lib.VocCfg(dvae_idim=int(dvae_cfg.get("idim", 384)), dvae_hidden=int(dvae_cfg.get("hidden", 512)),
+                               dvae_bn=int(dvae_cfg.get("bn_dim", 128)), dvae_layers=int(dvae_cfg.get("n_layer", 12)),
+                               n_mels=int(dvae_cfg.get("n_mels", 100)), vocos_dim=int(vocos_cfg.get("dim", 512)),
+                               vocos_inter=int(vocos_cfg.get("intermediate_dim", 1536)), vocos_layers=int(vocos_cfg.get("num_layers", 8)),
+                               n_fft=int(vocos_cfg.get("n_fft", 1024)), hop=int(vocos_cfg.get("hop_length", 256)), max_frames=int(max_frames))
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_voc_create(C.byref(self.cfg), C.byref(self._h)), "ctts_voc_create")
+        self._loaded = set()
+        self._finalized = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._lib.ctts_voc_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def load(self, prefix: str, sd: Dict[str, np.ndarray]):
+        for k, v in sd.items():
+            if prefix == "vocos." and k.startswith("feature_extractor."):
+                continue                                     # mel extractor: encode path only
+            if prefix == "dvae." and not (k.startswith("decoder.") or k in ("out_conv.weight", "coef")):
+                continue                                     # encoder / vq / downsample_conv: zero-shot path (next)
+            a = _np(v)
+            _lib.check(self._lib.ctts_voc_set_weight(self._h, (prefix + k).encode(), a.ctypes.data_as(C.c_void_p), a.size), f"set_weight({prefix + k})")
+        self._loaded.add(prefix)
+        if {"dvae.", "vocos."} <= self._loaded and not self._finalized:
+            with torch.cuda.device(self.device):
+                _lib.check(self._lib.ctts_voc_finalize(self._h), "ctts_voc_finalize")
+            self._finalized = True
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def dvae_decode(self, hidden: torch.Tensor) -> torch.Tensor:
+        """hidden [n,768] fp32 device -> mel [100, 2n]."""
+        if not self._finalized:
+            raise _lib.HipBackendError("DVAE / Vocos weights not loaded")
+        hidden = hidden.to(self.device, dtype=torch.float32).contiguous()
+        n = int(hidden.shape[0])
+        mel = torch.empty(self.cfg.n_mels, 2 * n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_dvae_decode(self._h, hidden.data_ptr(), n, mel.data_ptr(), self._stream()), "dvae_decode")
+        return mel
+
+    def vocos_decode(self, mel: torch.Tensor) -> torch.Tensor:
+        """mel [100,F] fp32 device -> wav [256 (F-1)]."""
+        if not self._finalized:
+            raise _lib.HipBackendError("DVAE / Vocos weights not loaded")
+        mel = mel.to(self.device, dtype=torch.float32).contiguous()
+        F = int(mel.shape[1])
+        wav = torch.empty(self.cfg.hop * (F - 1), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_vocos_decode(self._h, mel.data_ptr(), F, wav.data_ptr(), self._stream()), "vocos_decode")
+        return wav
+
+
+class DVAE:
+    """Call surface of models.DVAE for the decode branch: DVAE(decoder_config, dim, coef, model_path)(inp[1,768,n]) -> mel[1,100,2n]."""
+
+    def __init__(self, decoder_config: dict, encoder_config: Optional[dict] = None, vq_config: Optional[dict] = None, dim=384,
+                 coef=None, synth: Optional[Synth] = None, **kwargs):
+        if encoder_config is not None or vq_config is not None:
+            raise _lib.HipBackendError("the hip DVAE serves the decode branch only (dvae_decode); encoder/vq = zero-shot path (SURVEY 8f N2)")
+        self.decoder_config = dict(decoder_config)
+        self.dim = dim
+        self.synth = synth
+        self.model_path = kwargs.get("model_path")
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        self.synth.load("dvae.", sd)
+        return self
+
+    def from_pretrained(self, path):
+        return self.load_state_dict(torch.load(path, weights_only=True, mmap=True))
+
+    @torch.inference_mode()
+    def __call__(self, inp: torch.Tensor, mode="decode") -> torch.Tensor:
+        if mode != "decode":
+            raise _lib.HipBackendError("hip DVAE: only mode='decode'")
+        assert inp.dim() == 3 and inp.shape[0] == 1, "reference calls the decoder per utterance (pipeline:298-300)"
+        hidden = inp[0].permute(1, 0)                      # [n,768]; the pipeline passed hiddens.permute(1,0)[None]
+        return self.synth.dvae_decode(hidden)[None]
+
+
+class Vocos:
+    """Call surface the pipeline uses: .decode(mel[1,100,F]) -> wav[1,S], .parameters(), .load_state_dict, .eval(), .to()."""
+
+    def __init__(self, synth: Synth):
+        self.synth = synth
+        self._p = torch.nn.Parameter(torch.zeros(1, device=synth.device), requires_grad=False)
+
+    def parameters(self):
+        return iter([self._p])
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        self.synth.load("vocos.", sd)
+        return self
+
+    @torch.inference_mode()
+    def decode(self, mel: torch.Tensor) -> torch.Tensor:
+        assert mel.dim() == 3 and mel.shape[0] == 1
+        return self.synth.vocos_decode(mel[0])[None]

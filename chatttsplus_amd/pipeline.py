@@ -1,0 +1,305 @@
+"""ChatTTSPlusPipeline with `infer_type: "hip"` -- the drop-in surface of the reference's
+chattts_plus/pipelines/chattts_plus_pipeline.py for the hot path:
+
+    pipe = ChatTTSPlusPipeline(cfg, device=torch.device("cuda"))
+    for wavs in pipe.infer(text, params_infer_code=InferCodeParams(...), skip_refine_text=True, ...): ...
+
+What is kept: constructor kwargs, YAML layout (MODELS.<key>.{name,infer_type,kwargs}), `infer()` /
+`_infer()` / `_infer_code()` / `_decode_to_wavs()` / speaker helpers, the generator-of-wav-lists result,
+InferCodeParams / RefineTextParams.  What is delegated (out of the hot-path scope): text
+normalisation / splitting (pluggable callables, identity by default) and the refine-text pass
+(`skip_refine_text=True` is required this round -- it fails loudly otherwise).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib, codec, hip_models
+
+
+@dataclass(repr=False, eq=False)
+class RefineTextParams:                      # reference commons/utils.py:12-22
+    prompt: str = ""
+    top_P: float = 0.7
+    top_K: int = 20
+    temperature: float = 0.7
+    repetition_penalty: float = 1.0
+    max_new_token: int = 384
+    min_new_token: int = 0
+    show_tqdm: bool = True
+    ensure_non_empty: bool = True
+
+
+@dataclass(repr=False, eq=False)
+class InferCodeParams(RefineTextParams):     # reference commons/utils.py:25-36
+    prompt: str = "[speed_5]"
+    spk_emb: Optional[str] = None
+    spk_smp: Optional[str] = None
+    txt_smp: Optional[str] = None
+    temperature: float = 0.3
+    repetition_penalty: float = 1.05
+    max_new_token: int = 2048
+    stream_batch: int = 24
+    stream_speed: int = 12000
+    pass_first_n_batches: int = 2
+
+
+class _TopP:                                  # scalar carriers with the attribute names the HF warpers expose
+    def __init__(self, top_p, min_tokens_to_keep):
+        self.top_p, self.min_tokens_to_keep = float(top_p), int(min_tokens_to_keep)
+
+
+class _TopK:
+    def __init__(self, top_k, min_tokens_to_keep):
+        self.top_k, self.min_tokens_to_keep = max(int(top_k), int(min_tokens_to_keep)), int(min_tokens_to_keep)
+
+
+class _RepPenalty:
+    def __init__(self, penalty, max_input_ids, past_window):
+        if not isinstance(penalty, float) or not (penalty > 0):
+            raise ValueError(f"`penalty` has to be a strictly positive float, but is {penalty}")   # processors.py:9-12
+        self.penalty, self.max_input_ids, self.past_window = penalty, int(max_input_ids), int(past_window)
+
+
+def gen_logits(num_code: int, top_P=0.7, top_K=20, repetition_penalty=1.0):
+    """models/processors.py:37-57 -- same construction, scalar carriers instead of HF objects (the hip GPT
+    also accepts the real transformers / reference objects: it only reads their attributes)."""
+    warpers, processors = [], []
+    if top_P is not None:
+        warpers.append(_TopP(top_P, 3))
+    if top_K is not None:
+        warpers.append(_TopK(top_K, 3))
+    if repetition_penalty is not None and repetition_penalty != 1:
+        processors.append(_RepPenalty(repetition_penalty, num_code, 16))
+    return warpers, processors
+
+
+def _get(cfg, key, default=None):
+    try:
+        return cfg[key]
+    except Exception:
+        return getattr(cfg, key, default)
+
+
+def load_config(path: str) -> dict:
+    import yaml
+    with open(path) as f:
+        return yaml.safe_load(f)
+
+
+def load_lora_adapter(path: str):
+    """peft adapter directory -> [(layer, target, A[r,in], B[out,r], scale)] (pipeline:420-432; train config
+    configs/train/train_voice_clone_lora.yaml:72-80: r=8, alpha=16 on q/k/v/o).  Reads adapter_config.json +
+    adapter_model.safetensors directly; peft is not needed."""
+    from safetensors.numpy import load_file
+    with open(os.path.join(path, "adapter_config.json")) as f:
+        ac = json.load(f)
+    scale = float(ac["lora_alpha"]) / float(ac["r"])
+    sd = load_file(os.path.join(path, "adapter_model.safetensors"))
+    out = []
+    for k, A in sd.items():
+        if ".lora_A" not in k:
+            continue
+        parts = k.split(".")
+        li = parts.index("layers")
+        layer, target = int(parts[li + 1]), parts[li + 3]
+        Bk = k.replace("lora_A", "lora_B")
+        out.append((layer, target, np.asarray(A, dtype=np.float32), np.asarray(sd[Bk], dtype=np.float32), scale))
+    return out
+
+
+class ChatTTSPlusPipeline:
+    def __init__(self, cfg, **kwargs):
+        self.logger = logging.getLogger(self.__class__.__name__)
+        self.cfg = cfg
+        self.device = torch.device(kwargs.get("device", "cuda"))
+        self.dtype = torch.float32                 # activations / outputs are fp32; weights per `weight_dtype`
+        self.normalizer: Callable = kwargs.get("normalizer") or (lambda t, *a, **k: t)
+        self.text_splitter: Optional[Callable] = kwargs.get("text_splitter")
+        self.load_lora = False
+        self._lora_models = {}
+        self.load_models(**kwargs)
+
+    # -- loading (pipeline:53-155) -----------------------------------------------------------------
+    def load_models(self, **kwargs):
+        self.models_dict = {}
+        models = _get(self.cfg, "MODELS")
+        coef = kwargs.get("coef", None)
+        if coef is None:
+            coef = codec.coef_to_string(torch.rand(100).numpy())            # pipeline:56-59
+        self.dave_coef = coef
+        ckpt_dir = kwargs.get("checkpoint_dir") or os.environ.get("CHATTTS_PLUS_CHECKPOINT_DIR", "checkpoints")
+        self.infer_type = None
+        synth = None
+        for model_name in models:
+            m = models[model_name]
+            kw = dict(_get(m, "kwargs") or {})
+            mp = kw.get("model_path")
+            if mp and not os.path.isabs(mp):
+                kw["model_path"] = os.path.join(ckpt_dir, mp.replace("checkpoints/", ""))   # pipeline:70-71
+            itype = _get(m, "infer_type")
+            if model_name == "tokenizer":
+                tok = kwargs.get("tokenizer")
+                if tok is None:
+                    from .tokenizer import Tokenizer
+                    tok = Tokenizer(**kw)
+                self.models_dict[model_name] = tok
+                continue
+            if model_name == "dvae_encode":
+                continue                                    # zero-shot speaker sampling: next
+            if itype != "hip":
+                raise _lib.HipBackendError(f"model {model_name}: infer_type={itype!r}; this pipeline serves infer_type 'hip' only")
+            self.infer_type = self.infer_type or itype
+            if model_name in ("dvae_decode", "vocos") and synth is None:
+                dk = dict(_get(models["dvae_decode"], "kwargs"))
+                vk = dict(_get(models["vocos"], "kwargs"))
+                dcfg = dict(dk["decoder_config"]); dcfg["n_mels"] = 100
+                vcfg = dict(vk["backbone_config"]); vcfg.update(vk["head_config"])
+                synth = hip_models.Synth(dcfg, vcfg, max_frames=int(kwargs.get("max_frames", 2 * 2048 + 64)), device=self.device)
+            if model_name == "vocos":                       # pipeline:93-111
+                model_ = hip_models.Vocos(synth)
+                model_.load_state_dict(torch.load(kw["model_path"], weights_only=True, mmap=True))
+            elif model_name == "dvae_decode":
+                kw["coef"] = coef
+                path = kw.pop("model_path")
+                model_ = hip_models.DVAE(synth=synth, **kw)
+                sd = dict(torch.load(path, weights_only=True, mmap=True))
+                if "coef" not in sd:                        # the buffer is persistent: a checkpoint value wins (dvae.py:222,241-247)
+                    sd["coef"] = torch.from_numpy(codec.coef_from_string(coef)).view(1, -1, 1)
+                model_.load_state_dict(sd)
+            else:
+                kw.setdefault("device", str(self.device))
+                model_ = getattr(hip_models, _get(m, "name"))(**kw)          # pipeline:113-129 dispatch
+            self.models_dict[model_name] = model_.eval().to(self.device)
+        spk_stat_path = os.path.join(ckpt_dir, "asset/spk_stat.pt")
+        if os.path.exists(spk_stat_path):                   # pipeline:131-145
+            spk_stat = torch.load(spk_stat_path, weights_only=True, mmap=True).to(self.device, dtype=self.dtype)
+            self.std, self.mean = spk_stat.chunk(2)
+        else:
+            self.std = self.mean = None
+
+    # -- speakers (pipeline:306-331) ---------------------------------------------------------------
+    def sample_random_speaker(self) -> str:
+        return self._encode_spk_emb(self._sample_random_speaker())
+
+    @staticmethod
+    def _encode_spk_emb(spk_emb: torch.Tensor) -> str:
+        return codec.encode_spk_emb(spk_emb)
+
+    def _sample_random_speaker(self) -> torch.Tensor:
+        if self.std is None:
+            raise _lib.HipBackendError("spk_stat.pt not loaded: pass a speaker embedding explicitly")
+        dim = self.std.shape[-1]
+        return torch.randn(dim, device=self.std.device, dtype=self.std.dtype).mul_(self.std).add_(self.mean)
+
+    # -- hot path callers --------------------------------------------------------------------------
+    @torch.no_grad()
+    def _infer_code(self, text, stream: bool, return_hidden: bool, params: InferCodeParams, gpt=None):
+        """pipeline:157-235 -- same argument plumbing; the GPT object is the hip backend."""
+        gpt = gpt or self.models_dict["gpt"]
+        tok = self.models_dict["tokenizer"]
+        if not isinstance(text, list):
+            text = [text]
+        assert len(text), "text should not be empty"
+        temperature = params.temperature if isinstance(params.temperature, list) else [params.temperature] * gpt.num_vq
+        text = [t.replace("[Stts]", "").replace("[spk_emb]", "").replace("[empty_spk]", "").strip() for t in text]
+        if params.prompt:
+            text = [params.prompt + i for i in text]
+        txt_smp = "" if params.txt_smp is None else params.txt_smp
+        tag = "[spk_emb]" if params.spk_emb is not None else "[empty_spk]"
+        text = [f"[Stts]{tag}{txt_smp}{i}[Ptts]" for i in text]
+        input_ids, attention_mask, text_mask = tok.encode(text, gpt.num_vq, prompt_str=params.spk_smp, device=self.device)
+        emb = gpt(input_ids, text_mask)
+        if params.spk_emb is not None:
+            emb = codec.apply_spk_emb(emb, params.spk_emb, input_ids, tok.spk_emb_ids)
+        num_code = int(gpt.emb_code[0].num_embeddings - 1)
+        warpers, processors = gen_logits(num_code=num_code, top_P=params.top_P, top_K=params.top_K,
+                                         repetition_penalty=params.repetition_penalty)
+        return gpt.generate(emb, input_ids, temperature=torch.tensor(temperature), eos_token=num_code, attention_mask=attention_mask,
+                            max_new_token=params.max_new_token, min_new_token=params.min_new_token, logits_warpers=warpers,
+                            logits_processors=processors, infer_text=False, return_hidden=return_hidden, stream=stream,
+                            show_tqdm=params.show_tqdm, ensure_non_empty=params.ensure_non_empty, stream_batch=params.stream_batch)
+
+    @torch.inference_mode()
+    def _decode_to_wavs(self, result_list, use_decoder: bool = True):
+        """pipeline:286-305: per utterance hidden[n,768] -> DVAE -> mel[1,100,2n] -> Vocos -> wav[256(2n-1)]."""
+        if not use_decoder:
+            raise _lib.HipBackendError("use_decoder=False (decode codes through dvae_encode) is not served by the hip backend")
+        wavs = []
+        decoder, vocos = self.models_dict["dvae_decode"], self.models_dict["vocos"]
+        for h in result_list:
+            if h.shape[0] == 0:
+                wavs.append(torch.zeros(0, device=self.device))
+                continue
+            mel = decoder(h.permute(1, 0)[None])
+            wavs.append(vocos.decode(mel)[0])
+        return wavs
+
+    def _gpt_for_lora(self, lora_path: Optional[str]):
+        if not lora_path:
+            return self.models_dict["gpt"]
+        if lora_path not in self._lora_models:
+            base = self.models_dict["gpt"]
+            self._lora_models[lora_path] = base.with_lora(load_lora_adapter(lora_path))
+        return self._lora_models[lora_path]
+
+    def _infer(self, text_in, stream=False, lang=None, skip_refine_text=False, refine_text_only=False, use_decoder=True,
+               do_text_normalization=True, do_text_optimization=True, do_homophone_replacement=True,
+               params_refine_text=RefineTextParams(), params_infer_code=InferCodeParams(), **kwargs):
+        if not isinstance(text_in, list):
+            text_in = [text_in]
+        if do_text_optimization and self.text_splitter is not None:
+            text_in = self.text_splitter(text_in)                         # pipeline:353-377 (pluggable; CPU text work)
+        text_in = [self.normalizer(t, do_text_normalization, do_homophone_replacement, lang) for t in text_in]
+        if not skip_refine_text or refine_text_only:
+            raise _lib.HipBackendError("the refine-text pass (infer_text=True, head_text) is not served by the hip backend this "
+                                       "round (SURVEY 8f N1): pass skip_refine_text=True")
+        slice_size = int(kwargs.get("slice_size", self.models_dict["gpt"].max_batch))     # reference: 4 (pipeline:391)
+        gpt = self._gpt_for_lora(kwargs.get("lora_path"))
+        for ii in range(0, len(text_in), slice_size):
+            text = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in text_in[ii:ii + slice_size]]   # pipeline:414-416
+            length, pass_batch_count, wavs = 0, 0, None
+            for result in self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt):
+                wavs = self._decode_to_wavs(result.hiddens, use_decoder)
+                if stream:
+                    # the reference's stream branch indexes a python list with .shape; we yield padded arrays
+                    pass_batch_count += 1
+                    if pass_batch_count <= params_infer_code.pass_first_n_batches:
+                        continue
+                    arr = torch.nn.utils.rnn.pad_sequence(wavs, batch_first=True)
+                    b = min(length + params_infer_code.stream_speed, arr.shape[1])
+                    new = arr[:, length:b]
+                    length = b
+                    yield new
+                else:
+                    yield wavs
+            if stream and wavs is not None:
+                arr = torch.nn.utils.rnn.pad_sequence(wavs, batch_first=True)
+                yield arr[:, length:]
+
+    @torch.no_grad()
+    def infer(self, text, stream=False, lang=None, skip_refine_text=False, refine_text_only=False, use_decoder=True,
+              do_text_normalization=True, do_text_optimization=True, do_homophone_replacement=True,
+              params_refine_text=RefineTextParams(), params_infer_code=InferCodeParams(), **kwargs):
+        """pipeline:472-579.  Speaker resolution: `speaker_emb_path` (.pt holding a base16384 str or a tensor),
+        else params_infer_code.spk_emb as given, else a random speaker from spk_stat."""
+        if kwargs.get("speaker_audio_path"):
+            raise _lib.HipBackendError("zero-shot speaker_audio_path needs the DVAE encoder (SURVEY 8f N2), not served this round")
+        if kwargs.get("speaker_emb_path"):
+            p = kwargs["speaker_emb_path"]
+            assert os.path.exists(p), f"speaker_emb_path {p} not exists!"
+            obj = torch.load(p, weights_only=True, map_location="cpu")
+            if isinstance(obj, dict):
+                obj = next(iter(obj.values()))
+            params_infer_code.spk_emb = obj if isinstance(obj, str) else codec.speaker_to_vector(obj)
+        elif params_infer_code.spk_emb is None:
+            params_infer_code.spk_emb = self.sample_random_speaker()
+        return self._infer(text, stream, lang, skip_refine_text, refine_text_only, use_decoder, do_text_normalization,
+                           do_text_optimization, do_homophone_replacement, params_refine_text, params_infer_code, **kwargs)

@@ -1,0 +1,73 @@
+"""GPU parity of the DVAE decoder and Vocos kernels through the C ABI.
+DVAE: against the golden mel minted from the imported reference and against the oracle (tolerance 1e-3 RMS
+relative to the signal RMS, north_star; we assert a much tighter 2e-4 max-abs on O(1) mels).
+Vocos: parity-unpinned upstream; checked against the oracle restatement only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from chatttsplus_amd import synth
+from oracle import ref_cpu
+from tests.helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def voc():
+    from chatttsplus_amd.hip_models import DVAE, Synth, Vocos
+    s = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2048)
+    d = DVAE(dict(idim=384, odim=384, hidden=512, n_layer=12, bn_dim=128), dim=384, synth=s)
+    v = Vocos(s)
+    d.load_state_dict(synth.dvae_state_dict(synth.DVAE_REAL, 1234))
+    v.load_state_dict(synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
+    return s, d, v
+
+
+def _rms(x):
+    return float(np.sqrt(np.mean(np.square(x))))
+
+
+def test_dvae_golden(voc):
+    s, d, v = voc
+    z = np.load(os.path.join(GOLDEN, "dvae_real.npz"))
+    n = int(z["n"])
+    hid = np.random.Generator(np.random.Philox(key=int(z["hidden_seed"]))).standard_normal((n, 768)).astype(np.float32)
+    mel = d(torch.from_numpy(hid).permute(1, 0)[None].cuda())[0].cpu().numpy()
+    assert mel.shape == z["mel"].shape
+    err = np.abs(mel - z["mel"]).max()
+    assert _rms(mel - z["mel"]) <= 1e-3 * _rms(z["mel"]) and err <= 2e-4, f"max err {err}, rms {_rms(mel - z['mel'])}"
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 333, 1000])
+def test_dvae_vs_oracle(voc, n):
+    s, d, v = voc
+    hid = np.random.Generator(np.random.Philox(key=100 + n)).standard_normal((n, 768)).astype(np.float32)
+    ref = ref_cpu.dvae_decode(synth.dvae_state_dict(synth.DVAE_REAL, 1234), torch.from_numpy(hid)).numpy()
+    mel = s.dvae_decode(torch.from_numpy(hid).cuda()).cpu().numpy()
+    assert mel.shape == ref.shape == (100, 2 * n)
+    assert _rms(mel - ref) <= 1e-3 * _rms(ref) and np.abs(mel - ref).max() <= 5e-4, f"n={n}: max err {np.abs(mel - ref).max()}"
+
+
+@pytest.mark.parametrize("F", [2, 9, 74, 513])
+def test_vocos_vs_oracle(voc, F):
+    s, d, v = voc
+    mel = np.random.Generator(np.random.Philox(key=200 + F)).standard_normal((100, F)).astype(np.float32)
+    ref = ref_cpu.vocos_decode(synth.vocos_state_dict(synth.VOCOS_REAL, 1234), torch.from_numpy(mel)).numpy()
+    wav = v.decode(torch.from_numpy(mel)[None].cuda())[0].cpu().numpy()
+    assert wav.shape == ref.shape == (256 * (F - 1),)
+    assert _rms(wav - ref) <= 1e-3 * _rms(ref), f"F={F}: rms err {_rms(wav - ref)} vs signal {_rms(ref)}; max {np.abs(wav - ref).max()}"
+
+
+def test_hidden_to_wav_chain(voc):
+    """P1 (_decode_to_wavs, pipeline:286-305): hidden -> mel -> wav; chained error still within 1e-3 RMS."""
+    s, d, v = voc
+    n = 96
+    hid = np.random.Generator(np.random.Philox(key=77)).standard_normal((n, 768)).astype(np.float32)
+    mel_ref = ref_cpu.dvae_decode(synth.dvae_state_dict(synth.DVAE_REAL, 1234), torch.from_numpy(hid))
+    wav_ref = ref_cpu.vocos_decode(synth.vocos_state_dict(synth.VOCOS_REAL, 1234), mel_ref).numpy()
+    wav = v.decode(d(torch.from_numpy(hid).permute(1, 0)[None].cuda()))[0].cpu().numpy()
+    assert wav.shape == (256 * (2 * n - 1),)
+    assert _rms(wav - wav_ref) <= 1e-3 * _rms(wav_ref)
