@@ -31,6 +31,9 @@ def cpu_baseline(prompt_len: int, sample_steps: int):
     """The oracle (CPU restatement of the reference, kind="port") timed on this host, rank 0 only."""
     from chatttsplus_amd import synth
     from oracle import ref_cpu
+    # small-matrix GEMV workload: 16 threads is near the best the oracle gets on a many-core host (one thread per
+    # logical CPU is ~10x slower); the thread count used is what `cores` reports
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     cfg = synth.GPT_REAL
     sd = synth.gpt_state_dict(cfg, 1234)
     ids, mask = synth.prompt_ids(1, prompt_len, cfg["num_text_tokens"], 1234)

@@ -181,7 +181,21 @@ class GPT:
             self._kv = torch.empty(nbytes, dtype=torch.uint8, device=self.device)       # torch owns the KV cache
             _lib.check(self._lib.ctts_gpt_bind_kv(self._h, self._kv.data_ptr(), nbytes), "bind_kv")
         self._finalized = True
+        self._ctor = dict(gpt_config=self.gpt_config, num_audio_tokens=self.num_audio_tokens, num_text_tokens=self.num_text_tokens,
+                          num_vq=self.num_vq, max_batch=self.max_batch, max_seq_len=self.max_seq,
+                          weight_dtype="fp16" if self.dtype_code == _lib.DTYPE_F16 else "fp32", chunk_steps=self.chunk_steps,
+                          use_graph=self.use_graph, device=str(self.device))
+        self._sd_host = {k: v for k, v in sd.items()}        # kept for LoRA-merged siblings (pipeline:420-432)
         return self
+
+    def with_lora(self, adapters) -> "GPT":
+        """A sibling engine whose q/k/v/o weights carry W += scale * B @ A (peft merge_and_unload, pipeline:420-432);
+        the base engine stays untouched, like the reference's gpt_org swap (pipeline:424,465-470)."""
+        g = GPT(**self._ctor)
+        for (layer, target, A, B, scale) in adapters:
+            g.add_lora(layer, target, A, B, scale)
+        g.load_state_dict(self._sd_host)
+        return g
 
     # -- get_emb (gpt.py:125-149) ----------------------------------------------------------------
     def __call__(self, input_ids: torch.Tensor, text_mask: torch.Tensor) -> torch.Tensor:
@@ -290,6 +304,8 @@ class GPT:
                 prev = steps.value
                 _lib.check(lib.ctts_gpt_progress(h, C.byref(steps), C.byref(alld), st), "progress")
                 used_draws += steps.value - prev
+                if steps.value == prev and not alld.value:
+                    raise _lib.HipBackendError("decode made no progress (device state inconsistent)")
                 if stream and not alld.value and steps.value < max_new_token:
                     yield self._outputs(ids, hid, end_idx)
             self._restore_rng(rng_states, used_draws)

@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import torch
+        # the CPU oracle runs many small matmuls: torch's default of one thread per logical CPU (256 on the GPU
+        # box) makes it 10x slower and erratic
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

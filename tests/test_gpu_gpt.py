@@ -129,10 +129,10 @@ def test_finish_bookkeeping_and_early_stop_vs_oracle():
     g = GPT(LLAMA, max_batch=4, max_seq_len=200, weight_dtype="fp32")
     g.load_state_dict(sd)
     o = ref_cpu.OracleGPT(sd, 12)
-    B, T, N = 4, 12, 60
+    B, T, N = 4, 12, 40
     ids, mask = synth.prompt_ids(B, T, synth.GPT_REAL["num_text_tokens"], 55, pad_left=[0, 2, 0, 5])
     emb = o.embed(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))
-    for seed in (1, 2, 3):
+    for seed in (1, 2):
         torch.manual_seed(seed)
         ref = o.generate(emb, torch.from_numpy(ids), ref_cpu.SamplerParams(min_new_token=1), attention_mask=torch.from_numpy(mask), max_new_token=N)
         torch.manual_seed(seed)

@@ -1,0 +1,98 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol, header/binding agree,
+sampler-config plumbing, RoPE table, tokenizer batching, no-GPU failure is loud (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from chatttsplus_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "ctts_hip.h")).read()
+    declared = set(re.findall(r"\b(ctts_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ctts_gpt", "ctts_voc"}
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert declared == bound, f"header vs binding mismatch: {declared ^ bound}"
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ctts_version() >= 1
+
+
+def test_struct_layouts_match_header_sizes():
+    import ctypes as C
+    assert C.sizeof(_lib.GptCfg) == 9 * 4
+    assert C.sizeof(_lib.SamplerCfg) == 4 * 4 + 4 + 3 * 4 + 17 * 4 + 5 * 4
+    assert C.sizeof(_lib.VocCfg) == 11 * 4
+    assert C.sizeof(_lib.GenIO) == 5 * 8 + 8 + 8          # 5 pointers, int32 (+pad), uint64
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly():
+    from chatttsplus_amd.hip_models import GPT
+    with pytest.raises(_lib.HipBackendError):
+        GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=1))
+
+
+def test_sampler_cfg_from_reference_style_objects():
+    from chatttsplus_amd.hip_models.gpt import sampler_cfg_from_objects
+    from chatttsplus_amd.pipeline import gen_logits
+    w, p = gen_logits(625, 0.7, 20, 1.05)
+    sc = sampler_cfg_from_objects(torch.tensor([0.3, 0.4, 0.5, 0.6]), 625, 2048, 3, w, p, 4)
+    assert [round(sc.temperature[i], 6) for i in range(4)] == [0.3, 0.4, 0.5, 0.6]
+    assert sc.top_p_threshold == float(np.float32(1 - 0.7)) and sc.top_k == 20 and sc.min_tokens_to_keep == 3
+    assert sc.use_penalty == 1 and sc.past_window == 16 and sc.max_input_ids == 625
+    tab = torch.pow(1.05, torch.arange(17))
+    assert all(sc.penalty_table[i] == float(tab[i]) for i in range(17))
+    # HF objects carry the same attribute names
+    from transformers.generation import TopKLogitsWarper, TopPLogitsWarper
+    sc2 = sampler_cfg_from_objects(torch.tensor([0.3]), 625, 10, 0, [TopPLogitsWarper(0.7, min_tokens_to_keep=3), TopKLogitsWarper(1, min_tokens_to_keep=3)], [], 4)
+    assert sc2.top_k == 3 and sc2.use_penalty == 0 and sc2.top_p_threshold == sc.top_p_threshold
+    with pytest.raises(_lib.HipBackendError):
+        sampler_cfg_from_objects(torch.tensor([0.3]), 625, 10, 0, [object()], [], 4)
+
+
+def test_rope_table_matches_oracle():
+    from chatttsplus_amd.hip_models.gpt import rope_table
+    from oracle import ref_cpu
+    o = object.__new__(ref_cpu.OracleGPT)
+    o.inv_freq = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, dtype=torch.int64).float() / 64))
+    cos, sin = ref_cpu.OracleGPT._rope(o, torch.arange(300)[None])
+    tab = rope_table(300)
+    assert np.array_equal(tab[:, :32], cos[0, :, :32].numpy()) and np.array_equal(tab[:, 32:], sin[0, :, :32].numpy())
+
+
+def test_tokenizer_left_padding_and_prompt(tmp_path):
+    from transformers import BertTokenizerFast
+    from chatttsplus_amd import codec
+    from chatttsplus_amd.tokenizer import Tokenizer
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "[Stts]", "[Ptts]", "[spk_emb]", "[empty_spk]", "[uv_break]", "[break_0]",
+             "[Ebreak]", "[speed_5]", "a", "b", "c", "d"]
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab))
+    bt = BertTokenizerFast(vocab_file=str(tmp_path / "vocab.txt"), do_lower_case=False)
+    bt.add_special_tokens({"additional_special_tokens": [v for v in vocab if v.startswith("[") and v not in ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]")]})
+    tok = Tokenizer(tokenizer=bt)
+    assert tok.spk_emb_ids == 7 and tok.eos_token == 11 and tok.break_0_ids == 10
+    ids, att, tm = tok.encode(["[Stts][spk_emb]a b c[Ptts]", "[Stts][spk_emb]a[Ptts]"], 4)
+    assert ids.shape == (2, 6, 4) and att.tolist() == [[1] * 6, [0, 0, 1, 1, 1, 1]]
+    assert (ids[..., 0] == ids[..., 3]).all() and ids[1, 2, 0] == 5 and ids[1, 0, 0] == 0
+    prompt = torch.randint(0, 626, (4, 5))
+    ids2, att2, tm2 = tok.encode(["[Stts][spk_emb]a[Ptts]"], 4, prompt_str=codec.encode_prompt(prompt))
+    assert ids2.shape == (1, 9, 4) and torch.equal(ids2[0, 4:], prompt.t()) and tm2[0].tolist() == [True] * 4 + [False] * 5 and att2.all()
+
+
+def test_load_lora_adapter_reads_peft_files(tmp_path):
+    import json
+    from safetensors.numpy import save_file
+    from chatttsplus_amd.pipeline import load_lora_adapter
+    (tmp_path / "adapter_config.json").write_text(json.dumps(dict(r=8, lora_alpha=16, target_modules=["q_proj", "v_proj"])))
+    A = np.random.randn(8, 768).astype(np.float32); B = np.random.randn(768, 8).astype(np.float32)
+    save_file({"base_model.model.layers.3.self_attn.q_proj.lora_A.weight": A, "base_model.model.layers.3.self_attn.q_proj.lora_B.weight": B},
+              str(tmp_path / "adapter_model.safetensors"))
+    ad = load_lora_adapter(str(tmp_path))
+    assert len(ad) == 1 and ad[0][0] == 3 and ad[0][1] == "q_proj" and ad[0][4] == 2.0 and np.array_equal(ad[0][2], A)
