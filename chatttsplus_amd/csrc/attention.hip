@@ -125,6 +125,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
             for (int j = 0; j < 8; ++j) O[j] = O[j] * s1 + merge[w][tid][2 + j] * s2;
             M = mn;
         }
+        if (a.packed_out != nullptr) {
+            // single split: finish the softmax here and hand the o_proj kernel a ready MFMA B operand (no combine prologue)
+            const float inv = 1.0f / L;
+            const int NBr = 16 * a.nbg, K = a.NH * CTTS_HEAD_DIM, kt = K / WTraits<WT>::KT;
+            const int chunk = r / NBr, n = r % NBr, k = h * CTTS_HEAD_DIM + 8 * tid;
+            WT* dst = (WT*)a.packed_out + (size_t)chunk * a.nbg * kt * 64 * WTraits<WT>::EPL;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[xfrag_index<WT>(n, k + j, kt)] = (WT)(O[j] * inv);
+            return;
+        }
         const size_t pi = ((size_t)r * a.NH + h) * a.S + s;
         if (tid == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = L; }
         float* po = a.part_o + pi * CTTS_HEAD_DIM + 8 * tid;

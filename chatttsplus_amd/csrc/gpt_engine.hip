@@ -54,6 +54,7 @@ struct ctts_gpt {
     size_t kv_bytes = 0;
     float *x_dec = nullptr, *x_last = nullptr, *x_pre = nullptr, *q_buf = nullptr, *part_ml = nullptr, *part_o = nullptr, *logits = nullptr;
     void* act = nullptr;
+    void* attn_packed = nullptr;
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
     DevState* st = nullptr;
     int* last_rows = nullptr;
@@ -108,7 +109,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     void* bufs[] = {h->wblob, h->lnf, h->emb_code, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
-                    h->act, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
+                    h->act, h->attn_packed, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& l : h->lw) { if (l.ln1) (void)hipFree(l.ln1); if (l.ln2) (void)hipFree(l.ln2); }
     if (h->host_pin) (void)hipHostFree(h->host_pin);
@@ -265,7 +266,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->q_buf, (size_t)PASS_ROWS * H * 4) ||
         dev_alloc((void**)&h->part_ml, (size_t)PASS_ROWS * NH * SMAX * 2 * 4) ||
         dev_alloc((void**)&h->part_o, (size_t)PASS_ROWS * NH * SMAX * CTTS_HEAD_DIM * 4) ||
-        dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * h->NVQ * h->V * 4) || dev_alloc(&h->act, act_bytes) ||
+        dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * h->NVQ * h->V * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc(&h->attn_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4))
@@ -321,11 +322,13 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, int R, int S, 
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
+        at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
         if (launch_attention(dt, at, s)) return 1;
-        // softmax combine + o_proj + residual
+        // softmax combine + o_proj + residual (S == 1: attention already wrote the normalised, packed B operand)
         GemmArgs g2 = a;
         g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = S; g2.x_out = x;
-        if (launch_gemm(dt, nbg, PRO_ATTN, EPI_RESID, g2, chunks, s)) return 1;
+        g2.xpacked = h->attn_packed;
+        if (launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, EPI_RESID, g2, chunks, s)) return 1;
         // RMSNorm + gate|up + SiLU*up
         GemmArgs g3 = a;
         g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.lnw = h->lw[l].ln2; g3.act_out = h->act;

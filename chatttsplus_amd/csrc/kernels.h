@@ -48,6 +48,8 @@ struct AttnArgs {
     const DevState* st;
     float* part_ml;         // [R][NH][S][2]
     float* part_o;          // [R][NH][S][64]
+    void* packed_out;       // S == 1 only: normalised output written straight into the o_proj kernel's fragment-major B operand
+    int nbg;                //   rows per chunk = 16*nbg
 };
 
 struct SamplerCfgDev {      // mirrors ctts_sampler_cfg

@@ -318,12 +318,15 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
 template <typename WT, int NBG>
 static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s, bool cfg) {
     constexpr bool F16 = sizeof(WT) == 2;
-    constexpr int W768 = F16 ? 4 : 8, P768 = 6;
+    // K=768 : fp16 24 k-tiles, fp32 48.  17-32 rows (NBG=2): twice the waves so the (replicated) prologue has twice the threads
+    constexpr int W768 = F16 ? (NBG == 1 ? 4 : 8) : (NBG == 1 ? 8 : 16), P768 = (NBG == 1) ? 6 : 3;
+    // K=3072: fp16 96 k-tiles = 16 x 6, fp32 192 = 16 x 12
     constexpr int W3072 = 16, P3072 = F16 ? 6 : 12;
     if (cfg) {
         int rc = 0;
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID>(a, chunks, s, true);
+        rc |= launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, true);
@@ -332,6 +335,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     if (pro == PRO_NORM && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV>(a, chunks, s, false);
     if (pro == PRO_ATTN && epi == EPI_RESID) return launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU>(a, chunks, s, false);
+    if (pro == PRO_PACKED && epi == EPI_RESID && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_PACKED && epi == EPI_RESID) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_NORM && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, false);
     ctts_set_error("skinny_gemm: unsupported prologue/epilogue %d/%d", pro, epi);
