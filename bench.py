@@ -147,6 +147,12 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
+        traffic = None
+        try:      # HBM bytes/step from the committed rocprofv3 PMC passes (profiles/), same kernels and batch; not live
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = tr.get(f"b{B}_{args.dtype}", {}).get("hbm_bytes_per_step")
+        except Exception:
+            pass
         mean_ctx = P + W + K / 2.0
         step_bytes = g.step_bytes(B, mean_ctx)
         step_ms = ev_ms / K
@@ -161,7 +167,8 @@ def main():
                        "batch_per_gpu": B, "prompt_len": P, "weights": args.dtype, "kv_cache": args.dtype, "accumulate": "f32",
                        "hipgraph": bool(use_graph), "parallelism": f"replicas x{world} (utterance sharding)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_note": "PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE bytes per step from profiles/r01_pmc_*.json (separate rocprofv3 --pmc passes at --steps 64)",
                          "per": "decode step (one hipGraph replay = 102 kernel launches)",
                          "algorithmic_bytes_per_step": int(step_bytes), "step_ms_hip_events": round(step_ms, 5)},
             "rtf_decode_only": round(B * K * world * (512 / 24000.0) / dt, 2),

@@ -11,6 +11,40 @@
 // (running max, running sum, unnormalised output) that the o_proj kernel's prologue combines.
 #include "kernels.h"
 
+// one 16-row o_proj tile x one head's 64 input dims on MFMA (B operand = the head's attention output in column 0)
+template <typename WT> struct HeadMma;
+template <> struct HeadMma<half_t> {
+    static constexpr int FR = 2;                      // 64 dims = 2 k-tiles of 32
+    typedef half8 frag;
+    __device__ static inline f32x4 run(const frag (&w)[FR], const float* o_s, int lane) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+            half8 b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = ((lane & 15) == 0) ? (half_t)o_s[f * 32 + 8 * (lane >> 4) + j] : (half_t)0.f;
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f], b, c, 0, 0, 0);
+        }
+        return c;
+    }
+};
+template <> struct HeadMma<float> {
+    static constexpr int FR = 4;                      // 64 dims = 4 k-tiles of 16
+    typedef f32x4 frag;
+    __device__ static inline f32x4 run(const frag (&w)[FR], const float* o_s, int lane) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < FR; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float b = ((lane & 15) == 0) ? o_s[f * 16 + 4 * (lane >> 4) + j] : 0.f;
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[f][j], b, c, 0, 0, 0);
+            }
+        return c;
+    }
+};
+#define FUSE_TPW 3      // o_proj tiles per wave in the fused kernel: 48 tiles = JT(4) x 4 waves x 3
+
 template <typename WT> struct KvLoad;
 template <> struct KvLoad<half_t> {
     __device__ static inline void load8(const half_t* p, float (&o)[8]) {
@@ -29,17 +63,35 @@ template <> struct KvLoad<float> {
 
 __device__ inline float safe_exp_diff(float m, float mn) { return (m == -INFINITY) ? 0.f : expf(m - mn); }
 
-template <typename WT>
+// FUSED: grid.y = JT column groups instead of key splits; every block runs the whole (row, head) attention and then
+// multiplies its head's output with its share of the o_proj rows (weights prefetched at kernel entry), writing a
+// per-head partial sum  opart[row][head][:]  that the next kernels add to the residual stream in head order.
+// Drops one of the five dependent launches per layer in the launch-latency-bound small-batch regime.
+template <typename WT, bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     if (a.st != nullptr && a.st->all_done) return;
     constexpr int UN = 4;
     __shared__ float merge[4][8][10];
+    __shared__ float o_s[CTTS_HEAD_DIM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 3, sub = lane & 7;
-    const int r = blockIdx.x / a.NH, h = blockIdx.x % a.NH, s = blockIdx.y;
+    const int r = blockIdx.x / a.NH, h = blockIdx.x % a.NH, s = FUSED ? 0 : blockIdx.y;
+    typedef HeadMma<WT> HM;
+    typename HM::frag wfr[FUSE_TPW][HM::FR];
+    if (FUSED) {        // this wave's o_proj tiles: issued first, consumed after the attention loop
+        const int ktiles = (a.NH * CTTS_HEAD_DIM) / WTraits<WT>::KT;
+#pragma unroll
+        for (int t = 0; t < FUSE_TPW; ++t) {
+            const int rt = (blockIdx.y * 4 + wave) * FUSE_TPW + t;
+#pragma unroll
+            for (int f = 0; f < HM::FR; ++f)
+                wfr[t][f] = __builtin_nontemporal_load((const typename HM::frag*)a.wo + ((size_t)rt * ktiles + h * HM::FR + f) * 64 + lane);
+        }
+    }
     const RowMeta m = a.meta[r];
     const int kv0 = m.kv_start, kv1 = m.slot + 1;
-    const int chunk = (kv1 - kv0 + a.S - 1) / a.S;
+    const int nsplit = FUSED ? 1 : a.S;
+    const int chunk = (kv1 - kv0 + nsplit - 1) / nsplit;
     const int p0 = kv0 + s * chunk;
     const int p1 = min(p0 + chunk, kv1);
 
@@ -125,7 +177,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
             for (int j = 0; j < 8; ++j) O[j] = O[j] * s1 + merge[w][tid][2 + j] * s2;
             M = mn;
         }
-        if (a.packed_out != nullptr) {
+        if (FUSED) {
+            const float inv = 1.0f / L;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o_s[8 * tid + j] = O[j] * inv;
+        } else if (a.packed_out != nullptr) {
             // single split: finish the softmax here and hand the o_proj kernel a ready MFMA B operand (no combine prologue)
             const float inv = 1.0f / L;
             const int NBr = 16 * a.nbg, K = a.NH * CTTS_HEAD_DIM, kt = K / WTraits<WT>::KT;
@@ -136,17 +192,33 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
             return;
         }
         const size_t pi = ((size_t)r * a.NH + h) * a.S + s;
-        if (tid == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = L; }
+        if (!FUSED && tid == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = L; }
         float* po = a.part_o + pi * CTTS_HEAD_DIM + 8 * tid;
-        *(f32x4*)po = (f32x4){O[0], O[1], O[2], O[3]};
-        *(f32x4*)(po + 4) = (f32x4){O[4], O[5], O[6], O[7]};
+        if (!FUSED) {
+            *(f32x4*)po = (f32x4){O[0], O[1], O[2], O[3]};
+            *(f32x4*)(po + 4) = (f32x4){O[4], O[5], O[6], O[7]};
+        }
+    }
+    if (FUSED) {
+        __syncthreads();
+        const int H = a.NH * CTTS_HEAD_DIM;
+#pragma unroll
+        for (int t = 0; t < FUSE_TPW; ++t) {
+            const int rt = (blockIdx.y * 4 + wave) * FUSE_TPW + t;
+            const f32x4 c = HM::run(wfr[t], o_s, lane);                 // C[row=(lane>>4)*4+reg][col=lane&15]; col 0 is ours
+            if ((lane & 15) == 0) *(f32x4*)(a.opart + ((size_t)r * a.NH + h) * H + rt * 16 + (lane >> 4) * 4) = c;
+        }
     }
 }
 
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
-    dim3 grid(a.R * a.NH, a.S), block(256);
-    if (dtype == 1) hipLaunchKernelGGL(attn_decode_kernel<half_t>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, 0, s, a);
+    dim3 grid(a.R * a.NH, a.jt > 0 ? a.jt : a.S), block(256);
+    if (a.jt > 0) {
+        if (a.jt * 4 * FUSE_TPW * 16 != a.NH * CTTS_HEAD_DIM) { ctts_set_error("fused attention: jt=%d does not tile H=%d", a.jt, a.NH * CTTS_HEAD_DIM); return 1; }
+        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<float, true>), grid, block, 0, s, a);
+    } else if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, false>), grid, block, 0, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }

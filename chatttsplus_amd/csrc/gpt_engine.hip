@@ -32,8 +32,7 @@ extern "C" int ctts_version(void) { return 1; }
 #define SMAX 8        // == ATT_SMAX in skinny_gemm.hip
 
 struct LayerW {
-    void *qkv, *o, *gu, *d;
-    float *ln1, *ln2;
+    void *qkv, *o, *gu, *d;      // RMSNorm weights are folded into qkv / gu columns
 };
 
 struct ctts_gpt {
@@ -55,6 +54,9 @@ struct ctts_gpt {
     float *x_dec = nullptr, *x_last = nullptr, *x_pre = nullptr, *q_buf = nullptr, *part_ml = nullptr, *part_o = nullptr, *logits = nullptr;
     void* act = nullptr;
     void* attn_packed = nullptr;
+    float* opart = nullptr;                      // fused path: per-head o_proj partials [rows<=16][12][768]
+    int fuse_rows = 0;                           // decode batches up to this size use the fused attention+o_proj launch (env CTTS_FUSE_ROWS;
+                                                 // measured: 102 -> 82 launches/step but 2 % slower at batch 1, so off by default)
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
     DevState* st = nullptr;
     int* last_rows = nullptr;
@@ -94,6 +96,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->cfg = *c;
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
+    if (const char* fr = getenv("CTTS_FUSE_ROWS")) { h->fuse_rows = atoi(fr); if (h->fuse_rows > 16) h->fuse_rows = 16; }
     if (const char* gs = getenv("CTTS_GRAPH_STEPS")) { h->graph_steps = atoi(gs); if (h->graph_steps < 1) h->graph_steps = 1; }
     if (gemm_configure()) { delete h; return 1; }
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -109,9 +112,8 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     void* bufs[] = {h->wblob, h->lnf, h->emb_code, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
-                    h->act, h->attn_packed, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
+                    h->act, h->attn_packed, h->opart, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    for (auto& l : h->lw) { if (l.ln1) (void)hipFree(l.ln1); if (l.ln2) (void)hipFree(l.ln2); }
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -153,7 +155,7 @@ template <> inline half_t cvt<half_t>(float v) { return (half_t)v; }
 
 // rows(pr) -> pointer to the source row (K floats) or nullptr for zero padding
 template <typename WT, typename RowFn>
-static void pack_tiles(WT* dst, int n_row_tiles, int K, RowFn rows) {
+static void pack_tiles(WT* dst, int n_row_tiles, int K, RowFn rows, const float* colscale = nullptr) {
     constexpr int KT = WTraits<WT>::KT, EPL = WTraits<WT>::EPL;
     const int ktiles = K / KT;
     for (int rt = 0; rt < n_row_tiles; ++rt)
@@ -163,7 +165,7 @@ static void pack_tiles(WT* dst, int n_row_tiles, int K, RowFn rows) {
                 for (int kq = 0; kq < 4; ++kq) {
                     WT* d = dst + (((size_t)rt * ktiles + kt) * 64 + i + 16 * kq) * EPL;
                     const int k0 = kt * KT + kq * EPL;
-                    for (int j = 0; j < EPL; ++j) d[j] = src ? cvt<WT>(src[k0 + j]) : cvt<WT>(0.f);
+                    for (int j = 0; j < EPL; ++j) d[j] = src ? cvt<WT>(colscale ? src[k0 + j] * colscale[k0 + j] : src[k0 + j]) : cvt<WT>(0.f);
                 }
         }
 }
@@ -203,22 +205,19 @@ static int finalize_t(ctts_gpt* h) {
             const int dd = (i < 8) ? 8 * tq + i : 8 * tq + (i - 8) + 32;
             const std::vector<float>* src = which == 0 ? q : (which == 1 ? k : v);
             return src->data() + (size_t)(hh * CTTS_HEAD_DIM + dd) * H;
-        });
+        }, l1->data());      // RMSNorm weight folded into the columns: W (w * xn) == (W diag(w)) xn  (llama.py:87,619-621)
         pack_tiles<WT>(base + n_qkv, HT, H, [&](int pr) { return o->data() + (size_t)pr * H; });
         // gate|up: tile rows = [8 gate rows | the matching 8 up rows]
         pack_tiles<WT>(base + n_qkv + n_o, 2 * I / 16, H, [&](int pr) -> const float* {
             const int rt = pr / 16, i = pr % 16;
             return (i < 8) ? g->data() + (size_t)(rt * 8 + i) * H : u->data() + (size_t)(rt * 8 + i - 8) * H;
-        });
+        }, l2->data());
         pack_tiles<WT>(base + n_qkv + n_o + n_gu, HT, I, [&](int pr) { return d->data() + (size_t)pr * I; });
         char* dv = h->wblob + per_layer * l * sizeof(WT);
         h->lw[l].qkv = dv;
         h->lw[l].o = dv + n_qkv * sizeof(WT);
         h->lw[l].gu = dv + (n_qkv + n_o) * sizeof(WT);
         h->lw[l].d = dv + (n_qkv + n_o + n_gu) * sizeof(WT);
-        if (dev_alloc((void**)&h->lw[l].ln1, H * 4) || dev_alloc((void**)&h->lw[l].ln2, H * 4)) return 1;
-        CTTS_HIP_CHECK(hipMemcpy(h->lw[l].ln1, l1->data(), H * 4, hipMemcpyHostToDevice));
-        CTTS_HIP_CHECK(hipMemcpy(h->lw[l].ln2, l2->data(), H * 4, hipMemcpyHostToDevice));
     }
     // heads: fold weight norm, W = v * (g / ||v||_row)  (gpt.py:57-77; torch._weight_norm dim=0)
     std::vector<float> folded((size_t)h->NVQ * V * H);
@@ -236,13 +235,13 @@ static int finalize_t(ctts_gpt* h) {
         }
     }
     const int nvalid = h->NVQ * V;
-    pack_tiles<WT>(blob.data() + per_layer * L, head_tiles, H, [&](int pr) -> const float* {
-        return pr < nvalid ? folded.data() + (size_t)pr * H : nullptr;
-    });
-    h->whead = h->wblob + per_layer * L * sizeof(WT);
-    CTTS_HIP_CHECK(hipMemcpy(h->wblob, blob.data(), total * sizeof(WT), hipMemcpyHostToDevice));
     const std::vector<float>* nf = need(h, "gpt.norm.weight", H);
     if (!nf) return 1;
+    pack_tiles<WT>(blob.data() + per_layer * L, head_tiles, H, [&](int pr) -> const float* {
+        return pr < nvalid ? folded.data() + (size_t)pr * H : nullptr;
+    }, nf->data());
+    h->whead = h->wblob + per_layer * L * sizeof(WT);
+    CTTS_HIP_CHECK(hipMemcpy(h->wblob, blob.data(), total * sizeof(WT), hipMemcpyHostToDevice));
     if (dev_alloc((void**)&h->lnf, H * 4)) return 1;
     CTTS_HIP_CHECK(hipMemcpy(h->lnf, nf->data(), H * 4, hipMemcpyHostToDevice));
     if (dev_alloc((void**)&h->emb_code, (size_t)h->NVQ * V * H * 4)) return 1;
@@ -266,7 +265,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->q_buf, (size_t)PASS_ROWS * H * 4) ||
         dev_alloc((void**)&h->part_ml, (size_t)PASS_ROWS * NH * SMAX * 2 * 4) ||
         dev_alloc((void**)&h->part_o, (size_t)PASS_ROWS * NH * SMAX * CTTS_HEAD_DIM * 4) ||
-        dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * h->NVQ * h->V * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc(&h->attn_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
+        dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * h->NVQ * h->V * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc((void**)&h->opart, (size_t)16 * NH * H * 4) || dev_alloc(&h->attn_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4))
@@ -316,27 +315,35 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, int R, int S, 
         a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq;
         // RMSNorm + QKV + RoPE + KV append
         GemmArgs g1 = a;
-        g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x; g1.lnw = h->lw[l].ln1;
+        g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x;
         g1.q_out = h->q_buf; g1.k_cache = kv_layer(h, l, 0); g1.v_cache = kv_layer(h, l, 1); g1.rope = h->rope;
         if (launch_gemm(dt, nbg, PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
-        at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
-        if (launch_attention(dt, at, s)) return 1;
-        // softmax combine + o_proj + residual (S == 1: attention already wrote the normalised, packed B operand)
-        GemmArgs g2 = a;
-        g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = S; g2.x_out = x;
-        g2.xpacked = h->attn_packed;
-        if (launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, EPI_RESID, g2, chunks, s)) return 1;
+        const bool fused = (st != nullptr) && (R <= h->fuse_rows);
+        if (fused) {
+            // small batch: attention + per-head o_proj partial in one launch; the residual add is deferred to the
+            // consumers (gate|up prologue, down epilogue) which sum the 12 partials in head order
+            at.wo = h->lw[l].o; at.opart = h->opart; at.jt = (h->H / 16) / (4 * 3);
+            if (launch_attention(dt, at, s)) return 1;
+        } else {
+            at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
+            if (launch_attention(dt, at, s)) return 1;
+            // softmax combine + o_proj + residual (S == 1: attention already wrote the normalised, packed B operand)
+            GemmArgs g2 = a;
+            g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = S; g2.x_out = x;
+            g2.xpacked = h->attn_packed;
+            if (launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, EPI_RESID, g2, chunks, s)) return 1;
+        }
         // RMSNorm + gate|up + SiLU*up
         GemmArgs g3 = a;
-        g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.lnw = h->lw[l].ln2; g3.act_out = h->act;
-        if (launch_gemm(dt, nbg, PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
+        g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act; g3.opart = h->opart;
+        if (launch_gemm(dt, nbg, fused ? PRO_NORM_P : PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
         // down + residual
         GemmArgs g4 = a;
-        g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x;
-        if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID, g4, chunks, s)) return 1;
+        g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x; g4.opart = h->opart;
+        if (launch_gemm(dt, nbg, PRO_PACKED, fused ? EPI_RESID_P : EPI_RESID, g4, chunks, s)) return 1;
     }
     return 0;
 }

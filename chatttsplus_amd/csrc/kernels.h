@@ -2,8 +2,9 @@
 #pragma once
 #include "common.h"
 
-enum { PRO_NORM = 0, PRO_ATTN = 1, PRO_PACKED = 2 };
-enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
+enum { PRO_NORM = 0, PRO_ATTN = 1, PRO_PACKED = 2, PRO_NORM_P = 3 };     // _P: residual stream = x + sum of per-head o_proj partials
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_P = 4 };
+#define CTTS_NPART 12      // o_proj partials per row = attention heads (fused attention+o_proj path)
 
 // out[R rows][N] = prologue(x)[R][K] . W[N][K]^T  followed by a fused epilogue.
 // W is pre-packed in 16-row x KT-col MFMA-A tiles, [row tile][k tile][lane][16 B] (gpt_engine.cpp).
@@ -15,7 +16,8 @@ struct GemmArgs {
     const DevState* st;     // may be null (prefill / tests)
     // prologues
     const float* x;         // PRO_NORM: residual stream [R][K] fp32
-    const float* lnw;       // PRO_NORM: RMSNorm weight [K]
+    const float* lnw;       // PRO_NORM: RMSNorm weight [K] -- only for hidden_out (the weight is folded into W's columns)
+    const float* opart;     // PRO_NORM_P / EPI_RESID_P: per-head o_proj partial sums [R][CTTS_NPART][K] fp32
     float eps;
     float* hidden_out;      // PRO_NORM (heads only): normalised rows -> hiddens[seq][step][K]; may be null
     int hidden_stride;      //   = max_new_token * K
@@ -48,6 +50,9 @@ struct AttnArgs {
     const DevState* st;
     float* part_ml;         // [R][NH][S][2]
     float* part_o;          // [R][NH][S][64]
+    const void* wo;         // fused path: packed o_proj weight; each block also computes its head's partial o_proj for n_row_tiles/JT tiles
+    float* opart;           //   [R][NH][H] fp32
+    int jt;                 //   column groups (grid.y) when fused, 0 otherwise
     void* packed_out;       // S == 1 only: normalised output written straight into the o_proj kernel's fragment-major B operand
     int nbg;                //   rows per chunk = 16*nbg
 };

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     constexpr int KTILES = WAVES * KPW;
     constexpr int K = KTILES * KT;
     constexpr int NB = 16 * NBG;
-    constexpr int XS_BYTES = (PRO == PRO_PACKED) ? 0 : NBG * KTILES * 1024;
+    constexpr int XS_BYTES = (PRO == PRO_PACKED) ? 0 : NBG * KTILES * 1024;   // LDS image of the B operand
     constexpr int PER = K / 256;                      // float4 per lane per row in the prologues
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -80,12 +80,24 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     //     their L2/HBM round trips overlap the weight stream instead of forming a dependent tail
     constexpr int RITEMS = (16 * NB + WAVES * 64 - 1) / (WAVES * 64);
     float resid_pf[RITEMS];
-    if (EPI == EPI_RESID) {
+    if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
 #pragma unroll
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
             const int r = row0 + (t >> 4);
-            resid_pf[u] = (t < 16 * NB && r < a.R) ? a.x_out[(size_t)r * (a.n_row_tiles * 16) + rt * 16 + (t & 15)] : 0.f;
+            const int N = a.n_row_tiles * 16, col = rt * 16 + (t & 15);
+            float v = 0.f;
+            if (t < 16 * NB && r < a.R) {
+                v = a.x_out[(size_t)r * N + col];
+                if (EPI == EPI_RESID_P) {            // x_mid = ((x + p0) + p1) + ... : attention/o_proj partials in head order
+                    float pp[CTTS_NPART];
+#pragma unroll
+                    for (int q = 0; q < CTTS_NPART; ++q) pp[q] = a.opart[((size_t)r * CTTS_NPART + q) * N + col];
+#pragma unroll
+                    for (int q = 0; q < CTTS_NPART; ++q) v += pp[q];
+                }
+            }
+            resid_pf[u] = v;
         }
     }
     RowMeta meta_pf = {0, 0, 0, 0};
@@ -101,24 +113,34 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     }
 
     // 2. prologue: build the B operand (activations) in LDS, fragment-major
-    if (PRO == PRO_NORM) {
+    if (PRO == PRO_NORM || PRO == PRO_NORM_P) {
+        // y = x * rsqrt(mean(x^2)+eps); the RMSNorm *weight* is folded into W's columns at pack time (gpt_engine.hip).
         // rows beyond R are left unwritten: an MFMA output column depends only on its own B column, and the
         // epilogues never read columns >= R.  A wave owns rows wave, wave+WAVES, ...; the loads of RB rows are
         // issued together (one L2 round trip per batch instead of one per row: 8 serial trips at batch 32).
-        constexpr int RB = 4;
+        constexpr int RB = (PRO == PRO_NORM_P) ? 1 : 4;
         const int rows = min(NB, a.R - row0);
         for (int nb = wave; nb < rows; nb += WAVES * RB) {
             f32x4 v[RB][PER];
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 const int n = nb + u * WAVES;
-                const f32x4* xr = (const f32x4*)(a.x + (size_t)(row0 + (n < rows ? n : nb)) * K);
+                const size_t rr = (size_t)(row0 + (n < rows ? n : nb));
+                const f32x4* xr = (const f32x4*)(a.x + rr * K);
 #pragma unroll
                 for (int i = 0; i < PER; ++i) v[u][i] = xr[lane + 64 * i];
-            }
-            f32x4 w[PER];
+                if (PRO == PRO_NORM_P) {     // residual stream = x + per-head o_proj partials (fused attention path), head order
+                    f32x4 pp[CTTS_NPART][PER];
 #pragma unroll
-            for (int i = 0; i < PER; ++i) w[i] = *(const f32x4*)(a.lnw + 4 * (lane + 64 * i));
+                    for (int q = 0; q < CTTS_NPART; ++q)
+#pragma unroll
+                        for (int i = 0; i < PER; ++i) pp[q][i] = ((const f32x4*)(a.opart + (rr * CTTS_NPART + q) * K))[lane + 64 * i];
+#pragma unroll
+                    for (int q = 0; q < CTTS_NPART; ++q)
+#pragma unroll
+                        for (int i = 0; i < PER; ++i) v[u][i] += pp[q][i];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 const int n = nb + u * WAVES;
@@ -135,10 +157,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     const int k = 4 * (lane + 64 * i);
-                    const float y0 = w[i][0] * (v[u][i][0] * rs), y1 = w[i][1] * (v[u][i][1] * rs);
-                    const float y2 = w[i][2] * (v[u][i][2] * rs), y3 = w[i][3] * (v[u][i][3] * rs);
+                    const float y0 = v[u][i][0] * rs, y1 = v[u][i][1] * rs, y2 = v[u][i][2] * rs, y3 = v[u][i][3] * rs;
                     store_x4<WT>(smem, n, k, KTILES, y0, y1, y2, y3);
-                    if (write_hidden) *(f32x4*)(hrow + k) = (f32x4){y0, y1, y2, y3};
+                    if (write_hidden) {                                       // hidden = weight * (x * rs)  (llama.py:87)
+                        const f32x4 w = *(const f32x4*)(a.lnw + k);
+                        *(f32x4*)(hrow + k) = (f32x4){w[0] * y0, w[1] * y1, w[2] * y2, w[3] * y3};
+                    }
                 }
             }
         }
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     __syncthreads();
 
     // 5. fused epilogue
-    if (EPI == EPI_RESID || EPI == EPI_LOGITS) {
+    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_LOGITS) {
 #pragma unroll
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
@@ -252,7 +276,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
             if (r >= a.R) continue;
             const int col = rt * 16 + i;
             const float v = outt[i * NB + n];
-            if (EPI == EPI_RESID) {
+            if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
                 a.x_out[(size_t)r * (a.n_row_tiles * 16) + col] = resid_pf[u] + v;   // residual + proj (llama.py:731,739)
             } else if (col < a.n_valid) {
                 a.logits[(size_t)r * a.n_valid + col] = v;
@@ -330,6 +354,10 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, true);
+        if constexpr (NBG == 1) {
+            rc |= launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_SWIGLU>(a, chunks, s, true);
+            rc |= launch_one<WT, 1, W3072, P3072, PRO_PACKED, EPI_RESID_P>(a, chunks, s, true);
+        }
         return rc;
     }
     if (pro == PRO_NORM && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV>(a, chunks, s, false);
@@ -338,6 +366,10 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     if (pro == PRO_PACKED && epi == EPI_RESID && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_PACKED && epi == EPI_RESID) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_NORM && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, false);
+    if constexpr (NBG == 1) {
+        if (pro == PRO_NORM_P && epi == EPI_SWIGLU) return launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_SWIGLU>(a, chunks, s, false);
+        if (pro == PRO_PACKED && epi == EPI_RESID_P) return launch_one<WT, 1, W3072, P3072, PRO_PACKED, EPI_RESID_P>(a, chunks, s, false);
+    }
     ctts_set_error("skinny_gemm: unsupported prologue/epilogue %d/%d", pro, epi);
     return 1;
 }
