@@ -45,7 +45,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(obj)
     failed = False
     for src, p in procs:
-        out, _ = p.communicate()
+        try:
+            out, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+            out = (out or "") + "\n[build] hipcc timed out after 900 s"
         if out.strip() and verbose:
             print(out)
         if p.returncode != 0:
@@ -58,7 +63,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    subprocess.check_call(cmd, timeout=900)
     return LIB_PATH
 
 

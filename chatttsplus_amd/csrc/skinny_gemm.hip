@@ -70,7 +70,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     const int rt = blockIdx.x, chunk = blockIdx.y;
     const int row0 = chunk * NB;
 
-    // 1. this wave's weight fragments: KPW x 1 KiB, coalesced, streamed once -> non-temporal
+    // 1. this wave's weight fragments: KPW x 1 KiB, coalesced, read once per step -> non-temporal.  (Measured: plain loads
+    //    for all or for a cache-sized subset of the layers are not faster end to end, and a per-load runtime select
+    //    between the two de-pipelines the loads: +6 % step time.)
     const frag* Wp = (const frag*)a.W + ((size_t)rt * KTILES + (size_t)wave * KPW) * 64 + lane;
     frag wf[KPW];
 #pragma unroll
