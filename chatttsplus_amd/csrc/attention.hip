@@ -67,11 +67,12 @@ __device__ inline float safe_exp_diff(float m, float mn) { return (m == -INFINIT
 // multiplies its head's output with its share of the o_proj rows (weights prefetched at kernel entry), writing a
 // per-head partial sum  opart[row][head][:]  that the next kernels add to the residual stream in head order.
 // Drops one of the five dependent launches per layer in the launch-latency-bound small-batch regime.
-template <typename WT, bool FUSED>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
+template <typename WT, bool FUSED, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnArgs a) {
+    static_assert(!FUSED || NW == 4, "fused o_proj phase assumes 4 waves");
     if (a.st != nullptr && a.st->all_done) return;
     constexpr int UN = 4;
-    __shared__ float merge[4][8][10];
+    __shared__ float merge[NW][8][10];
     __shared__ float o_s[CTTS_HEAD_DIM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 3, sub = lane & 7;
@@ -110,14 +111,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.f;
 
-    // wave w, lane-group g handle keys p0 + 8*(4*it + w) + g; the loop bound is wave-uniform (shuffles inside)
-    for (int wb = p0 + 8 * wave; wb < p1; wb += 32 * UN) {
+    // wave w, lane-group g handle keys p0 + 8*(NW*it + w) + g; the loop bound is wave-uniform (cross-lane ops inside)
+    for (int wb = p0 + 8 * wave; wb < p1; wb += 8 * NW * UN) {
         const int base = wb + grp;
         float kf[UN][8], vf[UN][8];
         bool ok[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int p = base + 32 * u;
+            const int p = base + 8 * NW * u;
             ok[u] = p < p1;
             const int pc = ok[u] ? p : kv0;                 // clamp: always a valid address
             KvLoad<WT>::load8(kb + (size_t)pc * CTTS_HEAD_DIM, kf[u]);
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) O[j] = merge[0][tid][2 + j];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NW; ++w) {
             const float m2 = merge[w][tid][0], l2 = merge[w][tid][1];
             const float mn = fmaxf(M, m2);
             const float s1 = safe_exp_diff(M, mn), s2 = safe_exp_diff(m2, mn);
@@ -213,12 +214,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     dim3 grid(a.R * a.NH, a.jt > 0 ? a.jt : a.S), block(256);
-    if (a.jt > 0) {
+    // unsplit rows (large batches): 8 waves per (row, head) keep twice the K/V bytes in flight per CU
+    const bool wide = (a.jt == 0) && (a.S == 1) && (a.st != nullptr);
+    if (wide) {
+        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 8>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<float, false, 8>), grid, dim3(512), 0, s, a);
+    } else if (a.jt > 0) {
         if (a.jt * 4 * FUSE_TPW * 16 != a.NH * CTTS_HEAD_DIM) { ctts_set_error("fused attention: jt=%d does not tile H=%d", a.jt, a.NH * CTTS_HEAD_DIM); return 1; }
-        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((attn_decode_kernel<float, true>), grid, block, 0, s, a);
-    } else if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<float, false>), grid, block, 0, s, a);
+        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, true, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<float, true, 4>), grid, block, 0, s, a);
+    } else if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 4>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, false, 4>), grid, block, 0, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -48,6 +48,7 @@ struct ctts_gpt {
     float* lnf = nullptr;
     float* emb_code = nullptr;
     float* rope = nullptr;
+    float *rope_pre = nullptr, *rope_dec = nullptr;   // per-row copies of the table rows (prefill rows / decode rows)
     int rope_n = 0;
     char* kv = nullptr;
     size_t kv_bytes = 0;
@@ -55,6 +56,7 @@ struct ctts_gpt {
     void* act = nullptr;
     void* attn_packed = nullptr;
     float* opart = nullptr;                      // fused path: per-head o_proj partials [rows<=16][12][768]
+    int ablate = 0;                              // diagnostic (env CTTS_ABLATE): bit i set -> skip kernel class i (qkv, attn, o_proj, gate|up, down)
     int fuse_rows = 0;                           // decode batches up to this size use the fused attention+o_proj launch (env CTTS_FUSE_ROWS;
                                                  // measured: 102 -> 82 launches/step but 2 % slower at batch 1, so off by default)
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
@@ -69,7 +71,8 @@ struct ctts_gpt {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     std::string graph_sig;
-    int graph_steps = 1;                         // decode steps captured per graph (env CTTS_GRAPH_STEPS)
+    int graph_steps = 4;                         // decode steps captured per graph (env CTTS_GRAPH_STEPS): a replay costs ~8 us of
+                                                 // GPU-side gap, amortised over 4 x 102 kernel nodes
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -96,6 +99,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->cfg = *c;
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
+    if (const char* ab = getenv("CTTS_ABLATE")) h->ablate = atoi(ab);
     if (const char* fr = getenv("CTTS_FUSE_ROWS")) { h->fuse_rows = atoi(fr); if (h->fuse_rows > 16) h->fuse_rows = 16; }
     if (const char* gs = getenv("CTTS_GRAPH_STEPS")) { h->graph_steps = atoi(gs); if (h->graph_steps < 1) h->graph_steps = 1; }
     if (gemm_configure()) { delete h; return 1; }
@@ -112,7 +116,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     void* bufs[] = {h->wblob, h->lnf, h->emb_code, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
-                    h->act, h->attn_packed, h->opart, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
+                    h->act, h->attn_packed, h->opart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -265,7 +269,8 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->q_buf, (size_t)PASS_ROWS * H * 4) ||
         dev_alloc((void**)&h->part_ml, (size_t)PASS_ROWS * NH * SMAX * 2 * 4) ||
         dev_alloc((void**)&h->part_o, (size_t)PASS_ROWS * NH * SMAX * CTTS_HEAD_DIM * 4) ||
-        dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * h->NVQ * h->V * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc((void**)&h->opart, (size_t)16 * NH * H * 4) || dev_alloc(&h->attn_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
+        dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * h->NVQ * h->V * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc((void**)&h->rope_pre, (size_t)MB * h->cfg.max_seq * 64 * 4) ||
+        dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->opart, (size_t)16 * NH * H * 4) || dev_alloc(&h->attn_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4))
@@ -305,7 +310,7 @@ static inline int decode_splits(const ctts_gpt* h, int B) {
 }
 
 // 20 decoder layers on R rows starting at row `r0` of residual stream x (llama.py:719-749 per layer)
-static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, int R, int S, const DevState* st, hipStream_t s) {
+static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* rope_rows, int R, int S, const DevState* st, hipStream_t s) {
     const int dt = h->cfg.dtype;
     const int nbg = (R <= 16) ? 1 : 2;
     const int NB = 16 * nbg;
@@ -316,8 +321,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, int R, int S, 
         // RMSNorm + QKV + RoPE + KV append
         GemmArgs g1 = a;
         g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x;
-        g1.q_out = h->q_buf; g1.k_cache = kv_layer(h, l, 0); g1.v_cache = kv_layer(h, l, 1); g1.rope = h->rope;
-        if (launch_gemm(dt, nbg, PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
+        g1.q_out = h->q_buf; g1.k_cache = kv_layer(h, l, 0); g1.v_cache = kv_layer(h, l, 1); g1.rope_rows = rope_rows;
+        if (!(h->ablate & 1) && launch_gemm(dt, nbg, PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
@@ -326,24 +331,24 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, int R, int S, 
             // small batch: attention + per-head o_proj partial in one launch; the residual add is deferred to the
             // consumers (gate|up prologue, down epilogue) which sum the 12 partials in head order
             at.wo = h->lw[l].o; at.opart = h->opart; at.jt = (h->H / 16) / (4 * 3);
-            if (launch_attention(dt, at, s)) return 1;
+            if (!(h->ablate & 2) && launch_attention(dt, at, s)) return 1;
         } else {
             at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
-            if (launch_attention(dt, at, s)) return 1;
+            if (!(h->ablate & 2) && launch_attention(dt, at, s)) return 1;
             // softmax combine + o_proj + residual (S == 1: attention already wrote the normalised, packed B operand)
             GemmArgs g2 = a;
             g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = S; g2.x_out = x;
             g2.xpacked = h->attn_packed;
-            if (launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, EPI_RESID, g2, chunks, s)) return 1;
+            if (!(h->ablate & 4) && launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, EPI_RESID, g2, chunks, s)) return 1;
         }
         // RMSNorm + gate|up + SiLU*up
         GemmArgs g3 = a;
         g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act; g3.opart = h->opart;
-        if (launch_gemm(dt, nbg, fused ? PRO_NORM_P : PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
+        if (!(h->ablate & 8) && launch_gemm(dt, nbg, fused ? PRO_NORM_P : PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
         // down + residual
         GemmArgs g4 = a;
         g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x; g4.opart = h->opart;
-        if (launch_gemm(dt, nbg, PRO_PACKED, fused ? EPI_RESID_P : EPI_RESID, g4, chunks, s)) return 1;
+        if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, fused ? EPI_RESID_P : EPI_RESID, g4, chunks, s)) return 1;
     }
     return 0;
 }
@@ -364,7 +369,7 @@ static int run_sample_phase(ctts_gpt* h, hipStream_t s) {
     sa.cfg = h->sc; sa.logits = h->logits; sa.V = h->V; sa.B = h->B; sa.st = h->st;
     sa.ids = h->io.ids; sa.finish = h->io.finish; sa.end_idx = h->io.end_idx;
     sa.noise = h->io.noise; sa.n_draws = h->io.n_draws; sa.seed = h->io.seed;
-    sa.emb_code = h->emb_code; sa.H = h->H; sa.x_next = h->x_dec; sa.meta = h->meta_dec;
+    sa.emb_code = h->emb_code; sa.H = h->H; sa.x_next = h->x_dec; sa.meta = h->meta_dec; sa.rope = h->rope; sa.rope_rows = h->rope_dec;
     return launch_sampler(sa, h->B, s);
 }
 
@@ -394,7 +399,7 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
     h->sc.use_penalty = sc->use_penalty; memcpy(h->sc.penalty_table, sc->penalty_table, sizeof(sc->penalty_table));
     h->sc.past_window = sc->past_window; h->sc.max_input_ids = sc->max_input_ids; h->sc.eos = sc->eos_token;
     h->sc.min_new = sc->min_new_token; h->sc.max_new = sc->max_new_token;
-    if (launch_fill_meta(h->meta_pre, h->meta_dec0, h->st, mask, B, T, s)) return 1;
+    if (launch_fill_meta(h->meta_pre, h->meta_dec0, h->st, mask, B, T, h->rope, h->rope_pre, s)) return 1;
     return reset_state(h, false, s);
 }
 
@@ -406,7 +411,7 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* h, const float* emb, void* stream) {
     for (int r0 = 0; r0 < R; r0 += PASS_ROWS) {
         const int n = (R - r0 < PASS_ROWS) ? R - r0 : PASS_ROWS;
         CTTS_HIP_CHECK(hipMemcpyAsync(h->x_pre, emb + (size_t)r0 * h->H, (size_t)n * h->H * 4, hipMemcpyDeviceToDevice, s));
-        if (run_layers(h, h->x_pre, h->meta_pre + r0, n, 1, nullptr, s)) return 1;
+        if (run_layers(h, h->x_pre, h->meta_pre + r0, h->rope_pre + (size_t)r0 * 64, n, 1, nullptr, s)) return 1;
         // rows (b, T-1) that live in this pass -> x_dec[b]
         bool any = false;
         for (int b = 0; b < h->B; ++b) {
@@ -438,7 +443,7 @@ extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
 }
 
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
-    if (run_layers(h, h->x_dec, h->meta_dec, h->B, decode_splits(h, h->B), h->st, s)) return 1;
+    if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, decode_splits(h, h->B), h->st, s)) return 1;
     return run_sample_phase(h, s);
 }
 

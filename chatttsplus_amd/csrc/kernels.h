@@ -32,7 +32,7 @@ struct GemmArgs {
     void* v_cache;
     int Lmax;
     const RowMeta* meta;
-    const float* rope;      // [max_seq][64] = cos[32] | sin[32]
+    const float* rope_rows; // [rows][64] = cos[32] | sin[32] of each row's position (copied from the table by fill_meta / the sampler)
     void* act_out;          // EPI_SWIGLU: fragment-major [chunk][g][kt'][lane][16 B], K' = N/2
     float* logits;          // EPI_LOGITS: [R][n_valid]
     int n_valid;            // valid output rows (2504)
@@ -88,6 +88,8 @@ struct SamplerArgs {
     int H;
     float* x_next;          // [B][H]
     RowMeta* meta;          // decode rows [B]
+    const float* rope;      // table [max_seq][64]
+    float* rope_rows;       // decode rows' table rows [B][64], refreshed for the next step's positions
     // stand-alone mode (ctts_sampler_run)
     const int* history;     // [rows][hist_len]
     int hist_len;
@@ -100,5 +102,5 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s);
 int launch_gather_rows(const float* src, float* dst, const int* src_rows, int n, int H, hipStream_t s);
 int launch_embed_ids(const int* ids, const float* emb_code, float* x, int B, int V, int H, hipStream_t s);
-int launch_fill_meta(RowMeta* prefill_meta, RowMeta* decode_meta, DevState* st, const int* mask, int B, int T, hipStream_t s);
+int launch_fill_meta(RowMeta* prefill_meta, RowMeta* decode_meta, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre, hipStream_t s);
 int gemm_configure();

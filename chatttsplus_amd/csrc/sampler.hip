@@ -57,8 +57,12 @@ __device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn&
         int cnt[VPL];
 #pragma unroll
         for (int i = 0; i < VPL; ++i) cnt[i] = 0;
-        for (int hh = 0; hh < in.nh; ++hh) {
-            const int id = in.hist[(size_t)hh * in.hist_stride];
+        // one parallel load of the <=16 window ids (lane hh holds id hh), then wave-uniform broadcasts: the former
+        // per-id scalar loads were a chain of up to 16 dependent L2 round trips (~11 us of the 24 us kernel)
+        const int myid = (lane < in.nh) ? in.hist[(size_t)lane * in.hist_stride] : -1;
+#pragma unroll
+        for (int hh = 0; hh < 16; ++hh) {
+            const int id = __builtin_amdgcn_readlane(myid, hh);
 #pragma unroll
             for (int i = 0; i < VPL; ++i) cnt[i] += (id == lane + 64 * i) ? 1 : 0;
         }
@@ -83,33 +87,41 @@ __device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn&
     for (int i = 0; i < VPL; ++i) { pr[i] *= inv; tot += (double)pr[i]; }
     tot = wave_sum_d(tot);
 
-    unsigned taken = ~valid, kept = 0;
+    // Each lane sorts its 10 (value,index) keys once (descending, odd-even transposition network); every selection round
+    // then only compares the 64 lane heads (one DPP arg-max) and the winner's lane pops its head.
+    unsigned long long key[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+        key[i] = ((valid >> i) & 1u) ? (((unsigned long long)f32_key(x[i]) << 32) | (unsigned)(lane + 64 * i)) : 0ull;
+#pragma unroll
+    for (int pass = 0; pass < VPL; ++pass)
+#pragma unroll
+        for (int i = pass & 1; i + 1 < VPL; i += 2) {
+            const unsigned long long a = key[i], b = key[i + 1];
+            key[i] = a > b ? a : b;
+            key[i + 1] = a > b ? b : a;
+        }
+    unsigned kept = 0;
     double cum_before = 0.0;
     float vk = 0.f;
     const int topk = (c.top_k > 0) ? c.top_k : V;
     for (int r = 0; r < V; ++r) {
-        // wave-wide arg-max of (value, index): one 64-bit key per lane, larger index wins ties (== reversed stable ascending sort)
-        unsigned long long key = 0ull;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const unsigned long long k = ((unsigned long long)f32_key(x[i]) << 32) | (unsigned)(lane + 64 * i);
-            if (!((taken >> i) & 1u)) key = umax64(key, k);
-        }
-        key = wave_max_u64(key);
-        if (key == 0ull) break;                                    // nothing left
-        const float bv = key_f32((unsigned)(key >> 32));
-        const int bi = (int)(unsigned)key;
+        const unsigned long long best = wave_max_u64(key[0]);     // larger index wins ties (== reversed stable ascending sort)
+        if (best == 0ull) break;                                   // nothing left
+        const float bv = key_f32((unsigned)(best >> 32));
+        const int bi = (int)(unsigned)best;
         const int owner = bi & 63, slot = bi >> 6;
-        float cand = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) cand = (i == slot) ? pr[i] : cand;
-        const float bp = readlane_f(cand, owner);
         if (r >= topk && bv != vk) break;                          // beyond top-k and not tied with the k-th value
         const float cr = (float)(tot - cum_before);               // ascending cumsum at this element
         if (cr <= c.top_p_threshold && r >= c.min_keep) break;     // removed by top-p (and so is every smaller one)
-        if (lane == owner) { taken |= 1u << slot; kept |= 1u << slot; }
+        if (lane == owner) {
+            kept |= 1u << slot;
+#pragma unroll
+            for (int i = 0; i + 1 < VPL; ++i) key[i] = key[i + 1];
+            key[VPL - 1] = 0ull;
+        }
         if (r == topk - 1) vk = bv;
-        cum_before += (double)bp;
+        cum_before += (double)(expf(bv - mx) * inv);               // the same fp32 expression that produced pr[] for this element
     }
     if (in.step < c.min_new) {                                     // gpt.py:477-478
         if (lane == (c.eos & 63)) kept &= ~(1u << (c.eos >> 6));
@@ -150,6 +162,7 @@ __device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn&
 __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs a) {
     __shared__ float tab[17];
     __shared__ int idx_s[CTTS_NUM_VQ];
+    __shared__ int pos_s;
     DevState* st = a.st;
     if (st->all_done) return;
     const int tid = threadIdx.x, lane = tid & 63, vq = tid >> 6;
@@ -191,6 +204,7 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
         RowMeta m = a.meta[b];                                                     // next decode row
         m.pos += 1; m.slot += 1;
         a.meta[b] = m;
+        pos_s = m.pos;
         // One agent-scope atomic carries both the arrival ticket (low 16 bits) and the number of finished
         // sequences (high 16 bits, persistent over the steps): no fences, no cross-block plain loads.
         const int add = 1 + ((fin && !was) ? 0x10000 : 0);
@@ -203,6 +217,8 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
             if (nfin == a.B || step + 1 >= a.cfg.max_new) st->all_done = 1;         // gpt.py:545 / loop bound :389
         }
     }
+    __syncthreads();
+    if (tid < 64) a.rope_rows[(size_t)b * 64 + tid] = a.rope[(size_t)pos_s * 64 + tid];   // RoPE row of the next step's position
 }
 
 // stand-alone mode (ctts_sampler_run): block = 4 rows
@@ -269,9 +285,12 @@ int launch_embed_ids(const int* ids, const float* emb_code, float* x, int B, int
 
 // position ids / cache slots from the left-padded attention mask (gpt.py:238-245):
 //   pos = cumsum(mask) - 1, pad -> 1;   decode rows start at slot T with pos = (#valid tokens)
-__global__ void fill_meta_kernel(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T) {
+__global__ void fill_meta_kernel(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre) {
     const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0) {
+        // lanes 1..63 wait for lane 0's metadata, then the whole wave copies the RoPE rows (below)
+    }
+    if (threadIdx.x == 0) {
     int cum = 0, pad = 0;
     bool seen = false;
     for (int t = 0; t < T; ++t) {
@@ -291,9 +310,12 @@ __global__ void fill_meta_kernel(RowMeta* pm, RowMeta* dm, DevState* st, const i
     dm[b] = d;
     st->pad[b] = pad;
     if (b == 0) { st->step = 0; st->all_done = 0; st->ticket = 0; st->B = B; st->T = T; }
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) rope_pre[((size_t)b * T + t) * 64 + threadIdx.x] = rope[(size_t)pm[b * T + t].pos * 64 + threadIdx.x];
 }
-int launch_fill_meta(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T, hipStream_t s) {
-    hipLaunchKernelGGL(fill_meta_kernel, dim3(B), dim3(64), 0, s, pm, dm, st, mask, B, T);
+int launch_fill_meta(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre, hipStream_t s) {
+    hipLaunchKernelGGL(fill_meta_kernel, dim3(B), dim3(64), 0, s, pm, dm, st, mask, B, T, rope, rope_pre);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }

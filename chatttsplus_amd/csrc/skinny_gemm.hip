@@ -70,13 +70,16 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     const int rt = blockIdx.x, chunk = blockIdx.y;
     const int row0 = chunk * NB;
 
-    // 1. this wave's weight fragments: KPW x 1 KiB, coalesced, read once per step -> non-temporal.  (Measured: plain loads
-    //    for all or for a cache-sized subset of the layers are not faster end to end, and a per-load runtime select
-    //    between the two de-pipelines the loads: +6 % step time.)
+    // LOAD ORDER MATTERS: vmcnt retires in order, so a wait on any load issued after the weight stream is a wait on
+    // the whole stream.  Everything the prologue needs is therefore requested first, the (non-temporal) weight
+    // fragments last; nothing issued after them is consumed before the MFMAs.
     const frag* Wp = (const frag*)a.W + ((size_t)rt * KTILES + (size_t)wave * KPW) * 64 + lane;
     frag wf[KPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) wf[i] = __builtin_nontemporal_load(Wp + i * 64);
+    // (sched_barrier: hipcc otherwise hoists the weight loads above the prologue loads again)
+#define CTTS_ISSUE_WEIGHT_LOADS()                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    _Pragma("unroll") for (int i = 0; i < KPW; ++i) wf[i] = __builtin_nontemporal_load(Wp + i * 64); \
+    __builtin_amdgcn_sched_barrier(0)
 
     // 1b. epilogue operands that do not depend on the GEMM are requested now and consumed at the very end, so
     //     their L2/HBM round trips overlap the weight stream instead of forming a dependent tail
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         if (tid < 8 * NB && r < a.R) {
             meta_pf = a.meta[r];
             const int d = (((rt % (K / 16)) & 3) << 3) + (tid & 7);
-            rope_c = a.rope[(size_t)meta_pf.pos * 64 + d];
-            rope_s = a.rope[(size_t)meta_pf.pos * 64 + 32 + d];
+            rope_c = a.rope_rows[(size_t)r * 64 + d];                 // per-row copy of the table row: independent of meta
+            rope_s = a.rope_rows[(size_t)r * 64 + 32 + d];
         }
     }
 
@@ -120,51 +123,62 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         // rows beyond R are left unwritten: an MFMA output column depends only on its own B column, and the
         // epilogues never read columns >= R.  A wave owns rows wave, wave+WAVES, ...; the loads of RB rows are
         // issued together (one L2 round trip per batch instead of one per row: 8 serial trips at batch 32).
-        constexpr int RB = (PRO == PRO_NORM_P) ? 1 : 4;
+        constexpr int RB = (NB + WAVES - 1) / WAVES;          // rows per wave: one batch (<= 4 for every tiling used)
+        static_assert(PRO != PRO_NORM_P || RB <= 4, "partials path is for <= 16 rows");
         const int rows = min(NB, a.R - row0);
-        for (int nb = wave; nb < rows; nb += WAVES * RB) {
-            f32x4 v[RB][PER];
+        f32x4 v[RB][PER];
 #pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const int n = nb + u * WAVES;
-                const size_t rr = (size_t)(row0 + (n < rows ? n : nb));
-                const f32x4* xr = (const f32x4*)(a.x + rr * K);
+        for (int u = 0; u < RB; ++u) {
+            const int n = wave + u * WAVES;
+            if (n < rows) {
+                const f32x4* xr = (const f32x4*)(a.x + (size_t)(row0 + n) * K);
 #pragma unroll
                 for (int i = 0; i < PER; ++i) v[u][i] = xr[lane + 64 * i];
-                if (PRO == PRO_NORM_P) {     // residual stream = x + per-head o_proj partials (fused attention path), head order
-                    f32x4 pp[CTTS_NPART][PER];
+            } else {
 #pragma unroll
-                    for (int q = 0; q < CTTS_NPART; ++q)
-#pragma unroll
-                        for (int i = 0; i < PER; ++i) pp[q][i] = ((const f32x4*)(a.opart + (rr * CTTS_NPART + q) * K))[lane + 64 * i];
-#pragma unroll
-                    for (int q = 0; q < CTTS_NPART; ++q)
-#pragma unroll
-                        for (int i = 0; i < PER; ++i) v[u][i] += pp[q][i];
-                }
+                for (int i = 0; i < PER; ++i) v[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        }
+        if (PRO == PRO_NORM_P) {     // residual stream = x + per-head o_proj partials (fused attention path), head order
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
-                const int n = nb + u * WAVES;
+                const int n = wave + u * WAVES;
                 if (n >= rows) break;
-                const int r = row0 + n;
-                float ss = 0.f;
+                const size_t rr = (size_t)(row0 + n);
+                f32x4 pp[CTTS_NPART][PER];
 #pragma unroll
-                for (int i = 0; i < PER; ++i) ss += v[u][i][0] * v[u][i][0] + v[u][i][1] * v[u][i][1] + v[u][i][2] * v[u][i][2] + v[u][i][3] * v[u][i][3];
-                ss = wave_sum(ss);
-                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);          // torch.rsqrt(mean(x^2) + eps)
-                const bool write_hidden = (a.hidden_out != nullptr) && (rt == 0);
-                float* hrow = nullptr;
-                if (write_hidden) hrow = a.hidden_out + (size_t)a.meta[r].seq * a.hidden_stride + (size_t)a.st->step * K;
+                for (int q = 0; q < CTTS_NPART; ++q)
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) pp[q][i] = ((const f32x4*)(a.opart + (rr * CTTS_NPART + q) * K))[lane + 64 * i];
+#pragma unroll
+                for (int q = 0; q < CTTS_NPART; ++q)
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) v[u][i] += pp[q][i];
+            }
+        }
+        CTTS_ISSUE_WEIGHT_LOADS();
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int n = wave + u * WAVES;
+            if (n >= rows) break;
+            const int r = row0 + n;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) ss += v[u][i][0] * v[u][i][0] + v[u][i][1] * v[u][i][1] + v[u][i][2] * v[u][i][2] + v[u][i][3] * v[u][i][3];
+            ss = wave_sum(ss);
+            const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);          // torch.rsqrt(mean(x^2) + eps)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = 4 * (lane + 64 * i);
+                store_x4<WT>(smem, n, k, KTILES, v[u][i][0] * rs, v[u][i][1] * rs, v[u][i][2] * rs, v[u][i][3] * rs);
+            }
+            if (a.hidden_out != nullptr && rt == 0) {                      // heads only: hidden = weight * (x * rs) (llama.py:87)
+                float* hrow = a.hidden_out + (size_t)a.meta[r].seq * a.hidden_stride + (size_t)a.st->step * K;
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     const int k = 4 * (lane + 64 * i);
-                    const float y0 = v[u][i][0] * rs, y1 = v[u][i][1] * rs, y2 = v[u][i][2] * rs, y3 = v[u][i][3] * rs;
-                    store_x4<WT>(smem, n, k, KTILES, y0, y1, y2, y3);
-                    if (write_hidden) {                                       // hidden = weight * (x * rs)  (llama.py:87)
-                        const f32x4 w = *(const f32x4*)(a.lnw + k);
-                        *(f32x4*)(hrow + k) = (f32x4){w[0] * y0, w[1] * y1, w[2] * y2, w[3] * y3};
-                    }
+                    const f32x4 w = *(const f32x4*)(a.lnw + k);
+                    *(f32x4*)(hrow + k) = (f32x4){w[0] * (v[u][i][0] * rs), w[1] * (v[u][i][1] * rs), w[2] * (v[u][i][2] * rs), w[3] * (v[u][i][3] * rs)};
                 }
             }
         }
@@ -178,6 +192,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         const int S = a.S;
         const int rows = min(NB, a.R - row0);
         if (S == 1) {
+            CTTS_ISSUE_WEIGHT_LOADS();
             constexpr int IB = 8;
             for (int it0 = tid; it0 < rows * K4; it0 += WAVES * 64 * IB) {
                 float ls[IB];
@@ -200,7 +215,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
                 }
             }
         } else {
-            for (int it = tid; it < rows * K4; it += WAVES * 64) {
+            bool issued = false;
+            for (int it = tid; it < rows * K4 || !issued; it += WAVES * 64) {
+                if (it >= rows * K4) { CTTS_ISSUE_WEIGHT_LOADS(); issued = true; break; }
                 const int n = it / K4, k = 4 * (it % K4);
                 const int r = row0 + n, h = k >> 6, d = k & 63;
                 const float* ml = a.part_ml + ((size_t)(r * NH + h) * S) * 2;
@@ -215,6 +232,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
                     ls[s] = t.y;
                     os[s] = *(const f32x4*)(po + (size_t)sc * CTTS_HEAD_DIM);
                 }
+                if (!issued) { CTTS_ISSUE_WEIGHT_LOADS(); issued = true; }     // after this thread's first batch of partial loads
                 float mx = -INFINITY;
 #pragma unroll
                 for (int s = 0; s < ATT_SMAX; ++s) mx = fmaxf(mx, ms[s]);
@@ -231,6 +249,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         }
         __syncthreads();
     }
+
+    if (PRO == PRO_PACKED) { CTTS_ISSUE_WEIGHT_LOADS(); }
 
     // 3. MFMA over this wave's K slice
     f32x4 acc[NBG];
@@ -296,6 +316,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
             WT* dst = (WT*)a.act_out + (size_t)chunk * NBG * ktiles_out * 64 * WTraits<WT>::EPL;
             dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = (WT)y;
         } else if (r < a.R) {  // EPI_QKV: packed rows per tile = dims [8t..8t+7 | 8t+32..8t+39] of one head
+            // keep hipcc from scheduling the cache-address arithmetic (and with it a wait on the meta load) at kernel entry
+            asm volatile("" : "+v"(meta_pf.seq), "+v"(meta_pf.slot));
             constexpr int HT = K / 16;                   // tiles per projection (H == K for q/k/v)
             constexpr int NH = K / CTTS_HEAD_DIM;
             const int which = rt / HT, within = rt % HT;

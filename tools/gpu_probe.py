@@ -20,7 +20,8 @@ def main():
     lib, h, dev = g._lib, g._h, g.device
     lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
     lp = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
-    for B in (1, 2, 4, 8, 16, 32):
+    Bs = [int(os.environ['CTTS_PROBE_B'])] if os.environ.get('CTTS_PROBE_B') else (1, 2, 4, 8, 16, 32)
+    for B in Bs:
         P, N = 48, 300
         ids, mask = synth.prompt_ids(B, P, 21178, 1)
         emb = g(torch.from_numpy(ids), torch.ones(B, P, dtype=torch.bool))

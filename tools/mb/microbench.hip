@@ -2,6 +2,7 @@
 // Build: timeout 120 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mb/microbench.hip -o tools/mb/microbench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -41,6 +42,33 @@ __global__ void k_stream_lds(const f32x4* W, float* out, const float* x) {
     out[(size_t)blockIdx.x * blockDim.x + tid] = acc + lds[tid ^ 1];
 }
 
+// cache-policy variants through inline asm: POL 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0
+template <int POL>
+__device__ inline f32x4 ld16(const f32x4* p) {
+    f32x4 v;
+    if (POL == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 4) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int NL, int POL>
+__global__ void k_pol(const f32x4* W, float* out, const float* x) {
+    const int tid = threadIdx.x;
+    const f32x4* wp = W + ((size_t)blockIdx.x * blockDim.x + tid) * NL;
+    f32x4 w[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) w[i] = ld16<POL>(wp + i);
+    const f32x4 xv = *(const f32x4*)(x + 4 * (tid & 127));
+    float acc = xv[0] + xv[1] + xv[2] + xv[3];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { asm volatile("" : "+v"(w[i])); acc += w[i][0] * w[i][1] + w[i][2] * w[i][3]; }
+    out[(size_t)blockIdx.x * blockDim.x + tid] = acc;
+}
+
 typedef void (*kern_t)(const f32x4*, float*, const float*);
 
 static int run(const char* name, kern_t k, int blocks, int threads, const f32x4* W, size_t w_per_launch, int nbuf, float* x, int reps) {
@@ -67,7 +95,12 @@ static int run(const char* name, kern_t k, int blocks, int threads, const f32x4*
 int main() {
     const size_t wbytes = (size_t)400 << 20;           // 400 MB of "weights" > MALL (256 MB)
     f32x4* W; float* x;
-    CK(hipMalloc(&W, wbytes)); CK(hipMemset(W, 1, wbytes));
+    CK(hipMalloc(&W, wbytes));
+    {   // random-ish contents (not a constant fill)
+        unsigned* hbuf = (unsigned*)malloc(wbytes); unsigned v = 12345u;
+        for (size_t i = 0; i < wbytes / 4; ++i) { v = v * 1664525u + 1013904223u; hbuf[i] = (v >> 9) | 0x3F800000u; }
+        CK(hipMemcpy(W, hbuf, wbytes, hipMemcpyHostToDevice)); free(hbuf);
+    }
     CK(hipMalloc(&x, (size_t)2 * (1 << 20) * 4)); CK(hipMemset(x, 0, (size_t)2 * (1 << 20) * 4));
     const int reps = 30;
     run("empty", k_empty, 144, 256, W, 0, 1, x, reps);
@@ -83,6 +116,19 @@ int main() {
     run("plain 72x256x12", k_stream<12, false>, 72, 256, W, 72 * 256 * 12, 100, x, reps);
     run("nt    72x256x12", k_stream<12, true>, 72, 256, W, 72 * 256 * 12, 100, x, reps);
     run("plain 144x256x6 same weights each launch", k_stream<6, false>, 144, 256, W, 144 * 256 * 6, 1, x, reps);
+    run("nt    288x128x6", k_stream<6, true>, 288, 128, W, 288 * 128 * 6, 100, x, reps);
+    run("nt    576x64x6", k_stream<6, true>, 576, 64, W, 576 * 64 * 6, 100, x, reps);
+    run("nt    288x256x3", k_stream<3, true>, 288, 256, W, 288 * 256 * 3, 100, x, reps);
+    run("nt    576x256x... 576x128x3", k_stream<3, true>, 576, 128, W, 576 * 128 * 3, 100, x, reps);
+    run("asm plain        144x256x6", k_pol<6, 0>, 144, 256, W, 144 * 256 * 6, 100, x, reps);
+    run("asm nt           144x256x6", k_pol<6, 1>, 144, 256, W, 144 * 256 * 6, 100, x, reps);
+    run("asm sc1          144x256x6", k_pol<6, 2>, 144, 256, W, 144 * 256 * 6, 100, x, reps);
+    run("asm sc0 sc1      144x256x6", k_pol<6, 3>, 144, 256, W, 144 * 256 * 6, 100, x, reps);
+    run("asm sc1 nt       144x256x6", k_pol<6, 4>, 144, 256, W, 144 * 256 * 6, 100, x, reps);
+    run("asm sc0          144x256x6", k_pol<6, 5>, 144, 256, W, 144 * 256 * 6, 100, x, reps);
+    printf("--- 3.5 MB per launch, 110 different blocks of a 385 MB cycle (engine-like footprint), plain vs nt\n");
+    run("plain 144x256x6, 385 MB cycle", k_stream<6, false>, 144, 256, W, 144 * 256 * 6, 110, x, reps);
+    run("nt    144x256x6, 385 MB cycle", k_stream<6, true>, 144, 256, W, 144 * 256 * 6, 110, x, reps);
     printf("--- 9.4 MB per launch (gate|up-like), 40 blocks\n");
     run("nt    384x256x6", k_stream<6, true>, 384, 256, W, 384 * 256 * 6, 40, x, reps);
     run("plain 384x256x6", k_stream<6, false>, 384, 256, W, 384 * 256 * 6, 40, x, reps);
