@@ -52,6 +52,36 @@ def cpu_baseline(prompt_len: int, sample_steps: int):
                        f"after a 4-step run is subtracted, same synthetic weights; host has {os.cpu_count()} logical CPUs")
 
 
+def dry_run(args, world, rank):
+    """Same collective sequence as the real run (speaker broadcast, barrier, timed region, barrier, MAX all-reduce, rank-0
+    JSON) on the gloo backend with a sleep instead of the decode loop -- validates the N>1 control flow on CPU."""
+    import torch.distributed as dist
+    from chatttsplus_amd import synth
+    from chatttsplus_amd.dist import broadcast_speakers
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    table = torch.from_numpy(synth.speaker_vector(1234))[None] if rank == 0 else None
+    spk = broadcast_speakers(table, 1, 768, torch.device("cpu"))
+    assert abs(float(spk.norm()) - float(torch.from_numpy(synth.speaker_vector(1234)).norm())) < 1e-4
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (1 + rank))            # ranks finish at different times: the MAX must win
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "decode tokens/s", "value": round(args.batch * args.steps * world / float(dt), 2), "unit": "tokens/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(dt) / args.steps * 1e3, 5),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                          "config": {"workload": "DRY RUN (no GPU work)"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +92,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--cpu-steps", type=int, default=192, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank control flow (no HIP work, fake timing); used by tests/test_bench_dryrun.py")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -69,6 +100,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

@@ -76,6 +76,9 @@ def test_rng_state_after_generate_matches_reference_consumption():
     ("fp32", 1, 48, None, 40, 2e-5), ("fp32", 4, 30, [0, 3, 11, 29], 24, 2e-5), ("fp32", 17, 20, None, 6, 2e-5),
     ("fp32", 32, 24, list(range(0, 23, 1)) + [0] * 9, 6, 2e-5),
     ("fp16", 1, 48, None, 40, 2e-3), ("fp16", 32, 24, list(range(0, 23, 1)) + [0] * 9, 6, 2e-3), ("fp16", 8, 100, None, 8, 2e-3),
+    # prompt pass larger than one 2048-row pass (B*T = 2340): multi-pass prefill + last-row gather across passes
+    ("fp32", 9, 260, [0, 1, 17, 100, 259, 3, 0, 200, 64], 4, 2e-5),
+    ("fp16", 5, 500, [0, 499, 250, 7, 0], 3, 2e-3),
 ])
 def test_teacher_forced_hiddens_vs_oracle(wd, B, T, pad, N, tol):
     """Free-running oracle ids are forced into the HIP path step by step (ctts_gpt_force_ids); hiddens compared."""
