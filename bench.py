@@ -177,15 +177,14 @@ def main():
     # RTF leg (outside the timed decode region): DVAE decoder + Vocos on the generated hiddens of every local sequence
     voc_ms = None
     try:
-        from chatttsplus_amd.hip_models import Synth
-        syn = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2 * expect + 64, device=str(dev))
+        from chatttsplus_amd.hip_models import SynthPool
+        syn = SynthPool(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2 * expect + 64, device=str(dev), max_batch=B)
         syn.load("dvae.", synth.dvae_state_dict(synth.DVAE_REAL, 1234))
         syn.load("vocos.", synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
         wav = syn.vocos_decode(syn.dvae_decode(hid[0, :expect]))          # warm
         torch.cuda.synchronize(dev)
         tv = time.perf_counter()
-        for b in range(B):
-            wav = syn.vocos_decode(syn.dvae_decode(hid[b, :expect]))
+        wav = syn.decode_batch([hid[b, :expect] for b in range(B)])[-1]
         torch.cuda.synchronize(dev)
         voc_ms = (time.perf_counter() - tv) * 1e3
         assert wav.shape[0] == 256 * (2 * expect - 1) and bool(torch.isfinite(wav).all())

@@ -49,7 +49,7 @@ class GenIO(C.Structure):
 
 class VocCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dvae_idim", "dvae_hidden", "dvae_bn", "dvae_layers", "n_mels", "vocos_dim",
-                                          "vocos_inter", "vocos_layers", "n_fft", "hop", "max_frames")]
+                                          "vocos_inter", "vocos_layers", "n_fft", "hop", "max_frames", "max_batch")]
 
 
 # every symbol include/ctts_hip.h declares: (name, restype, argtypes)
@@ -82,6 +82,7 @@ SYMBOLS = [
     ("ctts_voc_finalize", C.c_int, [_P]),
     ("ctts_dvae_decode", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("ctts_vocos_decode", C.c_int, [_P, _P, C.c_int, _P, _P]),
+    ("ctts_synth_batch", C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
 ]
 
 _lib = None

@@ -24,8 +24,9 @@ def _np(v) -> np.ndarray:
 class Synth:
     """Owner of the native DVAE-decoder + Vocos handle."""
 
-    def __init__(self, dvae_cfg: dict, vocos_cfg: dict, max_frames: int = 4096, device="cuda"):
+    def __init__(self, dvae_cfg: dict, vocos_cfg: dict, max_frames: int = 4096, device="cuda", max_batch: int = 1):
         self.device = torch.device(device)
+        self.max_batch = int(max_batch)
         self._lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.HipBackendError("infer_type='hip' needs a visible MI355X; no CPU fallback")
@@ -33,7 +34,8 @@ class Synth:
                                dvae_bn=int(dvae_cfg.get("bn_dim", 128)), dvae_layers=int(dvae_cfg.get("n_layer", 12)),
                                n_mels=int(dvae_cfg.get("n_mels", 100)), vocos_dim=int(vocos_cfg.get("dim", 512)),
                                vocos_inter=int(vocos_cfg.get("intermediate_dim", 1536)), vocos_layers=int(vocos_cfg.get("num_layers", 8)),
-                               n_fft=int(vocos_cfg.get("n_fft", 1024)), hop=int(vocos_cfg.get("hop_length", 256)), max_frames=int(max_frames))
+                               n_fft=int(vocos_cfg.get("n_fft", 1024)), hop=int(vocos_cfg.get("hop_length", 256)), max_frames=int(max_frames),
+                               max_batch=int(max_batch))
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ctts_voc_create(C.byref(self.cfg), C.byref(self._h)), "ctts_voc_create")
@@ -86,6 +88,36 @@ class Synth:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ctts_vocos_decode(self._h, mel.data_ptr(), F, wav.data_ptr(), self._stream()), "vocos_decode")
         return wav
+
+
+    def decode_batch(self, hiddens):
+        """[hidden [n_b,768]] -> [wav [256 (2 n_b - 1)]]: the whole of _decode_to_wavs (pipeline:286-305) for a batch in ONE
+        launch sequence (ctts_synth_batch, grid.z = utterance) instead of the reference's per-utterance loop."""
+        if not self._finalized:
+            raise _lib.HipBackendError("DVAE / Vocos weights not loaded")
+        outs = [None] * len(hiddens)
+        todo = [i for i, h in enumerate(hiddens) if h.shape[0] > 0]
+        for i, h in enumerate(hiddens):
+            if h.shape[0] == 0:
+                outs[i] = torch.zeros(0, device=self.device)
+        with torch.cuda.device(self.device):
+            for c0 in range(0, len(todo), self.max_batch):
+                idx = todo[c0:c0 + self.max_batch]
+                hs = [hiddens[i].to(self.device, dtype=torch.float32).contiguous() for i in idx]
+                ns = [int(h.shape[0]) for h in hs]
+                wavs = [torch.empty(self.cfg.hop * (2 * n - 1), dtype=torch.float32, device=self.device) for n in ns]
+                hp = (C.c_void_p * len(idx))(*[h.data_ptr() for h in hs])
+                wp = (C.c_void_p * len(idx))(*[w.data_ptr() for w in wavs])
+                nt = (C.c_int32 * len(idx))(*ns)
+                _lib.check(self._lib.ctts_synth_batch(self._h, hp, nt, len(idx), wp, self._stream()), "synth_batch")
+                for i, w in zip(idx, wavs):
+                    outs[i] = w
+        return outs
+
+
+def SynthPool(dvae_cfg: dict, vocos_cfg: dict, max_frames: int = 4096, device="cuda", n_streams: int = 4, max_batch: int = 32) -> Synth:
+    """Kept for callers of the earlier multi-stream pool: batching across utterances inside the library replaced it."""
+    return Synth(dvae_cfg, vocos_cfg, max_frames=max_frames, device=device, max_batch=max_batch)
 
 
 class DVAE:

@@ -162,7 +162,9 @@ class ChatTTSPlusPipeline:
                 vk = dict(_get(models["vocos"], "kwargs"))
                 dcfg = dict(dk["decoder_config"]); dcfg["n_mels"] = 100
                 vcfg = dict(vk["backbone_config"]); vcfg.update(vk["head_config"])
-                synth = hip_models.Synth(dcfg, vcfg, max_frames=int(kwargs.get("max_frames", 2 * 2048 + 64)), device=self.device)
+                synth = hip_models.SynthPool(dcfg, vcfg, max_frames=int(kwargs.get("max_frames", 2 * 2048 + 64)), device=self.device,
+                                             max_batch=int(kwargs.get("vocoder_batch", 32)))
+                self.synth = synth
             if model_name == "vocos":                       # pipeline:93-111
                 model_ = hip_models.Vocos(synth)
                 model_.load_state_dict(torch.load(kw["model_path"], weights_only=True, mmap=True))
@@ -232,6 +234,8 @@ class ChatTTSPlusPipeline:
         """pipeline:286-305: per utterance hidden[n,768] -> DVAE -> mel[1,100,2n] -> Vocos -> wav[256(2n-1)]."""
         if not use_decoder:
             raise _lib.HipBackendError("use_decoder=False (decode codes through dvae_encode) is not served by the hip backend")
+        if len(result_list) > 1 and getattr(self, "synth", None) is not None:
+            return self.synth.decode_batch(list(result_list))           # utterances vocoded concurrently on K streams
         wavs = []
         decoder, vocos = self.models_dict["dvae_decode"], self.models_dict["vocos"]
         for h in result_list:

@@ -179,7 +179,8 @@ typedef struct {
     int32_t vocos_layers;   /* 8 */
     int32_t n_fft;          /* 1024 */
     int32_t hop;            /* 256 */
-    int32_t max_frames;     /* capacity in mel frames (2 per generated token) */
+    int32_t max_frames;     /* capacity in mel frames (2 per generated token) per utterance */
+    int32_t max_batch;      /* utterances synthesised by one ctts_synth_batch call (<= 64) */
 } ctts_voc_cfg;
 
 /* replaces DVAE.__init__ (dvae.py:203-239) + vocos.Vocos construction (pipeline:93-111) */
@@ -194,6 +195,10 @@ int ctts_voc_finalize(ctts_voc* h);
 int ctts_dvae_decode(ctts_voc* h, const float* hidden_dev, int n_tokens, float* mel_dev, void* stream);
 /* vocos.Vocos.decode (pipeline:303): mel fp32 [100][F] device -> wav fp32 [hop*(F-1)] device */
 int ctts_vocos_decode(ctts_voc* h, const float* mel_dev, int frames, float* wav_dev, void* stream);
+/* the whole of ChatTTSPlusPipeline._decode_to_wavs (pipeline:286-305) for B utterances in one launch sequence:
+ * hidden_ptrs[u] fp32 [n_tokens[u]][768] device -> wav_ptrs[u] fp32 [hop*(2*n_tokens[u]-1)] device; the two pointer
+ * arrays and n_tokens are HOST arrays of length B (<= max_batch).  Same arithmetic as dvae_decode + vocos_decode. */
+int ctts_synth_batch(ctts_voc* h, const float* const* hidden_ptrs, const int32_t* n_tokens, int B, float* const* wav_ptrs, void* stream);
 
 #ifdef __cplusplus
 }

@@ -71,3 +71,23 @@ def test_hidden_to_wav_chain(voc):
     wav = v.decode(d(torch.from_numpy(hid).permute(1, 0)[None].cuda()))[0].cpu().numpy()
     assert wav.shape == (256 * (2 * n - 1),)
     assert _rms(wav - wav_ref) <= 1e-3 * _rms(wav_ref)
+
+
+def test_batched_synthesis_matches_per_utterance(voc):
+    """Synth.decode_batch (ctts_synth_batch: ragged lengths, an empty utterance, more utterances than max_batch)
+    == per-utterance dvae_decode + vocos_decode, bit for bit."""
+    from chatttsplus_amd.hip_models import Synth
+    s, d, v = voc
+    pool = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2048, max_batch=4)
+    pool.load("dvae.", synth.dvae_state_dict(synth.DVAE_REAL, 1234))
+    pool.load("vocos.", synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
+    rng = np.random.Generator(np.random.Philox(key=5))
+    hs = [torch.from_numpy(rng.standard_normal((n, 768)).astype(np.float32)).cuda() for n in (40, 7, 0, 300, 41, 99, 1, 64, 17)]
+    outs = pool.decode_batch(hs)
+    torch.cuda.synchronize()
+    for h, w in zip(hs, outs):
+        if h.shape[0] == 0:
+            assert w.numel() == 0
+            continue
+        ref = s.vocos_decode(s.dvae_decode(h))
+        assert torch.equal(w, ref), "batched result differs from the per-utterance result"
