@@ -128,9 +128,7 @@ def main():
     if world > 1:
         dist.broadcast(spk, src=0)
     ids_t = torch.from_numpy(ids).to(dev)
-    emb = g(ids_t, torch.ones(B, P, dtype=torch.bool, device=dev))
-    n = torch.nn.functional.normalize(spk, p=2.0, dim=0, eps=1e-12)            # tokenizer.py:150-178
-    emb = torch.where(ids_t[..., 0:1].eq(spk_id).expand(emb.shape), n.expand(emb.shape), emb)
+    emb = g(ids_t, torch.ones(B, P, dtype=torch.bool, device=dev), spk_emb=spk, spk_emb_ids=spk_id)   # get_emb + apply_spk_emb (one HIP launch)
 
     lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
     lp = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("ctts_gpt_kv_bytes", C.c_size_t, [_P]),
     ("ctts_gpt_bind_kv", C.c_int, [_P, _P, C.c_size_t]),
     ("ctts_gpt_set_rope", C.c_int, [_P, _P, C.c_int]),
+    ("ctts_gpt_embed", C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     ("ctts_gpt_begin", C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(SamplerCfg), C.POINTER(GenIO), _P]),
     ("ctts_gpt_prefill", C.c_int, [_P, _P, _P]),
     ("ctts_gpt_sample", C.c_int, [_P, _P]),

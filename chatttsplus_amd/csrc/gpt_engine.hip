@@ -47,6 +47,8 @@ struct ctts_gpt {
     void* whead = nullptr;
     float* lnf = nullptr;
     float* emb_code = nullptr;
+    float* emb_text = nullptr;                   // [V_text][H] prompt embedding table (optional)
+    int vocab_text = 0;
     float* rope = nullptr;
     float *rope_pre = nullptr, *rope_dec = nullptr;   // per-row copies of the table rows (prefill rows / decode rows)
     int rope_n = 0;
@@ -115,7 +117,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
-    void* bufs[] = {h->wblob, h->lnf, h->emb_code, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
+    void* bufs[] = {h->wblob, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->opart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
@@ -129,7 +131,7 @@ extern "C" int ctts_gpt_set_weight(ctts_gpt* h, const char* name, const float* d
     if (!h || !name || !data) { ctts_set_error("null argument"); return 1; }
     if (h->finalized) { ctts_set_error("weights already finalized"); return 1; }
     std::string n(name);
-    if (n.rfind("emb_text", 0) == 0 || n.rfind("head_text", 0) == 0) return 0;   // text path: host side / next round
+    if (n.rfind("head_text", 0) == 0) return 0;   // refine-text head: next round
     h->host[n].assign(data, data + numel);
     return 0;
 }
@@ -276,9 +278,23 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4))
         return 1;
     CTTS_HIP_CHECK(hipHostMalloc((void**)&h->host_pin, 64));
+    {
+        auto it = h->host.find("emb_text.weight");
+        if (it != h->host.end() && it->second.size() % H == 0) {
+            h->vocab_text = (int)(it->second.size() / H);
+            if (dev_alloc((void**)&h->emb_text, it->second.size() * 4)) return 1;
+            CTTS_HIP_CHECK(hipMemcpy(h->emb_text, it->second.data(), it->second.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     h->host.clear();
     h->finalized = true;
     return 0;
+}
+
+extern "C" int ctts_gpt_embed(ctts_gpt* h, const int32_t* ids, const int32_t* text_mask, int B, int T, const float* spk, int spk_id, float* emb_out, void* stream) {
+    if (!h || !h->finalized || !ids || !text_mask || !emb_out || B < 1 || T < 1) { ctts_set_error("embed: bad argument"); return 1; }
+    if (!h->emb_text) { ctts_set_error("embed: emb_text.weight was not loaded"); return 1; }
+    return launch_embed_prompt(ids, text_mask, h->emb_text, h->emb_code, spk, spk_id, emb_out, B * T, T, h->V, h->H, (hipStream_t)stream);
 }
 
 extern "C" size_t ctts_gpt_kv_bytes(const ctts_gpt* h) {

@@ -103,4 +103,6 @@ int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s);
 int launch_gather_rows(const float* src, float* dst, const int* src_rows, int n, int H, hipStream_t s);
 int launch_embed_ids(const int* ids, const float* emb_code, float* x, int B, int V, int H, hipStream_t s);
 int launch_fill_meta(RowMeta* prefill_meta, RowMeta* decode_meta, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre, hipStream_t s);
+int launch_embed_prompt(const int* ids, const int* text_mask, const float* emb_text, const float* emb_code, const float* spk, int spk_id,
+                        float* out, int rows, int T, int V, int H, hipStream_t s);
 int gemm_configure();

@@ -319,3 +319,30 @@ int launch_fill_meta(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, in
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// GPT.forward "get_emb" (gpt.py:125-149) + Tokenizer.apply_spk_emb (tokenizer.py:150-178) for the prompt rows:
+//   text row  -> emb_text[id0];  code row -> ((e0[id0] + e1[id1]) + e2[id2]) + e3[id3];
+//   rows whose first id == spk_id <- the (already L2-normalised) speaker vector of their sequence.
+__global__ void embed_prompt_kernel(const int* ids, const int* text_mask, const float* emb_text, const float* emb_code, const float* spk,
+                                    int spk_id, float* out, int T, int V, int H) {
+    const int row = blockIdx.x, b = row / T;
+    const int* id = ids + (size_t)row * CTTS_NUM_VQ;
+    const bool is_spk = (spk != nullptr) && (id[0] == spk_id);
+    const bool is_text = text_mask[row] != 0;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        float v;
+        if (is_spk) v = spk[(size_t)b * H + k];
+        else if (is_text) v = emb_text[(size_t)id[0] * H + k];
+        else {
+            v = emb_code[((size_t)0 * V + id[0]) * H + k];
+            for (int q = 1; q < CTTS_NUM_VQ; ++q) v += emb_code[((size_t)q * V + id[q]) * H + k];
+        }
+        out[(size_t)row * H + k] = v;
+    }
+}
+int launch_embed_prompt(const int* ids, const int* text_mask, const float* emb_text, const float* emb_code, const float* spk, int spk_id,
+                        float* out, int rows, int T, int V, int H, hipStream_t s) {
+    hipLaunchKernelGGL(embed_prompt_kernel, dim3(rows), dim3(256), 0, s, ids, text_mask, emb_text, emb_code, spk, spk_id, out, T, V, H);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -127,8 +127,6 @@ class GPT:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ctts_gpt_create(C.byref(cfg), C.byref(self._h)), "ctts_gpt_create")
         self._finalized = False
-        self._emb_text = None
-        self._emb_code_t = None
         self._kv = None
         self._lora = []
         self.model_path = kwargs.get("model_path", None)
@@ -166,15 +164,11 @@ class GPT:
             a = np.ascontiguousarray(a)
             keep.append(a)
             _lib.check(self._lib.ctts_gpt_set_weight(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), f"set_weight({k})")
-            if k == "emb_text.weight":
-                self._emb_text = torch.from_numpy(a).to(self.device)
         for (layer, target, A, B, scale) in self._lora:
             _lib.check(self._lib.ctts_gpt_merge_lora(self._h, layer, target.encode(), A.ctypes.data_as(C.c_void_p),
                                                      B.ctypes.data_as(C.c_void_p), A.shape[0], scale), "merge_lora")
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ctts_gpt_finalize(self._h), "ctts_gpt_finalize")
-            self._emb_code_t = torch.stack([torch.as_tensor(np.asarray(sd[f"emb_code.{i}.weight"], dtype=np.float32) if not isinstance(sd[f"emb_code.{i}.weight"], torch.Tensor)
-                                                            else sd[f"emb_code.{i}.weight"].float()) for i in range(self.num_vq)]).to(self.device)
             rope = rope_table(self.max_seq)
             _lib.check(self._lib.ctts_gpt_set_rope(self._h, rope.ctypes.data_as(C.c_void_p), self.max_seq), "set_rope")
             nbytes = self._lib.ctts_gpt_kv_bytes(self._h)
@@ -198,18 +192,27 @@ class GPT:
         return g
 
     # -- get_emb (gpt.py:125-149) ----------------------------------------------------------------
-    def __call__(self, input_ids: torch.Tensor, text_mask: torch.Tensor) -> torch.Tensor:
-        input_ids = input_ids.to(self.device)
-        text_mask = text_mask.to(self.device).bool()
-        emb = torch.zeros(input_ids.shape[:-1] + (self.model_dim,), device=self.device, dtype=torch.float32)
-        if text_mask.any():
-            if self._emb_text is None:
-                raise _lib.HipBackendError("emb_text.weight was not loaded")
-            emb[text_mask] = F.embedding(input_ids[text_mask][:, 0], self._emb_text)
-        inv = ~text_mask
-        if inv.any():
-            mids = input_ids[inv]
-            emb[inv] = torch.stack([F.embedding(mids[:, i], self._emb_code_t[i]) for i in range(self.num_vq)], 2).sum(2)
+    def __call__(self, input_ids: torch.Tensor, text_mask: torch.Tensor, spk_emb=None, spk_emb_ids: Optional[int] = None) -> torch.Tensor:
+        """emb[B,T,H] fp32 on the device, computed by embed_prompt_kernel (ctts_gpt_embed).  With `spk_emb` (a [H] vector, a
+        [B,H] table or a base16384 string) the rows whose id == spk_emb_ids are overwritten by F.normalize(spk) in the same
+        launch (Tokenizer.apply_spk_emb, tokenizer.py:150-178)."""
+        if not self._finalized:
+            raise _lib.HipBackendError("weights not loaded")
+        ids = input_ids.to(self.device).to(torch.int32).contiguous()
+        tm = text_mask.to(self.device).to(torch.int32).contiguous()
+        B, T = int(ids.shape[0]), int(ids.shape[1])
+        emb = torch.empty(B, T, self.model_dim, dtype=torch.float32, device=self.device)
+        spk_t, sid = None, -1
+        if spk_emb is not None:
+            from .. import codec
+            v = codec.speaker_to_vector(spk_emb) if (isinstance(spk_emb, str) or torch.as_tensor(spk_emb).dim() == 1) else torch.as_tensor(spk_emb).float()
+            v = v.reshape(-1, self.model_dim)
+            v = F.normalize(v, p=2.0, dim=1, eps=1e-12)                    # == normalize(dim=0) of each [H] vector
+            spk_t = v.expand(B, -1).contiguous().to(self.device)
+            sid = int(spk_emb_ids)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_gpt_embed(self._h, ids.data_ptr(), tm.data_ptr(), B, T, spk_t.data_ptr() if spk_t is not None else None,
+                                                sid, emb.data_ptr(), self._stream()), "embed")
         return emb
 
     forward = __call__

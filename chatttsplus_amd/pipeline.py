@@ -218,9 +218,7 @@ class ChatTTSPlusPipeline:
         tag = "[spk_emb]" if params.spk_emb is not None else "[empty_spk]"
         text = [f"[Stts]{tag}{txt_smp}{i}[Ptts]" for i in text]
         input_ids, attention_mask, text_mask = tok.encode(text, gpt.num_vq, prompt_str=params.spk_smp, device=self.device)
-        emb = gpt(input_ids, text_mask)
-        if params.spk_emb is not None:
-            emb = codec.apply_spk_emb(emb, params.spk_emb, input_ids, tok.spk_emb_ids)
+        emb = gpt(input_ids, text_mask, spk_emb=params.spk_emb, spk_emb_ids=tok.spk_emb_ids)     # get_emb + apply_spk_emb, one launch
         num_code = int(gpt.emb_code[0].num_embeddings - 1)
         warpers, processors = gen_logits(num_code=num_code, top_P=params.top_P, top_K=params.top_K,
                                          repetition_penalty=params.repetition_penalty)

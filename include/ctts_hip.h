@@ -64,8 +64,8 @@ void ctts_gpt_destroy(ctts_gpt* h);
  * state-dict key; `data` is HOST fp32, row-major, `numel` elements.
  * Accepted keys: gpt.layers.N.{self_attn.{q,k,v,o}_proj,mlp.{gate,up,down}_proj,input_layernorm,
  * post_attention_layernorm}.weight, gpt.norm.weight, emb_code.N.weight,
- * head_code.N.parametrizations.weight.original{0,1}.  Other keys (emb_text, head_text) are ignored
- * with return code 0 (text path is host-side / next round). */
+ * emb_text.weight, head_code.N.parametrizations.weight.original{0,1}.  head_text.* is ignored with return code 0
+ * (refine-text pass: next round). */
 int ctts_gpt_set_weight(ctts_gpt* h, const char* name, const float* data, size_t numel);
 
 /* LoRA merge rule of peft merge_and_unload (pipeline:420-432): W += scale * B @ A for one target
@@ -114,6 +114,13 @@ typedef struct {
     int32_t n_draws;
     uint64_t seed;
 } ctts_gen_io;
+
+/* GPT.forward / get_emb (gpt.py:125-149) fused with Tokenizer.apply_spk_emb (tokenizer.py:150-178):
+ * input_ids int32 [B][T][4] device, text_mask int32 [B][T] device (1 = text row -> emb_text, 0 = code row -> sum of the
+ * 4 code embeddings); rows whose first id == spk_id receive spk fp32 [B][hidden] (already L2-normalised; NULL = none).
+ * emb_out fp32 [B][T][hidden] device.  Ids must be < the table sizes (no bounds check on the device). */
+int ctts_gpt_embed(ctts_gpt* h, const int32_t* input_ids_dev, const int32_t* text_mask_dev, int B, int T, const float* spk_dev, int spk_id,
+                   float* emb_out_dev, void* stream);
 
 /* Start a generate() call for B sequences with a T-token (left padded) prompt.
  * attention_mask int32 [B][T] device (1 = token, 0 = pad; tokenizer.py:96-115).

@@ -145,3 +145,24 @@ def test_finish_bookkeeping_and_early_stop_vs_oracle():
         assert [int(i.shape[0]) for i in out.ids] == [int(i.shape[0]) for i in ref.ids], f"seed {seed}"
         for b in range(B):
             assert torch.equal(out.ids[b].cpu(), ref.ids[b]), f"seed {seed} row {b}"
+
+
+def test_embed_kernel_with_speaker_matches_oracle():
+    """A1 + A2: get_emb (text rows, code rows = sum of 4 code embeddings) and apply_spk_emb in one launch."""
+    import os
+    from chatttsplus_amd import codec
+    from tests.helpers import GOLDEN
+    g, sd = model("fp32")
+    o = ref_cpu.OracleGPT(sd, 12)
+    rng = np.random.Generator(np.random.Philox(key=8))
+    B, T = 3, 9
+    ids = torch.from_numpy(rng.integers(0, 21178, size=(B, T, 1))).expand(-1, -1, 4).clone()
+    tm = torch.ones(B, T, dtype=torch.bool)
+    tm[:, 6:] = False                                           # audio-prompt rows: 4 independent code ids
+    ids[:, 6:] = torch.from_numpy(rng.integers(0, 626, size=(B, 3, 4)))
+    ids[:, 1, :] = 21143
+    spk = torch.load(os.path.join(GOLDEN, "speakers", "2222.pt"), weights_only=True)
+    ref = o.apply_spk_emb(o.embed(ids, tm), torch.from_numpy(codec.decode_spk_emb(spk)), ids, 21143)
+    got = g(ids, tm, spk_emb=spk, spk_emb_ids=21143).cpu()
+    assert torch.equal(got, ref)
+    assert torch.equal(g(ids, tm).cpu(), o.embed(ids, tm))
