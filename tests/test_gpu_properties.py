@@ -1,0 +1,135 @@
+"""Size-independent properties at BASELINE.json's full sizes (512 generated tokens, batch 32 mixed lengths) and the edge
+cases of the path -- where the CPU oracle would take minutes, the HIP path is checked against itself through
+properties that only hold if the kernels are right:
+  * replay determinism and hipGraph == eager launches over 512 steps;
+  * KV-cache append consistency: the decode path's hidden for token i == the prompt-pass path (32-row chunks, causal
+    attention row by row) over prompt + tokens[:i]  (two different code paths over the same cache semantics);
+  * batch invariance: a row of a left-padded batch of 32 == the same utterance generated alone with the same noise rows.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from chatttsplus_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+LP = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20)
+
+
+@pytest.fixture(scope="module")
+def gpt32():
+    from chatttsplus_amd.hip_models import GPT
+    g = GPT(LLAMA, max_batch=32, max_seq_len=640, weight_dtype="fp32")
+    g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+    return g
+
+
+def _gen(g, ids, mask, n, noise, use_graph=True, min_new=None):
+    g.use_graph = use_graph
+    emb = g(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
+    out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=n,
+                          min_new_token=n if min_new is None else min_new, logits_warpers=LW, logits_processors=LP, return_hidden=True, noise=noise))[-1]
+    g.use_graph = True
+    return emb, out
+
+
+def test_512_tokens_deterministic_graph_equals_eager_and_cache_consistent(gpt32):
+    g = gpt32
+    B, T, N = 1, 48, 512                                        # BASELINE configs[1]
+    ids, mask = synth.prompt_ids(B, T, 21178, 77)
+    q = torch.from_numpy(np.stack([synth.exp_noise(9, i, 4, 626) for i in range(N)]))
+    emb, a = _gen(g, ids, mask, N, q, use_graph=True)
+    _, b = _gen(g, ids, mask, N, q, use_graph=True)
+    _, c = _gen(g, ids, mask, N, q, use_graph=False)
+    assert a.ids[0].shape == (N, 4)
+    assert torch.equal(a.ids[0], b.ids[0]) and torch.equal(a.hiddens[0], b.hiddens[0]), "replay is not deterministic"
+    assert torch.equal(a.ids[0], c.ids[0]) and torch.equal(a.hiddens[0], c.hiddens[0]), "hipGraph replay != eager launches"
+    # prompt-pass path over prompt + generated tokens must reproduce the decode path's hiddens (fp32: to rounding)
+    for upto in (1, 200, 511):
+        toks = a.ids[0][:upto].to(torch.int64).cpu().numpy()
+        ids2 = np.concatenate([ids, toks[None]], axis=1)
+        tm = torch.ones(1, T + upto, dtype=torch.bool); tm[:, T:] = False
+        emb2 = g(torch.from_numpy(ids2), tm)
+        assert torch.equal(emb2[:, :T], emb)
+        out = list(g.generate(emb2, torch.from_numpy(ids2), torch.tensor([0.3] * 4), 625, max_new_token=1, min_new_token=1, logits_warpers=LW,
+                              logits_processors=LP, return_hidden=True, noise=q[upto:upto + 1]))[-1]
+        d = float((out.hiddens[0][0] - a.hiddens[0][upto]).abs().max())
+        assert d <= 2e-5, f"prefill path vs decode path at token {upto}: {d}"
+        assert torch.equal(out.ids[0][0], a.ids[0][upto]), f"token {upto} differs between the two paths"
+
+
+def test_batch32_mixed_lengths_rows_equal_single_runs(gpt32):
+    g = gpt32
+    B, T, N = 32, 96, 64                                        # BASELINE configs[2] shape: left-padded mixed prompt lengths
+    rng = np.random.Generator(np.random.Philox(key=3))
+    pads = [int(p) for p in rng.integers(0, 80, size=B)]
+    pads[0] = 0
+    ids, mask = synth.prompt_ids(B, T, 21178, 78, pad_left=pads)
+    q = torch.from_numpy(np.stack([synth.exp_noise(10, i, 4 * B, 626) for i in range(N)]))
+    _, big = _gen(g, ids, mask, N, q, min_new=2)
+    for b in (0, 7, 31):
+        p = pads[b]
+        ids1, mask1 = ids[b:b + 1, p:], mask[b:b + 1, p:]
+        _, one = _gen(g, ids1, mask1, N, q[:, 4 * b:4 * b + 4].contiguous(), min_new=2)
+        n = min(one.ids[0].shape[0], big.ids[b].shape[0])
+        assert one.ids[0].shape[0] == big.ids[b].shape[0], f"row {b}: lengths differ ({one.ids[0].shape[0]} vs {big.ids[b].shape[0]})"
+        assert torch.equal(one.ids[0][:n], big.ids[b][:n]), f"row {b}: padded batch of 32 != single utterance"
+        assert float((one.hiddens[0][:n] - big.hiddens[b][:n]).abs().max()) <= 5e-5
+
+
+@pytest.mark.parametrize("B,T,N", [(1, 1, 1), (1, 1, 5), (3, 2, 1), (2, 40, 600)])
+def test_edge_shapes(gpt32, B, T, N):
+    """one-token prompts, one-token generations, and a generation that fills the KV cache exactly to max_seq."""
+    g = gpt32
+    ids, mask = synth.prompt_ids(B, T, 21178, 5)
+    n_run = min(N, 40)
+    max_new = N
+    emb = g(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))
+    out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=max_new,
+                          min_new_token=max_new, logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="device", seed=4))[-1]
+    assert all(i.shape == (max_new, 4) for i in out.ids) and all(h.shape == (max_new, 768) for h in out.hiddens)
+    assert all(bool(torch.isfinite(h).all()) for h in out.hiddens)
+    assert all(int(i.min()) >= 0 and int(i.max()) < 625 for i in out.ids)          # EOS masked by min_new_token == max_new_token
+
+
+def test_capacity_and_argument_errors(gpt32):
+    g = gpt32
+    ids, mask = synth.prompt_ids(1, 50, 21178, 5)
+    emb = g(torch.from_numpy(ids), torch.ones(1, 50, dtype=torch.bool))
+    with pytest.raises(_lib.HipBackendError, match="max_seq"):
+        list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, max_new_token=640, logits_warpers=LW, logits_processors=LP))
+    ids33, _ = synth.prompt_ids(33, 4, 21178, 5)
+    with pytest.raises(_lib.HipBackendError):
+        emb33 = g(torch.from_numpy(ids33), torch.ones(33, 4, dtype=torch.bool))
+        list(g.generate(emb33, torch.from_numpy(ids33), torch.tensor([0.3] * 4), 625, max_new_token=4, logits_warpers=LW, logits_processors=LP))
+    with pytest.raises(_lib.HipBackendError):
+        list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, max_new_token=4, infer_text=True))
+
+
+def test_interrupt_context_stops_generation(gpt32):
+    """Context interrupt flag (gpt.py:87-95,545): checked between chunks; a pre-set flag stops after step 0."""
+    from chatttsplus_amd.hip_models.gpt import Context
+    g = gpt32
+    ids, mask = synth.prompt_ids(1, 8, 21178, 6)
+    emb = g(torch.from_numpy(ids), torch.ones(1, 8, dtype=torch.bool))
+    ctx = Context(); ctx.set(True)
+    out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, max_new_token=200, min_new_token=200, logits_warpers=LW,
+                          logits_processors=LP, return_hidden=True, context=ctx, noise="device"))[-1]
+    assert out.ids[0].shape[0] == 1
+
+
+def test_stream_mode_yields_growing_prefixes(gpt32):
+    g = gpt32
+    ids, mask = synth.prompt_ids(2, 8, 21178, 6)
+    emb = g(torch.from_numpy(ids), torch.ones(2, 8, dtype=torch.bool))
+    outs = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, max_new_token=80, min_new_token=80, logits_warpers=LW,
+                           logits_processors=LP, return_hidden=True, stream=True, stream_batch=24, noise="device"))
+    lens = [o.ids[0].shape[0] for o in outs]
+    assert lens == sorted(lens) and lens[-1] == 80 and len(outs) >= 3
+    for o in outs[:-1]:
+        assert torch.equal(o.ids[0], outs[-1].ids[0][:o.ids[0].shape[0]])
