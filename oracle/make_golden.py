@@ -143,6 +143,36 @@ def golden_gpt_real(ref):
     save_gen("gpt_real_greedy", meta, emb, out)
 
 
+def golden_refine_text(ref):
+    """infer_text=True pass (pipeline:237-277 -> gpt.py infer_text branches): real config, 21178-way text head."""
+    cfg = synth.GPT_REAL
+    sd = synth.gpt_state_dict(cfg, 1234)
+    g = build_ref_gpt(ref, cfg, sd)
+    for name, B, T, pad, N, min_new, eos_boost, seed in (("gpt_real_text_b2", 2, 14, [0, 4], 20, 0, 1.0, 5), ("gpt_real_text_eos", 3, 10, [0, 0, 2], 40, 1, 9.0, 6)):
+        sd2 = sd
+        eos = 21177                                  # stands in for [Ebreak]
+        if eos_boost != 1.0:
+            sd2 = dict(sd)
+            g0 = sd["head_text.parametrizations.weight.original0"].copy(); g0[eos] *= eos_boost
+            sd2["head_text.parametrizations.weight.original0"] = g0
+            g = build_ref_gpt(ref, cfg, sd2)
+        ids, mask = synth.prompt_ids(B, T, cfg["num_text_tokens"], 40 + B, pad_left=pad)
+        ids_t = torch.from_numpy(ids); mask_t = torch.from_numpy(mask)
+        with torch.no_grad():
+            emb = g(ids_t, torch.ones(B, T, dtype=torch.bool))
+        lw, lp = ref.processors.gen_logits(num_code=cfg["num_text_tokens"], top_P=0.7, top_K=20, repetition_penalty=1.0)
+        torch.manual_seed(seed)
+        out = next(g.generate(emb, ids_t, temperature=torch.tensor([0.7]), eos_token=eos, attention_mask=mask_t, max_new_token=N,
+                              min_new_token=min_new, logits_warpers=lw, logits_processors=lp, infer_text=True, stream=False, show_tqdm=False))
+        lens = np.array([i.shape[0] for i in out.ids], dtype=np.int32)
+        arr = np.full((B, int(lens.max())), -1, dtype=np.int32)
+        for b in range(B):
+            arr[b, :lens[b]] = out.ids[b].numpy()
+        meta = dict(weight_seed=1234, prompt_seed=40 + B, torch_seed=seed, B=B, T=T, pad_left=pad, max_new=N, min_new=min_new, eos=eos, eos_boost=eos_boost)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), lens=lens, ids=arr, **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
+        print(name, "lens", lens.tolist())
+
+
 def golden_sampler(ref):
     """The reference's actual objects (Custom rep-penalty + HF TopP/TopK + torch.multinomial) on random rows."""
     from transformers.generation import TopKLogitsWarper, TopPLogitsWarper  # noqa: F401
@@ -214,6 +244,7 @@ def main():
     golden_gpt_tiny_regen(ref)
     golden_dvae(ref)
     golden_gpt_real(ref)
+    golden_refine_text(ref)
 
 
 if __name__ == "__main__":

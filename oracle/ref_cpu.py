@@ -184,6 +184,10 @@ class OracleGPT:
             g = self.sd[f"head_code.{i}.parametrizations.weight.original0"]
             v = self.sd[f"head_code.{i}.parametrizations.weight.original1"]
             self.head_code.append(torch._weight_norm(v, g, 0))
+        self.head_text = None
+        if "head_text.parametrizations.weight.original0" in self.sd:
+            self.head_text = torch._weight_norm(self.sd["head_text.parametrizations.weight.original1"],
+                                                self.sd["head_text.parametrizations.weight.original0"], 0)      # gpt.py:57-64
         self.inv_freq = 1.0 / (ROPE_BASE ** (torch.arange(0, HEAD_DIM, 2, dtype=torch.int64).float() / HEAD_DIM))  # llama.py:100
 
     # -- embedding ----------------------------------------------------------------------------
@@ -282,6 +286,54 @@ class OracleGPT:
         """4 folded heads on the last position -> [B*num_vq, V] (gpt.py:429-447)."""
         lg = torch.stack([F.linear(hidden_last, w) for w in self.head_code], 1)   # [B,4,V]
         return lg.reshape(-1, self.V)
+
+    # -- generate (refine-text pass: infer_text=True) -------------------------------------------
+    @torch.no_grad()
+    def generate_text(self, emb, inputs_ids, temperature: float, eos_token: int, top_p=0.7, top_k=20, attention_mask=None,
+                      max_new_token=384, min_new_token=0, noise=None, ensure_non_empty=True) -> GenerationOutputs:
+        """GPT.generate with infer_text=True (gpt.py:400-401,425-426,458-467,489-494; called by pipeline:237-277):
+        one 21178-way head, a single temperature, next input = emb_text[id], ids returned as [n] (first column).
+        repetition_penalty must be 1 (the reference's processor path mis-broadcasts the [B,n,1] history for this mode)."""
+        emb = _t(emb).float(); inputs_ids = _t(inputs_ids)
+        B, T = inputs_ids.shape[0], inputs_ids.shape[1]
+        noise = noise or TorchExpNoise()
+        Vt = self.head_text.shape[0]
+        end_idx = torch.zeros(B, dtype=torch.long); finish = torch.zeros(B, dtype=torch.bool)
+        mask_cache = torch.ones(B, T + max_new_token, dtype=torch.bool)
+        if attention_mask is not None:
+            mask_cache[:, :T] = _t(attention_mask).bool()
+        ids_buf = torch.zeros(B, T + max_new_token, dtype=torch.long)
+        self.alloc_cache(B, T + max_new_token)
+        progress = T
+        for i in range(max_new_token):
+            m = mask_cache[:, :progress]
+            pos = m.long().cumsum(-1) - 1
+            pos.masked_fill_(m.eq(0), 1)
+            if i == 0:
+                x, p = emb, pos
+            else:
+                x, p = F.embedding(ids_buf[:, progress - 1:progress], self.sd["emb_text.weight"]), pos[:, -1:]     # gpt.py:400-401
+            last = self.forward(x, m, p)[:, -1]
+            logits = F.linear(last, self.head_text) / torch.tensor(float(temperature), dtype=torch.float32)          # gpt.py:426,469
+            if top_p is not None:
+                logits = top_p_warp(logits, top_p, 3)
+            if top_k is not None:
+                logits = top_k_warp(logits, top_k, 3)
+            if i < min_new_token:
+                logits = logits.clone(); logits[:, eos_token] = -torch.inf
+            idx = torch.argmax(F.softmax(logits, dim=-1) / noise.next(B, Vt), dim=-1)
+            finish |= idx.eq(eos_token)                                                                             # gpt.py:490-491
+            ids_buf[:, progress] = idx
+            if i == 0 and finish.any():
+                if ensure_non_empty:
+                    return self.generate_text(emb, inputs_ids, temperature, eos_token, top_p, top_k, attention_mask, max_new_token,
+                                              min_new_token, noise, ensure_non_empty)
+                return GenerationOutputs([], [], [], 1, None)
+            progress += 1
+            end_idx += (~finish).long()
+            if finish.all():
+                break
+        return GenerationOutputs([ids_buf[b, T:T + int(end_idx[b])] for b in range(B)], [], [], 0, None)
 
     # -- generate -----------------------------------------------------------------------------
     @torch.no_grad()

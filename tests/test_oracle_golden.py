@@ -74,3 +74,23 @@ def test_vocos_istft_self_consistency():
     wav2 = ref_cpu.istft_direct(re, im, sd["head.istft.window"])
     scale = wav.abs().max().item()
     assert (wav - wav2).abs().max().item() <= 1e-4 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("name", ["gpt_real_text_b2", "gpt_real_text_eos"])
+def test_refine_text_generate_matches_reference(name):
+    """infer_text=True pass (21178-way head_text, single temperature, emb_text re-embed) against the imported reference."""
+    z, meta = load_golden(name)
+    cfg = synth.GPT_REAL
+    sd = synth.gpt_state_dict(cfg, int(meta["weight_seed"]))
+    eos = int(meta["eos"])
+    sd["head_text.parametrizations.weight.original0"][eos] *= float(meta["eos_boost"])
+    B, T = int(meta["B"]), int(meta["T"])
+    ids, mask = synth.prompt_ids(B, T, cfg["num_text_tokens"], int(meta["prompt_seed"]), pad_left=[int(x) for x in meta["pad_left"]])
+    o = ref_cpu.OracleGPT(sd, cfg["num_attention_heads"])
+    emb = o.embed(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))
+    torch.manual_seed(int(meta["torch_seed"]))
+    out = o.generate_text(emb, torch.from_numpy(ids), 0.7, eos, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]),
+                          min_new_token=int(meta["min_new"]))
+    assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist()
+    for b, n in enumerate(z["lens"]):
+        assert np.array_equal(out.ids[b].numpy(), z["ids"][b, :n].astype(np.int64))
