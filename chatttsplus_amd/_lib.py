@@ -32,6 +32,7 @@ class SamplerCfg(C.Structure):
         ("eos_token", C.c_int32),
         ("min_new_token", C.c_int32),
         ("max_new_token", C.c_int32),
+        ("infer_text", C.c_int32),
     ]
 
 

@@ -45,10 +45,13 @@ struct ctts_gpt {
     char* wblob = nullptr;
     std::vector<LayerW> lw;
     void* whead = nullptr;
+    void* whead_text = nullptr;                  // refine-text head (21178 x H), packed like whead; optional
+    int text_mode = 0;                           // current generate() call: infer_text=True
     float* lnf = nullptr;
     float* emb_code = nullptr;
     float* emb_text = nullptr;                   // [V_text][H] prompt embedding table (optional)
     int vocab_text = 0;
+    int vocab_text_head = 0;
     float* rope = nullptr;
     float *rope_pre = nullptr, *rope_dec = nullptr;   // per-row copies of the table rows (prefill rows / decode rows)
     int rope_n = 0;
@@ -117,7 +120,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
-    void* bufs[] = {h->wblob, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
+    void* bufs[] = {h->wblob, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->opart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
@@ -131,7 +134,6 @@ extern "C" int ctts_gpt_set_weight(ctts_gpt* h, const char* name, const float* d
     if (!h || !name || !data) { ctts_set_error("null argument"); return 1; }
     if (h->finalized) { ctts_set_error("weights already finalized"); return 1; }
     std::string n(name);
-    if (n.rfind("head_text", 0) == 0) return 0;   // refine-text head: next round
     h->host[n].assign(data, data + numel);
     return 0;
 }
@@ -247,6 +249,26 @@ static int finalize_t(ctts_gpt* h) {
         return pr < nvalid ? folded.data() + (size_t)pr * H : nullptr;
     }, nf->data());
     h->whead = h->wblob + per_layer * L * sizeof(WT);
+    {   // refine-text head (gpt.py:57-64): same weight-norm fold + final-norm fold, its own allocation
+        auto g0 = h->host.find("head_text.parametrizations.weight.original0");
+        auto v1 = h->host.find("head_text.parametrizations.weight.original1");
+        if (g0 != h->host.end() && v1 != h->host.end() && v1->second.size() == g0->second.size() * (size_t)H) {
+            const int Vt = (int)g0->second.size(), tiles = (Vt + 15) / 16;
+            std::vector<float> ft((size_t)Vt * H);
+            for (int r = 0; r < Vt; ++r) {
+                double ss = 0.0;
+                const float* vr = v1->second.data() + (size_t)r * H;
+                for (int c = 0; c < H; ++c) ss += (double)vr[c] * vr[c];
+                const float a = g0->second[r] / (float)sqrt(ss);
+                for (int c = 0; c < H; ++c) ft[(size_t)r * H + c] = vr[c] * a;
+            }
+            std::vector<WT> packed((size_t)tiles * 16 * H);
+            pack_tiles<WT>(packed.data(), tiles, H, [&](int pr) -> const float* { return pr < Vt ? ft.data() + (size_t)pr * H : nullptr; }, nf->data());
+            if (dev_alloc(&h->whead_text, packed.size() * sizeof(WT))) return 1;
+            CTTS_HIP_CHECK(hipMemcpy(h->whead_text, packed.data(), packed.size() * sizeof(WT), hipMemcpyHostToDevice));
+            h->vocab_text_head = Vt;
+        }
+    }
     CTTS_HIP_CHECK(hipMemcpy(h->wblob, blob.data(), total * sizeof(WT), hipMemcpyHostToDevice));
     if (dev_alloc((void**)&h->lnf, H * 4)) return 1;
     CTTS_HIP_CHECK(hipMemcpy(h->lnf, nf->data(), H * 4, hipMemcpyHostToDevice));
@@ -271,7 +293,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->q_buf, (size_t)PASS_ROWS * H * 4) ||
         dev_alloc((void**)&h->part_ml, (size_t)PASS_ROWS * NH * SMAX * 2 * 4) ||
         dev_alloc((void**)&h->part_o, (size_t)PASS_ROWS * NH * SMAX * CTTS_HEAD_DIM * 4) ||
-        dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * h->NVQ * h->V * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc((void**)&h->rope_pre, (size_t)MB * h->cfg.max_seq * 64 * 4) ||
+        dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * (h->NVQ * h->V > h->vocab_text_head ? h->NVQ * h->V : h->vocab_text_head) * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc((void**)&h->rope_pre, (size_t)MB * h->cfg.max_seq * 64 * 4) ||
         dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->opart, (size_t)16 * NH * H * 4) || dev_alloc(&h->attn_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
@@ -373,8 +395,9 @@ static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
     const int nbg = (h->B <= 16) ? 1 : 2;
     GemmArgs a = {};
     a.st = h->st; a.R = h->B; a.eps = 1e-6f; a.meta = h->meta_dec;
-    a.W = h->whead; a.n_row_tiles = (h->NVQ * h->V + 15) / 16; a.K = h->H; a.x = h->x_dec; a.lnw = h->lnf;
-    a.logits = h->logits; a.n_valid = h->NVQ * h->V;
+    const int nv = h->text_mode ? h->vocab_text_head : h->NVQ * h->V;
+    a.W = h->text_mode ? h->whead_text : h->whead; a.n_row_tiles = (nv + 15) / 16; a.K = h->H; a.x = h->x_dec; a.lnw = h->lnf;
+    a.logits = h->logits; a.n_valid = nv;
     if (write_hidden && h->io.hiddens) { a.hidden_out = h->io.hiddens; a.hidden_stride = h->sc.max_new * h->H; }
     return launch_gemm(h->cfg.dtype, nbg, PRO_NORM, EPI_LOGITS, a, 1, s);
 }
@@ -382,10 +405,11 @@ static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
 static int run_sample_phase(ctts_gpt* h, hipStream_t s) {
     if (run_heads(h, true, s)) return 1;
     SamplerArgs sa = {};
-    sa.cfg = h->sc; sa.logits = h->logits; sa.V = h->V; sa.B = h->B; sa.st = h->st;
+    sa.cfg = h->sc; sa.logits = h->logits; sa.V = h->text_mode ? h->vocab_text_head : h->V; sa.B = h->B; sa.st = h->st;
+    sa.text_mode = h->text_mode;
     sa.ids = h->io.ids; sa.finish = h->io.finish; sa.end_idx = h->io.end_idx;
     sa.noise = h->io.noise; sa.n_draws = h->io.n_draws; sa.seed = h->io.seed;
-    sa.emb_code = h->emb_code; sa.H = h->H; sa.x_next = h->x_dec; sa.meta = h->meta_dec; sa.rope = h->rope; sa.rope_rows = h->rope_dec;
+    sa.emb_code = h->text_mode ? h->emb_text : h->emb_code; sa.H = h->H; sa.x_next = h->x_dec; sa.meta = h->meta_dec; sa.rope = h->rope; sa.rope_rows = h->rope_dec;
     return launch_sampler(sa, h->B, s);
 }
 
@@ -407,7 +431,12 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
         ctts_set_error("begin: B=%d T=%d max_new=%d exceed max_batch=%d / max_seq=%d", B, T, sc->max_new_token, h->cfg.max_batch, h->cfg.max_seq);
         return 1;
     }
-    if (sc->past_window > 16 || sc->eos_token >= h->V) { ctts_set_error("begin: past_window>16 or eos out of range"); return 1; }
+    h->text_mode = sc->infer_text ? 1 : 0;
+    if (h->text_mode) {
+        if (!h->whead_text || !h->emb_text) { ctts_set_error("begin: infer_text needs head_text.* and emb_text.weight"); return 1; }
+        if (sc->use_penalty) { ctts_set_error("begin: infer_text supports repetition_penalty == 1 only (the reference's processor mis-broadcasts the [B,n,1] history in this mode)"); return 1; }
+        if (sc->eos_token >= h->vocab_text_head) { ctts_set_error("begin: eos out of range"); return 1; }
+    } else if (sc->past_window > 16 || sc->eos_token >= h->V) { ctts_set_error("begin: past_window>16 or eos out of range"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     h->B = B; h->T = T; h->io = *io;
     memcpy(h->sc.temperature, sc->temperature, sizeof(sc->temperature));
@@ -470,7 +499,7 @@ static int ensure_graph(ctts_gpt* h) {
              h->sc.max_new, h->sc.temperature[0], h->sc.top_p_threshold, h->sc.top_k, h->sc.min_new, h->sc.use_penalty, h->sc.eos);
     std::string key(sig);
     for (int i = 0; i < 4; ++i) key += "|" + std::to_string(h->sc.temperature[i]);
-    key += "|" + std::to_string(h->sc.penalty_table[1]);
+    key += "|" + std::to_string(h->sc.penalty_table[1]) + "|" + std::to_string(h->text_mode);
     if (h->gexec && key == h->graph_sig) return 0;
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -511,7 +540,7 @@ extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_
 
 extern "C" int ctts_gpt_logits(ctts_gpt* h, float* out, void* stream) {
     if (!h || !out || h->B == 0) { ctts_set_error("logits: call begin first"); return 1; }
-    CTTS_HIP_CHECK(hipMemcpyAsync(out, h->logits, (size_t)h->B * h->NVQ * h->V * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    CTTS_HIP_CHECK(hipMemcpyAsync(out, h->logits, (size_t)h->B * (h->text_mode ? h->vocab_text_head : h->NVQ * h->V) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 

@@ -84,6 +84,7 @@ struct SamplerArgs {
     const float* noise;     // [n_draws][B*4][V] or null
     int n_draws;
     unsigned long long seed;
+    int text_mode;          // refine-text pass: one V_text-wide row per sequence, emb_code points at emb_text [V_text][H]
     const float* emb_code;  // [4][V][H] fp32
     int H;
     float* x_next;          // [B][H]

@@ -221,6 +221,168 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
     if (tid < 64) a.rope_rows[(size_t)b * 64 + tid] = a.rope[(size_t)pos_s * 64 + tid];   // RoPE row of the next step's position
 }
 
+// ---- refine-text pass (infer_text=True): one 21178-way row per sequence ------------------------------------------------
+// gpt.py:400-401,425-426,458-467,489-494 (called from pipeline:237-277): single temperature, no repetition penalty
+// (repetition_penalty == 1 is the only value the reference's processor handles for this mode), top-p then top-k,
+// min-length, softmax + multinomial, finish on EOS = [Ebreak], next input = emb_text[id].
+// One 1024-thread block per sequence, 21 values per thread; the same "extract the <= top_k largest, fp64 ascending
+// cumsum" scheme as the code sampler with block-wide (DPP + LDS) reductions.
+#define TVPT 21
+struct BlockRed {
+    float f[16];
+    double d[16];
+    unsigned long long k[16];
+};
+__device__ inline float block_max_f(BlockRed& r, float v, int lane, int wave) {
+    v = wave_max(v);
+    if (lane == 0) r.f[wave] = v;
+    __syncthreads();
+    float m = r.f[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, r.f[i]);
+    __syncthreads();
+    return m;
+}
+__device__ inline float block_sum_f(BlockRed& r, float v, int lane, int wave) {
+    v = wave_sum(v);
+    if (lane == 0) r.f[wave] = v;
+    __syncthreads();
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m += r.f[i];
+    __syncthreads();
+    return m;
+}
+__device__ inline double block_sum_d(BlockRed& r, double v, int lane, int wave) {
+    v = wave_sum_d(v);
+    if (lane == 0) r.d[wave] = v;
+    __syncthreads();
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m += r.d[i];
+    __syncthreads();
+    return m;
+}
+__device__ inline unsigned long long block_max_u64(BlockRed& r, unsigned long long v, int lane, int wave) {
+    v = wave_max_u64(v);
+    if (lane == 0) r.k[wave] = v;
+    __syncthreads();
+    unsigned long long m = r.k[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = umax64(m, r.k[i]);
+    __syncthreads();
+    return m;
+}
+
+__global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a) {
+    __shared__ BlockRed red;
+    __shared__ int pos_s;
+    DevState* st = a.st;
+    if (st->all_done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, V = a.V;
+    const int step = st->step, draw = st->draw;
+    const float* lg = a.logits + (size_t)b * V;
+    const float* q = (a.noise != nullptr) ? a.noise + ((size_t)min(draw, a.n_draws - 1) * a.B + b) * V : nullptr;
+    const float T = a.cfg.temperature[0];
+    float x[TVPT];
+    unsigned valid = 0;
+#pragma unroll
+    for (int i = 0; i < TVPT; ++i) {
+        const int j = tid + 1024 * i;
+        if (j < V) { x[i] = __fdiv_rn(lg[j], T); valid |= 1u << i; }          // gpt.py:469
+        else x[i] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < TVPT; ++i) mx = fmaxf(mx, x[i]);
+    mx = block_max_f(red, mx, lane, wave);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < TVPT; ++i) se += ((valid >> i) & 1u) ? expf(x[i] - mx) : 0.f;
+    se = block_sum_f(red, se, lane, wave);
+    const float inv = 1.0f / se;
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < TVPT; ++i) tot += ((valid >> i) & 1u) ? (double)(expf(x[i] - mx) * inv) : 0.0;
+    tot = block_sum_d(red, tot, lane, wave);
+
+    unsigned taken = ~valid, kept = 0;
+    double cum_before = 0.0;
+    float vk = 0.f;
+    const int topk = (a.cfg.top_k > 0) ? a.cfg.top_k : V;
+    for (int r = 0; r < V; ++r) {
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int i = 0; i < TVPT; ++i) {
+            const unsigned long long k = ((unsigned long long)f32_key(x[i]) << 32) | (unsigned)(tid + 1024 * i);
+            if (!((taken >> i) & 1u)) key = umax64(key, k);
+        }
+        const unsigned long long best = block_max_u64(red, key, lane, wave);
+        if (best == 0ull) break;
+        const float bv = key_f32((unsigned)(best >> 32));
+        const int bi = (int)(unsigned)best;
+        if (r >= topk && bv != vk) break;
+        const float cr = (float)(tot - cum_before);
+        if (cr <= a.cfg.top_p_threshold && r >= a.cfg.min_keep) break;
+        if (tid == (bi & 1023)) { taken |= 1u << (bi >> 10); kept |= 1u << (bi >> 10); }
+        if (r == topk - 1) vk = bv;
+        cum_before += (double)(expf(bv - mx) * inv);
+    }
+    if (step < a.cfg.min_new && tid == (a.cfg.eos & 1023)) kept &= ~(1u << (a.cfg.eos >> 10));      // gpt.py:477-478
+    float m2 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < TVPT; ++i) if ((kept >> i) & 1u) m2 = fmaxf(m2, x[i]);
+    m2 = block_max_f(red, m2, lane, wave);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TVPT; ++i) s2 += ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f;
+    s2 = block_sum_f(red, s2, lane, wave);
+    const float inv2 = 1.0f / s2;
+    unsigned long long bkey = 0ull;
+#pragma unroll
+    for (int i = 0; i < TVPT; ++i) {
+        const int j = tid + 1024 * i;
+        if (j < V) {
+            float qq;
+            if (q != nullptr) qq = q[j];
+            else {
+                const uint4 rnd = philox4x32_10(make_uint4((unsigned)j, (unsigned)b, (unsigned)draw, 0x54585453u),
+                                                make_uint2((unsigned)a.seed, (unsigned)(a.seed >> 32)));
+                qq = -logf(((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f));
+            }
+            const float e = ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f;
+            bkey = umax64(bkey, ((unsigned long long)f32_key(__fdiv_rn(e * inv2, qq)) << 32) | (unsigned)(0x7FFFFFFF - j));
+        }
+    }
+    bkey = block_max_u64(red, bkey, lane, wave);
+    const int idx = 0x7FFFFFFF - (int)(unsigned)bkey;
+    // next input = emb_text[idx]  (gpt.py:400-401); ids buffer keeps the reference's [.., num_vq] layout (gpt.py:492-494)
+    for (int k = tid; k < a.H; k += 1024) a.x_next[(size_t)b * a.H + k] = a.emb_code[(size_t)idx * a.H + k];
+    if (tid < CTTS_NUM_VQ) a.ids[((size_t)b * a.cfg.max_new + step) * CTTS_NUM_VQ + tid] = idx;
+    if (tid == 0) {
+        const bool was = a.finish[b] != 0;
+        const bool fin = was || (idx == a.cfg.eos);                                  // gpt.py:490-491
+        a.finish[b] = fin ? 1 : 0;
+        if (!fin) a.end_idx[b] += 1;
+        RowMeta m = a.meta[b];
+        m.pos += 1; m.slot += 1;
+        a.meta[b] = m;
+        pos_s = m.pos;
+        const int add = 1 + ((fin && !was) ? 0x10000 : 0);
+        const int tot_t = __hip_atomic_fetch_add(&st->ticket, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        if ((tot_t & 0xFFFF) == a.B) {
+            const int nfin = tot_t >> 16;
+            st->ticket = nfin << 16;
+            st->step = step + 1;
+            st->draw = draw + 1;
+            if (nfin == a.B || step + 1 >= a.cfg.max_new) st->all_done = 1;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) a.rope_rows[(size_t)b * 64 + tid] = a.rope[(size_t)pos_s * 64 + tid];
+}
+
 // stand-alone mode (ctts_sampler_run): block = 4 rows
 __global__ __launch_bounds__(256) void sampler_rows_kernel(const SamplerArgs a) {
     const int rows = a.B;
@@ -246,8 +408,11 @@ __global__ __launch_bounds__(256) void sampler_rows_kernel(const SamplerArgs a) 
 }
 
 int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s) {
-    if (a.V > 64 * VPL) { ctts_set_error("sampler: vocab %d > %d", a.V, 64 * VPL); return 1; }
-    if (a.st != nullptr) hipLaunchKernelGGL(sampler_generate_kernel, dim3(a.B), dim3(256), 0, s, a);
+    if (!a.text_mode && a.V > 64 * VPL) { ctts_set_error("sampler: vocab %d > %d", a.V, 64 * VPL); return 1; }
+    if (a.st != nullptr && a.text_mode) {
+        if (a.V > 1024 * TVPT) { ctts_set_error("text sampler: vocab %d > %d", a.V, 1024 * TVPT); return 1; }
+        hipLaunchKernelGGL(sampler_text_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    } else if (a.st != nullptr) hipLaunchKernelGGL(sampler_generate_kernel, dim3(a.B), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(sampler_rows_kernel, dim3(blocks), dim3(256), 0, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;

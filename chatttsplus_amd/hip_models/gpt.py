@@ -52,7 +52,7 @@ class Context:                    # gpt.py:87-95
 
 
 def sampler_cfg_from_objects(temperature, eos_token, max_new_token, min_new_token, logits_warpers, logits_processors,
-                             num_vq=4) -> _lib.SamplerCfg:
+                             num_vq=4, infer_text=False) -> _lib.SamplerCfg:
     """Reads the scalars off the HF warpers / reference processor objects that processors.gen_logits builds
     (models/processors.py:37-57).  Unknown object types are rejected (no silent host fallback)."""
     sc = _lib.SamplerCfg()
@@ -90,6 +90,10 @@ def sampler_cfg_from_objects(temperature, eos_token, max_new_token, min_new_toke
     sc.eos_token = int(eos_token)
     sc.min_new_token = int(min_new_token)
     sc.max_new_token = int(max_new_token)
+    sc.infer_text = 1 if infer_text else 0
+    if infer_text and sc.use_penalty:
+        raise _lib.HipBackendError("infer_text=True supports repetition_penalty == 1 only: the reference's processor receives a [B,n,1] "
+                                   "history in this mode and mis-broadcasts it (models/processors.py:18-34 with gpt.py:458-467)")
     return sc
 
 
@@ -230,8 +234,6 @@ class GPT:
         """`noise`: "torch" draws q = empty(B*4,V).exponential_() per step from torch's CPU generator -- the
         very numbers torch.multinomial consumes in the reference, so TorchSeedContext(seed) reproduces the CPU
         path's tokens; "device" uses the on-device Philox generator (`seed`); or an array [n_draws, B*4, V]."""
-        if infer_text:
-            raise _lib.HipBackendError("infer_text=True (refine-text path) is not served by the hip backend yet (SURVEY 8f N1)")
         if return_attn:
             raise _lib.HipBackendError("return_attn=True is unsupported (the reference's eager attention path is broken, SURVEY F2)")
         if not self._finalized:
@@ -239,10 +241,12 @@ class GPT:
         context = context or Context()
         lib, h = self._lib, self._h
         B, T = int(inputs_ids.shape[0]), int(inputs_ids.shape[1])
-        V, H, NVQ = self.num_audio_tokens, self.model_dim, self.num_vq
+        V, H, NVQ = (self.num_text_tokens if infer_text else self.num_audio_tokens), self.model_dim, self.num_vq
+        rows_per_seq = 1 if infer_text else NVQ          # multinomial rows per sequence: [B, V_text] vs [B*4, 626] (gpt.py:444-467)
         dev = self.device
         max_new_token = int(max_new_token)
-        sc = sampler_cfg_from_objects(temperature, int(eos_token), max_new_token, min_new_token, logits_warpers, logits_processors, NVQ)
+        sc = sampler_cfg_from_objects(temperature, int(eos_token), max_new_token, min_new_token, logits_warpers, logits_processors, NVQ,
+                                      infer_text=infer_text)
         mask = torch.ones(B, T, dtype=torch.int32, device=dev) if attention_mask is None else attention_mask.to(dev).to(torch.int32).contiguous()
         emb = emb.to(dev, dtype=torch.float32).contiguous()
         ids = torch.zeros(B, max_new_token, NVQ, dtype=torch.int32, device=dev)
@@ -254,7 +258,7 @@ class GPT:
         rng_states = []
         host_q = None
         if isinstance(noise, str) and noise == "torch":
-            qbuf = torch.empty(n_draws, B * NVQ, V, dtype=torch.float32, device=dev)
+            qbuf = torch.empty(n_draws, B * rows_per_seq, V, dtype=torch.float32, device=dev)
         elif isinstance(noise, str) and noise == "device":
             qbuf = None
         else:
@@ -276,7 +280,7 @@ class GPT:
             chunk = []
             for _ in range(n - drawn):
                 rng_states.append(torch.random.get_rng_state())
-                chunk.append(torch.empty(B * NVQ, V, dtype=torch.float32).exponential_(1))
+                chunk.append(torch.empty(B * rows_per_seq, V, dtype=torch.float32).exponential_(1))
             qbuf[drawn:n].copy_(torch.stack(chunk), non_blocking=False)
             drawn = n
 
@@ -310,9 +314,9 @@ class GPT:
                 if steps.value == prev and not alld.value:
                     raise _lib.HipBackendError("decode made no progress (device state inconsistent)")
                 if stream and not alld.value and steps.value < max_new_token:
-                    yield self._outputs(ids, hid, end_idx)
+                    yield self._outputs(ids, hid, end_idx, infer_text)
             self._restore_rng(rng_states, used_draws)
-            yield self._outputs(ids, hid, end_idx)
+            yield self._outputs(ids, hid, end_idx, infer_text)
 
     @staticmethod
     def _restore_rng(states, used):
@@ -320,9 +324,11 @@ class GPT:
         if states and used < len(states):
             torch.random.set_rng_state(states[used])
 
-    def _outputs(self, ids, hid, end_idx) -> GenerationOutputs:
+    def _outputs(self, ids, hid, end_idx, infer_text=False) -> GenerationOutputs:
         n = end_idx.cpu().tolist()
         out_ids = [ids[b, :n[b]].to(torch.long) for b in range(len(n))]                # gpt.py:295-297
+        if infer_text:
+            out_ids = [i[:, 0] for i in out_ids]                                        # gpt.py:298-299
         out_h = [hid[b, :n[b]] for b in range(len(n))] if hid is not None else []     # gpt.py:301-305
         return GenerationOutputs(ids=out_ids, attentions=[], hiddens=out_h)
 

@@ -7,8 +7,7 @@ chattts_plus/pipelines/chattts_plus_pipeline.py for the hot path:
 What is kept: constructor kwargs, YAML layout (MODELS.<key>.{name,infer_type,kwargs}), `infer()` /
 `_infer()` / `_infer_code()` / `_decode_to_wavs()` / speaker helpers, the generator-of-wav-lists result,
 InferCodeParams / RefineTextParams.  What is delegated (out of the hot-path scope): text
-normalisation / splitting (pluggable callables, identity by default) and the refine-text pass
-(`skip_refine_text=True` is required this round -- it fails loudly otherwise).  There is no CPU fallback.
+normalisation / splitting (pluggable callables, identity by default).  There is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -227,6 +226,19 @@ class ChatTTSPlusPipeline:
                             logits_processors=processors, infer_text=False, return_hidden=return_hidden, stream=stream,
                             show_tqdm=params.show_tqdm, ensure_non_empty=params.ensure_non_empty, stream_batch=params.stream_batch)
 
+    @torch.no_grad()
+    def _refine_text(self, text, params: RefineTextParams):
+        """pipeline:237-277: "[Sbreak]{text}[Pbreak]{prompt}" -> GPT.generate(infer_text=True) on the 21178-way text head."""
+        gpt, tok = self.models_dict["gpt"], self.models_dict["tokenizer"]
+        text = [f"[Sbreak]{i}[Pbreak]{params.prompt}" for i in text]
+        input_ids, attention_mask, text_mask = tok.encode(text, gpt.num_vq, device=self.device)
+        warpers, processors = gen_logits(num_code=tok.len, top_P=params.top_P, top_K=params.top_K, repetition_penalty=params.repetition_penalty)
+        emb = gpt(input_ids, text_mask)
+        return next(gpt.generate(emb, input_ids, temperature=torch.tensor([params.temperature]), eos_token=tok.eos_token,
+                                 attention_mask=attention_mask, max_new_token=params.max_new_token, min_new_token=params.min_new_token,
+                                 logits_warpers=warpers, logits_processors=processors, infer_text=True, stream=False,
+                                 show_tqdm=params.show_tqdm, ensure_non_empty=params.ensure_non_empty))
+
     @torch.inference_mode()
     def _decode_to_wavs(self, result_list, use_decoder: bool = True):
         """pipeline:286-305: per utterance hidden[n,768] -> DVAE -> mel[1,100,2n] -> Vocos -> wav[256(2n-1)]."""
@@ -260,13 +272,20 @@ class ChatTTSPlusPipeline:
         if do_text_optimization and self.text_splitter is not None:
             text_in = self.text_splitter(text_in)                         # pipeline:353-377 (pluggable; CPU text work)
         text_in = [self.normalizer(t, do_text_normalization, do_homophone_replacement, lang) for t in text_in]
-        if not skip_refine_text or refine_text_only:
-            raise _lib.HipBackendError("the refine-text pass (infer_text=True, head_text) is not served by the hip backend this "
-                                       "round (SURVEY 8f N1): pass skip_refine_text=True")
         slice_size = int(kwargs.get("slice_size", self.models_dict["gpt"].max_batch))     # reference: 4 (pipeline:391)
         gpt = self._gpt_for_lora(kwargs.get("lora_path"))
+        tok = self.models_dict["tokenizer"]
         for ii in range(0, len(text_in), slice_size):
-            text = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in text_in[ii:ii + slice_size]]   # pipeline:414-416
+            text = list(text_in[ii:ii + slice_size])
+            if not skip_refine_text:                                                   # pipeline:399-411
+                refined = self._refine_text(text, params_refine_text)
+                text_tokens = [i[i.less(tok.break_0_ids)] for i in refined.ids]
+                text = tok.decode(text_tokens)
+                if refine_text_only:
+                    yield text
+            if refine_text_only:
+                continue
+            text = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in text]   # pipeline:414-416
             length, pass_batch_count, wavs = 0, 0, None
             for result in self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt):
                 wavs = self._decode_to_wavs(result.hiddens, use_decoder)

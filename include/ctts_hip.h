@@ -64,8 +64,8 @@ void ctts_gpt_destroy(ctts_gpt* h);
  * state-dict key; `data` is HOST fp32, row-major, `numel` elements.
  * Accepted keys: gpt.layers.N.{self_attn.{q,k,v,o}_proj,mlp.{gate,up,down}_proj,input_layernorm,
  * post_attention_layernorm}.weight, gpt.norm.weight, emb_code.N.weight,
- * emb_text.weight, head_code.N.parametrizations.weight.original{0,1}.  head_text.* is ignored with return code 0
- * (refine-text pass: next round). */
+ * emb_text.weight, head_code.N.parametrizations.weight.original{0,1}, head_text.parametrizations.weight.original{0,1}
+ * (the last two + emb_text enable the refine-text pass, infer_text=1). */
 int ctts_gpt_set_weight(ctts_gpt* h, const char* name, const float* data, size_t numel);
 
 /* LoRA merge rule of peft merge_and_unload (pipeline:420-432): W += scale * B @ A for one target
@@ -97,6 +97,8 @@ typedef struct {
     int32_t eos_token;                /* num_embeddings-1 = 625 (pipeline:209) */
     int32_t min_new_token;            /* (gpt.py:477-478) */
     int32_t max_new_token;
+    int32_t infer_text;               /* 1: refine-text pass (gpt.py infer_text=True: 21178-way head_text, temperature[0] only,
+                                         next input = emb_text[id], use_penalty must be 0); noise is then [n_draws][B][vocab_text] */
 } ctts_sampler_cfg;
 
 /* Outputs of one generate() call, all device memory provided by the caller:

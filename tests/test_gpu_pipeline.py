@@ -62,15 +62,44 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
         rms = float(np.sqrt(np.mean((wavs[b] - wav_ref) ** 2))) / float(np.sqrt(np.mean(wav_ref ** 2)))
         assert rms <= 1e-3, f"utterance {b}: waveform rms-rel {rms}"
 
+    # default infer() path: refine-text pass first (pipeline:399-411), then code inference on the refined text
+    from chatttsplus_amd.pipeline import RefineTextParams
+    rp = RefineTextParams(max_new_token=6, show_tqdm=False)
+    only = list(pipe.infer(list(texts), skip_refine_text=False, refine_text_only=True, do_text_optimization=False, params_refine_text=rp,
+                           params_infer_code=InferCodeParams(spk_emb=spk, max_new_token=8, show_tqdm=False)))
+    assert len(only) == 1 and len(only[0]) == 2 and all(isinstance(t, str) for t in only[0])
+    full = list(pipe.infer(list(texts), skip_refine_text=False, do_text_optimization=False, params_refine_text=rp,
+                           params_infer_code=InferCodeParams(spk_emb=spk, max_new_token=8, min_new_token=8, show_tqdm=False)))
+    assert len(full) == 1 and [w.shape[0] for w in full[0]] == [256 * 15, 256 * 15]
 
-def test_pipeline_rejects_unserved_paths(tmp_path):
-    from chatttsplus_amd import _lib
-    from chatttsplus_amd.pipeline import ChatTTSPlusPipeline
-    pipe = object.__new__(ChatTTSPlusPipeline)
-    pipe.normalizer = lambda t, *a, **k: t
-    pipe.text_splitter = None
-    with pytest.raises(_lib.HipBackendError):
-        next(pipe._infer(["x"], skip_refine_text=False))
+
+def test_refine_text_generate_golden_bit_exact():
+    """infer_text=True on the HIP path (21178-way head, emb_text re-embed, 1024-thread text sampler) reproduces the token ids
+    of the imported reference under the same torch seed (fp32 parity mode), including a ragged early-EOS batch."""
+    from chatttsplus_amd.hip_models import GPT
+    from chatttsplus_amd.pipeline import gen_logits
+    from tests.helpers import load_golden
+    for name in ("gpt_real_text_b2", "gpt_real_text_eos"):
+        z, meta = load_golden(name)
+        sd = synth.gpt_state_dict(synth.GPT_REAL, int(meta["weight_seed"]))
+        eos = int(meta["eos"])
+        sd["head_text.parametrizations.weight.original0"][eos] *= float(meta["eos_boost"])
+        g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=4, max_seq_len=128, weight_dtype="fp32")
+        g.load_state_dict(sd)
+        B, T = int(meta["B"]), int(meta["T"])
+        ids, mask = synth.prompt_ids(B, T, 21178, int(meta["prompt_seed"]), pad_left=[int(x) for x in meta["pad_left"]])
+        emb = g(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))
+        w, p = gen_logits(21178, 0.7, 20, 1.0)
+        torch.manual_seed(int(meta["torch_seed"]))
+        out = next(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.7]), eos, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]),
+                              min_new_token=int(meta["min_new"]), logits_warpers=w, logits_processors=p, infer_text=True))
+        assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist(), name
+        for b, n in enumerate(z["lens"]):
+            assert out.ids[b].dim() == 1 and np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64)), f"{name} row {b}"
+        with pytest.raises(Exception):
+            w2, p2 = gen_logits(21178, 0.7, 20, 1.2)
+            next(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.7]), eos, max_new_token=4, logits_warpers=w2, logits_processors=p2, infer_text=True))
+        del g
 
 
 def test_lora_merge_matches_oracle():
