@@ -107,8 +107,10 @@ def test_capacity_and_argument_errors(gpt32):
     with pytest.raises(_lib.HipBackendError):
         emb33 = g(torch.from_numpy(ids33), torch.ones(33, 4, dtype=torch.bool))
         list(g.generate(emb33, torch.from_numpy(ids33), torch.tensor([0.3] * 4), 625, max_new_token=4, logits_warpers=LW, logits_processors=LP))
+    with pytest.raises(_lib.HipBackendError, match="repetition_penalty"):       # the only unsupported combination of the text pass
+        list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.7]), 21177, max_new_token=4, logits_warpers=LW, logits_processors=LP, infer_text=True))
     with pytest.raises(_lib.HipBackendError):
-        list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, max_new_token=4, infer_text=True))
+        list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, max_new_token=4, return_attn=True))
 
 
 def test_interrupt_context_stops_generation(gpt32):
