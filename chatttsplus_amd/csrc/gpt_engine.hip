@@ -331,7 +331,7 @@ extern "C" int ctts_gpt_bind_kv(ctts_gpt* h, void* kv, size_t bytes) {
 extern "C" int ctts_gpt_set_rope(ctts_gpt* h, const float* rope_host, int n_pos) {
     if (!h || !rope_host || n_pos < h->cfg.max_seq) { ctts_set_error("set_rope: need at least max_seq=%d positions", h ? h->cfg.max_seq : 0); return 1; }
     if (h->rope) (void)hipFree(h->rope);
-    if (dev_alloc((void**)&h->rope, (size_t)n_pos * 64 * 4)) return 1;
+    if (dev_alloc((void**)&h->rope, (size_t)(n_pos + 1) * 64 * 4)) return 1;   // +1: the sampler prefetches the row of the position after the last one
     CTTS_HIP_CHECK(hipMemcpy(h->rope, rope_host, (size_t)n_pos * 64 * 4, hipMemcpyHostToDevice));
     h->rope_n = n_pos;
     return 0;
@@ -343,6 +343,7 @@ static inline void* kv_layer(ctts_gpt* h, int l, int which) {
     return h->kv + ((size_t)l * 2 + which) * per;
 }
 static inline int decode_splits(const ctts_gpt* h, int B) {
+    if (const char* e = getenv("CTTS_SPLITS")) { int v = atoi(e); if (v >= 1 && v <= SMAX) return v; }
     int s = 256 / (B * h->NH);
     return s < 1 ? 1 : (s > SMAX ? SMAX : s);
 }

@@ -141,15 +141,19 @@ __device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn&
     for (int i = 0; i < VPL; ++i) {
         const int j = lane + 64 * i;
         if (j < V) {
-            float q;
-            if (in.q != nullptr) q = in.q[j];
-            else {
-                const uint4 rnd = philox4x32_10(make_uint4((unsigned)j, in.row, in.draw, 0x43545453u),
-                                                make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
-                const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
-                q = -logf(u);
+            // elements outside the kept set have p == 0 -> ratio 0 whatever q is: only kept ones draw noise
+            float ratio = 0.f;
+            if ((kept >> i) & 1u) {
+                float q;
+                if (in.q != nullptr) q = in.q[j];
+                else {
+                    const uint4 rnd = philox4x32_10(make_uint4((unsigned)j, in.row, in.draw, 0x43545453u),
+                                                    make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
+                    const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                    q = -logf(u);
+                }
+                ratio = __fdiv_rn(e2[i] * inv2, q);
             }
-            const float ratio = __fdiv_rn(e2[i] * inv2, q);
             bkey = umax64(bkey, ((unsigned long long)f32_key(ratio) << 32) | (unsigned)(0x7FFFFFFF - j));
         }
     }
@@ -162,13 +166,17 @@ __device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn&
 __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs a) {
     __shared__ float tab[17];
     __shared__ int idx_s[CTTS_NUM_VQ];
-    __shared__ int pos_s;
     DevState* st = a.st;
     if (st->all_done) return;
     const int tid = threadIdx.x, lane = tid & 63, vq = tid >> 6;
     const int b = blockIdx.x;
     const int step = st->step, draw = st->draw;
     if (tid < 17) tab[tid] = a.cfg.penalty_table[tid];
+    // bookkeeping state and the next position's RoPE row are requested now, consumed after the sampling (they used to be
+    // a chain of dependent round trips at the tail of this single-block kernel)
+    const RowMeta meta_in = a.meta[b];
+    const int fin_in = a.finish[b], end_in = a.end_idx[b];
+    const float rope_next = (tid < 64) ? a.rope[(size_t)(meta_in.pos + 1) * 64 + tid] : 0.f;
     __syncthreads();
     const int row = b * CTTS_NUM_VQ + vq;
     RowIn in;
@@ -196,19 +204,19 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
         a.x_next[(size_t)b * a.H + k] = s;
     }
     if (tid == 0) {
-        const bool was = a.finish[b] != 0;
+        const bool was = fin_in != 0;
         bool fin = was;
         for (int v = 0; v < CTTS_NUM_VQ; ++v) fin = fin || (idx_s[v] == a.cfg.eos);   // gpt.py:486-487
         a.finish[b] = fin ? 1 : 0;
-        if (!fin) a.end_idx[b] += 1;                                                // gpt.py:530-531
-        RowMeta m = a.meta[b];                                                     // next decode row
+        if (!fin) a.end_idx[b] = end_in + 1;                                        // gpt.py:530-531
+        RowMeta m = meta_in;                                                       // next decode row
         m.pos += 1; m.slot += 1;
         a.meta[b] = m;
-        pos_s = m.pos;
         // One agent-scope atomic carries both the arrival ticket (low 16 bits) and the number of finished
         // sequences (high 16 bits, persistent over the steps): no fences, no cross-block plain loads.
         const int add = 1 + ((fin && !was) ? 0x10000 : 0);
-        const int tot = __hip_atomic_fetch_add(&st->ticket, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        // single sequence: no other block to wait for, no atomic round trip
+        const int tot = (a.B == 1) ? (st->ticket + add) : (__hip_atomic_fetch_add(&st->ticket, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add);
         if ((tot & 0xFFFF) == a.B) {                           // last block of this step: advance the step state
             const int nfin = tot >> 16;
             st->ticket = nfin << 16;
@@ -217,8 +225,7 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
             if (nfin == a.B || step + 1 >= a.cfg.max_new) st->all_done = 1;         // gpt.py:545 / loop bound :389
         }
     }
-    __syncthreads();
-    if (tid < 64) a.rope_rows[(size_t)b * 64 + tid] = a.rope[(size_t)pos_s * 64 + tid];   // RoPE row of the next step's position
+    if (tid < 64) a.rope_rows[(size_t)b * 64 + tid] = rope_next;      // RoPE row of the next step's position (prefetched)
 }
 
 // ---- refine-text pass (infer_text=True): one 21178-way row per sequence ------------------------------------------------
