@@ -3,7 +3,7 @@
 #include "common.h"
 
 enum { PRO_NORM = 0, PRO_ATTN = 1, PRO_PACKED = 2, PRO_NORM_P = 3 };     // _P: residual stream = x + sum of per-head o_proj partials
-enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_P = 4 };
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_P = 4, EPI_PART = 5 };   // PART: write a split-K partial, no residual
 #define CTTS_NPART 12      // o_proj partials per row = attention heads (fused attention+o_proj path)
 
 // out[R rows][N] = prologue(x)[R][K] . W[N][K]^T  followed by a fused epilogue.
@@ -17,7 +17,10 @@ struct GemmArgs {
     // prologues
     const float* x;         // PRO_NORM: residual stream [R][K] fp32
     const float* lnw;       // PRO_NORM: RMSNorm weight [K] -- only for hidden_out (the weight is folded into W's columns)
-    const float* opart;     // PRO_NORM_P / EPI_RESID_P: per-head o_proj partial sums [R][CTTS_NPART][K] fp32
+    const float* opart;     // PRO_NORM_P / EPI_RESID_P: partial sums added to the residual stream in index order, [R][np][K] fp32
+    int np;                 //   how many (<= CTTS_NPART): 12 per-head o_proj partials (fused attention) or 4 split-K down partials
+    int ktiles_total;       // EPI_PART: k-tiles of the whole matrix (the block's slice is blockIdx.z * KTILES); 0 = KTILES
+    float* part_out;        // EPI_PART: [R][gridDim.z][N] fp32
     float eps;
     float* hidden_out;      // PRO_NORM (heads only): normalised rows -> hiddens[seq][step][K]; may be null
     int hidden_stride;      //   = max_new_token * K

@@ -73,7 +73,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     // LOAD ORDER MATTERS: vmcnt retires in order, so a wait on any load issued after the weight stream is a wait on
     // the whole stream.  Everything the prologue needs is therefore requested first, the (non-temporal) weight
     // fragments last; nothing issued after them is consumed before the MFMAs.
-    const frag* Wp = (const frag*)a.W + ((size_t)rt * KTILES + (size_t)wave * KPW) * 64 + lane;
+    // split-K launches (EPI_PART): this block owns k-tiles [blockIdx.z*KTILES, +KTILES) of a matrix with ktiles_total k-tiles
+    const int kt_all = (EPI == EPI_PART) ? a.ktiles_total : KTILES;
+    const int kt_off = (EPI == EPI_PART) ? (int)blockIdx.z * KTILES : 0;
+    const frag* Wp = (const frag*)a.W + ((size_t)rt * kt_all + kt_off + (size_t)wave * KPW) * 64 + lane;
     frag wf[KPW];
     // (sched_barrier: hipcc otherwise hoists the weight loads above the prologue loads again)
 #define CTTS_ISSUE_WEIGHT_LOADS()                                                            \
@@ -94,10 +97,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
             float v = 0.f;
             if (t < 16 * NB && r < a.R) {
                 v = a.x_out[(size_t)r * N + col];
-                if (EPI == EPI_RESID_P) {            // x_mid = ((x + p0) + p1) + ... : attention/o_proj partials in head order
+                if (EPI == EPI_RESID_P) {            // x = ((x + p0) + p1) + ... : partial sums in index order
                     float pp[CTTS_NPART];
 #pragma unroll
-                    for (int q = 0; q < CTTS_NPART; ++q) pp[q] = a.opart[((size_t)r * CTTS_NPART + q) * N + col];
+                    for (int q = 0; q < CTTS_NPART; ++q) pp[q] = (q < a.np) ? a.opart[((size_t)r * a.np + q) * N + col] : 0.f;
 #pragma unroll
                     for (int q = 0; q < CTTS_NPART; ++q) v += pp[q];
                 }
@@ -149,7 +152,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
 #pragma unroll
                 for (int q = 0; q < CTTS_NPART; ++q)
 #pragma unroll
-                    for (int i = 0; i < PER; ++i) pp[q][i] = ((const f32x4*)(a.opart + (rr * CTTS_NPART + q) * K))[lane + 64 * i];
+                    for (int i = 0; i < PER; ++i)
+                        pp[q][i] = (q < a.np) ? ((const f32x4*)(a.opart + (rr * a.np + q) * K))[lane + 64 * i] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < CTTS_NPART; ++q)
 #pragma unroll
@@ -257,14 +261,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
 #pragma unroll
     for (int g = 0; g < NBG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const frag* xs = (const frag*)smem;
-    const frag* xg = (const frag*)a.xpacked + (size_t)chunk * NBG * KTILES * 64;
+    const frag* xg = (const frag*)a.xpacked + (size_t)chunk * NBG * kt_all * 64;
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         const int kt = wave * KPW + i;
 #pragma unroll
         for (int g = 0; g < NBG; ++g) {
             frag b;
-            if (PRO == PRO_PACKED) b = xg[(size_t)(g * KTILES + kt) * 64 + lane];
+            if (PRO == PRO_PACKED) b = xg[(size_t)(g * kt_all + kt_off + kt) * 64 + lane];
             else b = xs[(g * KTILES + kt) * 64 + lane];
             acc[g] = Mma<WT>::run(wf[i], b, acc[g]);
         }
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     __syncthreads();
 
     // 5. fused epilogue
-    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_LOGITS) {
+    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_LOGITS || EPI == EPI_PART) {
 #pragma unroll
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
@@ -298,7 +302,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
             if (r >= a.R) continue;
             const int col = rt * 16 + i;
             const float v = outt[i * NB + n];
-            if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
+            if (EPI == EPI_PART) {
+                a.part_out[((size_t)r * gridDim.z + blockIdx.z) * (a.n_row_tiles * 16) + col] = v;
+            } else if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
                 a.x_out[(size_t)r * (a.n_row_tiles * 16) + col] = resid_pf[u] + v;   // residual + proj (llama.py:731,739)
             } else if (col < a.n_valid) {
                 a.logits[(size_t)r * a.n_valid + col] = v;
@@ -351,11 +357,15 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         return 0;
     }
-    if (a.K != KTILES * WTraits<WT>::KT) {
+    int nz = 1;
+    if (EPI == EPI_PART) {
+        if (a.ktiles_total % KTILES || a.K != a.ktiles_total * WTraits<WT>::KT) { ctts_set_error("skinny_gemm: split-K tiling mismatch"); return 1; }
+        nz = a.ktiles_total / KTILES;
+    } else if (a.K != KTILES * WTraits<WT>::KT) {
         ctts_set_error("skinny_gemm: K=%d does not match the compiled tiling %d", a.K, KTILES * WTraits<WT>::KT);
         return 1;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles, chunks), dim3(WAVES * 64), LDS, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles, chunks, nz), dim3(WAVES * 64), LDS, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -381,6 +391,10 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         if constexpr (NBG == 1) {
             rc |= launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_SWIGLU>(a, chunks, s, true);
             rc |= launch_one<WT, 1, W3072, P3072, PRO_PACKED, EPI_RESID_P>(a, chunks, s, true);
+            rc |= launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_QKV>(a, chunks, s, true);
+            rc |= launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_LOGITS>(a, chunks, s, true);
+            rc |= launch_one<WT, 1, W768, P768, PRO_ATTN, EPI_RESID_P>(a, chunks, s, true);
+            rc |= launch_one<WT, 1, W768, P768, PRO_PACKED, EPI_PART>(a, chunks, s, true);
         }
         return rc;
     }
@@ -392,6 +406,10 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     if (pro == PRO_NORM && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, false);
     if constexpr (NBG == 1) {
         if (pro == PRO_NORM_P && epi == EPI_SWIGLU) return launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_SWIGLU>(a, chunks, s, false);
+        if (pro == PRO_NORM_P && epi == EPI_QKV) return launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_QKV>(a, chunks, s, false);
+        if (pro == PRO_NORM_P && epi == EPI_LOGITS) return launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_LOGITS>(a, chunks, s, false);
+        if (pro == PRO_ATTN && epi == EPI_RESID_P) return launch_one<WT, 1, W768, P768, PRO_ATTN, EPI_RESID_P>(a, chunks, s, false);
+        if (pro == PRO_PACKED && epi == EPI_PART) return launch_one<WT, 1, W768, P768, PRO_PACKED, EPI_PART>(a, chunks, s, false);
         if (pro == PRO_PACKED && epi == EPI_RESID_P) return launch_one<WT, 1, W3072, P3072, PRO_PACKED, EPI_RESID_P>(a, chunks, s, false);
     }
     ctts_set_error("skinny_gemm: unsupported prologue/epilogue %d/%d", pro, epi);
