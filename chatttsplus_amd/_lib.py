@@ -73,6 +73,7 @@ SYMBOLS = [
     ("ctts_gpt_restart", C.c_int, [_P, _P]),
     ("ctts_gpt_decode", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("ctts_gpt_progress", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
+    ("ctts_gpt_progress_enqueue", C.c_int, [_P, _P, _P]),
     ("ctts_gpt_logits", C.c_int, [_P, _P, _P]),
     ("ctts_gpt_force_ids", C.c_int, [_P, _P, _P]),
     ("ctts_sampler_run", C.c_int, [C.POINTER(SamplerCfg), _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -78,9 +79,12 @@ struct ctts_gpt {
     SamplerCfgDev sc;
     ctts_gen_io io = {};
     hipStream_t cap_stream = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
-    std::string graph_sig;
+    SamplerDyn* dyn = nullptr;                   // device copy of the per-call sampler state (rewritten by begin; read by the heads + sampler nodes)
+    // Captured decode graphs, keyed by what shapes the launches (batch, mode, KV binding): caller buffers and sampling
+    // parameters are read from `dyn` at run time, so consecutive generate() calls replay the same executable graph.
+    struct GraphEntry { hipGraph_t graph; hipGraphExec_t exec; };
+    std::map<std::string, GraphEntry> graphs;
+    hipGraphExec_t gexec = nullptr;              // entry selected by the last ensure_graph
     int graph_steps = 4;                         // decode steps captured per graph (env CTTS_GRAPH_STEPS): a replay costs ~8 us of
                                                  // GPU-side gap, amortised over 4 x 102 kernel nodes
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -124,9 +128,8 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
 
 extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
-    if (h->graph) (void)hipGraphDestroy(h->graph);
-    void* bufs[] = {h->wblob, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
+    for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+    void* bufs[] = {h->dyn, h->wblob, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->opart, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
@@ -303,7 +306,8 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->opart, (size_t)16 * NH * H * 4) || dev_alloc((void**)&h->dpart, (size_t)16 * 4 * H * 4) || dev_alloc(&h->attn_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
-        dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4))
+        dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4) ||
+        dev_alloc((void**)&h->dyn, sizeof(SamplerDyn)))
         return 1;
     CTTS_HIP_CHECK(hipHostMalloc((void**)&h->host_pin, 64));
     {
@@ -331,7 +335,7 @@ extern "C" size_t ctts_gpt_kv_bytes(const ctts_gpt* h) {
 extern "C" int ctts_gpt_bind_kv(ctts_gpt* h, void* kv, size_t bytes) {
     if (!h || !kv || bytes < ctts_gpt_kv_bytes(h)) { ctts_set_error("bind_kv: need %zu bytes", h ? ctts_gpt_kv_bytes(h) : 0); return 1; }
     h->kv = (char*)kv; h->kv_bytes = bytes;
-    h->graph_sig.clear();
+    // graphs are keyed by the KV pointer; entries captured against an older binding are simply never selected again
     return 0;
 }
 extern "C" int ctts_gpt_set_rope(ctts_gpt* h, const float* rope_host, int n_pos) {
@@ -415,7 +419,7 @@ static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
     const int nv = h->text_mode ? h->vocab_text_head : h->NVQ * h->V;
     a.W = h->text_mode ? h->whead_text : h->whead; a.n_row_tiles = (nv + 15) / 16; a.K = h->H; a.x = h->x_dec; a.lnw = h->lnf;
     a.logits = h->logits; a.n_valid = nv;
-    if (write_hidden && h->io.hiddens) { a.hidden_out = h->io.hiddens; a.hidden_stride = h->sc.max_new * h->H; }
+    a.dyn = write_hidden ? h->dyn : nullptr;       // the kernel tests dyn->hidden_out itself
     a.opart = h->dpart; a.np = h->x_has_parts ? 4 : 0;
     return launch_gemm(h->cfg.dtype, nbg, (nbg == 1 && h->split_rows > 0 && h->fuse_rows == 0) ? PRO_NORM_P : PRO_NORM, EPI_LOGITS, a, 1, s);
 }
@@ -423,10 +427,8 @@ static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
 static int run_sample_phase(ctts_gpt* h, hipStream_t s) {
     if (run_heads(h, true, s)) return 1;
     SamplerArgs sa = {};
-    sa.cfg = h->sc; sa.logits = h->logits; sa.V = h->text_mode ? h->vocab_text_head : h->V; sa.B = h->B; sa.st = h->st;
+    sa.dyn = h->dyn; sa.logits = h->logits; sa.V = h->text_mode ? h->vocab_text_head : h->V; sa.B = h->B; sa.st = h->st;
     sa.text_mode = h->text_mode;
-    sa.ids = h->io.ids; sa.finish = h->io.finish; sa.end_idx = h->io.end_idx;
-    sa.noise = h->io.noise; sa.n_draws = h->io.n_draws; sa.seed = h->io.seed;
     sa.emb_code = h->text_mode ? h->emb_text : h->emb_code; sa.H = h->H; sa.x_next = h->x_dec; sa.meta = h->meta_dec; sa.rope = h->rope; sa.rope_rows = h->rope_dec;
     return launch_sampler(sa, h->B, s);
 }
@@ -462,6 +464,10 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
     h->sc.use_penalty = sc->use_penalty; memcpy(h->sc.penalty_table, sc->penalty_table, sizeof(sc->penalty_table));
     h->sc.past_window = sc->past_window; h->sc.max_input_ids = sc->max_input_ids; h->sc.eos = sc->eos_token;
     h->sc.min_new = sc->min_new_token; h->sc.max_new = sc->max_new_token;
+    SamplerDyn d = {};
+    d.cfg = h->sc; d.n_draws = io->n_draws; d.ids = io->ids; d.finish = io->finish; d.end_idx = io->end_idx; d.noise = io->noise;
+    d.seed = io->seed; d.hidden_out = io->hiddens; d.hidden_stride = sc->max_new_token * h->H;
+    CTTS_HIP_CHECK(hipMemcpyAsync(h->dyn, &d, sizeof(d), hipMemcpyHostToDevice, s));       // pageable source: staged before the call returns
     if (launch_fill_meta(h->meta_pre, h->meta_dec0, h->st, mask, B, T, h->rope, h->rope_pre, s)) return 1;
     return reset_state(h, false, s);
 }
@@ -514,24 +520,26 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 }
 
 static int ensure_graph(ctts_gpt* h) {
-    char sig[256];
-    snprintf(sig, sizeof(sig), "%d|%p|%p|%p|%p|%p|%d|%llu|%p|%d|%f|%f|%d|%d|%d|%d", h->B, (void*)h->io.ids, (void*)h->io.hiddens,
-             (void*)h->io.finish, (void*)h->io.end_idx, (void*)h->io.noise, h->io.n_draws, (unsigned long long)h->io.seed, (void*)h->kv,
-             h->sc.max_new, h->sc.temperature[0], h->sc.top_p_threshold, h->sc.top_k, h->sc.min_new, h->sc.use_penalty, h->sc.eos);
-    std::string key(sig);
-    for (int i = 0; i < 4; ++i) key += "|" + std::to_string(h->sc.temperature[i]);
-    key += "|" + std::to_string(h->sc.penalty_table[1]) + "|" + std::to_string(h->text_mode);
-    if (h->gexec && key == h->graph_sig) return 0;
-    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    char sig[160];
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows);
+    const std::string key(sig);
+    auto it = h->graphs.find(key);
+    if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }
+    if (h->graphs.size() >= 16) {                  // bounded: a serving process cycles through few (batch, mode) shapes
+        for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+        h->graphs.clear(); h->gexec = nullptr;
+    }
+    ctts_gpt::GraphEntry ge = {nullptr, nullptr};
     CTTS_HIP_CHECK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = 0;
     for (int i = 0; i < h->graph_steps && !rc; ++i) rc = run_decode_step(h, h->cap_stream);
-    hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
-    if (rc) return 1;
+    hipError_t e = hipStreamEndCapture(h->cap_stream, &ge.graph);
+    if (rc) { if (ge.graph) (void)hipGraphDestroy(ge.graph); return 1; }
     if (e != hipSuccess) { ctts_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return 1; }
-    CTTS_HIP_CHECK(hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0));
-    h->graph_sig = key;
+    e = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(ge.graph); ctts_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return 1; }
+    h->graphs[key] = ge;
+    h->gexec = ge.exec;
     return 0;
 }
 
@@ -559,6 +567,12 @@ extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_
     return 0;
 }
 
+extern "C" int ctts_gpt_progress_enqueue(ctts_gpt* h, int32_t* host_pinned4, void* stream) {
+    if (!h || !host_pinned4) { ctts_set_error("progress_enqueue: null argument"); return 1; }
+    CTTS_HIP_CHECK(hipMemcpyAsync(host_pinned4, h->st, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int ctts_gpt_logits(ctts_gpt* h, float* out, void* stream) {
     if (!h || !out || h->B == 0) { ctts_set_error("logits: call begin first"); return 1; }
     CTTS_HIP_CHECK(hipMemcpyAsync(out, h->logits, (size_t)h->B * (h->text_mode ? h->vocab_text_head : h->NVQ * h->V) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -573,13 +587,28 @@ extern "C" int ctts_gpt_force_ids(ctts_gpt* h, const int32_t* ids, void* stream)
 extern "C" int ctts_sampler_run(const ctts_sampler_cfg* sc, const float* logits, const int32_t* history, int hist_len, const float* q,
                                 int rows, int vocab, int step, int32_t* idx, void* stream) {
     if (!sc || !logits || !q || !idx || (hist_len > 0 && !history)) { ctts_set_error("sampler_run: null argument"); return 1; }
+    // the kernels read their configuration from device memory: a small ring of slots, one per call in flight
+    static std::mutex mu;
+    static SamplerDyn* ring = nullptr;
+    static unsigned next = 0;
+    const unsigned NSLOT = 64;
+    SamplerDyn* slot;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!ring) CTTS_HIP_CHECK(hipMalloc((void**)&ring, NSLOT * sizeof(SamplerDyn)));
+        slot = ring + (next++ % NSLOT);
+    }
+    SamplerDyn d = {};
+    memcpy(d.cfg.temperature, sc->temperature, sizeof(sc->temperature));
+    d.cfg.top_p_threshold = sc->top_p_threshold; d.cfg.top_k = sc->top_k; d.cfg.min_keep = sc->min_tokens_to_keep;
+    d.cfg.use_penalty = sc->use_penalty; memcpy(d.cfg.penalty_table, sc->penalty_table, sizeof(sc->penalty_table));
+    d.cfg.past_window = sc->past_window; d.cfg.max_input_ids = sc->max_input_ids; d.cfg.eos = sc->eos_token;
+    d.cfg.min_new = sc->min_new_token; d.cfg.max_new = sc->max_new_token;
+    d.noise = q;
+    CTTS_HIP_CHECK(hipMemcpyAsync(slot, &d, sizeof(d), hipMemcpyHostToDevice, (hipStream_t)stream));
     SamplerArgs sa = {};
-    memcpy(sa.cfg.temperature, sc->temperature, sizeof(sc->temperature));
-    sa.cfg.top_p_threshold = sc->top_p_threshold; sa.cfg.top_k = sc->top_k; sa.cfg.min_keep = sc->min_tokens_to_keep;
-    sa.cfg.use_penalty = sc->use_penalty; memcpy(sa.cfg.penalty_table, sc->penalty_table, sizeof(sc->penalty_table));
-    sa.cfg.past_window = sc->past_window; sa.cfg.max_input_ids = sc->max_input_ids; sa.cfg.eos = sc->eos_token;
-    sa.cfg.min_new = sc->min_new_token; sa.cfg.max_new = sc->max_new_token;
-    sa.logits = logits; sa.V = vocab; sa.B = rows; sa.st = nullptr; sa.noise = q; sa.history = history; sa.hist_len = hist_len;
+    sa.dyn = slot;
+    sa.logits = logits; sa.V = vocab; sa.B = rows; sa.st = nullptr; sa.history = history; sa.hist_len = hist_len;
     sa.step_override = step; sa.idx_out = idx;
     return launch_sampler(sa, (rows + 3) / 4, (hipStream_t)stream);
 }

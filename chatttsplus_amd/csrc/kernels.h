@@ -8,6 +8,7 @@ enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_P =
 
 // out[R rows][N] = prologue(x)[R][K] . W[N][K]^T  followed by a fused epilogue.
 // W is pre-packed in 16-row x KT-col MFMA-A tiles, [row tile][k tile][lane][16 B] (gpt_engine.cpp).
+struct SamplerDyn;
 struct GemmArgs {
     const void* W;
     int n_row_tiles;        // N / 16 (grid.x)
@@ -22,8 +23,7 @@ struct GemmArgs {
     int ktiles_total;       // EPI_PART: k-tiles of the whole matrix (the block's slice is blockIdx.z * KTILES); 0 = KTILES
     float* part_out;        // EPI_PART: [R][gridDim.z][N] fp32
     float eps;
-    float* hidden_out;      // PRO_NORM (heads only): normalised rows -> hiddens[seq][step][K]; may be null
-    int hidden_stride;      //   = max_new_token * K
+    const SamplerDyn* dyn;  // PRO_NORM (heads only): dyn->hidden_out != null -> normalised rows -> hiddens[seq][step][K]
     const float* part_ml;   // PRO_ATTN: [R][NH][S][2]  (running max, running sum)
     const float* part_o;    // PRO_ATTN: [R][NH][S][64] unnormalised
     int S;
@@ -74,19 +74,31 @@ struct SamplerCfgDev {      // mirrors ctts_sampler_cfg
     int max_new;
 };
 
-struct SamplerArgs {
+// Everything one generate()/sampler call may change without changing the launch geometry.  It lives in DEVICE memory
+// (ctts_gpt_begin rewrites it) and the kernels read it through the constant address space (scalar loads), so a captured
+// decode graph never bakes in a caller's buffers or sampling parameters and is replayed across calls.
+struct SamplerDyn {
     SamplerCfgDev cfg;
+    int n_draws;
+    int* ids;               // [B][max_new][4]
+    int* finish;
+    int* end_idx;
+    const float* noise;     // [n_draws][rows][V] or null -> Philox
+    unsigned long long seed;
+    float* hidden_out;      // hiddens[seq][step][H] or null
+    int hidden_stride;      //   = max_new_token * H
+    int pad_;
+};
+#define CTTS_CONST_AS __attribute__((address_space(4)))
+typedef const CTTS_CONST_AS SamplerDyn* SamplerDynPtr;
+
+struct SamplerArgs {
+    const SamplerDyn* dyn;  // device memory
     const float* logits;    // [rows][V]
     int V;
     int B;
     DevState* st;           // null in stand-alone mode
     // generate mode
-    int* ids;               // [B][max_new][4]
-    int* finish;
-    int* end_idx;
-    const float* noise;     // [n_draws][B*4][V] or null
-    int n_draws;
-    unsigned long long seed;
     int text_mode;          // refine-text pass: one V_text-wide row per sequence, emb_code points at emb_text [V_text][H]
     const float* emb_code;  // [4][V][H] fp32
     int H;

@@ -43,8 +43,15 @@ struct RowIn {
     unsigned draw, row;
 };
 
+struct SampleKnobs { float top_p_threshold; int top_k, min_keep, eos, min_new; };
+__device__ inline SampleKnobs knobs_of(SamplerDynPtr d) {
+    SampleKnobs k;
+    k.top_p_threshold = d->cfg.top_p_threshold; k.top_k = d->cfg.top_k; k.min_keep = d->cfg.min_keep; k.eos = d->cfg.eos; k.min_new = d->cfg.min_new;
+    return k;
+}
+
 // returns the sampled index (identical in every lane)
-__device__ int sample_row(const SamplerCfgDev& c, const float* tab, const RowIn& in, int V, int lane) {
+__device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& in, int V, int lane) {
     float x[VPL];
     unsigned valid = 0;
 #pragma unroll
@@ -167,33 +174,34 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
     __shared__ float tab[17];
     __shared__ int idx_s[CTTS_NUM_VQ];
     DevState* st = a.st;
+    const SamplerDynPtr d = (SamplerDynPtr)a.dyn;
     if (st->all_done) return;
     const int tid = threadIdx.x, lane = tid & 63, vq = tid >> 6;
     const int b = blockIdx.x;
     const int step = st->step, draw = st->draw;
-    if (tid < 17) tab[tid] = a.cfg.penalty_table[tid];
+    if (tid < 17) tab[tid] = d->cfg.penalty_table[tid];
     // bookkeeping state and the next position's RoPE row are requested now, consumed after the sampling (they used to be
     // a chain of dependent round trips at the tail of this single-block kernel)
     const RowMeta meta_in = a.meta[b];
-    const int fin_in = a.finish[b], end_in = a.end_idx[b];
+    const int fin_in = d->finish[b], end_in = d->end_idx[b];
     const float rope_next = (tid < 64) ? a.rope[(size_t)(meta_in.pos + 1) * 64 + tid] : 0.f;
     __syncthreads();
     const int row = b * CTTS_NUM_VQ + vq;
     RowIn in;
     in.logits = a.logits + (size_t)row * a.V;
-    in.q = (a.noise != nullptr) ? a.noise + ((size_t)min(draw, a.n_draws - 1) * a.B * CTTS_NUM_VQ + row) * a.V : nullptr;
-    const int nh = min(step, a.cfg.past_window);
-    in.hist = a.ids + ((size_t)b * a.cfg.max_new + (step - nh)) * CTTS_NUM_VQ + vq;
+    in.q = (d->noise != nullptr) ? d->noise + ((size_t)min(draw, d->n_draws - 1) * a.B * CTTS_NUM_VQ + row) * a.V : nullptr;
+    const int nh = min(step, d->cfg.past_window);
+    in.hist = d->ids + ((size_t)b * d->cfg.max_new + (step - nh)) * CTTS_NUM_VQ + vq;
     in.hist_stride = CTTS_NUM_VQ;
     in.nh = nh;
-    in.T = a.cfg.temperature[vq];
-    in.penalize = a.cfg.use_penalty && (row < a.cfg.max_input_ids);      // quirk SURVEY F8
+    in.T = d->cfg.temperature[vq];
+    in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids);      // quirk SURVEY F8
     in.step = step;
-    in.seed = a.seed; in.draw = (unsigned)draw; in.row = (unsigned)row;
-    const int idx = sample_row(a.cfg, tab, in, a.V, lane);
+    in.seed = d->seed; in.draw = (unsigned)draw; in.row = (unsigned)row;
+    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane);
     if (lane == 0) {
         idx_s[vq] = idx;
-        a.ids[((size_t)b * a.cfg.max_new + step) * CTTS_NUM_VQ + vq] = idx;
+        d->ids[((size_t)b * d->cfg.max_new + step) * CTTS_NUM_VQ + vq] = idx;
     }
     __syncthreads();
     // next-token embedding: ((e0 + e1) + e2) + e3   (torch.stack(..., 3).sum(3), gpt.py:403-407)
@@ -206,9 +214,9 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
     if (tid == 0) {
         const bool was = fin_in != 0;
         bool fin = was;
-        for (int v = 0; v < CTTS_NUM_VQ; ++v) fin = fin || (idx_s[v] == a.cfg.eos);   // gpt.py:486-487
-        a.finish[b] = fin ? 1 : 0;
-        if (!fin) a.end_idx[b] = end_in + 1;                                        // gpt.py:530-531
+        for (int v = 0; v < CTTS_NUM_VQ; ++v) fin = fin || (idx_s[v] == d->cfg.eos);   // gpt.py:486-487
+        d->finish[b] = fin ? 1 : 0;
+        if (!fin) d->end_idx[b] = end_in + 1;                                        // gpt.py:530-531
         RowMeta m = meta_in;                                                       // next decode row
         m.pos += 1; m.slot += 1;
         a.meta[b] = m;
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
             st->ticket = nfin << 16;
             st->step = step + 1;
             st->draw = draw + 1;
-            if (nfin == a.B || step + 1 >= a.cfg.max_new) st->all_done = 1;         // gpt.py:545 / loop bound :389
+            if (nfin == a.B || step + 1 >= d->cfg.max_new) st->all_done = 1;         // gpt.py:545 / loop bound :389
         }
     }
     if (tid < 64) a.rope_rows[(size_t)b * 64 + tid] = rope_next;      // RoPE row of the next step's position (prefetched)
@@ -285,13 +293,14 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
     __shared__ BlockRed red;
     __shared__ int pos_s;
     DevState* st = a.st;
+    const SamplerDynPtr d = (SamplerDynPtr)a.dyn;
     if (st->all_done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, V = a.V;
     const int step = st->step, draw = st->draw;
     const float* lg = a.logits + (size_t)b * V;
-    const float* q = (a.noise != nullptr) ? a.noise + ((size_t)min(draw, a.n_draws - 1) * a.B + b) * V : nullptr;
-    const float T = a.cfg.temperature[0];
+    const float* q = (d->noise != nullptr) ? d->noise + ((size_t)min(draw, d->n_draws - 1) * a.B + b) * V : nullptr;
+    const float T = d->cfg.temperature[0];
     float x[TVPT];
     unsigned valid = 0;
 #pragma unroll
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
     unsigned taken = ~valid, kept = 0;
     double cum_before = 0.0;
     float vk = 0.f;
-    const int topk = (a.cfg.top_k > 0) ? a.cfg.top_k : V;
+    const int topk = (d->cfg.top_k > 0) ? d->cfg.top_k : V;
     for (int r = 0; r < V; ++r) {
         unsigned long long key = 0ull;
 #pragma unroll
@@ -331,12 +340,12 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
         const int bi = (int)(unsigned)best;
         if (r >= topk && bv != vk) break;
         const float cr = (float)(tot - cum_before);
-        if (cr <= a.cfg.top_p_threshold && r >= a.cfg.min_keep) break;
+        if (cr <= d->cfg.top_p_threshold && r >= d->cfg.min_keep) break;
         if (tid == (bi & 1023)) { taken |= 1u << (bi >> 10); kept |= 1u << (bi >> 10); }
         if (r == topk - 1) vk = bv;
         cum_before += (double)(expf(bv - mx) * inv);
     }
-    if (step < a.cfg.min_new && tid == (a.cfg.eos & 1023)) kept &= ~(1u << (a.cfg.eos >> 10));      // gpt.py:477-478
+    if (step < d->cfg.min_new && tid == (d->cfg.eos & 1023)) kept &= ~(1u << (d->cfg.eos >> 10));      // gpt.py:477-478
     float m2 = -INFINITY;
 #pragma unroll
     for (int i = 0; i < TVPT; ++i) if ((kept >> i) & 1u) m2 = fmaxf(m2, x[i]);
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
             if (q != nullptr) qq = q[j];
             else {
                 const uint4 rnd = philox4x32_10(make_uint4((unsigned)j, (unsigned)b, (unsigned)draw, 0x54585453u),
-                                                make_uint2((unsigned)a.seed, (unsigned)(a.seed >> 32)));
+                                                make_uint2((unsigned)d->seed, (unsigned)(d->seed >> 32)));
                 qq = -logf(((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f));
             }
             const float e = ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f;
@@ -366,12 +375,12 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
     const int idx = 0x7FFFFFFF - (int)(unsigned)bkey;
     // next input = emb_text[idx]  (gpt.py:400-401); ids buffer keeps the reference's [.., num_vq] layout (gpt.py:492-494)
     for (int k = tid; k < a.H; k += 1024) a.x_next[(size_t)b * a.H + k] = a.emb_code[(size_t)idx * a.H + k];
-    if (tid < CTTS_NUM_VQ) a.ids[((size_t)b * a.cfg.max_new + step) * CTTS_NUM_VQ + tid] = idx;
+    if (tid < CTTS_NUM_VQ) d->ids[((size_t)b * d->cfg.max_new + step) * CTTS_NUM_VQ + tid] = idx;
     if (tid == 0) {
-        const bool was = a.finish[b] != 0;
-        const bool fin = was || (idx == a.cfg.eos);                                  // gpt.py:490-491
-        a.finish[b] = fin ? 1 : 0;
-        if (!fin) a.end_idx[b] += 1;
+        const bool was = d->finish[b] != 0;
+        const bool fin = was || (idx == d->cfg.eos);                                  // gpt.py:490-491
+        d->finish[b] = fin ? 1 : 0;
+        if (!fin) d->end_idx[b] += 1;
         RowMeta m = a.meta[b];
         m.pos += 1; m.slot += 1;
         a.meta[b] = m;
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
             st->ticket = nfin << 16;
             st->step = step + 1;
             st->draw = draw + 1;
-            if (nfin == a.B || step + 1 >= a.cfg.max_new) st->all_done = 1;
+            if (nfin == a.B || step + 1 >= d->cfg.max_new) st->all_done = 1;
         }
     }
     __syncthreads();
@@ -393,24 +402,25 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
 // stand-alone mode (ctts_sampler_run): block = 4 rows
 __global__ __launch_bounds__(256) void sampler_rows_kernel(const SamplerArgs a) {
     const int rows = a.B;
+    const SamplerDynPtr d = (SamplerDynPtr)a.dyn;
     __shared__ float tab[17];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid < 17) tab[tid] = a.cfg.penalty_table[tid];
+    if (tid < 17) tab[tid] = d->cfg.penalty_table[tid];
     __syncthreads();
     const int row = blockIdx.x * 4 + w;
     if (row >= rows) return;
     RowIn in;
     in.logits = a.logits + (size_t)row * a.V;
-    in.q = a.noise + (size_t)row * a.V;
-    const int nh = min(a.hist_len, a.cfg.past_window);
+    in.q = d->noise + (size_t)row * a.V;
+    const int nh = min(a.hist_len, d->cfg.past_window);
     in.hist = a.history + (size_t)row * a.hist_len + (a.hist_len - nh);
     in.hist_stride = 1;
     in.nh = nh;
-    in.T = a.cfg.temperature[row % CTTS_NUM_VQ];
-    in.penalize = a.cfg.use_penalty && (row < a.cfg.max_input_ids);
+    in.T = d->cfg.temperature[row % CTTS_NUM_VQ];
+    in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids);
     in.step = a.step_override;
     in.seed = 0; in.draw = 0; in.row = (unsigned)row;
-    const int idx = sample_row(a.cfg, tab, in, a.V, lane);
+    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane);
     if (lane == 0) a.idx_out[row] = idx;
 }
 

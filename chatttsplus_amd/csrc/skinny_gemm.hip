@@ -176,8 +176,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
                 const int k = 4 * (lane + 64 * i);
                 store_x4<WT>(smem, n, k, KTILES, v[u][i][0] * rs, v[u][i][1] * rs, v[u][i][2] * rs, v[u][i][3] * rs);
             }
-            if (a.hidden_out != nullptr && rt == 0) {                      // heads only: hidden = weight * (x * rs) (llama.py:87)
-                float* hrow = a.hidden_out + (size_t)a.meta[r].seq * a.hidden_stride + (size_t)a.st->step * K;
+            float* const hid_out = (a.dyn != nullptr) ? ((SamplerDynPtr)a.dyn)->hidden_out : nullptr;
+            if (hid_out != nullptr && rt == 0) {                           // heads only: hidden = weight * (x * rs) (llama.py:87)
+                float* hrow = hid_out + (size_t)a.meta[r].seq * ((SamplerDynPtr)a.dyn)->hidden_stride + (size_t)a.st->step * K;
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     const int k = 4 * (lane + 64 * i);

@@ -230,10 +230,13 @@ class GPT:
                  eos_token: Union[int, torch.Tensor], attention_mask: Optional[torch.Tensor] = None, max_new_token=2048,
                  min_new_token=0, logits_warpers=[], logits_processors=[], infer_text=False, return_attn=False,
                  return_hidden=False, stream=False, show_tqdm=True, ensure_non_empty=True, stream_batch=24,
-                 context=None, noise="torch", seed: int = 0, max_restarts: int = 64):
-        """`noise`: "torch" draws q = empty(B*4,V).exponential_() per step from torch's CPU generator -- the
-        very numbers torch.multinomial consumes in the reference, so TorchSeedContext(seed) reproduces the CPU
-        path's tokens; "device" uses the on-device Philox generator (`seed`); or an array [n_draws, B*4, V]."""
+                 context=None, noise="auto", seed: Optional[int] = None, max_restarts: int = 64):
+        """`noise`: "torch" draws q = empty(B*4,V).exponential_() per step from torch's CPU generator -- the very numbers
+        torch.multinomial consumes in the reference, so TorchSeedContext(seed) reproduces the CPU path's tokens (costs
+        ~21 ns of host time per element: hidden behind the GPU up to batch ~8, 3x the step time at batch 32); "device"
+        uses the on-device Philox generator keyed by `seed` (None: one draw from torch's CPU generator, so manual_seed
+        still makes the call reproducible); "auto" (default) = "torch" for the batches the reference itself can run
+        (<= 4 sequences, pipeline:391-397) and "device" above; or an array [n_draws, B*4, V]."""
         if return_attn:
             raise _lib.HipBackendError("return_attn=True is unsupported (the reference's eager attention path is broken, SURVEY F2)")
         if not self._finalized:
@@ -247,6 +250,10 @@ class GPT:
         max_new_token = int(max_new_token)
         sc = sampler_cfg_from_objects(temperature, int(eos_token), max_new_token, min_new_token, logits_warpers, logits_processors, NVQ,
                                       infer_text=infer_text)
+        if isinstance(noise, str) and noise == "auto":
+            noise = "torch" if B <= 4 else "device"
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (isinstance(noise, str) and noise == "device") else 0
         mask = torch.ones(B, T, dtype=torch.int32, device=dev) if attention_mask is None else attention_mask.to(dev).to(torch.int32).contiguous()
         emb = emb.to(dev, dtype=torch.float32).contiguous()
         ids = torch.zeros(B, max_new_token, NVQ, dtype=torch.int32, device=dev)
@@ -269,6 +276,8 @@ class GPT:
                         end_idx=end_idx.data_ptr(), noise=qbuf.data_ptr() if qbuf is not None else None, n_draws=n_draws,
                         seed=int(seed))
         drawn = 0
+        stage_cap = max(int(self.chunk_steps), int(stream_batch) if stream else 1, 1)
+        stage = self._staging(B * rows_per_seq, V, stage_cap) if (isinstance(noise, str) and noise == "torch") else None
 
         def draw_to(n):
             nonlocal drawn
@@ -277,17 +286,40 @@ class GPT:
             n = min(n, n_draws)
             if n <= drawn:
                 return
-            chunk = []
-            for _ in range(n - drawn):
-                rng_states.append(torch.random.get_rng_state())
-                chunk.append(torch.empty(B * rows_per_seq, V, dtype=torch.float32).exponential_(1))
-            qbuf[drawn:n].copy_(torch.stack(chunk), non_blocking=False)
-            drawn = n
+            while drawn < n:
+                # persistent pinned staging ring (3 slots): exponential_ straight into pinned memory, stream-ordered async
+                # upload that lands after the chunk in flight and before the steps that read it; a slot is reused once the
+                # copy that last read it has completed
+                k = min(n - drawn, stage_cap)
+                slot = self._stage_next % 3
+                self._stage_next += 1
+                buf, ev = stage[slot]
+                if ev is not None:
+                    ev.synchronize()
+                for i in range(k):
+                    rng_states.append(torch.random.get_rng_state())
+                    buf[i].exponential_(1)
+                qbuf[drawn:drawn + k].copy_(buf[:k], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                stage[slot][1] = ev
+                drawn += k
+
+        import time as _t
+        tm = self.host_timing = {}
+        t_last = [_t.perf_counter()]
+
+        def tick(name):
+            now = _t.perf_counter()
+            tm[name] = tm.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
 
         with torch.cuda.device(dev):
             st = self._stream()
+            tick("setup")
             _lib.check(lib.ctts_gpt_begin(h, B, T, mask.data_ptr(), C.byref(sc), C.byref(io), st), "begin")
             _lib.check(lib.ctts_gpt_prefill(h, emb.data_ptr(), st), "prefill")
+            tick("begin+prefill")
             steps, alld = C.c_int32(0), C.c_int32(0)
             used_draws = 0
             # step 0 (+ ensure_non_empty regenerate, gpt.py:496-525)
@@ -303,20 +335,67 @@ class GPT:
                     self._restore_rng(rng_states, used_draws)
                     return                                   # gpt.py:525 bare return
                 break
+            tick("step0")
             chunk = int(stream_batch) if stream else self.chunk_steps
-            while not alld.value and steps.value < max_new_token and not context.get():
-                n = min(chunk, max_new_token - steps.value)
-                draw_to(used_draws + n)
-                _lib.check(lib.ctts_gpt_decode(h, n, 1 if self.use_graph else 0, st), "decode")
+            if stream:
+                # streaming yields after every chunk: synchronous polling
+                while not alld.value and steps.value < max_new_token and not context.get():
+                    n = min(chunk, max_new_token - steps.value)
+                    draw_to(used_draws + n)
+                    _lib.check(lib.ctts_gpt_decode(h, n, 1 if self.use_graph else 0, st), "decode")
+                    prev = steps.value
+                    _lib.check(lib.ctts_gpt_progress(h, C.byref(steps), C.byref(alld), st), "progress")
+                    used_draws += steps.value - prev
+                    if steps.value == prev and not alld.value:
+                        raise _lib.HipBackendError("decode made no progress (device state inconsistent)")
+                    if not alld.value and steps.value < max_new_token:
+                        yield self._outputs(ids, hid, end_idx, infer_text)
+            else:
+                # one chunk stays in flight while the previous chunk's progress words are inspected (no GPU bubble at the
+                # poll); steps launched after every sequence finished exit at their first instruction on the device
+                pins = [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(2)]
+                evs = [torch.cuda.Event() for _ in range(2)]
+                restarts = used_draws - steps.value            # draws spent on ensure_non_empty regenerations
+                launched, n_chunks, pending = steps.value, 0, []
+                while True:
+                    while len(pending) < 2 and launched < max_new_token and not context.get():
+                        n = min(chunk, max_new_token - launched)
+                        tick("loop_other")
+                        draw_to(restarts + launched + n)
+                        tick("draw")
+                        _lib.check(lib.ctts_gpt_decode(h, n, 1 if self.use_graph else 0, st), "decode")
+                        tick("decode_launch")
+                        launched += n
+                        slot = n_chunks % 2
+                        n_chunks += 1
+                        _lib.check(lib.ctts_gpt_progress_enqueue(h, pins[slot].data_ptr(), st), "progress_enqueue")
+                        evs[slot].record(torch.cuda.current_stream(dev))
+                        pending.append(slot)
+                    if not pending:
+                        break
+                    slot = pending.pop(0)
+                    tick("loop_other")
+                    evs[slot].synchronize()
+                    tick("event_wait")
+                    if int(pins[slot][2]) or int(pins[slot][0]) >= max_new_token or context.get():
+                        break
                 prev = steps.value
                 _lib.check(lib.ctts_gpt_progress(h, C.byref(steps), C.byref(alld), st), "progress")
                 used_draws += steps.value - prev
-                if steps.value == prev and not alld.value:
-                    raise _lib.HipBackendError("decode made no progress (device state inconsistent)")
-                if stream and not alld.value and steps.value < max_new_token:
-                    yield self._outputs(ids, hid, end_idx, infer_text)
+                tick("final_progress")
             self._restore_rng(rng_states, used_draws)
-            yield self._outputs(ids, hid, end_idx, infer_text)
+            out = self._outputs(ids, hid, end_idx, infer_text)
+            tick("outputs")
+            yield out
+
+    def _staging(self, rows: int, V: int, cap: int):
+        """Pinned [cap, rows, V] staging slots for the torch-generator noise, kept across calls (pinning is expensive)."""
+        key = (rows, V, cap)
+        if getattr(self, "_stage_key", None) != key:
+            self._stage_key = key
+            self._stage_bufs = [[torch.empty(cap, rows, V, dtype=torch.float32).pin_memory(), None] for _ in range(3)]
+            self._stage_next = 0
+        return self._stage_bufs
 
     @staticmethod
     def _restore_rng(states, used):

@@ -153,6 +153,11 @@ int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* stream);
  * Synchronises the stream. */
 int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_finished, void* stream);
 
+/* Non-blocking variant: enqueues a copy of {steps_done, draws, all_finished, -} into 4 int32 of PINNED host memory; the
+ * caller records an event after it and reads the words once the event has completed -- lets the host keep one chunk of
+ * decode steps in flight while it inspects the previous one. */
+int ctts_gpt_progress_enqueue(ctts_gpt* h, int32_t* host_pinned4, void* stream);
+
 /* Test hooks (parity tests call the stages one by one through the same ABI):
  * logits of the current hidden rows fp32 [B][4][vocab_code] into `logits_dev` without sampling. */
 int ctts_gpt_logits(ctts_gpt* h, float* logits_dev, void* stream);
