@@ -7,7 +7,7 @@ import os
 
 from . import build as _build
 
-LIB_PATH = _build.LIB_PATH
+LIB_PATH = os.environ.get("CTTS_HIP_LIB", _build.LIB_PATH)      # developer knob: A/B builds of the same ABI
 
 DTYPE_F32 = 0
 DTYPE_F16 = 1

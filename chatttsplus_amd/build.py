@@ -38,7 +38,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if not os.path.exists(sp):
             continue
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", obj]
+        # kernarg preload: the leading scalar kernel arguments arrive in SGPRs at wave launch instead of through a first s_load
+        # round trip (one serial scalar-cache miss per launch; a decode step is ~100 dependent launches)
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=8", "-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

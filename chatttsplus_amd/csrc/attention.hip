@@ -68,15 +68,18 @@ __device__ inline float safe_exp_diff(float m, float mn) { return (m == -INFINIT
 // per-head partial sum  opart[row][head][:]  that the next kernels add to the residual stream in head order.
 // Drops one of the five dependent launches per layer in the launch-latency-bound small-batch regime.
 template <typename WT, bool FUSED, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const int* done_p, const RowMeta* meta_p, const float* q_p, const void* k_p, const void* v_p,
+                                                            const int NHp, const int Sp, const AttnArgs a) {
+    // leading scalars = what the first loads need; preloaded into SGPRs at wave launch (see skinny_gemm.hip)
     static_assert(!FUSED || NW == 4, "fused o_proj phase assumes 4 waves");
-    if (a.st != nullptr && a.st->all_done) return;
+    int done_v = 0;                                   // requested with the first operand loads, tested once they are in flight (common.h)
+    if (done_p != nullptr) done_v = vload_flag(done_p);
     constexpr int UN = 4;
     __shared__ float merge[NW][8][10];
     __shared__ float o_s[CTTS_HEAD_DIM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 3, sub = lane & 7;
-    const int r = blockIdx.x / a.NH, h = blockIdx.x % a.NH, s = FUSED ? 0 : blockIdx.y;
+    const int r = blockIdx.x / NHp, h = blockIdx.x % NHp, s = FUSED ? 0 : blockIdx.y;
     typedef HeadMma<WT> HM;
     typename HM::frag wfr[FUSE_TPW][HM::FR];
     if (FUSED) {        // this wave's o_proj tiles: issued first, consumed after the attention loop
@@ -89,23 +92,24 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnArgs a) 
                 wfr[t][f] = __builtin_nontemporal_load((const typename HM::frag*)a.wo + ((size_t)rt * ktiles + h * HM::FR + f) * 64 + lane);
         }
     }
-    const RowMeta m = a.meta[r];
+    const RowMeta m = meta_p[r];
     const int kv0 = m.kv_start, kv1 = m.slot + 1;
-    const int nsplit = FUSED ? 1 : a.S;
+    const int nsplit = FUSED ? 1 : Sp;
     const int chunk = (kv1 - kv0 + nsplit - 1) / nsplit;
     const int p0 = kv0 + s * chunk;
     const int p1 = min(p0 + chunk, kv1);
 
     float q[8];
     {
-        const float* qp = a.q + ((size_t)r * a.NH + h) * CTTS_HEAD_DIM + 8 * sub;
+        const float* qp = q_p + ((size_t)r * NHp + h) * CTTS_HEAD_DIM + 8 * sub;
         const f32x4 q0 = *(const f32x4*)qp, q1 = *(const f32x4*)(qp + 4);
         q[0] = q0[0] * 0.125f; q[1] = q0[1] * 0.125f; q[2] = q0[2] * 0.125f; q[3] = q0[3] * 0.125f;
         q[4] = q1[0] * 0.125f; q[5] = q1[1] * 0.125f; q[6] = q1[2] * 0.125f; q[7] = q1[3] * 0.125f;
     }
-    const size_t head_off = ((size_t)m.seq * a.NH + h) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
-    const WT* kb = (const WT*)a.k_cache + head_off;
-    const WT* vb = (const WT*)a.v_cache + head_off;
+    if (__builtin_amdgcn_readfirstlane(done_v)) return;   // every sequence finished: skip on device
+    const size_t head_off = ((size_t)m.seq * NHp + h) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
+    const WT* kb = (const WT*)k_p + head_off;
+    const WT* vb = (const WT*)v_p + head_off;
 
     float mrun = -INFINITY, lrun = 0.f, o[8];
 #pragma unroll
@@ -214,17 +218,18 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnArgs a) 
 
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     dim3 grid(a.R * a.NH, a.jt > 0 ? a.jt : a.S), block(256);
+    const int* done_p = a.st ? &a.st->all_done : nullptr;
     // unsplit rows (large batches): 8 waves per (row, head) keep twice the K/V bytes in flight per CU
     const bool wide = (a.jt == 0) && (a.S == 1) && (a.st != nullptr);
     if (wide) {
-        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 8>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((attn_decode_kernel<float, false, 8>), grid, dim3(512), 0, s, a);
+        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<float, false, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
     } else if (a.jt > 0) {
         if (a.jt * 4 * FUSE_TPW * 16 != a.NH * CTTS_HEAD_DIM) { ctts_set_error("fused attention: jt=%d does not tile H=%d", a.jt, a.NH * CTTS_HEAD_DIM); return 1; }
-        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, true, 4>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((attn_decode_kernel<float, true, 4>), grid, block, 0, s, a);
-    } else if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 4>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<float, false, 4>), grid, block, 0, s, a);
+        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, true, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<float, true, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+    } else if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, false, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -120,3 +120,12 @@ void ctts_set_error(const char* fmt, ...);
             return 1;                                                                          \
         }                                                                                      \
     } while (0)
+
+// The "every sequence finished" flag is fetched with a VECTOR load (opaque zero lane offset) so that it travels together
+// with the kernel's first operand loads; a scalar load + branch at kernel entry costs one extra serial cache-miss round trip
+// in each of the ~100 dependent launches of a decode step.  The caller tests the value after its loads have been issued.
+__device__ inline int vload_flag(const int* p) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return p[z];
+}

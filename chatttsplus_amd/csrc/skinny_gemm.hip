@@ -53,8 +53,17 @@ __device__ inline void store_x4<float>(void* base, int n, int k, int ktiles, flo
     *(f32x4*)((float*)base + xfrag_index<float>(n, k, ktiles)) = v;
 }
 
-template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI>
-__global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs a) {
+// RT = weight row tiles per block: the activation prologue (replicated in every block) is paid once per RT tiles --
+// at 17-32 rows the 384 blocks of gate|up otherwise pull 37 MB of residual stream through L2 per launch.
+template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1>
+__global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done_p, const void* Wq, const void* in0, const void* in1,
+                                                                  const float* resid_in, const int R, const GemmArgs a) {
+    // The six leading scalars are what the first loads of the kernel need (flag, weights, the prologue's operands, the
+    // residual rows, the row count).  As plain kernel arguments they are preloaded into SGPRs at wave launch
+    // (-mllvm -amdgpu-kernarg-preload-count, build.py); the by-value struct behind them costs a scalar-cache miss that now
+    // overlaps the operand loads instead of preceding them.
+    //   in0/in1: PRO_NORM[_P] x / opart   PRO_ATTN part_ml / part_o   PRO_PACKED xpacked / -
+    static_assert(RT == 1 || EPI == EPI_QKV || EPI == EPI_SWIGLU, "multi-tile blocks: QKV / SwiGLU epilogues only");
     typedef typename FragOf<WT>::type frag;
     constexpr int KT = WTraits<WT>::KT;
     constexpr int KTILES = WAVES * KPW;
@@ -64,10 +73,13 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     constexpr int PER = K / 256;                      // float4 per lane per row in the prologues
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    if (a.st != nullptr && a.st->all_done) return;    // every sequence finished (gpt.py:545): skip on device
+    // every sequence finished (gpt.py:545): skip on device -- the flag is requested here, tested after the operand loads
+    int done_v = 0;
+    if (done_p != nullptr) done_v = vload_flag(done_p);
+#define CTTS_EXIT_IF_DONE() if (__builtin_amdgcn_readfirstlane(done_v)) return
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rt = blockIdx.x, chunk = blockIdx.y;
+    const int rt0 = blockIdx.x * RT, chunk = blockIdx.y;
     const int row0 = chunk * NB;
 
     // LOAD ORDER MATTERS: vmcnt retires in order, so a wait on any load issued after the weight stream is a wait on
@@ -76,12 +88,13 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
     // split-K launches (EPI_PART): this block owns k-tiles [blockIdx.z*KTILES, +KTILES) of a matrix with ktiles_total k-tiles
     const int kt_all = (EPI == EPI_PART) ? a.ktiles_total : KTILES;
     const int kt_off = (EPI == EPI_PART) ? (int)blockIdx.z * KTILES : 0;
-    const frag* Wp = (const frag*)a.W + ((size_t)rt * kt_all + kt_off + (size_t)wave * KPW) * 64 + lane;
-    frag wf[KPW];
+    const frag* Wp = (const frag*)Wq + ((size_t)rt0 * kt_all + kt_off + (size_t)wave * KPW) * 64 + lane;
+    frag wf[RT][KPW];
     // (sched_barrier: hipcc otherwise hoists the weight loads above the prologue loads again)
 #define CTTS_ISSUE_WEIGHT_LOADS()                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                       \
-    _Pragma("unroll") for (int i = 0; i < KPW; ++i) wf[i] = __builtin_nontemporal_load(Wp + i * 64); \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t)                                           \
+    _Pragma("unroll") for (int i = 0; i < KPW; ++i) wf[t][i] = __builtin_nontemporal_load(Wp + ((size_t)t * kt_all + i) * 64); \
     __builtin_amdgcn_sched_barrier(0)
 
     // 1b. epilogue operands that do not depend on the GEMM are requested now and consumed at the very end, so
@@ -93,10 +106,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
             const int r = row0 + (t >> 4);
-            const int N = a.n_row_tiles * 16, col = rt * 16 + (t & 15);
+            const int N = a.n_row_tiles * 16, col = rt0 * 16 + (t & 15);
             float v = 0.f;
-            if (t < 16 * NB && r < a.R) {
-                v = a.x_out[(size_t)r * N + col];
+            if (t < 16 * NB && r < R) {
+                v = resid_in[(size_t)r * N + col];
                 if (EPI == EPI_RESID_P) {            // x = ((x + p0) + p1) + ... : partial sums in index order
                     float pp[CTTS_NPART];
 #pragma unroll
@@ -109,14 +122,19 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         }
     }
     RowMeta meta_pf = {0, 0, 0, 0};
-    float rope_c = 1.f, rope_s = 0.f;
+    float rope_c[RT], rope_s[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) { rope_c[t] = 1.f; rope_s[t] = 0.f; }
     if (EPI == EPI_QKV) {
         const int r = row0 + (tid >> 3);
-        if (tid < 8 * NB && r < a.R) {
+        if (tid < 8 * NB && r < R) {
             meta_pf = a.meta[r];
-            const int d = (((rt % (K / 16)) & 3) << 3) + (tid & 7);
-            rope_c = a.rope_rows[(size_t)r * 64 + d];                 // per-row copy of the table row: independent of meta
-            rope_s = a.rope_rows[(size_t)r * 64 + 32 + d];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const int d = ((((rt0 + t) % (K / 16)) & 3) << 3) + (tid & 7);
+                rope_c[t] = a.rope_rows[(size_t)r * 64 + d];          // per-row copy of the table row: independent of meta
+                rope_s[t] = a.rope_rows[(size_t)r * 64 + 32 + d];
+            }
         }
     }
 
@@ -128,13 +146,13 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         // issued together (one L2 round trip per batch instead of one per row: 8 serial trips at batch 32).
         constexpr int RB = (NB + WAVES - 1) / WAVES;          // rows per wave: one batch (<= 4 for every tiling used)
         static_assert(PRO != PRO_NORM_P || RB <= 4, "partials path is for <= 16 rows");
-        const int rows = min(NB, a.R - row0);
+        const int rows = min(NB, R - row0);
         f32x4 v[RB][PER];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
             const int n = wave + u * WAVES;
             if (n < rows) {
-                const f32x4* xr = (const f32x4*)(a.x + (size_t)(row0 + n) * K);
+                const f32x4* xr = (const f32x4*)((const float*)in0 + (size_t)(row0 + n) * K);
 #pragma unroll
                 for (int i = 0; i < PER; ++i) v[u][i] = xr[lane + 64 * i];
             } else {
@@ -153,7 +171,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
                 for (int q = 0; q < CTTS_NPART; ++q)
 #pragma unroll
                     for (int i = 0; i < PER; ++i)
-                        pp[q][i] = (q < a.np) ? ((const f32x4*)(a.opart + (rr * a.np + q) * K))[lane + 64 * i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        pp[q][i] = (q < a.np) ? ((const f32x4*)((const float*)in1 + (rr * a.np + q) * K))[lane + 64 * i] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < CTTS_NPART; ++q)
 #pragma unroll
@@ -161,6 +179,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
             }
         }
         CTTS_ISSUE_WEIGHT_LOADS();
+        CTTS_EXIT_IF_DONE();
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
             const int n = wave + u * WAVES;
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
                 store_x4<WT>(smem, n, k, KTILES, v[u][i][0] * rs, v[u][i][1] * rs, v[u][i][2] * rs, v[u][i][3] * rs);
             }
             float* const hid_out = (a.dyn != nullptr) ? ((SamplerDynPtr)a.dyn)->hidden_out : nullptr;
-            if (hid_out != nullptr && rt == 0) {                           // heads only: hidden = weight * (x * rs) (llama.py:87)
+            if (hid_out != nullptr && rt0 == 0) {                          // heads only: hidden = weight * (x * rs) (llama.py:87)
                 float* hrow = hid_out + (size_t)a.meta[r].seq * ((SamplerDynPtr)a.dyn)->hidden_stride + (size_t)a.st->step * K;
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
@@ -195,9 +214,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         constexpr int NH = K / CTTS_HEAD_DIM;
         constexpr int K4 = K / 4;
         const int S = a.S;
-        const int rows = min(NB, a.R - row0);
+        const int rows = min(NB, R - row0);
         if (S == 1) {
             CTTS_ISSUE_WEIGHT_LOADS();
+            CTTS_EXIT_IF_DONE();
             constexpr int IB = 8;
             for (int it0 = tid; it0 < rows * K4; it0 += WAVES * 64 * IB) {
                 float ls[IB];
@@ -208,8 +228,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
                     const int itc = (it < rows * K4) ? it : it0;
                     const int n = itc / K4, k = 4 * (itc % K4);
                     const size_t ph = (size_t)(row0 + n) * NH + (k >> 6);
-                    ls[u] = a.part_ml[ph * 2 + 1];
-                    os[u] = *(const f32x4*)(a.part_o + ph * CTTS_HEAD_DIM + (k & 63));
+                    ls[u] = ((const float*)in0)[ph * 2 + 1];
+                    os[u] = *(const f32x4*)((const float*)in1 + ph * CTTS_HEAD_DIM + (k & 63));
                 }
 #pragma unroll
                 for (int u = 0; u < IB; ++u) {
@@ -222,11 +242,11 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         } else {
             bool issued = false;
             for (int it = tid; it < rows * K4 || !issued; it += WAVES * 64) {
-                if (it >= rows * K4) { CTTS_ISSUE_WEIGHT_LOADS(); issued = true; break; }
+                if (it >= rows * K4) { CTTS_ISSUE_WEIGHT_LOADS(); issued = true; CTTS_EXIT_IF_DONE(); break; }
                 const int n = it / K4, k = 4 * (it % K4);
                 const int r = row0 + n, h = k >> 6, d = k & 63;
-                const float* ml = a.part_ml + ((size_t)(r * NH + h) * S) * 2;
-                const float* po = a.part_o + ((size_t)(r * NH + h) * S) * CTTS_HEAD_DIM + d;
+                const float* ml = (const float*)in0 + ((size_t)(r * NH + h) * S) * 2;
+                const float* po = (const float*)in1 + ((size_t)(r * NH + h) * S) * CTTS_HEAD_DIM + d;
                 float ms[ATT_SMAX], ls[ATT_SMAX];
                 f32x4 os[ATT_SMAX];
 #pragma unroll
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
                     ls[s] = t.y;
                     os[s] = *(const f32x4*)(po + (size_t)sc * CTTS_HEAD_DIM);
                 }
-                if (!issued) { CTTS_ISSUE_WEIGHT_LOADS(); issued = true; }     // after this thread's first batch of partial loads
+                if (!issued) { CTTS_ISSUE_WEIGHT_LOADS(); issued = true; CTTS_EXIT_IF_DONE(); }     // after this thread's first batch of partial loads
                 float mx = -INFINITY;
 #pragma unroll
                 for (int s = 0; s < ATT_SMAX; ++s) mx = fmaxf(mx, ms[s]);
@@ -255,14 +275,16 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         __syncthreads();
     }
 
-    if (PRO == PRO_PACKED) { CTTS_ISSUE_WEIGHT_LOADS(); }
+    if (PRO == PRO_PACKED) { CTTS_ISSUE_WEIGHT_LOADS(); CTTS_EXIT_IF_DONE(); }
 
     // 3. MFMA over this wave's K slice
-    f32x4 acc[NBG];
+    f32x4 acc[RT][NBG];
 #pragma unroll
-    for (int g = 0; g < NBG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NBG; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const frag* xs = (const frag*)smem;
-    const frag* xg = (const frag*)a.xpacked + (size_t)chunk * NBG * kt_all * 64;
+    const frag* xg = (const frag*)in0 + (size_t)chunk * NBG * kt_all * 64;
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         const int kt = wave * KPW + i;
@@ -271,15 +293,20 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
             frag b;
             if (PRO == PRO_PACKED) b = xg[(size_t)(g * kt_all + kt_off + kt) * 64 + lane];
             else b = xs[(g * KTILES + kt) * 64 + lane];
-            acc[g] = Mma<WT>::run(wf[i], b, acc[g]);
+#pragma unroll
+            for (int ti = 0; ti < RT; ++ti) acc[ti][g] = Mma<WT>::run(wf[ti][i], b, acc[ti][g]);
         }
     }
 
-    // 4. deterministic cross-wave reduction through LDS
     float* red = (float*)(smem + XS_BYTES);                 // [WAVES][NBG][64][4]
     float* outt = red + WAVES * NBG * 256;                  // [16][NB]
 #pragma unroll
-    for (int g = 0; g < NBG; ++g) *(f32x4*)(red + ((wave * NBG + g) * 64 + lane) * 4) = acc[g];
+    for (int ti = 0; ti < RT; ++ti) {
+    const int rt = rt0 + ti;
+    if (ti > 0) __syncthreads();                             // the previous tile's epilogue is done with red / outt
+    // 4. deterministic cross-wave reduction through LDS
+#pragma unroll
+    for (int g = 0; g < NBG; ++g) *(f32x4*)(red + ((wave * NBG + g) * 64 + lane) * 4) = acc[ti][g];
     __syncthreads();
     if (tid < 64 * NBG) {
         const int g = tid >> 6, l = tid & 63;
@@ -291,7 +318,6 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         for (int r4 = 0; r4 < 4; ++r4) outt[((l >> 4) * 4 + r4) * NB + n] = s[r4];   // C: row=(lane>>4)*4+reg, col=lane&15
     }
     __syncthreads();
-
     // 5. fused epilogue
     if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_LOGITS || EPI == EPI_PART) {
 #pragma unroll
@@ -300,7 +326,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
             if (t >= 16 * NB) continue;
             const int n = t >> 4, i = t & 15;
             const int r = row0 + n;
-            if (r >= a.R) continue;
+            if (r >= R) continue;
             const int col = rt * 16 + i;
             const float v = outt[i * NB + n];
             if (EPI == EPI_PART) {
@@ -318,11 +344,11 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
         if (EPI == EPI_SWIGLU) {
             // packed rows: [8 gate | 8 up] per tile -> act[rt*8+p] = silu(g) * u
             float y = 0.f;
-            if (r < a.R) y = (va / (1.0f + expf(-va))) * vb;
+            if (r < R) y = (va / (1.0f + expf(-va))) * vb;
             const int ktiles_out = (a.n_row_tiles * 8) / KT;
             WT* dst = (WT*)a.act_out + (size_t)chunk * NBG * ktiles_out * 64 * WTraits<WT>::EPL;
             dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = (WT)y;
-        } else if (r < a.R) {  // EPI_QKV: packed rows per tile = dims [8t..8t+7 | 8t+32..8t+39] of one head
+        } else if (r < R) {  // EPI_QKV: packed rows per tile = dims [8t..8t+7 | 8t+32..8t+39] of one head
             // keep hipcc from scheduling the cache-address arithmetic (and with it a wait on the meta load) at kernel entry
             asm volatile("" : "+v"(meta_pf.seq), "+v"(meta_pf.slot));
             constexpr int HT = K / 16;                   // tiles per projection (H == K for q/k/v)
@@ -332,8 +358,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
             float ya = va, yb = vb;
             if (which < 2) {
                 // q*cos + rotate_half(q)*sin, products rounded separately like the reference (llama.py:180-181)
-                ya = __fadd_rn(__fmul_rn(va, rope_c), __fmul_rn(-vb, rope_s));
-                yb = __fadd_rn(__fmul_rn(vb, rope_c), __fmul_rn(va, rope_s));
+                ya = __fadd_rn(__fmul_rn(va, rope_c[ti]), __fmul_rn(-vb, rope_s[ti]));
+                yb = __fadd_rn(__fmul_rn(vb, rope_c[ti]), __fmul_rn(va, rope_s[ti]));
             }
             if (which == 0) {
                 float* q = a.q_out + ((size_t)r * NH + h) * CTTS_HEAD_DIM;
@@ -345,15 +371,16 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const GemmArgs 
             }
         }
     }
+    }   // row tiles of this block
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI>
+template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1>
 static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configure_only) {
     constexpr int KTILES = WAVES * KPW;
     constexpr int XS = (PRO == PRO_PACKED) ? 0 : NBG * KTILES * 1024;
     constexpr int LDS = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4;
-    auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI>;
+    auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI, RT>;
     if (configure_only) {
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         return 0;
@@ -366,7 +393,11 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
         ctts_set_error("skinny_gemm: K=%d does not match the compiled tiling %d", a.K, KTILES * WTraits<WT>::KT);
         return 1;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles, chunks, nz), dim3(WAVES * 64), LDS, s, a);
+    if (a.n_row_tiles % RT) { ctts_set_error("skinny_gemm: %d row tiles not a multiple of %d", a.n_row_tiles, RT); return 1; }
+    const int* done_p = a.st ? &a.st->all_done : nullptr;
+    const void* in0 = (PRO == PRO_ATTN) ? (const void*)a.part_ml : (PRO == PRO_PACKED) ? (const void*)a.xpacked : (const void*)a.x;
+    const void* in1 = (PRO == PRO_ATTN) ? (const void*)a.part_o : (PRO == PRO_NORM_P) ? (const void*)a.opart : nullptr;
+    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, (const float*)a.x_out, a.R, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -374,6 +405,9 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
 // Tilings (real ChatTTS shapes: H=768, I=3072):
 //   K=768  fp16: 24 k-tiles = 4 waves x 6      fp32: 48 = 8 x 6
 //   K=3072 fp16: 96 k-tiles = 16 waves x 6     fp32: 192 = 16 x 12
+#ifndef CTTS_RT_NORM
+#define CTTS_RT_NORM 2
+#endif
 template <typename WT, int NBG>
 static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s, bool cfg) {
     constexpr bool F16 = sizeof(WT) == 2;
@@ -383,10 +417,11 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     constexpr int W3072 = 16, P3072 = F16 ? 6 : 12;
     if (cfg) {
         int rc = 0;
-        rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV>(a, chunks, s, true);
+        constexpr int RT_NORM_C = (NBG == 2) ? CTTS_RT_NORM : 1;
+        rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV, RT_NORM_C>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
-        rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU>(a, chunks, s, true);
+        rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU, RT_NORM_C>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, true);
         if constexpr (NBG == 1) {
@@ -399,9 +434,11 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         }
         return rc;
     }
-    if (pro == PRO_NORM && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV>(a, chunks, s, false);
+    // 17-32 rows: RT_NORM weight row tiles per block for the two kernels whose prologue re-normalises every row in every block
+    constexpr int RT_NORM = (NBG == 2) ? CTTS_RT_NORM : 1;
+    if (pro == PRO_NORM && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV, RT_NORM>(a, chunks, s, false);
     if (pro == PRO_ATTN && epi == EPI_RESID) return launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID>(a, chunks, s, false);
-    if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU>(a, chunks, s, false);
+    if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU, RT_NORM>(a, chunks, s, false);
     if (pro == PRO_PACKED && epi == EPI_RESID && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_PACKED && epi == EPI_RESID) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_NORM && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, false);
