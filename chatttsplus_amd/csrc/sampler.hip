@@ -51,13 +51,14 @@ __device__ inline SampleKnobs knobs_of(SamplerDynPtr d) {
 }
 
 // returns the sampled index (identical in every lane)
-__device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& in, int V, int lane) {
+// lg: the row's logits, element lane + 64 i, loaded by the caller (ahead of everything it has to wait for)
+__device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& in, int V, int lane, const float (&lg)[VPL]) {
     float x[VPL];
     unsigned valid = 0;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int j = lane + 64 * i;
-        if (j < V) { x[i] = __fdiv_rn(in.logits[j], in.T); valid |= 1u << i; }
+        if (j < V) { x[i] = __fdiv_rn(lg[i], in.T); valid |= 1u << i; }
         else x[i] = -INFINITY;
     }
     if (in.penalize && in.nh > 0) {
@@ -112,6 +113,8 @@ __device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& i
     double cum_before = 0.0;
     float vk = 0.f;
     const int topk = (c.top_k > 0) ? c.top_k : V;
+    float myv = -INFINITY;                                         // lane r remembers the r-th selected element (first 64 selections)
+    int myi = 0, nsel = 0;
     for (int r = 0; r < V; ++r) {
         const unsigned long long best = wave_max_u64(key[0]);     // larger index wins ties (== reversed stable ascending sort)
         if (best == 0ull) break;                                   // nothing left
@@ -127,6 +130,8 @@ __device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& i
             for (int i = 0; i + 1 < VPL; ++i) key[i] = key[i + 1];
             key[VPL - 1] = 0ull;
         }
+        if (lane == r) { myv = bv; myi = bi; }
+        nsel = r + 1;
         if (r == topk - 1) vk = bv;
         cum_before += (double)(expf(bv - mx) * inv);               // the same fp32 expression that produced pr[] for this element
     }
@@ -134,6 +139,29 @@ __device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& i
         if (lane == (c.eos & 63)) kept &= ~(1u << (c.eos >> 6));
     }
     // final softmax over the kept set and the exponential race
+    unsigned long long bkey = 0ull;                                // (ratio, first index wins ties) as one 64-bit key
+    if (nsel <= 64) {
+        // usual case (top-k / top-p keep a handful): one kept element per lane -- one exp, one noise draw, one division per
+        // lane instead of ten predicated slots of each.  Elements outside the kept set have p == 0 -> ratio 0: element 0
+        // stands in for all of them (smallest index wins ties).
+        const bool on = (lane < nsel) && !(in.step < c.min_new && myi == c.eos);
+        const float m2 = wave_max(on ? myv : -INFINITY);
+        const float e = on ? expf(myv - m2) : 0.f;
+        const float inv2 = 1.0f / wave_sum(e);
+        bkey = ((unsigned long long)f32_key(0.f) << 32) | (unsigned)0x7FFFFFFF;
+        if (on) {
+            float q;
+            if (in.q != nullptr) q = in.q[myi];
+            else {
+                const uint4 rnd = philox4x32_10(make_uint4((unsigned)myi, in.row, in.draw, 0x43545453u),
+                                                make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
+                const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                q = -logf(u);
+            }
+            const float ratio = __fdiv_rn(e * inv2, q);
+            bkey = umax64(bkey, ((unsigned long long)f32_key(ratio) << 32) | (unsigned)(0x7FFFFFFF - myi));
+        }
+    } else {
     float m2 = -INFINITY;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) if ((kept >> i) & 1u) m2 = fmaxf(m2, x[i]);
@@ -143,7 +171,6 @@ __device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& i
     for (int i = 0; i < VPL; ++i) { e2[i] = ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f; s2 += e2[i]; }
     s2 = wave_sum(s2);
     const float inv2 = 1.0f / s2;
-    unsigned long long bkey = 0ull;                                // (ratio, first index wins ties) as one 64-bit key
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int j = lane + 64 * i;
@@ -164,25 +191,38 @@ __device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& i
             bkey = umax64(bkey, ((unsigned long long)f32_key(ratio) << 32) | (unsigned)(0x7FFFFFFF - j));
         }
     }
+    }
     bkey = wave_max_u64(bkey);
     const int besti = 0x7FFFFFFF - (int)(unsigned)bkey;
     return besti;
 }
 
 // generate mode: grid = B blocks, block = 4 waves (one per codebook)
-__global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs a) {
+// The leading scalars are preloaded into SGPRs (see skinny_gemm.hip): state header, logits and bookkeeping rows are all
+// requested before the first wait of the kernel.
+__global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_words, const float* logits_p, const SamplerDyn* dyn_p, const RowMeta* meta_p,
+                                                               const int V_p, const SamplerArgs a) {
     __shared__ float tab[17];
     __shared__ int idx_s[CTTS_NUM_VQ];
     DevState* st = a.st;
-    const SamplerDynPtr d = (SamplerDynPtr)a.dyn;
-    if (st->all_done) return;
+    const SamplerDynPtr d = (SamplerDynPtr)dyn_p;
     const int tid = threadIdx.x, lane = tid & 63, vq = tid >> 6;
     const int b = blockIdx.x;
-    const int step = st->step, draw = st->draw;
+    int zoff;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
+    const int4 hdr = *(const int4*)(st_words + zoff);             // DevState {step, draw, all_done, ticket}: one vector load
+    float lg[VPL];
+    {
+        const float* lrow = logits_p + (size_t)(b * CTTS_NUM_VQ + vq) * V_p;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { const int j = lane + 64 * i; lg[i] = (j < V_p) ? lrow[j] : 0.f; }
+    }
     if (tid < 17) tab[tid] = d->cfg.penalty_table[tid];
     // bookkeeping state and the next position's RoPE row are requested now, consumed after the sampling (they used to be
     // a chain of dependent round trips at the tail of this single-block kernel)
-    const RowMeta meta_in = a.meta[b];
+    const RowMeta meta_in = meta_p[b];
+    if (__builtin_amdgcn_readfirstlane(hdr.z)) return;            // every sequence finished (gpt.py:545)
+    const int step = __builtin_amdgcn_readfirstlane(hdr.x), draw = __builtin_amdgcn_readfirstlane(hdr.y);
     const int fin_in = d->finish[b], end_in = d->end_idx[b];
     const float rope_next = (tid < 64) ? a.rope[(size_t)(meta_in.pos + 1) * 64 + tid] : 0.f;
     __syncthreads();
@@ -198,7 +238,7 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
     in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids);      // quirk SURVEY F8
     in.step = step;
     in.seed = d->seed; in.draw = (unsigned)draw; in.row = (unsigned)row;
-    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane);
+    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg);
     if (lane == 0) {
         idx_s[vq] = idx;
         d->ids[((size_t)b * d->cfg.max_new + step) * CTTS_NUM_VQ + vq] = idx;
@@ -224,7 +264,7 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const SamplerArgs
         // sequences (high 16 bits, persistent over the steps): no fences, no cross-block plain loads.
         const int add = 1 + ((fin && !was) ? 0x10000 : 0);
         // single sequence: no other block to wait for, no atomic round trip
-        const int tot = (a.B == 1) ? (st->ticket + add) : (__hip_atomic_fetch_add(&st->ticket, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add);
+        const int tot = (a.B == 1) ? (__builtin_amdgcn_readfirstlane(hdr.w) + add) : (__hip_atomic_fetch_add(&st->ticket, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add);
         if ((tot & 0xFFFF) == a.B) {                           // last block of this step: advance the step state
             const int nfin = tot >> 16;
             st->ticket = nfin << 16;
@@ -420,7 +460,10 @@ __global__ __launch_bounds__(256) void sampler_rows_kernel(const SamplerArgs a) 
     in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids);
     in.step = a.step_override;
     in.seed = 0; in.draw = 0; in.row = (unsigned)row;
-    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane);
+    float lg[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { const int j = lane + 64 * i; lg[i] = (j < a.V) ? in.logits[j] : 0.f; }
+    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg);
     if (lane == 0) a.idx_out[row] = idx;
 }
 
@@ -429,7 +472,7 @@ int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s) {
     if (a.st != nullptr && a.text_mode) {
         if (a.V > 1024 * TVPT) { ctts_set_error("text sampler: vocab %d > %d", a.V, 1024 * TVPT); return 1; }
         hipLaunchKernelGGL(sampler_text_kernel, dim3(a.B), dim3(1024), 0, s, a);
-    } else if (a.st != nullptr) hipLaunchKernelGGL(sampler_generate_kernel, dim3(a.B), dim3(256), 0, s, a);
+    } else if (a.st != nullptr) hipLaunchKernelGGL(sampler_generate_kernel, dim3(a.B), dim3(256), 0, s, (const int*)a.st, a.logits, a.dyn, (const RowMeta*)a.meta, a.V, a);
     else hipLaunchKernelGGL(sampler_rows_kernel, dim3(blocks), dim3(256), 0, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;

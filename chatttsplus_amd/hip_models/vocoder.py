@@ -115,6 +115,36 @@ class Synth:
         return outs
 
 
+    # ---- streaming: vocode only what a stream step emits ------------------------------------------------
+    # Left/right context (in mel frames) beyond which an output sample no longer depends on the input: DVAE decoder conv_in
+    # 2 x k3 (+-2), 12 blocks x k7 dilation 2 (+-72), out_conv k3 (+-1); Vocos embed k7 (+-3), 8 blocks x k7 (+-24); four
+    # overlapping ISTFT frames (+-3).  LayerNorms are per frame.
+    HALO_FRAMES = 75 + 27 + 3
+
+    def decode_window(self, hiddens, starts, stops):
+        """Samples [starts[u], stops[u]) of the waveform `decode_batch` would return for hiddens[u] (the prefix generated so
+        far), computed from the tokens inside the receptive field of that window only.  Bit-identical to slicing the
+        full-prefix waveform: every output element runs the same K-order arithmetic whatever rows surround it.  The
+        reference's stream branch re-vocodes the whole prefix for every chunk it yields (pipeline:436-461)."""
+        hop, halo = self.cfg.hop, self.HALO_FRAMES + 1
+        subs, offs, meta = [], [], []
+        for h, s0, s1 in zip(hiddens, starts, stops):
+            n = int(h.shape[0])
+            total = hop * (2 * n - 1) if n > 0 else 0
+            s0, s1 = max(0, min(int(s0), total)), max(0, min(int(s1), total))
+            if s1 <= s0:
+                subs.append(h[:0]); offs.append(0); meta.append((0, 0))
+                continue
+            f0 = max(0, s0 // hop - halo)                       # first / one-past-last mel frame the window depends on
+            f1 = min(2 * n, (s1 + hop - 1) // hop + 1 + halo)
+            a, b = f0 // 2, (f1 + 1) // 2                       # tokens (2 frames each)
+            if 2 * n - 2 * b < 2 * halo:                         # a right edge inside the halo must be the true end of the prefix
+                b = n
+            subs.append(h[a:b]); offs.append(2 * a * hop); meta.append((s0, s1))
+        wavs = self.decode_batch(subs)
+        return [w[s0 - o:s1 - o] if s1 > s0 else w[:0] for w, o, (s0, s1) in zip(wavs, offs, meta)]
+
+
 def SynthPool(dvae_cfg: dict, vocos_cfg: dict, max_frames: int = 4096, device="cuda", n_streams: int = 4, max_batch: int = 32) -> Synth:
     """Kept for callers of the earlier multi-stream pool: batching across utterances inside the library replaced it."""
     return Synth(dvae_cfg, vocos_cfg, max_frames=max_frames, device=device, max_batch=max_batch)

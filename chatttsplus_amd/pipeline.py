@@ -286,24 +286,36 @@ class ChatTTSPlusPipeline:
             if refine_text_only:
                 continue
             text = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in text]   # pipeline:414-416
-            length, pass_batch_count, wavs = 0, 0, None
+            length, pass_batch_count, last = 0, 0, None
             for result in self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt):
-                wavs = self._decode_to_wavs(result.hiddens, use_decoder)
-                if stream:
-                    # the reference's stream branch indexes a python list with .shape; we yield padded arrays
-                    pass_batch_count += 1
-                    if pass_batch_count <= params_infer_code.pass_first_n_batches:
-                        continue
-                    arr = torch.nn.utils.rnn.pad_sequence(wavs, batch_first=True)
-                    b = min(length + params_infer_code.stream_speed, arr.shape[1])
-                    new = arr[:, length:b]
+                if not stream:
+                    yield self._decode_to_wavs(result.hiddens, use_decoder)
+                    continue
+                # The reference's stream branch vocodes the whole prefix for every chunk and indexes a python list with
+                # .shape (SURVEY F10).  Here every yield is the [length, b) sample window of that same prefix waveform,
+                # vocoded from the tokens inside the window's receptive field only (Synth.decode_window), zero padded
+                # like pad_sequence would pad the shorter utterances.
+                last = result.hiddens
+                pass_batch_count += 1
+                if pass_batch_count <= params_infer_code.pass_first_n_batches:
+                    continue
+                total = max((256 * (2 * int(h.shape[0]) - 1) if h.shape[0] > 0 else 0) for h in last)
+                b = min(length + params_infer_code.stream_speed, total)
+                if b > length:
+                    yield self._window(last, length, b)
                     length = b
-                    yield new
-                else:
-                    yield wavs
-            if stream and wavs is not None:
-                arr = torch.nn.utils.rnn.pad_sequence(wavs, batch_first=True)
-                yield arr[:, length:]
+            if stream and last is not None:
+                total = max((256 * (2 * int(h.shape[0]) - 1) if h.shape[0] > 0 else 0) for h in last)
+                if total > length:
+                    yield self._window(last, length, total)
+
+    def _window(self, hiddens, s0: int, s1: int) -> torch.Tensor:
+        """[B, s1-s0] samples s0..s1 of the padded batch of prefix waveforms."""
+        parts = self.synth.decode_window(list(hiddens), [s0] * len(hiddens), [s1] * len(hiddens))
+        out = torch.zeros(len(parts), s1 - s0, device=self.device)
+        for u, w in enumerate(parts):
+            out[u, :w.shape[0]] = w
+        return out
 
     @torch.no_grad()
     def infer(self, text, stream=False, lang=None, skip_refine_text=False, refine_text_only=False, use_decoder=True,

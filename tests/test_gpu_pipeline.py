@@ -62,6 +62,19 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
         rms = float(np.sqrt(np.mean((wavs[b] - wav_ref) ** 2))) / float(np.sqrt(np.mean(wav_ref ** 2)))
         assert rms <= 1e-3, f"utterance {b}: waveform rms-rel {rms}"
 
+    # stream=True: the yields are consecutive sample windows of the prefix waveform; their total length is the final length
+    sp = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=40, min_new_token=2, show_tqdm=False, stream_batch=8,
+                         stream_speed=3000, pass_first_n_batches=1)
+    torch.manual_seed(11)
+    chunks = list(pipe.infer(list(texts), stream=True, skip_refine_text=True, do_text_optimization=False, params_infer_code=sp))
+    assert len(chunks) >= 2 and all(c.shape[0] == 2 for c in chunks)
+    assert sum(int(c.shape[1]) for c in chunks) == max(w.shape[0] for w in wavs)
+    tail = chunks[-1].cpu().numpy()
+    for b in range(2):                              # the last window is vocoded from the complete utterance: equals the tail of infer()
+        n_tail = tail.shape[1] - (max(w.shape[0] for w in wavs) - wavs[b].shape[0])
+        if n_tail > 0:
+            assert np.array_equal(tail[b, :n_tail], wavs[b][wavs[b].shape[0] - n_tail:])
+
     # default infer() path: refine-text pass first (pipeline:399-411), then code inference on the refined text
     from chatttsplus_amd.pipeline import RefineTextParams
     rp = RefineTextParams(max_new_token=6, show_tqdm=False)

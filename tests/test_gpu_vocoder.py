@@ -91,3 +91,23 @@ def test_batched_synthesis_matches_per_utterance(voc):
             continue
         ref = s.vocos_decode(s.dvae_decode(h))
         assert torch.equal(w, ref), "batched result differs from the per-utterance result"
+
+
+def test_decode_window_is_a_slice_of_the_prefix_waveform(voc):
+    """Streaming: a window vocoded from the tokens inside its receptive field is bit-identical to the same
+    samples of the full-prefix waveform -- at the start, in the interior, at the end, for ragged batches and empty windows."""
+    s, d, v = voc
+    rng = np.random.Generator(np.random.Philox(key=77))
+    hs = [torch.from_numpy(rng.standard_normal((n, 768)).astype(np.float32)).cuda() for n in (400, 37, 130)]
+    full = s.decode_batch(hs)
+    total = [int(w.shape[0]) for w in full]
+    cases = [(0, 6000), (6000, 12000), (50000, 62000), (100000, 100001), (total[0] - 5000, total[0]), (0, total[0]), (70000, 70000)]
+    for s0, s1 in cases:
+        got = s.decode_window(hs, [s0] * 3, [s1] * 3)
+        for u in range(3):
+            ref = full[u][min(s0, total[u]):min(s1, total[u])]
+            assert got[u].shape == ref.shape, (s0, s1, u, got[u].shape, ref.shape)
+            assert torch.equal(got[u], ref), f"window [{s0},{s1}) of utterance {u}: max diff {float((got[u] - ref).abs().max())}"
+    # per-utterance windows
+    got = s.decode_window(hs, [1000, 0, 60000], [3000, total[1], 66000])
+    assert torch.equal(got[0], full[0][1000:3000]) and torch.equal(got[1], full[1]) and torch.equal(got[2], full[2][60000:66000])
