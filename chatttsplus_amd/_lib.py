@@ -53,6 +53,11 @@ class VocCfg(C.Structure):
                                           "vocos_inter", "vocos_layers", "n_fft", "hop", "max_frames", "max_batch")]
 
 
+class EncCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_mels", "dim", "enc_hidden", "enc_bn", "enc_layers", "enc_odim", "vq_groups", "vq_residuals",
+                                          "n_fft", "hop", "max_samples", "pre_bound")]
+
+
 # every symbol include/ctts_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = [
@@ -86,6 +91,11 @@ SYMBOLS = [
     ("ctts_dvae_decode", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("ctts_vocos_decode", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("ctts_synth_batch", C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
+    ("ctts_enc_create", C.c_int, [C.POINTER(EncCfg), C.POINTER(_P)]),
+    ("ctts_enc_destroy", None, [_P]),
+    ("ctts_enc_set_weight", C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),
+    ("ctts_enc_finalize", C.c_int, [_P]),
+    ("ctts_dvae_encode", C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
 ]
 
 _lib = None

@@ -25,149 +25,7 @@
 #include "../../include/ctts_hip.h"
 #include "common.h"
 
-enum { EP_NONE = 0, EP_BIAS = 1, EP_BIAS_GELU = 2, EP_GAMMA_RESID = 3, EP_SCALE_T = 4, EP_SCALE = 5 };
-
-// Every kernel below is batched over utterances with grid.z (or grid.y): utterance z owns its own zero-guarded region
-// of each workspace (batch stride s*), its frame count comes from a device table Ms[z].  One launch sequence serves the
-// whole batch: the reference's per-utterance loop (pipeline:298-304) left the chip ~3/4 idle and paid ~1.8 ms of fixed
-// latency (serial K loops, 70 launches) per utterance -- 71 ms for 32 x 272 tokens vs 24 ms batched.
-struct GemmF32Args {
-    const float* A; int lda; long sA;   // activations [M][lda] (row windows may overlap: conv-as-GEMM); batch stride in floats
-    const float* W; int ldw;            // weights [Npad][ldw], k-contiguous (shared by the batch)
-    float* C; int ldc; long sC;
-    int M, N, K;                        // M = max rows over the batch (grid.y); K multiple of 16
-    const int* Ms;                      // device table of rows per utterance (null: M)
-    const float* bias;                  // [N]
-    const float* gamma;                 // [N]   EP_GAMMA_RESID
-    const float* resid; int ldr; long sR;
-    const float* scale;                 // [N]   EP_SCALE / EP_SCALE_T
-    float* const* Cptrs;                // EP_SCALE_T: per-utterance output base (written transposed C[n*M_z + m]); null -> C
-};
-
-__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-// block = 4 waves (2x2), wave tile 32x32, block tile 64x64; fragments are loaded straight from global/L2
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args a) {
-    const int z = blockIdx.z;
-    const int M = a.Ms ? a.Ms[z] : a.M;
-    if ((int)blockIdx.y * 64 >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
-    const float* Ap = a.A + (size_t)z * a.sA + (size_t)(m0 + (lane & 15)) * a.lda + 4 * (lane >> 4);
-    const float* Wp = a.W + (size_t)(n0 + (lane & 15)) * a.ldw + 4 * (lane >> 4);
-    const size_t a16 = (size_t)16 * a.lda, w16 = (size_t)16 * a.ldw;
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // software-pipelined K loop (two register sets, order pinned with sched_barrier -- hipcc otherwise rotates the loop
-    // back into load -> wait -> MFMA): the fragments of the next 16-deep step are in flight during the 16 MFMAs
-    // (512 cycles) of the current one.
-#define GEMM_STEP(A0, A1, B0, B1)                                                                     \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], B0[j], acc[0][0], 0, 0, 0);           \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], B1[j], acc[0][1], 0, 0, 0);           \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], B0[j], acc[1][0], 0, 0, 0);           \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], B1[j], acc[1][1], 0, 0, 0);           \
-    }
-    f32x4 a0 = *(const f32x4*)(Ap), a1 = *(const f32x4*)(Ap + a16);
-    f32x4 b0 = *(const f32x4*)(Wp), b1 = *(const f32x4*)(Wp + w16);
-    for (int k0 = 0; k0 < a.K; k0 += 32) {
-        const int k1 = (k0 + 16 < a.K) ? k0 + 16 : k0;
-        const f32x4 c0 = *(const f32x4*)(Ap + k1), c1 = *(const f32x4*)(Ap + a16 + k1);
-        const f32x4 d0 = *(const f32x4*)(Wp + k1), d1 = *(const f32x4*)(Wp + w16 + k1);
-        __builtin_amdgcn_sched_barrier(0);
-        GEMM_STEP(a0, a1, b0, b1)
-        __builtin_amdgcn_sched_barrier(0);
-        if (k0 + 16 >= a.K) break;
-        const int k2 = (k0 + 32 < a.K) ? k0 + 32 : k0;
-        a0 = *(const f32x4*)(Ap + k2); a1 = *(const f32x4*)(Ap + a16 + k2);
-        b0 = *(const f32x4*)(Wp + k2); b1 = *(const f32x4*)(Wp + w16 + k2);
-        __builtin_amdgcn_sched_barrier(0);
-        GEMM_STEP(c0, c1, d0, d1)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#undef GEMM_STEP
-    float* Cb = (EPI == EP_SCALE_T && a.Cptrs) ? a.Cptrs[z] : a.C + (size_t)z * a.sC;
-    const float* Rb = (EPI == EP_GAMMA_RESID) ? a.resid + (size_t)z * a.sR : nullptr;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n = n0 + ni * 16 + (lane & 15);
-            if (n >= a.N) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + mi * 16 + (lane >> 4) * 4 + r;
-                if (m >= M) continue;
-                float v = acc[mi][ni][r];
-                if (EPI == EP_BIAS || EPI == EP_BIAS_GELU || EPI == EP_GAMMA_RESID) v += a.bias[n];
-                if (EPI == EP_BIAS_GELU) v = gelu_erf(v);
-                if (EPI == EP_GAMMA_RESID) v = __fadd_rn(__fmul_rn(v, a.gamma[n]), Rb[(size_t)m * a.ldr + n]);
-                if (EPI == EP_SCALE_T) { Cb[(size_t)n * M + m] = v * a.scale[n]; continue; }     // mel [n_mels][F_z]
-                if (EPI == EP_SCALE) v *= a.scale[n];
-                Cb[(size_t)m * a.ldc + n] = v;
-            }
-        }
-}
-
-static int launch_gemm_f32(int epi, const GemmF32Args& a, int nb, hipStream_t s) {
-    if (a.K % 16 || a.lda % 4 || a.ldw % 4) { ctts_set_error("gemm_f32: K=%d lda=%d ldw=%d alignment", a.K, a.lda, a.ldw); return 1; }
-    dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, nb), block(256);
-    switch (epi) {
-        case EP_NONE: hipLaunchKernelGGL(gemm_f32_kernel<EP_NONE>, grid, block, 0, s, a); break;
-        case EP_BIAS: hipLaunchKernelGGL(gemm_f32_kernel<EP_BIAS>, grid, block, 0, s, a); break;
-        case EP_BIAS_GELU: hipLaunchKernelGGL(gemm_f32_kernel<EP_BIAS_GELU>, grid, block, 0, s, a); break;
-        case EP_GAMMA_RESID: hipLaunchKernelGGL(gemm_f32_kernel<EP_GAMMA_RESID>, grid, block, 0, s, a); break;
-        case EP_SCALE_T: hipLaunchKernelGGL(gemm_f32_kernel<EP_SCALE_T>, grid, block, 0, s, a); break;
-        case EP_SCALE: hipLaunchKernelGGL(gemm_f32_kernel<EP_SCALE>, grid, block, 0, s, a); break;
-        default: ctts_set_error("gemm_f32: bad epilogue"); return 1;
-    }
-    CTTS_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-// depthwise conv (k7, dilation d, zero padding) fused with LayerNorm over C=512; one wave per frame, grid.y = utterance.
-// taps == 0 -> plain LayerNorm of the input row (Vocos' post-embed / final norms).  sx / so: batch strides of in / out.
-__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* x, float* out, const float* w /*[C][7]*/, const float* b,
-                                                        const float* lnw, const float* lnb, const int* Ts, long sx, long so, int C, int dil, int taps) {
-    const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int T = Ts[blockIdx.y];
-    if (t >= T) return;
-    x += (size_t)blockIdx.y * sx; out += (size_t)blockIdx.y * so;
-    float v[8];
-    const int c0 = lane * 8;                                  // C == 512: 8 channels per lane
-    if (taps == 0) {
-        const f32x4 p = *(const f32x4*)(x + (size_t)t * C + c0), q = *(const f32x4*)(x + (size_t)t * C + c0 + 4);
-        v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; v[4] = q[0]; v[5] = q[1]; v[6] = q[2]; v[7] = q[3];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = b[c0 + j];
-        for (int k = 0; k < taps; ++k) {
-            const int tt = t + (k - taps / 2) * dil;
-            if (tt < 0 || tt >= T) continue;
-            const f32x4 p = *(const f32x4*)(x + (size_t)tt * C + c0), q = *(const f32x4*)(x + (size_t)tt * C + c0 + 4);
-            const float xv[8] = {p[0], p[1], p[2], p[3], q[0], q[1], q[2], q[3]};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += w[(c0 + j) * taps + k] * xv[j];
-        }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[j];
-    const float mean = wave_sum(s) / (float)C;
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; ss += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + 1e-6f);
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (v[j] - mean) * rstd * lnw[c0 + j] + lnb[c0 + j];
-    *(f32x4*)(out + (size_t)t * C + c0) = (f32x4){o[0], o[1], o[2], o[3]};
-    *(f32x4*)(out + (size_t)t * C + c0 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-}
+#include "conv_gemm.h"
 
 // Stage the batch: copy each utterance's hidden rows ([n][768] == frames [2n][384], dvae.py:277-283) behind a zero guard
 // row and zero the guard rows / channel padding of every conv input (grid = (Fmax + 6, nb), one row per block).
@@ -274,21 +132,6 @@ static const std::vector<float>* vneed(ctts_voc* h, const std::string& k, size_t
     if (it->second.size() != n) { ctts_set_error("weight %s has %zu elements, expected %zu", k.c_str(), it->second.size(), n); return nullptr; }
     return &it->second;
 }
-// torch Conv1d weight [Cout][Cin][taps] -> GEMM weight [Npad][taps*ld_in], k = tap*ld_in + ci, zero padded
-static std::vector<float> conv_to_gemm(const std::vector<float>& w, int cout, int cin, int taps, int ld_in, int npad) {
-    std::vector<float> o((size_t)npad * taps * ld_in, 0.f);
-    for (int co = 0; co < cout; ++co)
-        for (int ci = 0; ci < cin; ++ci)
-            for (int t = 0; t < taps; ++t) o[(size_t)co * taps * ld_in + (size_t)t * ld_in + ci] = w[((size_t)co * cin + ci) * taps + t];
-    return o;
-}
-static std::vector<float> pad_rows(const std::vector<float>& w, int rows, int cols, int npad) {
-    std::vector<float> o((size_t)npad * cols, 0.f);
-    memcpy(o.data(), w.data(), (size_t)rows * cols * 4);
-    return o;
-}
-static inline int r64(int n) { return (n + 63) / 64 * 64; }
-
 static int load_convnext(ctts_voc* h, const std::string& p, int dim, int inter, ConvNext* cb) {
     const std::vector<float>*dw = vneed(h, p + "dwconv.weight", (size_t)dim * 7), *db = vneed(h, p + "dwconv.bias", dim),
                             *lw = vneed(h, p + "norm.weight", dim), *lb = vneed(h, p + "norm.bias", dim),
@@ -400,7 +243,7 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
 
 static int run_convnext(ctts_voc* h, const ConvNext& cb, int nb, int Fmax, int dim, int inter, int dil, hipStream_t s) {
     const long sd = (long)h->Fp * dim, sm = (long)h->Fp * h->mid_ld;
-    hipLaunchKernelGGL(dwconv_ln_kernel, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln, cb.dw_w, cb.dw_b, cb.ln_w, cb.ln_b, h->d_F, sd, sd, dim, dil, 7);
+    hipLaunchKernelGGL(dwconv_ln_kernel<8>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln, cb.dw_w, cb.dw_b, cb.ln_w, cb.ln_b, h->d_F, sd, sd, dim, dil, 7);
     CTTS_HIP_CHECK(hipGetLastError());
     GemmF32Args g = {};
     g.A = h->ln; g.lda = dim; g.sA = sd; g.W = cb.w1; g.ldw = dim; g.C = h->mid; g.ldc = inter; g.sC = sm;
@@ -476,12 +319,12 @@ static int run_vocos(ctts_voc* h, int nb, int Fmax, hipStream_t s) {
     g.A = h->mcl; g.lda = LD; g.sA = Fp * LD; g.W = h->em_w; g.ldw = 7 * LD; g.C = h->mid; g.ldc = VD; g.sC = Fp * h->mid_ld;
     g.M = Fmax; g.Ms = h->d_F; g.N = VD; g.K = 7 * LD; g.bias = h->em_b;
     if (launch_gemm_f32(EP_BIAS, g, nb, s)) return 1;                                     // embed conv k7 p3
-    hipLaunchKernelGGL(dwconv_ln_kernel, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->mid, h->y, nullptr, nullptr, h->n0_w, h->n0_b,
+    hipLaunchKernelGGL(dwconv_ln_kernel<8>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->mid, h->y, nullptr, nullptr, h->n0_w, h->n0_b,
                        h->d_F, Fp * h->mid_ld, Fp * VD, VD, 1, 0);                        // post-embed LayerNorm -> residual stream
     CTTS_HIP_CHECK(hipGetLastError());
     for (int i = 0; i < c.vocos_layers; ++i)
         if (run_convnext(h, h->vblocks[i], nb, Fmax, VD, c.vocos_inter, 1, s)) return 1;
-    hipLaunchKernelGGL(dwconv_ln_kernel, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln, nullptr, nullptr, h->nf_w, h->nf_b,
+    hipLaunchKernelGGL(dwconv_ln_kernel<8>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln, nullptr, nullptr, h->nf_w, h->nf_b,
                        h->d_F, Fp * VD, Fp * VD, VD, 1, 0);                               // final LayerNorm
     CTTS_HIP_CHECK(hipGetLastError());
     GemmF32Args g2 = {};

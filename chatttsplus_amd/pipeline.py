@@ -151,8 +151,15 @@ class ChatTTSPlusPipeline:
                     tok = Tokenizer(**kw)
                 self.models_dict[model_name] = tok
                 continue
-            if model_name == "dvae_encode":
-                continue                                    # zero-shot speaker sampling: next
+            if model_name == "dvae_encode":                 # zero-shot speaker prompt (pipeline:279-284): optional checkpoint
+                if itype == "hip" and kw.get("model_path") and os.path.exists(kw["model_path"]):
+                    path = kw.pop("model_path")
+                    enc = hip_models.DVAEEncoder(device=str(self.device), **kw)
+                    sd = dict(torch.load(path, weights_only=True, mmap=True))
+                    if "coef" not in sd:
+                        sd["coef"] = torch.from_numpy(codec.coef_from_string(coef)).view(1, -1, 1)
+                    self.models_dict[model_name] = enc.load_state_dict(sd)
+                continue
             if itype != "hip":
                 raise _lib.HipBackendError(f"model {model_name}: infer_type={itype!r}; this pipeline serves infer_type 'hip' only")
             self.infer_type = self.infer_type or itype
@@ -187,6 +194,16 @@ class ChatTTSPlusPipeline:
             self.std = self.mean = None
 
     # -- speakers (pipeline:306-331) ---------------------------------------------------------------
+    @torch.inference_mode()
+    def sample_audio_speaker(self, wav) -> str:
+        """pipeline:279-284: 24 kHz mono waveform -> base16384 audio-prompt string (`spk_smp`)."""
+        enc = self.models_dict.get("dvae_encode")
+        if enc is None:
+            raise _lib.HipBackendError("zero-shot speaker needs the dvae_encode checkpoint (DVAE_full.pt) configured with infer_type 'hip'")
+        wav = torch.as_tensor(wav, dtype=torch.float32)
+        codes = enc(wav.view(1, -1).to(self.device), "encode")[0]
+        return codec.encode_prompt(codes.cpu())
+
     def sample_random_speaker(self) -> str:
         return self._encode_spk_emb(self._sample_random_speaker())
 
@@ -323,9 +340,16 @@ class ChatTTSPlusPipeline:
               params_refine_text=RefineTextParams(), params_infer_code=InferCodeParams(), **kwargs):
         """pipeline:472-579.  Speaker resolution: `speaker_emb_path` (.pt holding a base16384 str or a tensor),
         else params_infer_code.spk_emb as given, else a random speaker from spk_stat."""
-        if kwargs.get("speaker_audio_path"):
-            raise _lib.HipBackendError("zero-shot speaker_audio_path needs the DVAE encoder (SURVEY 8f N2), not served this round")
-        if kwargs.get("speaker_emb_path"):
+        if kwargs.get("speaker_audio_path"):                                      # zero shot (pipeline:486-499)
+            from . import audio
+            p = kwargs["speaker_audio_path"]
+            assert os.path.exists(p), f"speaker_audio_path {p} not exists!"
+            wav, sr = audio.load_audio(p)
+            wav = torch.mean(audio.resample(wav, sr, 24000), 0)
+            params_infer_code.spk_smp = self.sample_audio_speaker(wav)
+            params_infer_code.txt_smp = kwargs.get("speaker_audio_text", "")
+            params_infer_code.spk_emb = None
+        elif kwargs.get("speaker_emb_path"):
             p = kwargs["speaker_emb_path"]
             assert os.path.exists(p), f"speaker_emb_path {p} not exists!"
             obj = torch.load(p, weights_only=True, map_location="cpu")

@@ -112,6 +112,41 @@ def dvae_state_dict(cfg: dict = DVAE_REAL, seed: int = 1234) -> Dict[str, np.nda
     return sd
 
 
+DVAE_ENC_REAL = dict(dim=512, n_mels=100, enc_idim=512, enc_odim=1024, enc_hidden=256, enc_n_layer=12, enc_bn_dim=128,
+                     vq_dim=1024, vq_levels=(5, 5, 5, 5), vq_G=2, vq_R=2)
+
+
+def dvae_encoder_state_dict(cfg: dict = DVAE_ENC_REAL, seed: int = 1234) -> Dict[str, np.ndarray]:
+    """The encode-side tensors of DVAE_full.pt (configs/infer/chattts_plus.yaml dvae_encode; dvae.py:224-231 downsample_conv
+    + encoder, :66-81 GFSQ -> vector_quantize_pytorch GroupedResidualFSQ `rvqs.{g}.project_in`): zero-shot speaker path."""
+    sd: Dict[str, np.ndarray] = {}
+    D = cfg["dim"]
+    sd["coef"] = _uniform(seed, "dvae_enc.coef", (1, cfg["n_mels"], 1), 0.5, 1.5)
+    sd.update(_conv(seed, "downsample_conv.0", D, cfg["n_mels"], 3))
+    sd.update(_conv(seed, "downsample_conv.2", D, D, 4))
+    sd.update(_conv(seed, "encoder.conv_in.0", cfg["enc_bn_dim"], cfg["enc_idim"], 3))
+    sd.update(_conv(seed, "encoder.conv_in.2", cfg["enc_hidden"], cfg["enc_bn_dim"], 3))
+    for i in range(cfg["enc_n_layer"]):
+        sd.update(_convnext(seed, f"encoder.decoder_block.{i}.", cfg["enc_hidden"], cfg["enc_hidden"] * 4, 7))
+    sd.update(_conv(seed, "encoder.conv_out", cfg["enc_odim"], cfg["enc_hidden"], 1, bias=False))
+    per = cfg["vq_dim"] // cfg["vq_G"]
+    for g in range(cfg["vq_G"]):
+        # project_in spreads the codes over all five levels (tanh(z) * 2.002 with |z| ~ 1)
+        sd.update(_linear(seed, f"vq_layer.quantizer.rvqs.{g}.project_in", len(cfg["vq_levels"]), per, gain=1.0))
+    return sd
+
+
+def speaker_wave(seed: int, n_samples: int) -> np.ndarray:
+    """Synthetic 24 kHz speech-like test signal in [-1, 1]: a few drifting harmonics plus noise."""
+    t = np.arange(n_samples, dtype=np.float64) / 24000.0
+    r = _rng(seed, "speaker_wave")
+    f0 = 110.0 + 40.0 * np.sin(2 * np.pi * 0.7 * t + r.random())
+    ph = 2 * np.pi * np.cumsum(f0) / 24000.0
+    x = sum(a * np.sin(k * ph + r.random() * 6.28) for k, a in ((1, 0.5), (2, 0.3), (3, 0.15), (5, 0.08), (9, 0.04)))
+    x = x * (0.6 + 0.4 * np.sin(2 * np.pi * 3.1 * t)) + 0.02 * r.standard_normal(n_samples)
+    return (0.8 * x / np.abs(x).max()).astype(np.float32)
+
+
 def vocos_state_dict(cfg: dict = VOCOS_REAL, seed: int = 1234) -> Dict[str, np.ndarray]:
     """Vocos checkpoint (upstream vocos 0.1.0 VocosBackbone + ISTFTHead key names)."""
     sd: Dict[str, np.ndarray] = {}

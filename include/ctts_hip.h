@@ -214,6 +214,39 @@ int ctts_vocos_decode(ctts_voc* h, const float* mel_dev, int frames, float* wav_
  * arrays and n_tokens are HOST arrays of length B (<= max_batch).  Same arithmetic as dvae_decode + vocos_decode. */
 int ctts_synth_batch(ctts_voc* h, const float* const* hidden_ptrs, const int32_t* n_tokens, int B, float* const* wav_ptrs, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Zero-shot speaker prompt: waveform -> audio-prompt codes.
+ * Replaces ChatTTSPlusPipeline.sample_audio_speaker (pipelines/chattts_plus_pipeline.py:279-284, called from :486-499) =
+ * DVAE.forward(mode="encode") (models/dvae.py:263-270): MelSpectrogramFeatures (:171-199), / coef, downsample_conv
+ * (:224-229), encoder = DVAEDecoder (:130-168), GFSQ (:66-126).  Weight names are the DVAE_full.pt state-dict keys
+ * ("downsample_conv.*", "encoder.*", "vq_layer.quantizer.rvqs.{g}.project_in.*", "coef") plus two host-computed tables:
+ * "mel.window" [n_fft] (periodic hann) and "mel.fb" [n_fft/2+1][n_mels] (torchaudio melscale_fbanks, htk, norm=None).
+ * --------------------------------------------------------------------------------------------------------------- */
+typedef struct ctts_enc ctts_enc;
+typedef struct {
+    int32_t n_mels;        /* 100 */
+    int32_t dim;           /* 512: downsample_conv width = encoder idim */
+    int32_t enc_hidden;    /* 256 */
+    int32_t enc_bn;        /* 128 */
+    int32_t enc_layers;    /* 12  */
+    int32_t enc_odim;      /* 1024 = vq dim */
+    int32_t vq_groups;     /* G = 2 */
+    int32_t vq_residuals;  /* R = 2 */
+    int32_t n_fft;         /* 1024 */
+    int32_t hop;           /* 256 */
+    int32_t max_samples;   /* longest reference clip, in 24 kHz samples */
+    int32_t pre_bound;     /* GroupedResidualFSQ release detail: 1 = residual starts from bound(project_in(x)) (1.17.8, see oracle) */
+} ctts_enc_cfg;
+
+int ctts_enc_create(const ctts_enc_cfg* cfg, ctts_enc** out);
+void ctts_enc_destroy(ctts_enc* h);
+int ctts_enc_set_weight(ctts_enc* h, const char* name, const float* host_data, size_t numel);
+int ctts_enc_finalize(ctts_enc* h);
+/* wav: n_samples fp32 on the device (mono, 24 kHz).  ids: int32 [G*R][T] on the device, T = ((1 + n_samples/hop) - 2)/2 + 1,
+ * row g*R + r like GFSQ.forward's `ind` (dvae.py:108-113,126).  Optional test hooks (device, may be null):
+ * mel_out [n_mels][F] = log-mel / coef, feat_out [T][enc_odim] = encoder output. */
+int ctts_dvae_encode(ctts_enc* h, const float* wav, int n_samples, int32_t* ids, float* mel_out, float* feat_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,6 +234,38 @@ def golden_dvae(ref):
     print("dvae_real mel", mel.shape, float(np.sqrt((mel ** 2).mean())))
 
 
+def golden_dvae_encode(ref):
+    """Zero-shot encode branch.  Pinned by the reference's own modules: downsample_conv + encoder (dvae.py:224-231,263-268)
+    on a given mel.  NOT pinned (third-party torchaudio / vector_quantize_pytorch absent): the mel extractor and the GFSQ
+    index computation -- the stored `mel` / `ids` are the oracle restatement's, kept so that the HIP path is checked
+    against one frozen answer."""
+    from oracle import ref_cpu
+    cfg = synth.DVAE_ENC_REAL
+    sd = synth.dvae_encoder_state_dict(cfg, 1234)
+    dec = synth.DVAE_REAL
+    m = ref.dvae.DVAE(decoder_config=dict(idim=cfg["dim"], odim=cfg["dim"], hidden=dec["hidden"], n_layer=1, bn_dim=dec["bn_dim"]),
+                      encoder_config=dict(idim=cfg["enc_idim"], odim=cfg["enc_odim"], hidden=cfg["enc_hidden"], n_layer=cfg["enc_n_layer"],
+                                          bn_dim=cfg["enc_bn_dim"]), vq_config=None, dim=cfg["dim"]).eval()
+    own = {k: torch.from_numpy(v) for k, v in sd.items() if k.startswith(("downsample_conv.", "encoder."))}
+    missing, unexpected = m.load_state_dict(own, strict=False)
+    assert not unexpected and all(k.startswith(("decoder.", "out_conv", "coef")) for k in missing), (missing, unexpected)
+    n_samples = 24000 + 77
+    wav = synth.speaker_wave(5, n_samples)
+    mel = ref_cpu.mel_features(torch.from_numpy(wav))                                  # restated (unpinned)
+    with torch.inference_mode():
+        x = mel[None] / torch.from_numpy(sd["coef"]).view(1, -1, 1)
+        feat = m.encoder(m.downsample_conv(x))[0].numpy()                              # the reference's modules
+    mine = ref_cpu.dvae_encoder_features(sd, mel).numpy()
+    assert np.abs(mine - feat).max() < 1e-4, np.abs(mine - feat).max()
+    ids = ref_cpu.gfsq_indices(torch.from_numpy(feat).transpose(0, 1), {k: torch.from_numpy(v) for k, v in sd.items()}, pre_bound=False).numpy()
+    ids_pb = ref_cpu.gfsq_indices(torch.from_numpy(feat).transpose(0, 1), {k: torch.from_numpy(v) for k, v in sd.items()}, pre_bound=True).numpy()
+    np.savez_compressed(os.path.join(OUT, "dvae_encode_real.npz"), wave_seed=np.array(5), n_samples=np.array(n_samples),
+                        weight_seed=np.array(1234), mel=mel.numpy().astype(np.float32), feat=feat.astype(np.float32),
+                        ids=ids.astype(np.int32), ids_pre_bound=ids_pb.astype(np.int32))
+    print("dvae_encode_real feat", feat.shape, "oracle-vs-reference max err", float(np.abs(mine - feat).max()), "ids", ids.shape,
+          "pre_bound differs in", int((ids != ids_pb).sum()), "of", ids.size)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -243,6 +275,7 @@ def main():
     golden_gpt_tiny(ref)
     golden_gpt_tiny_regen(ref)
     golden_dvae(ref)
+    golden_dvae_encode(ref)
     golden_gpt_real(ref)
     golden_refine_text(ref)
 

@@ -439,6 +439,95 @@ def dvae_decode(sd: Dict[str, np.ndarray], hidden: torch.Tensor) -> torch.Tensor
 
 
 # ----------------------------------------------------------------------------------------------
+# DVAE encode branch = zero-shot speaker prompt (models/dvae.py:171-199,263-270; pipeline:279-284,486-499)
+#   mel extractor:  third-party torchaudio.transforms.MelSpectrogram -- ABSENT here: PARITY UNPINNED, restated from its
+#                   documented algorithm (Spectrogram(power=1, center, reflect, periodic hann) -> MelScale(htk, norm=None))
+#   conv stack:     the reference's own modules -- pinned by tests/golden/dvae_encode_real.npz
+#   GFSQ:           third-party vector_quantize_pytorch==1.17.8 GroupedResidualFSQ -- ABSENT here: PARITY UNPINNED, restated
+#                   from the published FSQ / ResidualFSQ algorithm (see gfsq_indices)
+# ----------------------------------------------------------------------------------------------
+
+def mel_filterbank(n_freqs: int = 513, n_mels: int = 100, sample_rate: int = 24000) -> torch.Tensor:
+    """torchaudio.functional.melscale_fbanks(f_min=0, f_max=sr/2, norm=None, mel_scale="htk") -> [n_freqs, n_mels]."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min, m_max = 0.0, 2595.0 * math.log10(1.0 + (sample_rate / 2.0) / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.min(down, up), min=0.0)
+
+
+@torch.no_grad()
+def mel_features(wav: torch.Tensor, n_fft: int = 1024, hop: int = 256, n_mels: int = 100, sample_rate: int = 24000) -> torch.Tensor:
+    """MelSpectrogramFeatures.forward (dvae.py:171-199): log(clip(mel_spec(audio), 1e-5)); wav [n] -> [n_mels, 1 + n // hop]."""
+    wav = _t(wav).float()
+    window = torch.hann_window(n_fft, periodic=True)
+    spec = torch.stft(wav, n_fft, hop_length=hop, win_length=n_fft, window=window, center=True, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True).abs()                        # power = 1
+    mel = torch.matmul(spec.transpose(-1, -2), mel_filterbank(n_fft // 2 + 1, n_mels, sample_rate)).transpose(-1, -2)
+    return torch.log(torch.clip(mel, min=1e-5))
+
+
+def fsq_bound(z: torch.Tensor, levels: torch.Tensor, eps: float = 1e-3) -> torch.Tensor:
+    """FSQ.bound: (z + shift).tanh() * half_l - offset."""
+    half_l = (levels - 1) * (1 + eps) / 2
+    offset = torch.where(levels % 2 == 0, 0.5, 0.0)
+    shift = (offset / half_l).atanh()
+    return (z + shift).tanh() * half_l - offset
+
+
+def gfsq_indices(x: torch.Tensor, sd, levels=(5, 5, 5, 5), G: int = 2, R: int = 2, pre_bound: bool = True) -> torch.Tensor:
+    """GFSQ.forward (dvae.py:94-126) on x [T, G*dim_g] -> indices [G*R, T] (ind.permute(1,2,0,3).view(...).transpose).
+    Per group: ResidualFSQ = project_in (Linear dim_g -> len(levels)), then R FSQ layers on residual / scale_r with
+    scale_r = (levels - 1) ** -r; FSQ: codes = round(bound(z)) / (levels // 2); index = sum((codes * hw + hw) * basis),
+    basis = cumprod([1] + levels[:-1]).  `pre_bound`: the 1.1x releases bound the projected input once before the residual
+    loop (`residual = first(self.layers).bound(x)`); later releases replaced that by an optional soft clamp and start from
+    `residual = x`.  1.17.8 cannot be inspected offline: True is our best knowledge of that release, both variants are
+    implemented (oracle and HIP) and frozen in tests/golden/dvae_encode_real.npz (`ids_pre_bound` / `ids`)."""
+    lv = torch.tensor(levels, dtype=torch.float32)
+    hw = torch.tensor([l // 2 for l in levels], dtype=torch.float32)
+    basis = torch.cumprod(torch.tensor([1] + list(levels[:-1]), dtype=torch.float32), 0)
+    per = x.shape[-1] // G
+    out = []
+    for g in range(G):
+        w, b = _t(sd[f"vq_layer.quantizer.rvqs.{g}.project_in.weight"]).float(), _t(sd[f"vq_layer.quantizer.rvqs.{g}.project_in.bias"]).float()
+        z = F.linear(x[..., g * per:(g + 1) * per], w, b)
+        residual = fsq_bound(z, lv) if pre_bound else z
+        for r in range(R):
+            scale = (lv - 1) ** (-r)
+            codes = torch.round(fsq_bound(residual / scale, lv)) / hw
+            idx = ((codes * hw + hw) * basis).sum(-1).to(torch.int32)
+            residual = residual - codes * scale
+            out.append(idx)
+    return torch.stack(out, 0)                                                   # [G*R, T], row = g * R + r
+
+
+@torch.no_grad()
+def dvae_encoder_features(sd: Dict[str, np.ndarray], mel: torch.Tensor) -> torch.Tensor:
+    """mel [100, F] -> encoder output [1024, F // 2]: div by coef, downsample_conv, DVAEDecoder-as-encoder (dvae.py:263-268)."""
+    sd = {k: _t(v).float() for k, v in sd.items()}
+    x = (_t(mel).float() / sd["coef"].view(-1, 1))[None]
+    x = F.gelu(F.conv1d(x, sd["downsample_conv.0.weight"], sd["downsample_conv.0.bias"], stride=1, padding=1))
+    x = F.gelu(F.conv1d(x, sd["downsample_conv.2.weight"], sd["downsample_conv.2.bias"], stride=2, padding=1))
+    y = F.gelu(F.conv1d(x, sd["encoder.conv_in.0.weight"], sd["encoder.conv_in.0.bias"], padding=1))
+    y = F.conv1d(y, sd["encoder.conv_in.2.weight"], sd["encoder.conv_in.2.bias"], padding=1)
+    n_layer = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.decoder_block."))
+    for i in range(n_layer):
+        y = _convnext(sd, f"encoder.decoder_block.{i}.", y, dilation=2)
+    return F.conv1d(y, sd["encoder.conv_out.weight"])[0]
+
+
+@torch.no_grad()
+def dvae_encode(sd: Dict[str, np.ndarray], wav: torch.Tensor, pre_bound: bool = True) -> torch.Tensor:
+    """DVAE.forward(mode="encode") (dvae.py:263-270): wav [n] @ 24 kHz -> audio-prompt codes [4, T] (values < 625)."""
+    feat = dvae_encoder_features(sd, mel_features(wav))
+    return gfsq_indices(feat.transpose(0, 1), {k: _t(v).float() for k, v in sd.items()}, pre_bound=pre_bound)
+
+
+# ----------------------------------------------------------------------------------------------
 # Vocos (third-party vocos 0.1.0 -- PARITY UNPINNED, see module docstring)
 # ----------------------------------------------------------------------------------------------
 

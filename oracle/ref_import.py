@@ -74,6 +74,19 @@ def load_reference():
                 sys.modules[name] = types.ModuleType(name)
     if not hasattr(sys.modules["vector_quantize_pytorch"], "GroupedResidualFSQ"):
         sys.modules["vector_quantize_pytorch"].GroupedResidualFSQ = object
+    if not hasattr(sys.modules["torchaudio"], "transforms"):
+        # DVAE(encoder_config=...) constructs MelSpectrogramFeatures (dvae.py:185-192); torchaudio is absent, and the mel
+        # extractor is NOT what the encoder golden pins (only downsample_conv + encoder are run): a parameter-free placeholder
+        import torch
+
+        class _AbsentMelSpectrogram(torch.nn.Module):
+            def __init__(self, *a, **k):
+                super().__init__()
+
+            def forward(self, x):
+                raise RuntimeError("torchaudio is not installed: the mel extractor is restated in oracle/ref_cpu.mel_features")
+
+        sys.modules["torchaudio"].transforms = types.SimpleNamespace(MelSpectrogram=_AbsentMelSpectrogram)
 
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)

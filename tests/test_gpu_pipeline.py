@@ -35,7 +35,8 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
     gsd = synth.gpt_state_dict(synth.GPT_REAL, 1234)
     dsd = synth.dvae_state_dict(synth.DVAE_REAL, 1234)
     vsd = synth.vocos_state_dict(synth.VOCOS_REAL, 1234)
-    for name, sd in (("GPT.pt", gsd), ("Decoder.pt", dsd), ("Vocos.pt", vsd)):
+    esd = synth.dvae_encoder_state_dict(synth.DVAE_ENC_REAL, 1234)
+    for name, sd in (("GPT.pt", gsd), ("Decoder.pt", dsd), ("Vocos.pt", vsd), ("DVAE_full.pt", esd)):
         torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, tmp_path / "asset" / name)
     tok = _tokenizer(tmp_path)
     pipe = ChatTTSPlusPipeline(cfg, device="cuda", tokenizer=tok, checkpoint_dir=str(tmp_path))
@@ -74,6 +75,21 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
         n_tail = tail.shape[1] - (max(w.shape[0] for w in wavs) - wavs[b].shape[0])
         if n_tail > 0:
             assert np.array_equal(tail[b, :n_tail], wavs[b][wavs[b].shape[0] - n_tail:])
+
+    # zero shot (pipeline:486-499): a 16 kHz stereo clip -> mono 24 kHz -> DVAE encoder -> audio-prompt codes in front of the text
+    from scipy.io import wavfile
+    from chatttsplus_amd import audio
+    clip = synth.speaker_wave(9, 16000)
+    wavfile.write(tmp_path / "spk.wav", 16000, np.stack([clip, 0.5 * clip], 1))
+    mono = torch.mean(audio.resample(torch.from_numpy(np.stack([clip, 0.5 * clip], 0)), 16000, 24000), 0)
+    smp = pipe.sample_audio_speaker(mono)
+    codes = codec.decode_prompt(smp)
+    assert codes.shape == (4, ((1 + 24000 // 256) - 2) // 2 + 1) and int(codes.max()) < 625
+    ref_codes = ref_cpu.dvae_encode(esd, mono)
+    assert float((codes != ref_codes.to(torch.int64)).float().mean()) <= 0.01
+    zs = list(pipe.infer(list(texts), skip_refine_text=True, do_text_optimization=False, speaker_audio_path=str(tmp_path / "spk.wav"),
+                         speaker_audio_text="a b", params_infer_code=InferCodeParams(max_new_token=12, min_new_token=12, show_tqdm=False)))
+    assert len(zs) == 1 and [w.shape[0] for w in zs[0]] == [256 * 23, 256 * 23] and all(bool(torch.isfinite(w).all()) for w in zs[0])
 
     # default infer() path: refine-text pass first (pipeline:399-411), then code inference on the refined text
     from chatttsplus_amd.pipeline import RefineTextParams

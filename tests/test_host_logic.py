@@ -96,3 +96,25 @@ def test_load_lora_adapter_reads_peft_files(tmp_path):
               str(tmp_path / "adapter_model.safetensors"))
     ad = load_lora_adapter(str(tmp_path))
     assert len(ad) == 1 and ad[0][0] == 3 and ad[0][1] == "q_proj" and ad[0][4] == 2.0 and np.array_equal(ad[0][2], A)
+
+
+def test_audio_resample_and_loader(tmp_path):
+    """Zero-shot host pre-processing (pipeline:493-496): wav reader + windowed-sinc resampler."""
+    import numpy as np
+    import torch
+    from scipy.io import wavfile
+    from chatttsplus_amd import audio
+    sr = 16000
+    t = np.arange(sr, dtype=np.float64) / sr
+    x = 0.5 * np.sin(2 * np.pi * 440.0 * t)
+    wavfile.write(tmp_path / "a.wav", sr, np.stack([x, x], 1).astype(np.float32))
+    wav, got_sr = audio.load_audio(str(tmp_path / "a.wav"))
+    assert got_sr == sr and wav.shape == (2, sr)
+    y = audio.resample(wav, sr, 24000)
+    assert y.shape == (2, 24000)
+    ref = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(24000) / 24000.0)
+    assert np.abs(y[0].numpy()[200:-200] - ref[200:-200]).max() < 2e-3      # a 440 Hz tone survives 16 -> 24 kHz
+    assert audio.resample(wav, 24000, 24000) is wav
+    wavfile.write(tmp_path / "b.wav", sr, (x * 32767).astype(np.int16))
+    w16, _ = audio.load_audio(str(tmp_path / "b.wav"))
+    assert w16.shape == (1, sr) and abs(float(w16.abs().max()) - 0.5) < 1e-3

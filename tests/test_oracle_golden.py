@@ -1,12 +1,14 @@
 """The oracle (oracle/ref_cpu.py) against the golden vectors minted from the imported reference
 (oracle/make_golden.py).  CPU only.  Bit-exact for token ids; <=2e-5 abs on fp32 hiddens / mels."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from chatttsplus_amd import synth
 from oracle import ref_cpu
-from tests.helpers import gen_case_inputs, load_golden
+from tests.helpers import GOLDEN, gen_case_inputs, load_golden
 
 
 def _run_oracle(name, cfg):
@@ -94,3 +96,23 @@ def test_refine_text_generate_matches_reference(name):
     assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist()
     for b, n in enumerate(z["lens"]):
         assert np.array_equal(out.ids[b].numpy(), z["ids"][b, :n].astype(np.int64))
+
+
+def test_dvae_encode_oracle_golden():
+    """Zero-shot encode branch: the oracle's conv stack equals the reference's own downsample_conv + encoder modules (pinned);
+    mel extractor / GFSQ are restated third-party code (unpinned) frozen in the same fixture."""
+    import torch
+    from chatttsplus_amd import synth
+    from oracle import ref_cpu
+    z = np.load(os.path.join(GOLDEN, "dvae_encode_real.npz"))
+    sd = synth.dvae_encoder_state_dict(synth.DVAE_ENC_REAL, int(z["weight_seed"]))
+    wav = torch.from_numpy(synth.speaker_wave(int(z["wave_seed"]), int(z["n_samples"])))
+    mel = ref_cpu.mel_features(wav)
+    assert np.abs(mel.numpy() - z["mel"]).max() <= 1e-5
+    feat = ref_cpu.dvae_encoder_features(sd, torch.from_numpy(z["mel"])).numpy()
+    assert np.abs(feat - z["feat"]).max() <= 1e-4
+    f = torch.from_numpy(z["feat"]).transpose(0, 1)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    assert np.array_equal(ref_cpu.gfsq_indices(f, sdt, pre_bound=True).numpy(), z["ids_pre_bound"])
+    assert np.array_equal(ref_cpu.gfsq_indices(f, sdt, pre_bound=False).numpy(), z["ids"])
+    assert np.array_equal(ref_cpu.dvae_encode(sd, wav).numpy(), z["ids_pre_bound"])
