@@ -3,6 +3,7 @@
 // host-side weight re-layout helpers.
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -31,56 +32,59 @@ struct GemmF32Args {
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// block = 4 waves (2x2), wave tile 32x32, block tile 64x64; fragments are loaded straight from global/L2
-template <int EPI>
+// block = 4 waves (2x2); wave tile (16 MI) x (16 NJ): 32x32 (block 64x64) by default; the 64x64 wave tile (block 128x128,
+// half the L2 bytes per flop) is kept as a diagnostic variant (CTTS_VOC_TILE=128) -- it measured slower, see launch_gemm_f32.
+// Fragments are loaded straight from global/L2.  Every output element accumulates its K range in
+// the same order whatever the tiling, so results do not depend on M, on the tile shape or on the batch (decode_window relies
+// on this).
+template <int EPI, int MI, int NJ>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args a) {
     const int z = blockIdx.z;
     const int M = a.Ms ? a.Ms[z] : a.M;
-    if ((int)blockIdx.y * 64 >= M) return;
+    if ((int)blockIdx.y * (32 * MI) >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
+    const int m0 = blockIdx.y * (32 * MI) + (wave >> 1) * (16 * MI), n0 = blockIdx.x * (32 * NJ) + (wave & 1) * (16 * NJ);
     const float* Ap = a.A + (size_t)z * a.sA + (size_t)(m0 + (lane & 15)) * a.lda + 4 * (lane >> 4);
     const float* Wp = a.W + (size_t)(n0 + (lane & 15)) * a.ldw + 4 * (lane >> 4);
     const size_t a16 = (size_t)16 * a.lda, w16 = (size_t)16 * a.ldw;
-    f32x4 acc[2][2];
+    f32x4 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // software-pipelined K loop (two register sets, order pinned with sched_barrier -- hipcc otherwise rotates the loop
-    // back into load -> wait -> MFMA): the fragments of the next 16-deep step are in flight during the 16 MFMAs
-    // (512 cycles) of the current one.
-#define GEMM_STEP(A0, A1, B0, B1)                                                                     \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], B0[j], acc[0][0], 0, 0, 0);           \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], B1[j], acc[0][1], 0, 0, 0);           \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], B0[j], acc[1][0], 0, 0, 0);           \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], B1[j], acc[1][1], 0, 0, 0);           \
-    }
-    f32x4 a0 = *(const f32x4*)(Ap), a1 = *(const f32x4*)(Ap + a16);
-    f32x4 b0 = *(const f32x4*)(Wp), b1 = *(const f32x4*)(Wp + w16);
+    // back into load -> wait -> MFMA): the fragments of the next 16-deep step are in flight during the MFMAs of the current one.
+#define GEMM_LOAD(FA, FB, KO)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) FA[i] = *(const f32x4*)(Ap + i * a16 + (KO));          \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) FB[j] = *(const f32x4*)(Wp + j * w16 + (KO));
+#define GEMM_STEP(FA, FB)                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                        \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[i][e], FB[j][e], acc[i][j], 0, 0, 0);
+    f32x4 fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
+    GEMM_LOAD(fa0, fb0, 0)
     for (int k0 = 0; k0 < a.K; k0 += 32) {
         const int k1 = (k0 + 16 < a.K) ? k0 + 16 : k0;
-        const f32x4 c0 = *(const f32x4*)(Ap + k1), c1 = *(const f32x4*)(Ap + a16 + k1);
-        const f32x4 d0 = *(const f32x4*)(Wp + k1), d1 = *(const f32x4*)(Wp + w16 + k1);
+        GEMM_LOAD(fa1, fb1, k1)
         __builtin_amdgcn_sched_barrier(0);
-        GEMM_STEP(a0, a1, b0, b1)
+        GEMM_STEP(fa0, fb0)
         __builtin_amdgcn_sched_barrier(0);
         if (k0 + 16 >= a.K) break;
         const int k2 = (k0 + 32 < a.K) ? k0 + 32 : k0;
-        a0 = *(const f32x4*)(Ap + k2); a1 = *(const f32x4*)(Ap + a16 + k2);
-        b0 = *(const f32x4*)(Wp + k2); b1 = *(const f32x4*)(Wp + w16 + k2);
+        GEMM_LOAD(fa0, fb0, k2)
         __builtin_amdgcn_sched_barrier(0);
-        GEMM_STEP(c0, c1, d0, d1)
+        GEMM_STEP(fa1, fb1)
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef GEMM_STEP
+#undef GEMM_LOAD
     float* Cb = (EPI == EP_SCALE_T && a.Cptrs) ? a.Cptrs[z] : a.C + (size_t)z * a.sC;
     const float* Rb = (EPI == EP_GAMMA_RESID) ? a.resid + (size_t)z * a.sR : nullptr;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NJ; ++ni) {
             const int n = n0 + ni * 16 + (lane & 15);
             if (n >= a.N) continue;
 #pragma unroll
@@ -99,21 +103,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args a) {
         }
 }
 
-static int launch_gemm_f32(int epi, const GemmF32Args& a, int nb, hipStream_t s) {
-    if (a.K % 16 || a.lda % 4 || a.ldw % 4) { ctts_set_error("gemm_f32: K=%d lda=%d ldw=%d alignment", a.K, a.lda, a.ldw); return 1; }
-    dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, nb), block(256);
-    switch (epi) {
-        case EP_NONE: hipLaunchKernelGGL(gemm_f32_kernel<EP_NONE>, grid, block, 0, s, a); break;
-        case EP_BIAS: hipLaunchKernelGGL(gemm_f32_kernel<EP_BIAS>, grid, block, 0, s, a); break;
-        case EP_BIAS_GELU: hipLaunchKernelGGL(gemm_f32_kernel<EP_BIAS_GELU>, grid, block, 0, s, a); break;
-        case EP_GAMMA_RESID: hipLaunchKernelGGL(gemm_f32_kernel<EP_GAMMA_RESID>, grid, block, 0, s, a); break;
-        case EP_SCALE_T: hipLaunchKernelGGL(gemm_f32_kernel<EP_SCALE_T>, grid, block, 0, s, a); break;
-        case EP_SCALE: hipLaunchKernelGGL(gemm_f32_kernel<EP_SCALE>, grid, block, 0, s, a); break;
-        case EP_LOGCLIP_DIV: hipLaunchKernelGGL(gemm_f32_kernel<EP_LOGCLIP_DIV>, grid, block, 0, s, a); break;
-        default: ctts_set_error("gemm_f32: bad epilogue"); return 1;
-    }
+template <int EPI>
+static int launch_gemm_f32_epi(const GemmF32Args& a, int nb, hipStream_t s, bool big) {
+    if (big) hipLaunchKernelGGL((gemm_f32_kernel<EPI, 4, 4>), dim3((a.N + 127) / 128, (a.M + 127) / 128, nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_f32_kernel<EPI, 2, 2>), dim3((a.N + 63) / 64, (a.M + 63) / 64, nb), dim3(256), 0, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+// `row_pad`: rows the caller guarantees to be readable past M in A (the weights are padded to a multiple of 64 rows): the
+// 128-row tiles need row_pad >= 127 and N % 128 == 0.
+static int launch_gemm_f32(int epi, const GemmF32Args& a, int nb, hipStream_t s, int row_pad = 63) {
+    if (a.K % 16 || a.lda % 4 || a.ldw % 4) { ctts_set_error("gemm_f32: K=%d lda=%d ldw=%d alignment", a.K, a.lda, a.ldw); return 1; }
+    static const int force = getenv("CTTS_VOC_TILE") ? atoi(getenv("CTTS_VOC_TILE")) : 0;      // 64 / 128: diagnostic override
+    // measured (32 utterances x 272 tokens): 128x128 tiles 28.8 ms vs 64x64 25.6 ms -- the fragment loads (16 rows x 64 B per
+    // wave instruction) are what limits this kernel, not the L2 bytes per flop, so the small tile stays the default
+    const bool big = (force == 128) && row_pad >= 127 && a.N % 128 == 0;
+    switch (epi) {
+        case EP_NONE: return launch_gemm_f32_epi<EP_NONE>(a, nb, s, big);
+        case EP_BIAS: return launch_gemm_f32_epi<EP_BIAS>(a, nb, s, big);
+        case EP_BIAS_GELU: return launch_gemm_f32_epi<EP_BIAS_GELU>(a, nb, s, big);
+        case EP_GAMMA_RESID: return launch_gemm_f32_epi<EP_GAMMA_RESID>(a, nb, s, big);
+        case EP_SCALE_T: return launch_gemm_f32_epi<EP_SCALE_T>(a, nb, s, false);
+        case EP_SCALE: return launch_gemm_f32_epi<EP_SCALE>(a, nb, s, false);
+        case EP_LOGCLIP_DIV: return launch_gemm_f32_epi<EP_LOGCLIP_DIV>(a, nb, s, false);
+        default: ctts_set_error("gemm_f32: bad epilogue"); return 1;
+    }
 }
 
 // depthwise conv (k7, dilation d, zero padding) fused with LayerNorm over C = 64 * CPL channels (CPL = 8: the 512-wide

@@ -218,7 +218,7 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
         if (upload(h, &h->basis, B)) return 1;
     }
     // ---- workspaces: max_batch regions of Fp rows (rows padded so every 64-row GEMM tile stays in bounds)
-    const int Fp = r64(c.max_frames) + 64;
+    const int Fp = r64(c.max_frames) + 192;             // 128-row GEMM tiles + conv guard rows stay in bounds
     h->Fp = Fp;
     const size_t MB = c.max_batch;
     h->mid_ld = (HD * 4 > VI) ? HD * 4 : VI;
@@ -248,11 +248,11 @@ static int run_convnext(ctts_voc* h, const ConvNext& cb, int nb, int Fmax, int d
     GemmF32Args g = {};
     g.A = h->ln; g.lda = dim; g.sA = sd; g.W = cb.w1; g.ldw = dim; g.C = h->mid; g.ldc = inter; g.sC = sm;
     g.M = Fmax; g.Ms = h->d_F; g.N = inter; g.K = dim; g.bias = cb.b1;
-    if (launch_gemm_f32(EP_BIAS_GELU, g, nb, s)) return 1;
+    if (launch_gemm_f32(EP_BIAS_GELU, g, nb, s, 127)) return 1;
     GemmF32Args g2 = {};
     g2.A = h->mid; g2.lda = inter; g2.sA = sm; g2.W = cb.w2; g2.ldw = inter; g2.C = h->y; g2.ldc = dim; g2.sC = sd;
     g2.M = Fmax; g2.Ms = h->d_F; g2.N = dim; g2.K = inter; g2.bias = cb.b2; g2.gamma = cb.gamma; g2.resid = h->y; g2.ldr = dim; g2.sR = sd;
-    return launch_gemm_f32(EP_GAMMA_RESID, g2, nb, s);
+    return launch_gemm_f32(EP_GAMMA_RESID, g2, nb, s, 127);
 }
 
 // upload the per-call tables (frames, pointers): a ring of pinned staging slots guarded by events, no stream sync
@@ -289,26 +289,26 @@ static int run_dvae(ctts_voc* h, int nb, int Fmax, bool to_mcl, hipStream_t s) {
     GemmF32Args g = {};
     g.A = h->in384; g.lda = ID; g.sA = Fp * ID; g.W = h->ci0_w; g.ldw = 3 * ID; g.C = h->b128 + BN; g.ldc = BN; g.sC = Fp * BN;
     g.M = Fmax; g.Ms = h->d_F; g.N = BN; g.K = 3 * ID; g.bias = h->ci0_b;
-    if (launch_gemm_f32(EP_BIAS_GELU, g, nb, s)) return 1;                               // conv_in.0 + GELU (dvae.py:143-145)
+    if (launch_gemm_f32(EP_BIAS_GELU, g, nb, s, 127)) return 1;                               // conv_in.0 + GELU (dvae.py:143-145)
     GemmF32Args g2 = {};
     g2.A = h->b128; g2.lda = BN; g2.sA = Fp * BN; g2.W = h->ci2_w; g2.ldw = 3 * BN; g2.C = h->y; g2.ldc = HD; g2.sC = Fp * HD;
     g2.M = Fmax; g2.Ms = h->d_F; g2.N = HD; g2.K = 3 * BN; g2.bias = h->ci2_b;
-    if (launch_gemm_f32(EP_BIAS, g2, nb, s)) return 1;                                    // conv_in.2 (dvae.py:146)
+    if (launch_gemm_f32(EP_BIAS, g2, nb, s, 127)) return 1;                                    // conv_in.2 (dvae.py:146)
     for (int i = 0; i < c.dvae_layers; ++i)
         if (run_convnext(h, h->dblocks[i], nb, Fmax, HD, HD * 4, 2, s)) return 1;         // dvae.py:147-158,164-165
     GemmF32Args g3 = {};
     g3.A = h->y; g3.lda = HD; g3.sA = Fp * HD; g3.W = h->co_w; g3.ldw = HD; g3.C = h->co384 + ID; g3.ldc = ID; g3.sC = Fp * ID;
     g3.M = Fmax; g3.Ms = h->d_F; g3.N = ID; g3.K = HD;
-    if (launch_gemm_f32(EP_NONE, g3, nb, s)) return 1;                                    // conv_out 1x1, no bias (dvae.py:159,167)
+    if (launch_gemm_f32(EP_NONE, g3, nb, s, 127)) return 1;                                    // conv_out 1x1, no bias (dvae.py:159,167)
     GemmF32Args g4 = {};
     g4.A = h->co384; g4.lda = ID; g4.sA = Fp * ID; g4.W = h->oc_w; g4.ldw = 3 * ID; g4.M = Fmax; g4.Ms = h->d_F; g4.N = c.n_mels; g4.K = 3 * ID;
     g4.scale = h->coef;
     if (to_mcl) {
         g4.C = h->mcl + 3 * h->mel_ld; g4.ldc = h->mel_ld; g4.sC = Fp * h->mel_ld;
-        return launch_gemm_f32(EP_SCALE, g4, nb, s);                                      // out_conv k3 * coef (dvae.py:285-291)
+        return launch_gemm_f32(EP_SCALE, g4, nb, s, 127);                                      // out_conv k3 * coef (dvae.py:285-291)
     }
     g4.Cptrs = h->d_mel;
-    return launch_gemm_f32(EP_SCALE_T, g4, nb, s);                                        //   ... -> [100][F] API layout
+    return launch_gemm_f32(EP_SCALE_T, g4, nb, s, 127);                                        //   ... -> [100][F] API layout
 }
 
 static int run_vocos(ctts_voc* h, int nb, int Fmax, hipStream_t s) {
@@ -318,7 +318,7 @@ static int run_vocos(ctts_voc* h, int nb, int Fmax, hipStream_t s) {
     GemmF32Args g = {};
     g.A = h->mcl; g.lda = LD; g.sA = Fp * LD; g.W = h->em_w; g.ldw = 7 * LD; g.C = h->mid; g.ldc = VD; g.sC = Fp * h->mid_ld;
     g.M = Fmax; g.Ms = h->d_F; g.N = VD; g.K = 7 * LD; g.bias = h->em_b;
-    if (launch_gemm_f32(EP_BIAS, g, nb, s)) return 1;                                     // embed conv k7 p3
+    if (launch_gemm_f32(EP_BIAS, g, nb, s, 127)) return 1;                                     // embed conv k7 p3
     hipLaunchKernelGGL(dwconv_ln_kernel<8>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->mid, h->y, nullptr, nullptr, h->n0_w, h->n0_b,
                        h->d_F, Fp * h->mid_ld, Fp * VD, VD, 1, 0);                        // post-embed LayerNorm -> residual stream
     CTTS_HIP_CHECK(hipGetLastError());
@@ -330,13 +330,13 @@ static int run_vocos(ctts_voc* h, int nb, int Fmax, hipStream_t s) {
     GemmF32Args g2 = {};
     g2.A = h->ln; g2.lda = VD; g2.sA = Fp * VD; g2.W = h->hd_w; g2.ldw = VD; g2.C = h->hbuf; g2.ldc = h->head_ld; g2.sC = Fp * h->head_ld;
     g2.M = Fmax; g2.Ms = h->d_F; g2.N = 2 * NB; g2.K = VD; g2.bias = h->hd_b;
-    if (launch_gemm_f32(EP_BIAS, g2, nb, s)) return 1;                                    // ISTFTHead.out
+    if (launch_gemm_f32(EP_BIAS, g2, nb, s, 127)) return 1;                                    // ISTFTHead.out
     hipLaunchKernelGGL(head_spec_kernel, dim3(Fmax, nb), dim3(256), 0, s, h->hbuf, h->spec, h->d_F, Fp * h->head_ld, Fp * h->spec_ld, h->head_ld, h->spec_ld, NB);
     CTTS_HIP_CHECK(hipGetLastError());
     GemmF32Args g3 = {};
     g3.A = h->spec; g3.lda = h->spec_ld; g3.sA = Fp * h->spec_ld; g3.W = h->basis; g3.ldw = h->spec_ld; g3.C = h->frames; g3.ldc = c.n_fft;
     g3.sC = Fp * c.n_fft; g3.M = Fmax; g3.Ms = h->d_F; g3.N = c.n_fft; g3.K = h->spec_ld;
-    if (launch_gemm_f32(EP_NONE, g3, nb, s)) return 1;                                    // windowed irfft as GEMM
+    if (launch_gemm_f32(EP_NONE, g3, nb, s, 127)) return 1;                                    // windowed irfft as GEMM
     const int lenmax = c.hop * (Fmax - 1);
     hipLaunchKernelGGL(overlap_add_kernel, dim3((lenmax + 255) / 256, nb), dim3(256), 0, s, h->frames, h->win, h->d_wav, h->d_F, Fp * c.n_fft, c.n_fft, c.hop);
     CTTS_HIP_CHECK(hipGetLastError());
