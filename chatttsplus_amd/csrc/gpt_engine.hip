@@ -68,6 +68,10 @@ struct ctts_gpt {
                                                  // partial sums the next consumers add (env CTTS_SPLIT_ROWS; 0 = off): 48x1024-thread blocks -> 192x256;
                                                  // measured -3 % step time at batch 1-2, -1.7 % at 4, +0.5 % at 8
     float* dpart = nullptr;                      // [rows<=16][4][768]
+    int nbg2_rows = 33;                          // decode batches of at least this many rows use 32-row blocks instead of 16-row chunks (env
+                                                 // CTTS_NBG2_ROWS).  Measured: two 16-row chunks beat one 32-row block at batch 24 / 32 (598 vs 624,
+                                                 // 640 vs 660 us/step) -- per-block prologue latency, not L2 traffic, is what these launches pay for;
+                                                 // the prompt pass keeps 32-row blocks
     int fuse_rows = 0;                           // decode batches up to this size use the fused attention+o_proj launch (env CTTS_FUSE_ROWS;
                                                  // measured: 102 -> 82 launches/step but 2 % slower at batch 1, so off by default)
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
@@ -115,6 +119,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     if (const char* sr = getenv("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 16) h->split_rows = 16; }
     if (const char* ab = getenv("CTTS_ABLATE")) h->ablate = atoi(ab);
+    if (const char* nr = getenv("CTTS_NBG2_ROWS")) h->nbg2_rows = atoi(nr);
     if (const char* fr = getenv("CTTS_FUSE_ROWS")) { h->fuse_rows = atoi(fr); if (h->fuse_rows > 16) h->fuse_rows = 16; }
     if (const char* gs = getenv("CTTS_GRAPH_STEPS")) { h->graph_steps = atoi(gs); if (h->graph_steps < 1) h->graph_steps = 1; }
     if (gemm_configure()) { delete h; return 1; }
@@ -361,7 +366,7 @@ static inline int decode_splits(const ctts_gpt* h, int B) {
 // 20 decoder layers on R rows starting at row `r0` of residual stream x (llama.py:719-749 per layer)
 static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* rope_rows, int R, int S, const DevState* st, hipStream_t s) {
     const int dt = h->cfg.dtype;
-    const int nbg = (R <= 16) ? 1 : 2;
+    const int nbg = (R <= 16 || (st != nullptr && R < h->nbg2_rows)) ? 1 : 2;     // decode rows: see nbg2_rows
     const int NB = 16 * nbg;
     const int chunks = (R + NB - 1) / NB;
     // small decode batches: the down projection is launched as 4 split-K slices (192 blocks instead of 48 x 1024 threads);
@@ -413,7 +418,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
 }
 
 static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
-    const int nbg = (h->B <= 16) ? 1 : 2;
+    const int nbg = (h->B <= 16 || h->B < h->nbg2_rows) ? 1 : 2;
+    const int chunks = (h->B + 16 * nbg - 1) / (16 * nbg);
     GemmArgs a = {};
     a.st = h->st; a.R = h->B; a.eps = 1e-6f; a.meta = h->meta_dec;
     const int nv = h->text_mode ? h->vocab_text_head : h->NVQ * h->V;
@@ -421,7 +427,7 @@ static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
     a.logits = h->logits; a.n_valid = nv;
     a.dyn = write_hidden ? h->dyn : nullptr;       // the kernel tests dyn->hidden_out itself
     a.opart = h->dpart; a.np = h->x_has_parts ? 4 : 0;
-    return launch_gemm(h->cfg.dtype, nbg, (nbg == 1 && h->split_rows > 0 && h->fuse_rows == 0) ? PRO_NORM_P : PRO_NORM, EPI_LOGITS, a, 1, s);
+    return launch_gemm(h->cfg.dtype, nbg, (nbg == 1 && h->split_rows > 0 && h->fuse_rows == 0) ? PRO_NORM_P : PRO_NORM, EPI_LOGITS, a, chunks, s);
 }
 
 static int run_sample_phase(ctts_gpt* h, hipStream_t s) {
@@ -521,7 +527,7 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows);
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows);
     const std::string key(sig);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }
