@@ -68,6 +68,8 @@ struct ctts_gpt {
                                                  // partial sums the next consumers add (env CTTS_SPLIT_ROWS; 0 = off): 48x1024-thread blocks -> 192x256;
                                                  // measured -3 % step time at batch 1-2, -1.7 % at 4, +0.5 % at 8
     float* dpart = nullptr;                      // [rows<=16][4][768]
+    int cur_splits = 1;                          // key splits of the decode attention for the steps being launched (decode_splits)
+    int launched = 0;                            // decode steps enqueued since begin / restart: host-side bound on the context length
     int nbg2_rows = 33;                          // decode batches of at least this many rows use 32-row blocks instead of 16-row chunks (env
                                                  // CTTS_NBG2_ROWS).  Measured: two 16-row chunks beat one 32-row block at batch 24 / 32 (598 vs 624,
                                                  // 640 vs 660 us/step) -- per-block prologue latency, not L2 traffic, is what these launches pay for;
@@ -357,10 +359,20 @@ static inline void* kv_layer(ctts_gpt* h, int l, int which) {
     const size_t per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM * h->esz;
     return h->kv + ((size_t)l * 2 + which) * per;
 }
-static inline int decode_splits(const ctts_gpt* h, int B) {
+// Key splits of the decode attention for a batch of B rows whose longest context in the coming steps is L keys.
+// Cap: enough (row, head, split) blocks to cover the chip.  Measured (us/step, 256 steps from a 48-token prompt unless noted):
+//   B=1: S=1 412, 2 400, 4 392, 8 392;  L~1900: S=1 628, 2 589, 8 438        -> one row: always the cap
+//   B=4: S=1 438, 2 456, 4 449;  B=8: S=1 476, 2 535                          -> S > 1 pays a softmax-combine prologue per row
+// in o_proj (S = 1 lets the attention write o_proj's packed operand directly): from 4 rows on, split only when one
+// 8-wave block would otherwise loop over more than ~768 keys.
+static inline int decode_splits(const ctts_gpt* h, int B, int L) {
     if (const char* e = getenv("CTTS_SPLITS")) { int v = atoi(e); if (v >= 1 && v <= SMAX) return v; }
-    int s = 256 / (B * h->NH);
-    return s < 1 ? 1 : (s > SMAX ? SMAX : s);
+    int cap = 256 / (B * h->NH);
+    cap = cap < 1 ? 1 : (cap > SMAX ? SMAX : cap);
+    if (B <= 2) return cap;
+    if (B >= 8) return 1;                                  // B=8, L 1200..1700: S=1 703, S=2 746
+    const int want = (L + 767) / 768;
+    return want < 1 ? 1 : (want > cap ? cap : want);
 }
 
 // 20 decoder layers on R rows starting at row `r0` of residual stream x (llama.py:719-749 per layer)
@@ -399,7 +411,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = S; g2.x_out = x;
             g2.xpacked = h->attn_packed;
             g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;
-            const bool sp2 = splitd && S > 1;              // (decode batches <= 8 always have S > 1)
+            const bool sp2 = splitd;                       // the down projection's partial sums are folded into x here
             if (!(h->ablate & 4) && launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, sp2 ? EPI_RESID_P : EPI_RESID, g2, chunks, s)) return 1;
         }
         // RMSNorm + gate|up + SiLU*up
@@ -441,6 +453,7 @@ static int run_sample_phase(ctts_gpt* h, hipStream_t s) {
 
 static int reset_state(ctts_gpt* h, bool keep_draw, hipStream_t s) {
     // step/all_done/ticket <- 0; decode rows back to (slot T-1, pos cum-1); finish/end_idx <- 0
+    h->launched = 0;
     CTTS_HIP_CHECK(hipMemsetAsync(&h->st->step, 0, 4, s));
     if (!keep_draw) CTTS_HIP_CHECK(hipMemsetAsync(&h->st->draw, 0, 4, s));
     CTTS_HIP_CHECK(hipMemsetAsync(&h->st->all_done, 0, 8, s));          // all_done + ticket
@@ -518,7 +531,7 @@ extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
 }
 
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
-    if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, decode_splits(h, h->B), h->st, s)) return 1;
+    if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s)) return 1;
     h->x_has_parts = (h->B <= h->split_rows && h->B <= 16 && h->fuse_rows == 0) ? 1 : 0;    // same condition as `splitd` in run_layers
     const int rc = run_sample_phase(h, s);          // the heads add dpart[0..3]; the sampler then re-materialises x_dec
     h->x_has_parts = 0;
@@ -527,7 +540,7 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows);
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows, h->cur_splits);
     const std::string key(sig);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }
@@ -552,6 +565,8 @@ static int ensure_graph(ctts_gpt* h) {
 extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("decode: call begin first"); return 1; }
     hipStream_t s = (hipStream_t)stream;
+    h->cur_splits = decode_splits(h, h->B, h->T + h->launched + n_steps + 1);
+    h->launched += n_steps;
     if (use_graph) {
         if (ensure_graph(h)) return 1;
         int left = n_steps;
@@ -622,10 +637,22 @@ extern "C" int ctts_sampler_run(const ctts_sampler_cfg* sc, const float* logits,
 extern "C" int ctts_gpt_time_decode(ctts_gpt* h, int n_steps, float* ms_per_step, void* stream) {
     if (!h || h->B == 0 || n_steps < 1 || !ms_per_step) { ctts_set_error("time_decode: bad argument"); return 1; }
     hipStream_t s = (hipStream_t)stream;
-    if (ensure_graph(h)) return 1;
-    CTTS_HIP_CHECK(hipEventRecord(h->ev0, s));
+    // same chunking as generate(): 32 steps at a time, each chunk with the key-split count its context length asks for;
+    // the graphs of every split count the run will need are captured before the clock starts
     n_steps = (n_steps + h->graph_steps - 1) / h->graph_steps * h->graph_steps;
-    for (int i = 0; i < n_steps; i += h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+    const int CH = 32 / h->graph_steps * h->graph_steps > 0 ? 32 / h->graph_steps * h->graph_steps : h->graph_steps;
+    for (int pass = 0; pass < 2; ++pass) {
+        int launched = h->launched;
+        if (pass == 1) CTTS_HIP_CHECK(hipEventRecord(h->ev0, s));
+        for (int i = 0; i < n_steps; i += CH) {
+            const int n = (n_steps - i < CH) ? n_steps - i : CH;
+            h->cur_splits = decode_splits(h, h->B, h->T + launched + n + 1);
+            launched += n;
+            if (ensure_graph(h)) return 1;
+            if (pass == 1) for (int j = 0; j < n; j += h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+        }
+        if (pass == 1) h->launched = launched;
+    }
     CTTS_HIP_CHECK(hipEventRecord(h->ev1, s));
     CTTS_HIP_CHECK(hipEventSynchronize(h->ev1));
     float ms = 0.f;

@@ -427,6 +427,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         if constexpr (NBG == 1) {
             rc |= launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_SWIGLU>(a, chunks, s, true);
             rc |= launch_one<WT, 1, W3072, P3072, PRO_PACKED, EPI_RESID_P>(a, chunks, s, true);
+            rc |= launch_one<WT, 1, W768, P768, PRO_PACKED, EPI_RESID_P>(a, chunks, s, true);
             rc |= launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_QKV>(a, chunks, s, true);
             rc |= launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_LOGITS>(a, chunks, s, true);
             rc |= launch_one<WT, 1, W768, P768, PRO_ATTN, EPI_RESID_P>(a, chunks, s, true);
@@ -448,6 +449,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         if (pro == PRO_NORM_P && epi == EPI_LOGITS) return launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_LOGITS>(a, chunks, s, false);
         if (pro == PRO_ATTN && epi == EPI_RESID_P) return launch_one<WT, 1, W768, P768, PRO_ATTN, EPI_RESID_P>(a, chunks, s, false);
         if (pro == PRO_PACKED && epi == EPI_PART) return launch_one<WT, 1, W768, P768, PRO_PACKED, EPI_PART>(a, chunks, s, false);
+        if (pro == PRO_PACKED && epi == EPI_RESID_P && a.K == 768) return launch_one<WT, 1, W768, P768, PRO_PACKED, EPI_RESID_P>(a, chunks, s, false);
         if (pro == PRO_PACKED && epi == EPI_RESID_P) return launch_one<WT, 1, W3072, P3072, PRO_PACKED, EPI_RESID_P>(a, chunks, s, false);
     }
     ctts_set_error("skinny_gemm: unsupported prologue/epilogue %d/%d", pro, epi);
