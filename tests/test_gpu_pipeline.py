@@ -121,7 +121,7 @@ def test_refine_text_generate_golden_bit_exact():
         w, p = gen_logits(21178, 0.7, 20, 1.0)
         torch.manual_seed(int(meta["torch_seed"]))
         out = next(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.7]), eos, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]),
-                              min_new_token=int(meta["min_new"]), logits_warpers=w, logits_processors=p, infer_text=True))
+                              min_new_token=int(meta["min_new"]), logits_warpers=w, logits_processors=p, infer_text=True, noise="torch"))
         assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist(), name
         for b, n in enumerate(z["lens"]):
             assert out.ids[b].dim() == 1 and np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64)), f"{name} row {b}"

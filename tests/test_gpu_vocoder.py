@@ -111,3 +111,20 @@ def test_decode_window_is_a_slice_of_the_prefix_waveform(voc):
     # per-utterance windows
     got = s.decode_window(hs, [1000, 0, 60000], [3000, total[1], 66000])
     assert torch.equal(got[0], full[0][1000:3000]) and torch.equal(got[1], full[1]) and torch.equal(got[2], full[2][60000:66000])
+
+
+def test_batched_synthesis_equals_single_utterance_path(voc):
+    """ctts_synth_batch over a ragged batch reproduces, bit for bit, what each utterance gives alone: an output element's
+    arithmetic does not depend on the rows (or utterances) around it."""
+    s, d, v = voc
+    if s.max_batch < 8:
+        from chatttsplus_amd.hip_models import Synth
+        s = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2048, max_batch=8)
+        s.load("dvae.", synth.dvae_state_dict(synth.DVAE_REAL, 1234))
+        s.load("vocos.", synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
+    rng = np.random.Generator(np.random.Philox(key=78))
+    hs = [torch.from_numpy(rng.standard_normal((n, 768)).astype(np.float32)).cuda() for n in (400, 380, 399, 17, 256, 400, 311, 400)]
+    together = s.decode_batch(hs)
+    for u, h in enumerate(hs):
+        alone = s.decode_batch([h])[0]
+        assert torch.equal(together[u], alone), f"utterance {u}: max diff {float((together[u] - alone).abs().max())}"

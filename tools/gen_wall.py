@@ -11,6 +11,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--steps", type=int, default=512)
 ap.add_argument("--noise", default="torch")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--text", action="store_true", help="refine-text pass: infer_text=True on the 21178-way head (top-p 0.7, top-k 20, T 0.7)")
 a = ap.parse_args()
 cfg = synth.GPT_REAL
 g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=max(a.batch, 1),
@@ -26,8 +27,12 @@ for r in range(a.reps + 1):
     torch.manual_seed(11)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = list(g.generate(emb, ids, temp, eos_token=625, max_new_token=a.steps, min_new_token=a.steps, noise=a.noise, seed=5, logits_warpers=lw, logits_processors=lp, return_hidden=True,
-                          ensure_non_empty=False))
+    if a.text:
+        res = list(g.generate(emb, ids, torch.tensor([0.7]), eos_token=21177, max_new_token=a.steps, min_new_token=a.steps, noise=a.noise, seed=5,
+                              logits_warpers=lw, logits_processors=[], infer_text=True, ensure_non_empty=False))
+    else:
+        res = list(g.generate(emb, ids, temp, eos_token=625, max_new_token=a.steps, min_new_token=a.steps, noise=a.noise, seed=5, logits_warpers=lw,
+                              logits_processors=lp, return_hidden=True, ensure_non_empty=False))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if r:
