@@ -179,10 +179,11 @@ def main():
         syn = SynthPool(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2 * expect + 64, device=str(dev), max_batch=B)
         syn.load("dvae.", synth.dvae_state_dict(synth.DVAE_REAL, 1234))
         syn.load("vocos.", synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
-        wav = syn.vocos_decode(syn.dvae_decode(hid[0, :expect]))          # warm
+        batch = [hid[b, :expect] for b in range(B)]
+        wav = syn.decode_batch(batch)[-1]                                  # warm (same shapes as the timed call)
         torch.cuda.synchronize(dev)
         tv = time.perf_counter()
-        wav = syn.decode_batch([hid[b, :expect] for b in range(B)])[-1]
+        wav = syn.decode_batch(batch)[-1]
         torch.cuda.synchronize(dev)
         voc_ms = (time.perf_counter() - tv) * 1e3
         assert wav.shape[0] == 256 * (2 * expect - 1) and bool(torch.isfinite(wav).all())
