@@ -58,7 +58,9 @@ def test_sampler_golden_cases_bit_exact():
 
 
 @pytest.mark.parametrize("temp,top_p,top_k,rep,scale", [(0.3, 0.7, 20, 1.05, 0.55), (0.0003, 0.7, 20, 1.05, 0.55),
-                                                        (1.0, 0.9, 50, 1.3, 2.0), (0.7, 0.3, 3, 1.0, 4.0)])
+                                                        (1.0, 0.9, 50, 1.3, 2.0), (0.7, 0.3, 3, 1.0, 4.0),
+                                                        # more than 64 survivors: the slot-wise final race instead of one kept element per lane
+                                                        (1.0, 0.99, 200, 1.0, 0.5), (1.0, None, None, 1.1, 0.5), (0.5, 0.5, None, 1.0, 0.3)])
 def test_sampler_random_rows_vs_oracle(temp, top_p, top_k, rep, scale):
     rng = np.random.Generator(np.random.Philox(key=99))
     rows = 128
