@@ -57,7 +57,9 @@ __device__ inline void store_x4<float>(void* base, int n, int k, int ktiles, flo
 // at 17-32 rows the 384 blocks of gate|up otherwise pull 37 MB of residual stream through L2 per launch.
 template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done_p, const void* Wq, const void* in0, const void* in1,
-                                                                  const float* resid_in, const int R, const GemmArgs a) {
+                                                                  const float* resid_in, const int R, const int misc, const GemmArgs a) {
+    // misc = np | S << 8 | ktiles_total << 16: the three struct fields that address the first loads of some variants (partial
+    // sums, attention splits, split-K weight offset) -- kept out of the by-value struct for the same reason as the pointers
     // The six leading scalars are what the first loads of the kernel need (flag, weights, the prologue's operands, the
     // residual rows, the row count).  As plain kernel arguments they are preloaded into SGPRs at wave launch
     // (-mllvm -amdgpu-kernarg-preload-count, build.py); the by-value struct behind them costs a scalar-cache miss that now
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     // the whole stream.  Everything the prologue needs is therefore requested first, the (non-temporal) weight
     // fragments last; nothing issued after them is consumed before the MFMAs.
     // split-K launches (EPI_PART): this block owns k-tiles [blockIdx.z*KTILES, +KTILES) of a matrix with ktiles_total k-tiles
-    const int kt_all = (EPI == EPI_PART) ? a.ktiles_total : KTILES;
+    const int np_ = misc & 0xFF, S_ = (misc >> 8) & 0xFF;
+    const int kt_all = (EPI == EPI_PART) ? (misc >> 16) : KTILES;
     const int kt_off = (EPI == EPI_PART) ? (int)blockIdx.z * KTILES : 0;
     const frag* Wp = (const frag*)Wq + ((size_t)rt0 * kt_all + kt_off + (size_t)wave * KPW) * 64 + lane;
     frag wf[RT][KPW];
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 if (EPI == EPI_RESID_P) {            // x = ((x + p0) + p1) + ... : partial sums in index order
                     float pp[CTTS_NPART];
 #pragma unroll
-                    for (int q = 0; q < CTTS_NPART; ++q) pp[q] = (q < a.np) ? a.opart[((size_t)r * a.np + q) * N + col] : 0.f;
+                    for (int q = 0; q < CTTS_NPART; ++q) pp[q] = (q < np_) ? a.opart[((size_t)r * np_ + q) * N + col] : 0.f;
 #pragma unroll
                     for (int q = 0; q < CTTS_NPART; ++q) v += pp[q];
                 }
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 for (int q = 0; q < CTTS_NPART; ++q)
 #pragma unroll
                     for (int i = 0; i < PER; ++i)
-                        pp[q][i] = (q < a.np) ? ((const f32x4*)((const float*)in1 + (rr * a.np + q) * K))[lane + 64 * i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        pp[q][i] = (q < np_) ? ((const f32x4*)((const float*)in1 + (rr * np_ + q) * K))[lane + 64 * i] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < CTTS_NPART; ++q)
 #pragma unroll
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         // trips: 21 us per launch at batch 1 with 16 splits, 22 us at batch 32 with 24 serial items per thread).
         constexpr int NH = K / CTTS_HEAD_DIM;
         constexpr int K4 = K / 4;
-        const int S = a.S;
+        const int S = S_;
         const int rows = min(NB, R - row0);
         if (S == 1) {
             CTTS_ISSUE_WEIGHT_LOADS();
@@ -397,7 +400,8 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
     const int* done_p = a.st ? &a.st->all_done : nullptr;
     const void* in0 = (PRO == PRO_ATTN) ? (const void*)a.part_ml : (PRO == PRO_PACKED) ? (const void*)a.xpacked : (const void*)a.x;
     const void* in1 = (PRO == PRO_ATTN) ? (const void*)a.part_o : (PRO == PRO_NORM_P) ? (const void*)a.opart : nullptr;
-    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, (const float*)a.x_out, a.R, a);
+    const int misc = (a.np & 0xFF) | ((a.S & 0xFF) << 8) | (a.ktiles_total << 16);
+    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, (const float*)a.x_out, a.R, misc, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
