@@ -302,25 +302,24 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     }
 
     float* red = (float*)(smem + XS_BYTES);                 // [WAVES][NBG][64][4]
-    float* outt = red + WAVES * NBG * 256;                  // [16][NB]
 #pragma unroll
     for (int ti = 0; ti < RT; ++ti) {
     const int rt = rt0 + ti;
-    if (ti > 0) __syncthreads();                             // the previous tile's epilogue is done with red / outt
-    // 4. deterministic cross-wave reduction through LDS
+    if (ti > 0) __syncthreads();                             // the previous tile's epilogue is done with red
+    // 4. deterministic cross-wave reduction through LDS: every wave parks its partial C tile, the epilogue threads add the WAVES
+    //    partials of their own element in wave order (one barrier; the former second LDS staging round is gone)
 #pragma unroll
     for (int g = 0; g < NBG; ++g) *(f32x4*)(red + ((wave * NBG + g) * 64 + lane) * 4) = acc[ti][g];
     __syncthreads();
-    if (tid < 64 * NBG) {
-        const int g = tid >> 6, l = tid & 63;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    // C element (weight row i of the tile, activation row n): lane = (i / 4) * 16 + (n % 16), register i % 4, group n / 16
+    auto c_elem = [&](int i, int n) -> float {
+        const float* q = red + (((n >> 4) * 64) + ((i >> 2) << 4) + (n & 15)) * 4 + (i & 3);
+        float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) s += *(const f32x4*)(red + ((w * NBG + g) * 64 + l) * 4);
-        const int n = 16 * g + (l & 15);
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) outt[((l >> 4) * 4 + r4) * NB + n] = s[r4];   // C: row=(lane>>4)*4+reg, col=lane&15
-    }
-    __syncthreads();
+        for (int w = 0; w < WAVES; ++w) sum += q[w * NBG * 256];
+        return sum;
+    };
+
     // 5. fused epilogue
     if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_LOGITS || EPI == EPI_PART) {
 #pragma unroll
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             const int r = row0 + n;
             if (r >= R) continue;
             const int col = rt * 16 + i;
-            const float v = outt[i * NB + n];
+            const float v = c_elem(i, n);
             if (EPI == EPI_PART) {
                 a.part_out[((size_t)r * gridDim.z + blockIdx.z) * (a.n_row_tiles * 16) + col] = v;
             } else if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     } else if (tid < 8 * NB) {
         const int n = tid >> 3, p = tid & 7;
         const int r = row0 + n;
-        const float va = outt[p * NB + n], vb = outt[(p + 8) * NB + n];
+        const float va = c_elem(p, n), vb = c_elem(p + 8, n);
         if (EPI == EPI_SWIGLU) {
             // packed rows: [8 gate | 8 up] per tile -> act[rt*8+p] = silu(g) * u
             float y = 0.f;
