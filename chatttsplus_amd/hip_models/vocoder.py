@@ -126,23 +126,30 @@ class Synth:
         far), computed from the tokens inside the receptive field of that window only.  Bit-identical to slicing the
         full-prefix waveform: every output element runs the same K-order arithmetic whatever rows surround it.  The
         reference's stream branch re-vocodes the whole prefix for every chunk it yields (pipeline:436-461)."""
-        hop, halo = self.cfg.hop, self.HALO_FRAMES + 1
         subs, offs, meta = [], [], []
         for h, s0, s1 in zip(hiddens, starts, stops):
-            n = int(h.shape[0])
-            total = hop * (2 * n - 1) if n > 0 else 0
-            s0, s1 = max(0, min(int(s0), total)), max(0, min(int(s1), total))
-            if s1 <= s0:
-                subs.append(h[:0]); offs.append(0); meta.append((0, 0))
-                continue
-            f0 = max(0, s0 // hop - halo)                       # first / one-past-last mel frame the window depends on
-            f1 = min(2 * n, (s1 + hop - 1) // hop + 1 + halo)
-            a, b = f0 // 2, (f1 + 1) // 2                       # tokens (2 frames each)
-            if 2 * n - 2 * b < 2 * halo:                         # a right edge inside the halo must be the true end of the prefix
-                b = n
-            subs.append(h[a:b]); offs.append(2 * a * hop); meta.append((s0, s1))
+            a, b, off, s0, s1 = window_token_range(int(h.shape[0]), s0, s1, self.cfg.hop, self.HALO_FRAMES)
+            subs.append(h[a:b]); offs.append(off); meta.append((s0, s1))
         wavs = self.decode_batch(subs)
         return [w[s0 - o:s1 - o] if s1 > s0 else w[:0] for w, o, (s0, s1) in zip(wavs, offs, meta)]
+
+
+def window_token_range(n_tokens: int, s0: int, s1: int, hop: int = 256, halo_frames: int = 105):
+    """Tokens [a, b) whose vocoding contains samples [s0, s1) of the n_tokens-long prefix waveform exactly, the sample offset of
+    that sub-waveform, and the clamped window.  A sample s depends on ISTFT frames s/hop - 1 .. s/hop + 2, each of which depends
+    on `halo_frames - 3` mel frames either side (conv receptive fields); a token is two frames.  A right edge that would fall
+    inside the halo of the true end is moved to the true end (the zero padding there is part of the reference's result)."""
+    halo = halo_frames + 1
+    total = hop * (2 * n_tokens - 1) if n_tokens > 0 else 0
+    s0, s1 = max(0, min(int(s0), total)), max(0, min(int(s1), total))
+    if s1 <= s0:
+        return 0, 0, 0, 0, 0
+    f0 = max(0, s0 // hop - halo)
+    f1 = min(2 * n_tokens, (s1 + hop - 1) // hop + 1 + halo)
+    a, b = f0 // 2, (f1 + 1) // 2
+    if 2 * n_tokens - 2 * b < 2 * halo:
+        b = n_tokens
+    return a, b, 2 * a * hop, s0, s1
 
 
 def SynthPool(dvae_cfg: dict, vocos_cfg: dict, max_frames: int = 4096, device="cuda", n_streams: int = 4, max_batch: int = 32) -> Synth:

@@ -118,3 +118,30 @@ def test_audio_resample_and_loader(tmp_path):
     wavfile.write(tmp_path / "b.wav", sr, (x * 32767).astype(np.int16))
     w16, _ = audio.load_audio(str(tmp_path / "b.wav"))
     assert w16.shape == (1, sr) and abs(float(w16.abs().max()) - 0.5) < 1e-3
+
+
+def test_window_token_range_covers_the_receptive_field():
+    """Streaming: the token range chosen for a sample window contains every mel frame the window can depend on
+    (modelled with a symmetric dependency of halo-3 frames per ISTFT frame and 4 overlapping ISTFT frames), keeps real context on
+    both sides unless the range touches the utterance edge, and never exceeds the prefix."""
+    import chatttsplus_amd.hip_models.vocoder as voc        # pure python: importing does not touch the native library
+    hop, halo = 256, 105
+    rng = np.random.Generator(np.random.Philox(key=3))
+    for _ in range(2000):
+        n = int(rng.integers(1, 900))
+        total = hop * (2 * n - 1)
+        s0 = int(rng.integers(0, total + 50)); s1 = int(rng.integers(s0, total + 400))
+        a, b, off, c0, c1 = voc.window_token_range(n, s0, s1, hop, halo)
+        if c1 <= c0:
+            assert (a, b) == (0, 0)
+            continue
+        assert 0 <= a < b <= n and off == 2 * a * hop and 0 <= c0 < c1 <= total
+        need_lo = max(0, c0 // hop - 1 - (halo - 3))                    # first / last mel frame the window depends on
+        need_hi = min(2 * n - 1, (c1 - 1) // hop + 2 + (halo - 3))
+        assert 2 * a <= need_lo and need_hi <= 2 * b - 1
+        # context rule: a truncated edge lies at least a halo away from every needed output frame
+        if a > 0:
+            assert c0 // hop - 1 - 2 * a >= halo - 3
+        if b < n:
+            assert 2 * b - 1 - ((c1 - 1) // hop + 2) >= halo - 3
+        assert c1 - off <= hop * (2 * (b - a) - 1)                      # the window ends inside the sub-waveform
