@@ -287,6 +287,7 @@ struct BlockRed {
     float f[16];
     double d[16];
     unsigned long long k[16];
+    unsigned long long k2[2][16];      // alternating slots: one barrier per selection round (block_max_u64_alt)
 };
 __device__ inline float block_max_f(BlockRed& r, float v, int lane, int wave) {
     v = wave_max(v);
@@ -329,6 +330,19 @@ __device__ inline unsigned long long block_max_u64(BlockRed& r, unsigned long lo
     return m;
 }
 
+// block-wide max with alternating LDS slots: the write of round r+1 goes to the other slot, so the only barrier needed is the
+// one between this round's writes and reads
+__device__ inline unsigned long long block_max_u64_alt(BlockRed& r, unsigned long long v, int lane, int wave, int round) {
+    v = wave_max_u64(v);
+    unsigned long long* slot = r.k2[round & 1];
+    if (lane == 0) slot[wave] = v;
+    __syncthreads();
+    unsigned long long m = slot[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = umax64(m, slot[i]);
+    return m;
+}
+
 __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a) {
     __shared__ BlockRed red;
     __shared__ int pos_s;
@@ -367,24 +381,30 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
     double cum_before = 0.0;
     float vk = 0.f;
     const int topk = (d->cfg.top_k > 0) ? d->cfg.top_k : V;
-    for (int r = 0; r < V; ++r) {
+    // every thread caches the key of its largest untaken value; only the thread whose element was selected rescans its 21 values
+    auto my_best = [&]() -> unsigned long long {
         unsigned long long key = 0ull;
 #pragma unroll
         for (int i = 0; i < TVPT; ++i) {
             const unsigned long long k = ((unsigned long long)f32_key(x[i]) << 32) | (unsigned)(tid + 1024 * i);
             if (!((taken >> i) & 1u)) key = umax64(key, k);
         }
-        const unsigned long long best = block_max_u64(red, key, lane, wave);
+        return key;
+    };
+    unsigned long long mykey = my_best();
+    for (int r = 0; r < V; ++r) {
+        const unsigned long long best = block_max_u64_alt(red, mykey, lane, wave, r);
         if (best == 0ull) break;
         const float bv = key_f32((unsigned)(best >> 32));
         const int bi = (int)(unsigned)best;
         if (r >= topk && bv != vk) break;
         const float cr = (float)(tot - cum_before);
         if (cr <= d->cfg.top_p_threshold && r >= d->cfg.min_keep) break;
-        if (tid == (bi & 1023)) { taken |= 1u << (bi >> 10); kept |= 1u << (bi >> 10); }
+        if (tid == (bi & 1023)) { taken |= 1u << (bi >> 10); kept |= 1u << (bi >> 10); mykey = my_best(); }
         if (r == topk - 1) vk = bv;
         cum_before += (double)(expf(bv - mx) * inv);
     }
+    __syncthreads();                                                 // the last round's slot reads are done before `red` is reused
     if (step < d->cfg.min_new && tid == (d->cfg.eos & 1023)) kept &= ~(1u << (d->cfg.eos >> 10));      // gpt.py:477-478
     float m2 = -INFINITY;
 #pragma unroll
@@ -395,11 +415,14 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
     for (int i = 0; i < TVPT; ++i) s2 += ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f;
     s2 = block_sum_f(red, s2, lane, wave);
     const float inv2 = 1.0f / s2;
-    unsigned long long bkey = 0ull;
+    // elements outside the kept set have p == 0 -> ratio 0 whatever q is: element 0 stands in for all of them (smallest index
+    // wins ties) and only the kept ones draw noise
+    unsigned long long bkey = ((unsigned long long)f32_key(0.f) << 32) | (unsigned)0x7FFFFFFF;
+    if (kept != 0u) {
 #pragma unroll
-    for (int i = 0; i < TVPT; ++i) {
-        const int j = tid + 1024 * i;
-        if (j < V) {
+        for (int i = 0; i < TVPT; ++i) {
+            if (!((kept >> i) & 1u)) continue;
+            const int j = tid + 1024 * i;
             float qq;
             if (q != nullptr) qq = q[j];
             else {
@@ -407,7 +430,7 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
                                                 make_uint2((unsigned)d->seed, (unsigned)(d->seed >> 32)));
                 qq = -logf(((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f));
             }
-            const float e = ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f;
+            const float e = expf(x[i] - m2);
             bkey = umax64(bkey, ((unsigned long long)f32_key(__fdiv_rn(e * inv2, qq)) << 32) | (unsigned)(0x7FFFFFFF - j));
         }
     }

@@ -236,8 +236,8 @@ class GPT:
         ~21 ns of host time per element: hidden behind the GPU up to batch ~8, 3x the step time at batch 32); "device"
         uses the on-device Philox generator keyed by `seed` (None: one draw from torch's CPU generator, so manual_seed
         still makes the call reproducible); "auto" (default) = "torch" for the batches the reference itself can run
-        (<= 4 sequences, pipeline:391-397) as long as a step draws at most 32k numbers (code mode up to 4 sequences, the
-        refine-text pass for one), "device" otherwise; or an array [n_draws, B*4, V]."""
+        (<= 4 sequences, pipeline:391-397) as long as a step draws at most 16k numbers (code mode), "device" otherwise
+        (larger batches, the 21178-wide refine-text pass); or an array [n_draws, B*4, V]."""
         if return_attn:
             raise _lib.HipBackendError("return_attn=True is unsupported (the reference's eager attention path is broken, SURVEY F2)")
         if not self._finalized:
@@ -252,9 +252,9 @@ class GPT:
         sc = sampler_cfg_from_objects(temperature, int(eos_token), max_new_token, min_new_token, logits_warpers, logits_processors, NVQ,
                                       infer_text=infer_text)
         if isinstance(noise, str) and noise == "auto":
-            # host draws cost ~21 ns per element and step: 10k elements (4 sequences x 4 x 626) hide behind the GPU step, the
-            # 21178-wide refine-text rows only for a single sequence (measured: batch 4 text mode 1.2 ms/step vs 0.5 on device)
-            noise = "torch" if (B <= 4 and B * rows_per_seq * V <= 32768) else "device"
+            # host draws cost ~21 ns per element and step: 10k elements (4 sequences x 4 x 626) hide behind the GPU step, one
+            # 21178-wide refine-text row already does not (measured: 502 vs 423 us/step at batch 1, 1.2 vs 0.5 ms at batch 4)
+            noise = "torch" if (B <= 4 and B * rows_per_seq * V <= 16384) else "device"
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (isinstance(noise, str) and noise == "device") else 0
         mask = torch.ones(B, T, dtype=torch.int32, device=dev) if attention_mask is None else attention_mask.to(dev).to(torch.int32).contiguous()
