@@ -13,6 +13,7 @@ timeout 300 python bench.py --dtype fp32 --steps 256 --cpu-steps 0 > $O/bench_b1
 rm -f $O/gen_wall.log $O/pipe_wall.log
 for n in torch device; do timeout 200 python tools/gen_wall.py --noise $n 2>&1 | tail -1 >> $O/gen_wall.log; done
 timeout 200 python tools/gen_wall.py --batch 32 --steps 256 --noise device 2>&1 | tail -1 >> $O/gen_wall.log
+timeout 200 python tools/gen_wall.py --text --steps 128 --noise device 2>&1 | tail -1 >> $O/gen_wall.log
 timeout 250 python tools/pipe_wall.py 2>&1 | tail -1 >> $O/pipe_wall.log
 timeout 250 python tools/pipe_wall.py --n 32 --tokens 256 2>&1 | tail -1 >> $O/pipe_wall.log
 cat $O/gen_wall.log $O/pipe_wall.log
