@@ -62,6 +62,7 @@ struct ctts_gpt {
     float *x_dec = nullptr, *x_last = nullptr, *x_pre = nullptr, *q_buf = nullptr, *part_ml = nullptr, *part_o = nullptr, *logits = nullptr;
     void* act = nullptr;
     void* attn_packed = nullptr;
+    void* norm_packed = nullptr;                 // prompt pass: RMSNorm'ed rows in the GEMMs' fragment-major operand layout (norm_pack_kernel)
     float* opart = nullptr;                      // fused path: per-head o_proj partials [rows<=16][12][768]
     int ablate = 0;                              // diagnostic (env CTTS_ABLATE): bit i set -> skip kernel class i (qkv, attn, o_proj, gate|up, down)
     int split_rows = 4;                          // decode batches up to this size run the down projection as 4 split-K launch slices whose
@@ -137,7 +138,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
     void* bufs[] = {h->dyn, h->wblob, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
-                    h->act, h->attn_packed, h->opart, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
+                    h->act, h->attn_packed, h->norm_packed, h->opart, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -311,6 +312,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->part_o, (size_t)PASS_ROWS * NH * SMAX * CTTS_HEAD_DIM * 4) ||
         dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * (h->NVQ * h->V > h->vocab_text_head ? h->NVQ * h->V : h->vocab_text_head) * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc((void**)&h->rope_pre, (size_t)MB * h->cfg.max_seq * 64 * 4) ||
         dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->opart, (size_t)16 * NH * H * 4) || dev_alloc((void**)&h->dpart, (size_t)16 * 4 * H * 4) || dev_alloc(&h->attn_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
+        dev_alloc(&h->norm_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4) ||
@@ -385,6 +387,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // its partial sums dp[0..3] are added, in order, by the next consumers of the residual stream (QKV RMSNorm, o_proj
     // residual, final heads) -- deterministic, no atomics.  x itself is re-materialised by every o_proj.
     const bool splitd = (st != nullptr) && (R <= h->split_rows) && (nbg == 1) && (h->fuse_rows == 0);
+    // prompt pass over more than a few chunks: normalise every row once (norm_pack_kernel) instead of in every GEMM block
+    const bool prepack = (st == nullptr) && (nbg == 2) && (R > 64) && !getenv("CTTS_NO_PREPACK");
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
         a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq;
@@ -393,7 +397,10 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x;
         g1.q_out = h->q_buf; g1.k_cache = kv_layer(h, l, 0); g1.v_cache = kv_layer(h, l, 1); g1.rope_rows = rope_rows;
         g1.opart = h->dpart; g1.np = (splitd && l > 0) ? 4 : 0;
-        if (!(h->ablate & 1) && launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
+        if (prepack) {
+            g1.xpacked = h->norm_packed;
+            if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s) || launch_gemm(dt, nbg, PRO_PACKED, EPI_QKV, g1, chunks, s)) return 1;
+        } else if (!(h->ablate & 1) && launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
@@ -417,7 +424,10 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         // RMSNorm + gate|up + SiLU*up
         GemmArgs g3 = a;
         g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act; g3.opart = h->opart; g3.np = CTTS_NPART;
-        if (!(h->ablate & 8) && launch_gemm(dt, nbg, fused ? PRO_NORM_P : PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
+        if (prepack) {
+            g3.xpacked = h->norm_packed;
+            if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s) || launch_gemm(dt, nbg, PRO_PACKED, EPI_SWIGLU, g3, chunks, s)) return 1;
+        } else if (!(h->ablate & 8) && launch_gemm(dt, nbg, fused ? PRO_NORM_P : PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
         // down + residual
         GemmArgs g4 = a;
         g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x; g4.opart = h->opart; g4.np = CTTS_NPART;

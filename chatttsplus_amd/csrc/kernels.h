@@ -114,6 +114,7 @@ struct SamplerArgs {
 };
 
 int launch_gemm(int dtype, int nbg, int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s);
+int launch_norm_pack(int dtype, const float* x, void* out_packed, int R, int nbg, float eps, hipStream_t s);
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s);
 int launch_gather_rows(const float* src, float* dst, const int* src_rows, int n, int H, hipStream_t s);

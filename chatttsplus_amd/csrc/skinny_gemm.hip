@@ -425,6 +425,10 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         rc |= launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU, RT_NORM_C>(a, chunks, s, true);
+        if constexpr (NBG == 2) {
+            rc |= launch_one<WT, 2, W768, P768, PRO_PACKED, EPI_QKV, 4>(a, chunks, s, true);
+            rc |= launch_one<WT, 2, W768, P768, PRO_PACKED, EPI_SWIGLU, 4>(a, chunks, s, true);
+        }
         rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, true);
         if constexpr (NBG == 1) {
@@ -443,6 +447,10 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     if (pro == PRO_NORM && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV, RT_NORM>(a, chunks, s, false);
     if (pro == PRO_ATTN && epi == EPI_RESID) return launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU, RT_NORM>(a, chunks, s, false);
+    if constexpr (NBG == 2) {      // prompt pass on pre-normalised rows (norm_pack_kernel): 4 weight row tiles per block
+        if (pro == PRO_PACKED && epi == EPI_QKV) return launch_one<WT, 2, W768, P768, PRO_PACKED, EPI_QKV, 4>(a, chunks, s, false);
+        if (pro == PRO_PACKED && epi == EPI_SWIGLU) return launch_one<WT, 2, W768, P768, PRO_PACKED, EPI_SWIGLU, 4>(a, chunks, s, false);
+    }
     if (pro == PRO_PACKED && epi == EPI_RESID && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_PACKED && epi == EPI_RESID) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_NORM && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, false);
@@ -457,6 +465,39 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     }
     ctts_set_error("skinny_gemm: unsupported prologue/epilogue %d/%d", pro, epi);
     return 1;
+}
+
+// Prompt pass: RMSNorm once per row into the fragment-major B-operand image the GEMMs read with PRO_PACKED.  In the decode
+// step every block normalises its <= 32 rows itself (cheaper than a launch); over a whole prompt that replication is
+// tiles x rows x 3 KB of L2 reads per layer (13 GB per pass at 1536 rows), so the prompt pass normalises once instead.
+// Same arithmetic as the PRO_NORM prologue (x * rs, then the store_x4 conversion): bit-identical GEMM inputs.
+template <typename WT>
+__global__ __launch_bounds__(256) void norm_pack_kernel(const float* x, void* out, int R, int nbg, float eps) {
+    constexpr int K = 768, KT = WTraits<WT>::KT, KTILES = K / KT, PER = K / 256;
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int NB = 16 * nbg, chunk = r / NB, n = r % NB;
+    const f32x4* xr = (const f32x4*)(x + (size_t)r * K);
+    f32x4 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = xr[lane + 64 * i];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)K + eps);
+    char* base = (char*)out + (size_t)chunk * nbg * KTILES * 1024;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = 4 * (lane + 64 * i);
+        store_x4<WT>(base, n, k, KTILES, v[i][0] * rs, v[i][1] * rs, v[i][2] * rs, v[i][3] * rs);
+    }
+}
+int launch_norm_pack(int dtype, const float* x, void* out, int R, int nbg, float eps, hipStream_t s) {
+    if (dtype == 1) hipLaunchKernelGGL(norm_pack_kernel<half_t>, dim3((R + 3) / 4), dim3(256), 0, s, x, out, R, nbg, eps);
+    else hipLaunchKernelGGL(norm_pack_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, s, x, out, R, nbg, eps);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_gemm(int dtype, int nbg, int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s) {
