@@ -2,5 +2,5 @@
 chattts_plus/models/__init__.py) so the pipeline's getattr(models, name)(**kwargs) dispatch
 (pipelines/chattts_plus_pipeline.py:113-129) can select them."""
 from .gpt import GPT  # noqa: F401
-from .vocoder import DVAE, Synth, SynthPool, Vocos  # noqa: F401
+from .vocoder import DVAE, Synth, Vocos  # noqa: F401
 from .encoder import DVAEEncoder  # noqa: F401

@@ -152,11 +152,6 @@ def window_token_range(n_tokens: int, s0: int, s1: int, hop: int = 256, halo_fra
     return a, b, 2 * a * hop, s0, s1
 
 
-def SynthPool(dvae_cfg: dict, vocos_cfg: dict, max_frames: int = 4096, device="cuda", n_streams: int = 4, max_batch: int = 32) -> Synth:
-    """Kept for callers of the earlier multi-stream pool: batching across utterances inside the library replaced it."""
-    return Synth(dvae_cfg, vocos_cfg, max_frames=max_frames, device=device, max_batch=max_batch)
-
-
 class DVAE:
     """Call surface of models.DVAE for the decode branch: DVAE(decoder_config, dim, coef, model_path)(inp[1,768,n]) -> mel[1,100,2n]."""
 

@@ -168,8 +168,8 @@ class ChatTTSPlusPipeline:
                 vk = dict(_get(models["vocos"], "kwargs"))
                 dcfg = dict(dk["decoder_config"]); dcfg["n_mels"] = 100
                 vcfg = dict(vk["backbone_config"]); vcfg.update(vk["head_config"])
-                synth = hip_models.SynthPool(dcfg, vcfg, max_frames=int(kwargs.get("max_frames", 2 * 2048 + 64)), device=self.device,
-                                             max_batch=int(kwargs.get("vocoder_batch", 32)))
+                synth = hip_models.Synth(dcfg, vcfg, max_frames=int(kwargs.get("max_frames", 2 * 2048 + 64)), device=self.device,
+                                         max_batch=int(kwargs.get("vocoder_batch", 32)))
                 self.synth = synth
             if model_name == "vocos":                       # pipeline:93-111
                 model_ = hip_models.Vocos(synth)
@@ -262,7 +262,7 @@ class ChatTTSPlusPipeline:
         if not use_decoder:
             raise _lib.HipBackendError("use_decoder=False (decode codes through dvae_encode) is not served by the hip backend")
         if len(result_list) > 1 and getattr(self, "synth", None) is not None:
-            return self.synth.decode_batch(list(result_list))           # utterances vocoded concurrently on K streams
+            return self.synth.decode_batch(list(result_list))           # one launch sequence for the batch (ctts_synth_batch)
         wavs = []
         decoder, vocos = self.models_dict["dvae_decode"], self.models_dict["vocos"]
         for h in result_list:
