@@ -145,8 +145,10 @@ int ctts_gpt_sample(ctts_gpt* h, void* stream);
 int ctts_gpt_restart(ctts_gpt* h, void* stream);
 
 /* n_steps x { 20 decoder layers on the last sampled token ; sample phase } (gpt.py:389-546, i > 0).
- * Uses a captured hipGraph of one step (use_graph != 0).  Steps after every sequence has finished are
- * skipped on the device.  Asynchronous w.r.t. the host. */
+ * use_graph != 0: replays captured hipGraphs of 4 steps each (cached per batch size / mode / KV binding / attention split
+ * count; they contain no per-call state -- ctts_gpt_begin writes the output buffers, noise buffer, seed and sampling
+ * parameters into a device block the kernels read -- so consecutive generate() calls reuse them); a remainder of < 4 steps
+ * is launched kernel by kernel.  Steps after every sequence has finished exit early on the device.  Asynchronous w.r.t. the host. */
 int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* stream);
 
 /* Host-visible progress: number of sample steps executed and whether every row has finished.
