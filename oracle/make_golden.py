@@ -143,6 +143,29 @@ def golden_gpt_real(ref):
     save_gen("gpt_real_greedy", meta, emb, out)
 
 
+def golden_gpt_real_ragged(ref):
+    """B=4 (the reference's own batch limit), four different left paddings, EOS rows of the heads boosted so that the
+    sequences finish at different steps: staggered finish / end_idx bookkeeping against the reference itself."""
+    cfg = synth.GPT_REAL
+    for boost in (2.2, 2.0, 1.8, 2.5, 1.6):
+        sd = synth.gpt_state_dict(cfg, 1234)
+        for i in range(4):
+            sd[f"head_code.{i}.parametrizations.weight.original0"][625] *= boost
+        g = build_ref_gpt(ref, cfg, sd)
+        for torch_seed in range(21, 29):
+            pad = [0, 3, 1, 6]
+            ids, mask = synth.prompt_ids(4, 14, cfg["num_text_tokens"], 17, pad_left=pad)
+            emb, out = run_ref_generate(ref, g, ids, mask, torch_seed, 40, 4)
+            lens = sorted(int(i.shape[0]) for i in out.ids)
+            print("  ragged search: boost", boost, "seed", torch_seed, "lens", lens)
+            if len(set(lens)) >= 3:
+                meta = dict(weight_seed=1234, eos_boost=boost, prompt_seed=17, torch_seed=torch_seed, B=4, T=14, pad_left=pad, max_new=40,
+                            min_new=4, spk_seed=1234, spk_id=21143, spk_pos=-1)
+                save_gen("gpt_real_b4_ragged", meta, emb, out)
+                return
+    raise SystemExit("no staggered-finish case found")
+
+
 def golden_refine_text(ref):
     """infer_text=True pass (pipeline:237-277 -> gpt.py infer_text branches): real config, 21178-way text head."""
     cfg = synth.GPT_REAL
@@ -277,6 +300,7 @@ def main():
     golden_dvae(ref)
     golden_dvae_encode(ref)
     golden_gpt_real(ref)
+    golden_gpt_real_ragged(ref)
     golden_refine_text(ref)
 
 
