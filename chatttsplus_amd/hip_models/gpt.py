@@ -341,9 +341,11 @@ class GPT:
             tick("step0")
             chunk = int(stream_batch) if stream else self.chunk_steps
             if stream:
-                # streaming yields after every chunk: synchronous polling
+                # streaming: synchronous polling; like the reference (gpt.py:531-543) a partial result is yielded whenever the number
+                # of generated tokens is a multiple of stream_batch -- also when that step was the last one, so the final yield
+                # below can repeat it, exactly as the reference does
                 while not alld.value and steps.value < max_new_token and not context.get():
-                    n = min(chunk, max_new_token - steps.value)
+                    n = min(chunk - steps.value % chunk, max_new_token - steps.value)
                     draw_to(used_draws + n)
                     _lib.check(lib.ctts_gpt_decode(h, n, 1 if self.use_graph else 0, st), "decode")
                     prev = steps.value
@@ -351,7 +353,7 @@ class GPT:
                     used_draws += steps.value - prev
                     if steps.value == prev and not alld.value:
                         raise _lib.HipBackendError("decode made no progress (device state inconsistent)")
-                    if not alld.value and steps.value < max_new_token:
+                    if steps.value % chunk == 0 and steps.value > prev:
                         yield self._outputs(ids, hid, end_idx, infer_text)
             else:
                 # one chunk stays in flight while the previous chunk's progress words are inspected (no GPU bubble at the
