@@ -216,6 +216,254 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const int* done_p,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused decode launch for one or two rows: llama.py:82-87 (input RMSNorm) + :619-633 (q/k/v projection, RoPE, cache append) +
+// :653-661 (SDPA) in one kernel, so that a layer is 4 dependent launches instead of 5 and q/k/v never round-trip through HBM.
+//   grid.x = (row, head);  grid.y = kind:  kind < S   q projection (4 weight tiles = 96 KB fp16) + attention over split `kind`
+//                                                       of the CACHED keys [kv_start, slot)
+//                                          kind == S   q and k projections of the new token: its score q.k (partial slot S: m = score,
+//                                                       l = 1) and the K append
+//                                          kind == S+1 v projection: V append and the output row of partial slot S
+// Same arithmetic as the separate kernels (norm expression, tile order, RoPE with separately rounded products, K/V rounded to
+// the cache dtype before use); the K dimension is split over NW waves x 3 k-tiles instead of 4 (8) x 6, so sums differ in the
+// last bits from the 5-launch path.
+template <typename WT> struct FragSel;
+template <> struct FragSel<half_t> { typedef half8 type; };
+template <> struct FragSel<float> { typedef f32x4 type; };
+template <typename WT> struct MmaQ;
+template <> struct MmaQ<half_t> { __device__ static inline f32x4 run(half8 a, half8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); } };
+template <> struct MmaQ<float> {
+    __device__ static inline f32x4 run(f32x4 a, f32x4 b, f32x4 c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename WT, int NW, int TPP>
+__global__ __launch_bounds__(NW * 64) void qkv_attn_kernel(const int* done_p, const void* Wp, const float* x_p, const RowMeta* meta_p, const int NHp, const int nS,
+                                                          const QkvAttnArgs a) {
+    typedef typename FragSel<WT>::type frag;
+    constexpr int K = 768, KT = WTraits<WT>::KT, EPL = WTraits<WT>::EPL, KTILES = K / KT, KPW = KTILES / NW, UN = 4, HT = K / 16;
+    static_assert(KPW * NW == KTILES, "K split");
+    __shared__ float xn[K];
+    __shared__ float red[NW][8][16];
+    __shared__ float qk[2][CTTS_HEAD_DIM];
+    __shared__ float merge[NW][8][10];
+    int done_v = 0;
+    if (done_p != nullptr) done_v = vload_flag(done_p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x / NHp, h = blockIdx.x % NHp, kind = blockIdx.y, S = nS >> 8, np = nS & 0xFF;
+    const bool isK = kind == S, isV = kind == S + 1;
+    const int ntile = isK ? 8 : 4;
+    // weight tiles of this block: q = tiles h*4 .. h*4+3 of the first projection, k / v = the same tiles of the 2nd / 3rd
+    auto tile_of = [&](int t) -> int { return isV ? 2 * HT + h * 4 + t : (t < 4 ? h * 4 + t : HT + h * 4 + (t - 4)); };
+    frag wf[TPP][KPW];
+    auto load_tiles = [&](int t0) {
+#pragma unroll
+        for (int t = 0; t < TPP; ++t)
+            if (t0 + t < ntile) {
+                const frag* w = (const frag*)Wp + ((size_t)tile_of(t0 + t) * KTILES + wave * KPW) * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) wf[t][i] = __builtin_nontemporal_load(w + i * 64);
+            }
+    };
+    const RowMeta m = meta_p[r];
+    if (wave == 0) {                                  // the row's RMSNorm, same expression order as the PRO_NORM[_P] prologue
+        const f32x4* xr = (const f32x4*)(x_p + (size_t)r * K);
+        f32x4 v[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = xr[lane + 64 * i];
+        if (np > 0) {
+            f32x4 pp[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    pp[q][i] = (q < np) ? ((const f32x4*)(a.dpart + ((size_t)r * np + q) * K))[lane + 64 * i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) v[i] += pp[q][i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_tiles(0);
+        __builtin_amdgcn_sched_barrier(0);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        ss = wave_sum(ss);
+        const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *(f32x4*)(xn + 4 * (lane + 64 * i)) = (f32x4){v[i][0] * rs, v[i][1] * rs, v[i][2] * rs, v[i][3] * rs};
+    } else {
+        load_tiles(0);
+    }
+    if (__builtin_amdgcn_readfirstlane(done_v)) return;   // every sequence finished: skip on device
+    __syncthreads();
+    for (int t0 = 0; t0 < ntile; t0 += TPP) {
+        if (t0 > 0) load_tiles(t0);                   // parity mode: second phase of the 8-tile block
+        f32x4 acc[TPP];
+#pragma unroll
+        for (int t = 0; t < TPP; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int kt = wave * KPW + i;
+            frag b;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) b[j] = ((lane & 15) == 0) ? (WT)xn[kt * KT + (lane >> 4) * EPL + j] : (WT)0.f;
+#pragma unroll
+            for (int t = 0; t < TPP; ++t)
+                if (t0 + t < ntile) acc[t] = MmaQ<WT>::run(wf[t][i], b, acc[t]);
+        }
+        if ((lane & 15) == 0) {                       // column 0 of C = this row: lanes 0, 16, 32, 48 hold weight rows (lane / 16) * 4 + reg
+#pragma unroll
+            for (int t = 0; t < TPP; ++t)
+                if (t0 + t < ntile) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) red[wave][t0 + t][(lane >> 4) * 4 + g] = acc[t][g];
+                }
+        }
+    }
+    __syncthreads();
+    const size_t pslot = ((size_t)r * NHp + h) * (S + 1);
+    if (tid < ntile * 8) {
+        const int t = tid >> 3, p = tid & 7, d = (t & 3) * 8 + p;     // tile rows p, p + 8 = head dims d, d + 32
+        float va = 0.f, vb = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { va += red[w][t][p]; vb += red[w][t][p + 8]; }
+        const size_t cslot = (((size_t)m.seq * NHp + h) * a.Lmax + m.slot) * CTTS_HEAD_DIM;
+        if (isV) {
+            const WT ra = (WT)va, rb = (WT)vb;
+            WT* c = (WT*)a.v_cache + cslot;
+            c[d] = ra; c[d + 32] = rb;
+            float* po = a.part_o + (pslot + S) * CTTS_HEAD_DIM;
+            po[d] = (float)ra; po[d + 32] = (float)rb;
+        } else {
+            const float rc = a.rope_rows[(size_t)r * 64 + d], rsn = a.rope_rows[(size_t)r * 64 + 32 + d];
+            const float ya = __fadd_rn(__fmul_rn(va, rc), __fmul_rn(-vb, rsn));   // llama.py:180-181
+            const float yb = __fadd_rn(__fmul_rn(vb, rc), __fmul_rn(va, rsn));
+            if (t < 4) { qk[0][d] = ya; qk[0][d + 32] = yb; }
+            else {
+                const WT ra = (WT)ya, rb = (WT)yb;
+                WT* c = (WT*)a.k_cache + cslot;
+                c[d] = ra; c[d + 32] = rb;
+                qk[1][d] = (float)ra; qk[1][d + 32] = (float)rb;
+            }
+        }
+    }
+    if (isV) return;
+    __syncthreads();
+    const int grp = lane >> 3, sub = lane & 7;
+    float q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = qk[0][8 * sub + j] * 0.125f;
+    if (isK) {                                        // the new token attends to itself: partial (m = score, l = 1, o = v_new)
+        if (wave == 0) {
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += q[j] * qk[1][8 * sub + j];
+            dot += dpp_f<DPP_XOR1>(dot);
+            dot += dpp_f<DPP_XOR2>(dot);
+            dot += dpp_f<DPP_HALF_MIRROR>(dot);
+            if (lane == 0) { a.part_ml[(pslot + S) * 2] = dot; a.part_ml[(pslot + S) * 2 + 1] = 1.0f; }
+        }
+        return;
+    }
+    // cached keys of this split
+    const int kv0 = m.kv_start, kv1 = m.slot;
+    const int chunk = (max(kv1 - kv0, 0) + S - 1) / S;
+    const int p0 = kv0 + kind * chunk, p1 = min(p0 + chunk, kv1);
+    const size_t head_off = ((size_t)m.seq * NHp + h) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
+    const WT* kb = (const WT*)a.k_cache + head_off;
+    const WT* vb = (const WT*)a.v_cache + head_off;
+    float mrun = -INFINITY, lrun = 0.f, o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int wb = p0 + 8 * wave; wb < p1; wb += 8 * NW * UN) {
+        const int base = wb + grp;
+        float kf[UN][8], vf[UN][8];
+        bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int p = base + 8 * NW * u;
+            ok[u] = p < p1;
+            const int pc = ok[u] ? p : kv0;
+            KvLoad<WT>::load8(kb + (size_t)pc * CTTS_HEAD_DIM, kf[u]);
+            KvLoad<WT>::load8(vb + (size_t)pc * CTTS_HEAD_DIM, vf[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += q[j] * kf[u][j];
+            dot += dpp_f<DPP_XOR1>(dot);
+            dot += dpp_f<DPP_XOR2>(dot);
+            dot += dpp_f<DPP_HALF_MIRROR>(dot);
+            if (ok[u]) {
+                const float mn = fmaxf(mrun, dot);
+                const float sc = safe_exp_diff(mrun, mn);
+                const float pe = expf(dot - mn);
+                lrun = lrun * sc + pe;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = o[j] * sc + pe * vf[u][j];
+                mrun = mn;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(mrun, off), l2 = __shfl_xor(lrun, off);
+        const float mn = fmaxf(mrun, m2);
+        const float s1 = safe_exp_diff(mrun, mn), s2 = safe_exp_diff(m2, mn);
+        lrun = lrun * s1 + l2 * s2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float o2 = __shfl_xor(o[j], off);
+            o[j] = o[j] * s1 + o2 * s2;
+        }
+        mrun = mn;
+    }
+    if (grp == 0) {
+        merge[wave][sub][0] = mrun;
+        merge[wave][sub][1] = lrun;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) merge[wave][sub][2 + j] = o[j];
+    }
+    __syncthreads();
+    if (tid < 8) {
+        float M = merge[0][tid][0], L = merge[0][tid][1], O[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) O[j] = merge[0][tid][2 + j];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const float m2 = merge[w][tid][0], l2 = merge[w][tid][1];
+            const float mn = fmaxf(M, m2);
+            const float s1 = safe_exp_diff(M, mn), s2 = safe_exp_diff(m2, mn);
+            L = L * s1 + l2 * s2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) O[j] = O[j] * s1 + merge[w][tid][2 + j] * s2;
+            M = mn;
+        }
+        const size_t pi = pslot + kind;
+        if (tid == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = L; }
+        float* po = a.part_o + pi * CTTS_HEAD_DIM + 8 * tid;
+        *(f32x4*)po = (f32x4){O[0], O[1], O[2], O[3]};
+        *(f32x4*)(po + 4) = (f32x4){O[4], O[5], O[6], O[7]};
+    }
+}
+
+int launch_qkv_attention(int dtype, const QkvAttnArgs& a, hipStream_t s) {
+    if (a.S < 1 || a.S > 7 || a.np > 4) { ctts_set_error("qkv_attention: S=%d np=%d out of range", a.S, a.np); return 1; }
+    const dim3 grid(a.R * a.NH, a.S + 2);
+    const int* done_p = a.st ? &a.st->all_done : nullptr;
+    const int nS = (a.np & 0xFF) | (a.S << 8);
+    if (dtype == 1) hipLaunchKernelGGL((qkv_attn_kernel<half_t, 8, 8>), grid, dim3(512), 0, s, done_p, a.wqkv, a.x, a.meta, a.NH, nS, a);
+    else hipLaunchKernelGGL((qkv_attn_kernel<float, 16, 4>), grid, dim3(1024), 0, s, done_p, a.wqkv, a.x, a.meta, a.NH, nS, a);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     dim3 grid(a.R * a.NH, a.jt > 0 ? a.jt : a.S), block(256);
     const int* done_p = a.st ? &a.st->all_done : nullptr;

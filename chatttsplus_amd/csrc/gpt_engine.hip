@@ -71,6 +71,8 @@ struct ctts_gpt {
     float* dpart = nullptr;                      // [rows<=16][4][768]
     int cur_splits = 1;                          // key splits of the decode attention for the steps being launched (decode_splits)
     int launched = 0;                            // decode steps enqueued since begin / restart: host-side bound on the context length
+    int fuseqkv_rows = 0;                        // decode batches up to this size run RMSNorm + q/k/v projection + attention as ONE launch per
+                                                 // layer (attention.hip qkv_attn_kernel; env CTTS_FUSEQKV_ROWS): 4 dependent launches instead of 5
     int nbg2_rows = 33;                          // decode batches of at least this many rows use 32-row blocks instead of 16-row chunks (env
                                                  // CTTS_NBG2_ROWS).  Measured: two 16-row chunks beat one 32-row block at batch 24 / 32 (598 vs 624,
                                                  // 640 vs 660 us/step) -- per-block prologue latency, not L2 traffic, is what these launches pay for;
@@ -123,6 +125,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     if (const char* sr = getenv("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 16) h->split_rows = 16; }
     if (const char* ab = getenv("CTTS_ABLATE")) h->ablate = atoi(ab);
     if (const char* nr = getenv("CTTS_NBG2_ROWS")) h->nbg2_rows = atoi(nr);
+    if (const char* fq = getenv("CTTS_FUSEQKV_ROWS")) { h->fuseqkv_rows = atoi(fq); if (h->fuseqkv_rows > 4) h->fuseqkv_rows = 4; }
     if (const char* fr = getenv("CTTS_FUSE_ROWS")) { h->fuse_rows = atoi(fr); if (h->fuse_rows > 16) h->fuse_rows = 16; }
     if (const char* gs = getenv("CTTS_GRAPH_STEPS")) { h->graph_steps = atoi(gs); if (h->graph_steps < 1) h->graph_steps = 1; }
     if (gemm_configure()) { delete h; return 1; }
@@ -392,6 +395,20 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
         a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq;
+        const bool fused = (st != nullptr) && (R <= h->fuse_rows);
+        const bool fq = (st != nullptr) && !fused && (R <= h->fuseqkv_rows);
+        if (fq) {
+            // one launch: RMSNorm + q/k/v projection + RoPE + KV append + attention (S splits of the cached keys + the new key)
+            QkvAttnArgs qa = {};
+            qa.x = x; qa.dpart = h->dpart; qa.np = (splitd && l > 0) ? 4 : 0; qa.eps = a.eps; qa.wqkv = h->lw[l].qkv; qa.rope_rows = rope_rows;
+            qa.meta = meta; qa.st = st; qa.k_cache = kv_layer(h, l, 0); qa.v_cache = kv_layer(h, l, 1); qa.Lmax = h->cfg.max_seq; qa.NH = h->NH; qa.R = R;
+            qa.S = S > 7 ? 7 : S; qa.part_ml = h->part_ml; qa.part_o = h->part_o;
+            if (launch_qkv_attention(dt, qa, s)) return 1;
+            GemmArgs g2 = a;
+            g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = qa.S + 1; g2.x_out = x;
+            g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;
+            if (launch_gemm(dt, nbg, PRO_ATTN, splitd ? EPI_RESID_P : EPI_RESID, g2, chunks, s)) return 1;
+        } else {
         // RMSNorm + QKV + RoPE + KV append
         GemmArgs g1 = a;
         g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x;
@@ -404,7 +421,6 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
-        const bool fused = (st != nullptr) && (R <= h->fuse_rows);
         if (fused) {
             // small batch: attention + per-head o_proj partial in one launch; the residual add is deferred to the
             // consumers (gate|up prologue, down epilogue) which sum the 12 partials in head order
@@ -420,6 +436,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;
             const bool sp2 = splitd;                       // the down projection's partial sums are folded into x here
             if (!(h->ablate & 4) && launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, sp2 ? EPI_RESID_P : EPI_RESID, g2, chunks, s)) return 1;
+        }
         }
         // RMSNorm + gate|up + SiLU*up
         GemmArgs g3 = a;
@@ -550,7 +567,8 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows, h->cur_splits);
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows, h->cur_splits,
+             h->fuseqkv_rows);
     const std::string key(sig);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }

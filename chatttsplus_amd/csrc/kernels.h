@@ -113,6 +113,25 @@ struct SamplerArgs {
     int* idx_out;           // [rows]
 };
 
+// decode rows, very small batches: RMSNorm + the head's q/k/v projection + RoPE + KV append + attention in ONE launch
+// (attention.hip qkv_attn_kernel); per (row, head): S blocks over the cached keys, one block for the new key's score and K append,
+// one for its value and V append -> S + 1 flash-decoding partials for the o_proj prologue.
+struct QkvAttnArgs {
+    const float* x;           // [R][768] residual stream
+    const float* dpart;       // [R][np][768] split-K partial sums of the previous down projection (np = 0: none)
+    int np;
+    float eps;
+    const void* wqkv;         // packed QKV tiles [144][k tiles][64 lanes][16 B] (gpt_engine.hip pack order)
+    const float* rope_rows;   // [R][64] cos | sin of each row's position
+    const RowMeta* meta;
+    const DevState* st;
+    void* k_cache;            // this layer
+    void* v_cache;
+    int Lmax, NH, R, S;       // S >= 1 splits over the cached keys
+    float* part_ml;           // [R][NH][S + 1][2]
+    float* part_o;            // [R][NH][S + 1][64]
+};
+int launch_qkv_attention(int dtype, const QkvAttnArgs& a, hipStream_t s);
 int launch_gemm(int dtype, int nbg, int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s);
 int launch_norm_pack(int dtype, const float* x, void* out_packed, int R, int nbg, float eps, hipStream_t s);
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s);

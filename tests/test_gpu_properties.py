@@ -135,3 +135,23 @@ def test_stream_mode_yields_growing_prefixes(gpt32):
     assert lens == [24, 48, 72, 80]                  # gpt.py:531-543: partial results at multiples of stream_batch, then the final one
     for o in outs[:-1]:
         assert torch.equal(o.ids[0], outs[-1].ids[0][:o.ids[0].shape[0]])
+
+
+def test_fused_qkv_attention_launch_matches_golden(monkeypatch):
+    """CTTS_FUSEQKV_ROWS: RMSNorm + q/k/v projection + RoPE + KV append + attention as one launch per layer (kept as a switch:
+    measured slower than the two separate launches, profiles/README.md).  Same token ids as the reference golden."""
+    from chatttsplus_amd.hip_models import GPT
+    from tests.helpers import gen_case_inputs, load_golden
+    monkeypatch.setenv("CTTS_FUSEQKV_ROWS", "2")
+    z, meta = load_golden("gpt_real_b2_pad")
+    sd, ids, mask, spk = gen_case_inputs(meta, synth.GPT_REAL)
+    g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=2, max_seq_len=64, weight_dtype="fp32")
+    g.load_state_dict(sd)
+    emb = g(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
+    torch.manual_seed(int(meta["torch_seed"]))
+    out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]),
+                          min_new_token=int(meta["min_new"]), logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="torch"))[-1]
+    assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist()
+    for b, n in enumerate(z["lens"]):
+        assert np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64))
+        assert np.abs(out.hiddens[b].cpu().numpy() - z["hiddens"][b, :n]).max() <= 1e-4
