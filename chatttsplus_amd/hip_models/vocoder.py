@@ -155,10 +155,17 @@ def window_token_range(n_tokens: int, s0: int, s1: int, hop: int = 256, halo_fra
 class DVAE:
     """Call surface of models.DVAE for the decode branch: DVAE(decoder_config, dim, coef, model_path)(inp[1,768,n]) -> mel[1,100,2n]."""
 
+    def __new__(cls, decoder_config: Optional[dict] = None, encoder_config: Optional[dict] = None, vq_config: Optional[dict] = None, **kwargs):
+        # the reference builds both `dvae_encode` and `dvae_decode` from the class name "DVAE" (configs/infer/chattts_plus.yaml:7-48):
+        # a config with an encoder / quantiser is the zero-shot encode model
+        if encoder_config is not None or vq_config is not None:
+            from .encoder import DVAEEncoder
+            kwargs.pop("synth", None)
+            return DVAEEncoder(decoder_config=decoder_config, encoder_config=encoder_config, vq_config=vq_config, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, decoder_config: dict, encoder_config: Optional[dict] = None, vq_config: Optional[dict] = None, dim=384,
                  coef=None, synth: Optional[Synth] = None, **kwargs):
-        if encoder_config is not None or vq_config is not None:
-            raise _lib.HipBackendError("the hip DVAE serves the decode branch only (dvae_decode); encoder/vq = zero-shot path (SURVEY 8f N2)")
         self.decoder_config = dict(decoder_config)
         self.dim = dim
         self.synth = synth

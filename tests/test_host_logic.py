@@ -145,3 +145,13 @@ def test_window_token_range_covers_the_receptive_field():
         if b < n:
             assert 2 * b - 1 - ((c1 - 1) // hop + 2) >= halo - 3
         assert c1 - off <= hop * (2 * (b - a) - 1)                      # the window ends inside the sub-waveform
+
+
+def test_dvae_class_dispatches_to_the_encoder_for_encode_configs():
+    """`name: "DVAE"` builds both dvae_decode and dvae_encode in the reference's YAML: a config with encoder / vq goes to the
+    zero-shot encoder class (which, like every hip model, refuses to run without a GPU)."""
+    from chatttsplus_amd import _lib, hip_models
+    with pytest.raises(_lib.HipBackendError, match="MI355X"):
+        hip_models.DVAE(decoder_config=dict(idim=512, odim=512, hidden=256, n_layer=12, bn_dim=128),
+                        encoder_config=dict(idim=512, odim=1024, hidden=256, n_layer=12, bn_dim=128),
+                        vq_config=dict(dim=1024, levels=[5, 5, 5, 5], G=2, R=2), dim=512)
