@@ -6,6 +6,9 @@
 //   KV cache         [layers][2][max_batch][heads][max_seq][64]   (caller-owned, bound with ctts_gpt_bind_kv)
 //   residual stream  x_dec [B][768] fp32 (decode), x_pre [<=2048 rows][768] (prompt pass)
 //   act              fragment-major SwiGLU output for the down projection
+//   dpart            [rows <= 16][4][768] ordered split-K partial sums of the down projection (decode batches <= 4)
+//   st / dyn         DevState (per-step counters) and SamplerDyn (per-call buffers and sampling parameters): everything a captured
+//                    decode graph would otherwise bake in is read from these two device blocks
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
