@@ -24,7 +24,7 @@ LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, nu
 @pytest.fixture(scope="module")
 def gpt32():
     from chatttsplus_amd.hip_models import GPT
-    g = GPT(LLAMA, max_batch=32, max_seq_len=640, weight_dtype="fp32")
+    g = GPT(LLAMA, max_batch=64, max_seq_len=640, weight_dtype="fp32")
     g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
     return g
 
@@ -63,22 +63,23 @@ def test_512_tokens_deterministic_graph_equals_eager_and_cache_consistent(gpt32)
         assert torch.equal(out.ids[0][0], a.ids[0][upto]), f"token {upto} differs between the two paths"
 
 
-def test_batch32_mixed_lengths_rows_equal_single_runs(gpt32):
+@pytest.mark.parametrize("B", [32, 64])
+def test_batch32_mixed_lengths_rows_equal_single_runs(gpt32, B):
     g = gpt32
-    B, T, N = 32, 96, 64                                        # BASELINE configs[2] shape: left-padded mixed prompt lengths
+    T, N = 96, 64                                               # BASELINE configs[2] shape: left-padded mixed prompt lengths
     rng = np.random.Generator(np.random.Philox(key=3))
     pads = [int(p) for p in rng.integers(0, 80, size=B)]
     pads[0] = 0
     ids, mask = synth.prompt_ids(B, T, 21178, 78, pad_left=pads)
     q = torch.from_numpy(np.stack([synth.exp_noise(10, i, 4 * B, 626) for i in range(N)]))
     _, big = _gen(g, ids, mask, N, q, min_new=2)
-    for b in (0, 7, 31):
+    for b in (0, 7, B - 1):
         p = pads[b]
         ids1, mask1 = ids[b:b + 1, p:], mask[b:b + 1, p:]
         _, one = _gen(g, ids1, mask1, N, q[:, 4 * b:4 * b + 4].contiguous(), min_new=2)
         n = min(one.ids[0].shape[0], big.ids[b].shape[0])
         assert one.ids[0].shape[0] == big.ids[b].shape[0], f"row {b}: lengths differ ({one.ids[0].shape[0]} vs {big.ids[b].shape[0]})"
-        assert torch.equal(one.ids[0][:n], big.ids[b][:n]), f"row {b}: padded batch of 32 != single utterance"
+        assert torch.equal(one.ids[0][:n], big.ids[b][:n]), f"row {b}: padded batch of {B} != single utterance"
         assert float((one.hiddens[0][:n] - big.hiddens[b][:n]).abs().max()) <= 5e-5
 
 
@@ -103,10 +104,10 @@ def test_capacity_and_argument_errors(gpt32):
     emb = g(torch.from_numpy(ids), torch.ones(1, 50, dtype=torch.bool))
     with pytest.raises(_lib.HipBackendError, match="max_seq"):
         list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, max_new_token=640, logits_warpers=LW, logits_processors=LP))
-    ids33, _ = synth.prompt_ids(33, 4, 21178, 5)
+    ids65, _ = synth.prompt_ids(65, 4, 21178, 5)                                 # one more than CTTS_MAX_BATCH
     with pytest.raises(_lib.HipBackendError):
-        emb33 = g(torch.from_numpy(ids33), torch.ones(33, 4, dtype=torch.bool))
-        list(g.generate(emb33, torch.from_numpy(ids33), torch.tensor([0.3] * 4), 625, max_new_token=4, logits_warpers=LW, logits_processors=LP))
+        emb65 = g(torch.from_numpy(ids65), torch.ones(65, 4, dtype=torch.bool))
+        list(g.generate(emb65, torch.from_numpy(ids65), torch.tensor([0.3] * 4), 625, max_new_token=4, logits_warpers=LW, logits_processors=LP))
     with pytest.raises(_lib.HipBackendError, match="repetition_penalty"):       # the only unsupported combination of the text pass
         list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.7]), 21177, max_new_token=4, logits_warpers=LW, logits_processors=LP, infer_text=True))
     with pytest.raises(_lib.HipBackendError):
