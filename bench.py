@@ -176,7 +176,7 @@ def main():
     voc_ms = None
     try:
         from chatttsplus_amd.hip_models import Synth
-        syn = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2 * expect + 64, device=str(dev), max_batch=B)
+        syn = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2 * expect + 64, device=str(dev), max_batch=min(B, 64))   # decode_batch slices
         syn.load("dvae.", synth.dvae_state_dict(synth.DVAE_REAL, 1234))
         syn.load("vocos.", synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
         batch = [hid[b, :expect] for b in range(B)]

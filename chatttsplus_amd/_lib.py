@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("CTTS_HIP_LIB", _build.LIB_PATH)      # developer knob
 
 DTYPE_F32 = 0
 DTYPE_F16 = 1
-MAX_BATCH = 64
+MAX_BATCH = 128
 NUM_VQ = 4
 
 

@@ -5,7 +5,7 @@
 
 #define CTTS_HEAD_DIM 64
 #define CTTS_NUM_VQ 4
-#define CTTS_MAX_B 64
+#define CTTS_MAX_B 128
 
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

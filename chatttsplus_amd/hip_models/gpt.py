@@ -99,7 +99,7 @@ def sampler_cfg_from_objects(temperature, eos_token, max_new_token, min_new_toke
 
 class GPT:
     """See module docstring.  Extra kwargs (ride in the YAML `kwargs`):
-    max_batch (<=64), max_seq_len, weight_dtype "fp16" | "fp32", chunk_steps."""
+    max_batch (<=128), max_seq_len, weight_dtype "fp16" | "fp32", chunk_steps."""
 
     Context = Context
     GenerationOutputs = GenerationOutputs

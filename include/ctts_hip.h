@@ -32,7 +32,7 @@ extern "C" {
 #define CTTS_DTYPE_F32 0 /* parity mode: fp32 weights / KV / MFMA (v_mfma_f32_16x16x4_f32) */
 #define CTTS_DTYPE_F16 1 /* performance mode: fp16 weights / KV, fp32 accumulate (reference GPU dtype, pipeline:37-41) */
 
-#define CTTS_MAX_BATCH 64   /* sequences decoded together (reference caps at 4: pipeline:391-397) */
+#define CTTS_MAX_BATCH 128  /* sequences decoded together (reference caps at 4: pipeline:391-397) */
 #define CTTS_NUM_VQ 4
 
 const char* ctts_last_error(void);
