@@ -117,3 +117,50 @@ def test_dvae_encode_oracle_golden():
     assert np.array_equal(ref_cpu.gfsq_indices(f, sdt, pre_bound=True).numpy(), z["ids_pre_bound"])
     assert np.array_equal(ref_cpu.gfsq_indices(f, sdt, pre_bound=False).numpy(), z["ids"])
     assert np.array_equal(ref_cpu.dvae_encode(sd, wav).numpy(), z["ids_pre_bound"])
+
+
+def test_mel_features_against_direct_dft():
+    """The restated torchaudio MelSpectrogram (unpinned) against an independent float64 evaluation: reflect padding, periodic hann
+    window, |rfft|, HTK triangular filterbank, log(clip)."""
+    from chatttsplus_amd import synth
+    wav = synth.speaker_wave(2, 5000).astype(np.float64)
+    n_fft, hop = 1024, 256
+    xp = np.pad(wav, n_fft // 2, mode="reflect")
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)
+    F = 1 + len(wav) // hop
+    spec = np.stack([np.abs(np.fft.rfft(xp[f * hop:f * hop + n_fft] * win)) for f in range(F)], 1)      # [513, F]
+    hz = np.linspace(0, 12000, 513)
+    mel_pts = np.linspace(0.0, 2595.0 * np.log10(1.0 + 12000.0 / 700.0), 102)
+    f_pts = 700.0 * (10 ** (mel_pts / 2595.0) - 1.0)
+    fb = np.zeros((513, 100))
+    for m in range(100):
+        lo, ce, hi = f_pts[m], f_pts[m + 1], f_pts[m + 2]
+        fb[:, m] = np.maximum(0.0, np.minimum((hz - lo) / (ce - lo), (hi - hz) / (hi - ce)))
+    ref = np.log(np.clip(fb.T @ spec, 1e-5, None))
+    got = ref_cpu.mel_features(torch.from_numpy(wav.astype(np.float32))).numpy()
+    assert got.shape == ref.shape == (100, F)
+    assert np.abs(got - ref).max() <= 2e-3
+
+
+def test_gfsq_indices_are_nearest_codebook_entries():
+    """The restated GroupedResidualFSQ index arithmetic (unpinned) against the definition of the implicit FSQ codebook: index i
+    names the grid point ((i // 5^j) % 5 - 2) / 2 per dimension j, and the chosen entry is the nearest one to bound(z)."""
+    from chatttsplus_amd import synth
+    sd = {k: torch.from_numpy(v) for k, v in synth.dvae_encoder_state_dict(synth.DVAE_ENC_REAL, 1234).items()}
+    rng = np.random.Generator(np.random.Philox(key=8))
+    x = torch.from_numpy((rng.standard_normal((50, 1024)) * 1.5).astype(np.float32))
+    lv = torch.tensor([5.0] * 4)
+    grid = torch.stack([((torch.arange(625) // (5 ** j)) % 5 - 2) / 2.0 for j in range(4)], 1)          # implicit codebook [625, 4]
+    for pre_bound in (True, False):
+        ids = ref_cpu.gfsq_indices(x, sd, pre_bound=pre_bound)
+        assert ids.shape == (4, 50) and int(ids.min()) >= 0 and int(ids.max()) < 625
+        for g in range(2):
+            z = torch.nn.functional.linear(x[:, g * 512:(g + 1) * 512], sd[f"vq_layer.quantizer.rvqs.{g}.project_in.weight"],
+                                           sd[f"vq_layer.quantizer.rvqs.{g}.project_in.bias"])
+            res = ref_cpu.fsq_bound(z, lv) if pre_bound else z
+            for r in range(2):
+                scale = 4.0 ** (-r)
+                target = ref_cpu.fsq_bound(res / scale, lv) / 2.0                                        # bounded value in code units
+                nearest = torch.cdist(target, grid).argmin(1)
+                assert torch.equal(nearest.to(torch.int32), ids[g * 2 + r]), (pre_bound, g, r)
+                res = res - grid[nearest] * scale
