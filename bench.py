@@ -3,18 +3,28 @@
 A "step" is one pass of the hot path over one batch: 20 decoder layers + 4 heads + sampler for B sequences,
 i.e. B generated tokens (token = 4 code indices = 21.33 ms of audio).  Default workload =
 BASELINE.json configs[1]: batch 1, 48-token synthetic prompt, top-p 0.7 / top-k 20 / T 0.3 / rep 1.05,
-512 generated tokens (min_new = max_new forces exactly K steps), fp16 weights+KV with fp32 accumulate
-(the reference's GPU dtype, pipeline:37-41).  Inputs are resident in HBM when the timed region starts.
+a 512-token generation (min_new = max_new: EOS masked), fp16 weights+KV with fp32 accumulate (the reference's GPU
+dtype, pipeline:37-41).  Inputs are resident in HBM when the timed region starts.
+
+The timed window of K steps is placed in the MIDDLE of the 512-token generation whatever K is (the steps before it run
+untimed), so the measured context length -- and with it the KV bytes per step -- is that of the whole generation
+(mean context = prompt + 256 +- a few), not that of its first K steps.
 
     python bench.py --gpus 1 --steps 512 --warmup 16
+    python bench.py --gpus 8 ...                 # no env needed: re-executes itself through torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: utterances are independent -> every rank decodes its own batch (weak scaling); the only
-collective on the path is one RCCL broadcast of the speaker-embedding table before the timed region.
+N > 1: utterances are independent -> every rank decodes its own batch (weak scaling); the only collective on the
+path is one RCCL broadcast of the speaker-embedding table before the timed region.  The JSON line also carries an `extra`
+block (same process, after the headline leg): batch 32 per GPU (configs[2]; aggregated over the ranks = configs[3] at N=8),
+batch 32 with mixed-length left-padded prompts, a 512-token prompt (north_star's "synthetic 512-token prompts"), and batch 32
+through a LoRA-merged engine (configs[4]).  `--no-extras` skips them.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
 
@@ -25,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (6290 GB/s measured float4 copy, MI355X_MICROARCH.md)
+GEN_TOKENS = 512               # the generation the timed window is centred in (BASELINE configs[1])
+LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20)
 
 
 def cpu_baseline(prompt_len: int, sample_steps: int):
@@ -52,15 +64,31 @@ def cpu_baseline(prompt_len: int, sample_steps: int):
                        f"after a 4-step run is subtracted, same synthetic weights; host has {os.cpu_count()} logical CPUs")
 
 
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: replace this process by torch.distributed.run with N ranks on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "16")
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def dry_run(args, world, rank):
-    """Same collective sequence as the real run (speaker broadcast, barrier, timed region, barrier, MAX all-reduce, rank-0
-    JSON) on the gloo backend with a sleep instead of the decode loop -- validates the N>1 control flow on CPU."""
+    """Same collective sequence as the real run (speaker broadcast, barrier, timed region, barrier, MAX all-reduce, per-rank
+    gather, rank-0 JSON) on the gloo backend with a sleep instead of the decode loop -- validates the N>1 control flow on CPU."""
     import torch.distributed as dist
     from chatttsplus_amd import synth
     from chatttsplus_amd.dist import broadcast_speakers
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
     table = torch.from_numpy(synth.speaker_vector(1234))[None] if rank == 0 else None
     spk = broadcast_speakers(table, 1, 768, torch.device("cpu"))
     assert abs(float(spk.norm()) - float(torch.from_numpy(synth.speaker_vector(1234)).norm())) < 1e-4
@@ -68,18 +96,112 @@ def dry_run(args, world, rank):
         dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.05 * (1 + rank))            # ranks finish at different times: the MAX must win
+    mine = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_gather(per, torch.tensor([mine], dtype=torch.float64))
+    else:
+        per = [torch.tensor([mine], dtype=torch.float64)]
     if rank == 0:
         print(json.dumps({"metric": "decode tokens/s", "value": round(args.batch * args.steps * world / float(dt), 2), "unit": "tokens/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(dt) / args.steps * 1e3, 5),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                          "world_size": world, "per_rank_tokens_per_s": [round(args.batch * args.steps / float(p), 2) for p in per],
                           "config": {"workload": "DRY RUN (no GPU work)"}}))
     if world > 1:
         dist.destroy_process_group()
+
+
+class Leg:
+    """One timed decode leg on an engine: begin -> prompt pass -> first sample -> untimed steps up to the window -> K timed steps."""
+
+    def __init__(self, g, dev, rank, world):
+        self.g, self.dev, self.rank, self.world = g, dev, rank, world
+
+    def run(self, B, P, K, W, pad_left=None, spk=None, gen_tokens=GEN_TOKENS, use_graph=1, keep_hidden=False):
+        import torch.distributed as dist
+        from chatttsplus_amd import _lib, synth
+        from chatttsplus_amd.hip_models.gpt import sampler_cfg_from_objects
+        g, dev = self.g, self.dev
+        lib, h = g._lib, g._h
+        cfg = synth.GPT_REAL
+        s0 = W + max(0, (gen_tokens - K) // 2)               # generated tokens before the timed window (step 0 = first sample)
+        max_new = s0 + K
+        ids, mask = synth.prompt_ids(B, P, cfg["num_text_tokens"], 1234 + self.rank, pad_left=pad_left)
+        spk_id = 21143
+        for b in range(B):                                            # "[Stts][spk_emb]..." (pipeline:187-194): slot 1 of the unpadded text
+            ids[b, (pad_left[b] if pad_left is not None else 0) + 1, :] = spk_id
+        ids_t = torch.from_numpy(ids).to(dev)
+        emb = g(ids_t, torch.ones(B, P, dtype=torch.bool, device=dev), spk_emb=spk, spk_emb_ids=spk_id)   # get_emb + apply_spk_emb (one HIP launch)
+        lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+        lp = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+        sc = sampler_cfg_from_objects(torch.tensor([0.3] * 4), 625, max_new, max_new, lw, lp, 4)
+        out_ids = torch.zeros(B, max_new, 4, dtype=torch.int32, device=dev)
+        hid = torch.zeros(B, max_new, 768, dtype=torch.float32, device=dev) if keep_hidden else None
+        fin = torch.zeros(B, dtype=torch.int32, device=dev)
+        end = torch.zeros(B, dtype=torch.int32, device=dev)
+        io = _lib.GenIO(ids=out_ids.data_ptr(), hiddens=hid.data_ptr() if hid is not None else None, finish=fin.data_ptr(), end_idx=end.data_ptr(),
+                        noise=None, n_draws=0, seed=1234 + self.rank)             # on-device Philox noise
+        msk = torch.from_numpy(mask).to(dev).to(torch.int32)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.ctts_gpt_begin(h, B, P, msk.data_ptr(), C.byref(sc), C.byref(io), st), "begin")
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        _lib.check(lib.ctts_gpt_prefill(h, emb.data_ptr(), st), "prefill")
+        _lib.check(lib.ctts_gpt_sample(h, st), "sample")
+        torch.cuda.synchronize(dev)
+        prefill_ms = (time.perf_counter() - t0) * 1e3
+        # untimed: warm-up (graph capture) + the steps that bring the context to the window's start
+        left = s0 - 1
+        while left > 0:
+            n = min(left, 64)
+            _lib.check(lib.ctts_gpt_decode(h, n, use_graph, st), "decode (untimed)")
+            left -= n
+        torch.cuda.synchronize(dev)
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        # timed: exactly K steps; the same region is bracketed by HIP events on the launch stream
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(torch.cuda.current_stream(dev))
+        _lib.check(lib.ctts_gpt_decode(h, K, use_graph, st), "decode")
+        ev1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        mine = time.perf_counter() - t0
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1)
+        steps_done, alld = C.c_int32(0), C.c_int32(0)
+        _lib.check(lib.ctts_gpt_progress(h, C.byref(steps_done), C.byref(alld), st), "progress")
+        expect = max(s0, 1) + K
+        if steps_done.value != expect or int(end.min().item()) != expect:
+            raise SystemExit(f"bench invalid: {steps_done.value} steps executed, expected {expect} (end_idx min {int(end.min().item())})")
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        per = [torch.tensor([mine], device=dev, dtype=torch.float64)]
+        if self.world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            per = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(self.world)]
+            dist.all_gather(per, torch.tensor([mine], device=dev, dtype=torch.float64))
+        valid = (mask.sum(1)).astype(np.float64)                                   # attended prompt tokens per sequence
+        mean_ctx = float(valid.mean()) + s0 + K / 2.0
+        return dict(B=B, P=P, K=K, s0=s0, dt=float(tmax.item()), ev_ms=ev_ms, prefill_ms=prefill_ms, hid=hid, expect=expect, mean_ctx=mean_ctx,
+                    per_rank_s=[float(p.item()) for p in per], step_bytes=g.step_bytes(B, mean_ctx))
+
+
+def summarize(r, world):
+    step_ms = r["ev_ms"] / r["K"]
+    ach = r["step_bytes"] / (step_ms * 1e-3) / 1e9
+    return {"tokens_per_s": round(r["B"] * r["K"] * world / r["dt"], 1), "ms_per_step": round(r["dt"] / r["K"] * 1e3, 5),
+            "step_ms_hip_events": round(step_ms, 5), "batch_per_gpu": r["B"], "prompt_len": r["P"], "steps": r["K"],
+            "mean_context": round(r["mean_ctx"], 1), "algorithmic_bytes_per_step": int(r["step_bytes"]),
+            "achieved_GBps": round(ach, 1), "frac_of_8TBps": round(ach / HBM_PEAK_GBS, 4), "prefill_plus_first_sample_ms": round(r["prefill_ms"], 3)}
 
 
 def main():
@@ -92,14 +214,20 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--cpu-steps", type=int, default=192, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (batch 32, mixed prompts, 512-token prompt, LoRA)")
+    ap.add_argument("--extra-steps", type=int, default=128, help="timed steps of each extra leg")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank control flow (no HIP work, fake timing); used by tests/test_bench_dryrun.py")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        if not args.dry_run and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+        self_spawn(args)                       # does not return
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if args.dry_run:
         return dry_run(args, world, rank)
     torch.cuda.set_device(local_rank)
@@ -108,70 +236,27 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        assert dist.get_world_size() == args.gpus
 
-    import ctypes as C
-    from chatttsplus_amd import _lib, synth
-    from chatttsplus_amd.hip_models.gpt import GPT, sampler_cfg_from_objects
+    from chatttsplus_amd import synth
+    from chatttsplus_amd.hip_models.gpt import GPT
 
-    cfg = synth.GPT_REAL
     B, P, K, W = args.batch, args.prompt, args.steps, args.warmup
-    max_new = W + K
-    sd = synth.gpt_state_dict(cfg, 1234)                    # every rank holds a full replica (0.45 GB fp16)
-    g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=max(B, 1),
-            max_seq_len=P + max_new + 8, weight_dtype=args.dtype, device=str(dev))
+    extras = not args.no_extras
+    EB, EK = 32, args.extra_steps
+    sd = synth.gpt_state_dict(synth.GPT_REAL, 1234)                    # every rank holds a full replica (0.45 GB fp16)
+    need_seq = max(P, 512 if extras else 0) + W + max(GEN_TOKENS, K) + 16
+    g = GPT(LLAMA, max_batch=max(B, EB if extras else 1), max_seq_len=need_seq, weight_dtype=args.dtype, device=str(dev))
     g.load_state_dict(sd)
-    ids, mask = synth.prompt_ids(B, P, cfg["num_text_tokens"], 1234 + rank)
-    spk_id = 21143
-    ids[:, 1, :] = spk_id                                   # "[Stts][spk_emb]..." layout (pipeline:187-194)
     # speaker table lives on rank 0 and is broadcast over xGMI (the path's only collective)
     spk = torch.from_numpy(synth.speaker_vector(1234)).to(dev) if rank == 0 else torch.zeros(768, device=dev)
     if world > 1:
         dist.broadcast(spk, src=0)
-    ids_t = torch.from_numpy(ids).to(dev)
-    emb = g(ids_t, torch.ones(B, P, dtype=torch.bool, device=dev), spk_emb=spk, spk_emb_ids=spk_id)   # get_emb + apply_spk_emb (one HIP launch)
-
-    lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
-    lp = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
-    sc = sampler_cfg_from_objects(torch.tensor([0.3] * 4), 625, max_new, max_new, lw, lp, 4)
-    lib, h = g._lib, g._h
-    out_ids = torch.zeros(B, max_new, 4, dtype=torch.int32, device=dev)
-    hid = torch.zeros(B, max_new, 768, dtype=torch.float32, device=dev)
-    fin = torch.zeros(B, dtype=torch.int32, device=dev)
-    end = torch.zeros(B, dtype=torch.int32, device=dev)
-    io = _lib.GenIO(ids=out_ids.data_ptr(), hiddens=hid.data_ptr(), finish=fin.data_ptr(), end_idx=end.data_ptr(), noise=None,
-                    n_draws=0, seed=1234 + rank)             # on-device Philox noise
-    msk = torch.from_numpy(mask).to(dev).to(torch.int32)
-    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     use_graph = 0 if args.no_graph else 1
-    _lib.check(lib.ctts_gpt_begin(h, B, P, msk.data_ptr(), C.byref(sc), C.byref(io), st), "begin")
-    t0 = time.perf_counter()
-    _lib.check(lib.ctts_gpt_prefill(h, emb.data_ptr(), st), "prefill")
-    _lib.check(lib.ctts_gpt_sample(h, st), "sample")
-    torch.cuda.synchronize(dev)
-    prefill_ms = (time.perf_counter() - t0) * 1e3
-    # warmup: W-1 untimed decode steps (the first sample above is step 0), includes graph capture
-    _lib.check(lib.ctts_gpt_decode(h, max(W - 1, 1), use_graph, st), "decode warmup")
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    # timed: exactly K steps; the same region is bracketed by HIP events on the launch stream
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(torch.cuda.current_stream(dev))
-    _lib.check(lib.ctts_gpt_decode(h, K, use_graph, st), "decode")
-    ev1.record(torch.cuda.current_stream(dev))
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    steps_done, alld = C.c_int32(0), C.c_int32(0)
-    _lib.check(lib.ctts_gpt_progress(h, C.byref(steps_done), C.byref(alld), st), "progress")
-    expect = 1 + max(W - 1, 1) + K
-    if steps_done.value != expect or int(end.min().item()) != expect:
-        raise SystemExit(f"bench invalid: {steps_done.value} steps executed, expected {expect} (end_idx min {int(end.min().item())})")
+    leg = Leg(g, dev, rank, world)
+    r = leg.run(B, P, K, W, spk=spk, use_graph=use_graph, keep_hidden=True)
+    dt, expect, hid = r["dt"], r["expect"], r["hid"]
+
     # RTF leg (outside the timed decode region): DVAE decoder + Vocos on the generated hiddens of every local sequence
     voc_ms = None
     try:
@@ -187,45 +272,82 @@ def main():
         torch.cuda.synchronize(dev)
         voc_ms = (time.perf_counter() - tv) * 1e3
         assert wav.shape[0] == 256 * (2 * expect - 1) and bool(torch.isfinite(wav).all())
+        del syn
     except Exception as e:          # the decode metric stays valid; report the failure instead of hiding it
         voc_ms = f"failed: {e}"
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    del hid
+    r["hid"] = None
+
+    extra = {}
+    if extras:
+        try:
+            # configs[2] / configs[3]: batch 32 per GPU, uniform prompts; aggregated over the ranks (MAX time)
+            e = leg.run(EB, P, EK, W, spk=spk, use_graph=use_graph)
+            extra["batch32"] = summarize(e, world)
+            extra["batch32"]["per_rank_tokens_per_s"] = [round(EB * EK / p, 1) for p in e["per_rank_s"]]
+            # configs[2] as written: mixed-length utterances, left-padded to the longest prompt (P_b ~ U{16..96}), padded KV
+            rng = np.random.Generator(np.random.Philox(key=77 + rank))
+            plen = rng.integers(16, 97, size=EB)
+            plen[0] = 96
+            e = leg.run(EB, 96, EK, W, pad_left=[int(96 - p) for p in plen], spk=spk, use_graph=use_graph)
+            extra["batch32_mixed_prompts"] = summarize(e, world)
+            extra["batch32_mixed_prompts"]["prompt_lengths"] = "U{16..96} left-padded to 96"
+            # north_star: "decode tokens/s on synthetic 512-token prompts", batch 1
+            e = leg.run(1, 512, EK, W, spk=spk, use_graph=use_graph)
+            extra["prompt512_batch1"] = summarize(e, world)
+            e = leg.run(EB, 512, EK, W, spk=spk, use_graph=use_graph, gen_tokens=2 * EK)
+            extra["prompt512_batch32"] = summarize(e, world)
+            # configs[4]: LoRA (r=8, alpha=16 on q/k/v/o of all layers, train_voice_clone_lora.yaml:72-80) merged into the packed weights
+            rl = np.random.Generator(np.random.Philox(key=31))
+            adapters = [(l, t, (rl.standard_normal((8, 768)) * 0.02).astype(np.float32), (rl.standard_normal((768, 8)) * 0.02).astype(np.float32), 2.0)
+                        for l in range(LLAMA["num_hidden_layers"]) for t in ("q_proj", "k_proj", "v_proj", "o_proj")]
+            gl = g.with_lora(adapters)
+            e = Leg(gl, dev, rank, world).run(EB, P, EK, W, spk=spk, use_graph=use_graph)
+            extra["batch32_lora_merged"] = summarize(e, world)
+            gl.close()
+        except SystemExit:
+            raise
+        except Exception as ex:
+            extra["error"] = f"{type(ex).__name__}: {ex}"
 
     if rank == 0:
         traffic = None
         try:      # HBM bytes/step from the committed rocprofv3 PMC passes (profiles/), same kernels and batch; not live
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = tr.get(f"b{B}_{args.dtype}", {}).get("hbm_bytes_per_step")
+            for rr in ("r02", "r01"):
+                fp = os.path.join(ROOT, "profiles", f"{rr}_pmc_traffic.json")
+                if os.path.exists(fp):
+                    traffic = json.load(open(fp)).get(f"b{B}_{args.dtype}", {}).get("hbm_bytes_per_step")
+                    if traffic:
+                        break
         except Exception:
             pass
-        mean_ctx = P + W + K / 2.0
-        step_bytes = g.step_bytes(B, mean_ctx)
-        step_ms = ev_ms / K
+        step_bytes = r["step_bytes"]
+        step_ms = r["ev_ms"] / K
         achieved = step_bytes / (step_ms * 1e-3) / 1e9
         res = {
             "metric": "decode tokens/s", "value": round(B * K * world / dt, 2), "unit": "tokens/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(B * K * world / dt / 110.0, 2),   # 110 token/s (TensorRT fp16, RTX 3060)
             "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
-            "config": {"workload": f"ChatTTS GPT decode, batch {B}/GPU, prompt {P}, {K} generated tokens, top-p 0.7 top-k 20 T 0.3 rep 1.05 "
-                                   f"(BASELINE configs[{1 if B == 1 else 2}]), random-init weights of the real 20x768 architecture",
-                       "batch_per_gpu": B, "prompt_len": P, "weights": args.dtype, "kv_cache": args.dtype, "accumulate": "f32",
-                       "hipgraph": bool(use_graph), "parallelism": f"replicas x{world} (utterance sharding)"},
+            "world_size": world, "per_rank_tokens_per_s": [round(B * K / p, 2) for p in r["per_rank_s"]],
+            "config": {"workload": f"ChatTTS GPT decode, batch {B}/GPU, prompt {P}, steps {r['s0']}..{r['s0'] + K} of a {max(GEN_TOKENS, K)}-token generation "
+                                   f"(mean context {r['mean_ctx']:.0f}), top-p 0.7 top-k 20 T 0.3 rep 1.05 (BASELINE configs[{1 if B == 1 else 2}]), "
+                                   f"random-init weights of the real 20x768 architecture",
+                       "batch_per_gpu": B, "prompt_len": P, "untimed_steps_before_window": r["s0"], "weights": args.dtype, "kv_cache": args.dtype,
+                       "accumulate": "f32", "hipgraph": bool(use_graph), "parallelism": f"replicas x{world} (utterance sharding)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_note": "PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE bytes per step from profiles/r01_pmc_*.json (separate rocprofv3 --pmc passes at --steps 64)",
-                         "per": "decode step (one hipGraph replay = 102 kernel launches)",
+                         "traffic_note": "PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE bytes per step from profiles/r0N_pmc_*.json (separate rocprofv3 --pmc passes)",
+                         "per": "decode step (one hipGraph replay = 4 steps)",
                          "algorithmic_bytes_per_step": int(step_bytes), "step_ms_hip_events": round(step_ms, 5)},
             "rtf_decode_only": round(B * K * world * (512 / 24000.0) / dt, 2),
-            "rtf_end_to_end": (round(B * 256 * (2 * expect - 1) / 24000.0 / ((prefill_ms + (dt / K) * 1e3 * (expect - 1) + voc_ms) / 1e3), 2)
+            "rtf_end_to_end": (round(B * 256 * (2 * expect - 1) / 24000.0 / ((r["prefill_ms"] + (dt / K) * 1e3 * (expect - 1) + voc_ms) / 1e3), 2)
                                if isinstance(voc_ms, float) else None),
             "vocoder_ms_for_batch": voc_ms if not isinstance(voc_ms, float) else round(voc_ms, 3),
             "rtf_note": f"audio seconds of {B} utterances x {expect} tokens / (prompt pass + {expect - 1} decode steps at the measured rate + DVAE-decoder + Vocos), rank 0",
-            "prefill_plus_first_sample_ms": round(prefill_ms, 3),
+            "prefill_plus_first_sample_ms": round(r["prefill_ms"], 3),
             "reference_published_tok_s": {"tensorrt_fp16_rtx3060": 110, "pytorch_fp16_rtx3060": 28},
+            "extra": extra if extras else None,
         }
         if args.cpu_steps > 0 and world == 1:
             res["cpu_baseline"] = cpu_baseline(P, args.cpu_steps)

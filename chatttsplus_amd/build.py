@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 print(out, file=sys.stderr)
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, timeout=900)

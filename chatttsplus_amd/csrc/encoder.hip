@@ -16,6 +16,7 @@
 #include <string>
 
 #include "conv_gemm.h"
+#include "roctx_range.h"
 
 struct EncConvNext { float *dw_w, *dw_b, *ln_w, *ln_b, *w1, *b1, *w2, *b2, *gamma; };
 
@@ -218,6 +219,7 @@ extern "C" int ctts_enc_finalize(ctts_enc* h) {
 
 extern "C" int ctts_dvae_encode(ctts_enc* h, const float* wav, int n_samples, int32_t* ids, float* mel_out, float* feat_out, void* stream) {
     if (!h || !h->finalized || !wav || !ids) { ctts_set_error("dvae_encode: bad argument"); return 1; }
+    CTTS_RANGE("ctts_dvae_encode");
     const ctts_enc_cfg& c = h->cfg;
     const int N = c.n_fft, hop = c.hop, NB = N / 2 + 1, D = c.dim, HD = c.enc_hidden, BN = c.enc_bn, OD = c.enc_odim;
     if (n_samples <= N / 2 || n_samples > c.max_samples) {        // reflect padding needs n > n_fft / 2 (torch.stft raises otherwise)

@@ -21,6 +21,7 @@
 
 #include "../../include/ctts_hip.h"
 #include "kernels.h"
+#include "roctx_range.h"
 
 static thread_local char g_err[512] = "";
 void ctts_set_error(const char* fmt, ...) {
@@ -153,10 +154,38 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     delete h;
 }
 
+// The 196 keys of the reference's GPT state dict: 9 per decoder layer, gpt.norm, 4 emb_code, emb_text, 2 + 8 weight-norm
+// parametrizations of the heads.
+static bool known_weight_key(const ctts_gpt* h, const std::string& n) {
+    int l = -1, consumed = 0;
+    if (sscanf(n.c_str(), "gpt.layers.%d.%n", &l, &consumed) == 1 && consumed > 0) {
+        if (l < 0 || l >= h->L) return false;
+        const std::string rest = n.substr(consumed);
+        static const char* per_layer[] = {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                                          "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight", "input_layernorm.weight",
+                                          "post_attention_layernorm.weight"};
+        for (const char* k : per_layer) if (rest == k) return true;
+        return false;
+    }
+    if (n == "gpt.norm.weight" || n == "emb_text.weight" || n == "head_text.parametrizations.weight.original0" ||
+        n == "head_text.parametrizations.weight.original1") return true;
+    int i = -1; consumed = 0;
+    if (sscanf(n.c_str(), "emb_code.%d.weigh%n", &i, &consumed) == 1 && consumed > 0) return i >= 0 && i < h->NVQ && n.substr(consumed) == "t";
+    if (sscanf(n.c_str(), "head_code.%d.parametrizations.weight.origina%n", &i, &consumed) == 1 && consumed > 0) {
+        const std::string rest = n.substr(consumed);
+        return i >= 0 && i < h->NVQ && (rest == "l0" || rest == "l1");
+    }
+    return false;
+}
+
 extern "C" int ctts_gpt_set_weight(ctts_gpt* h, const char* name, const float* data, size_t numel) {
     if (!h || !name || !data) { ctts_set_error("null argument"); return 1; }
     if (h->finalized) { ctts_set_error("weights already finalized"); return 1; }
     std::string n(name);
+    if (!known_weight_key(h, n)) {          // strict load, like the reference's load_state_dict(strict=True) (gpt.py:84-85)
+        ctts_set_error("set_weight: unexpected key '%s' (not a tensor of the ChatTTS GPT state dict)", name);
+        return 1;
+    }
     h->host[n].assign(data, data + numel);
     return 0;
 }
@@ -333,6 +362,11 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
             CTTS_HIP_CHECK(hipMemcpy(h->emb_text, it->second.data(), it->second.size() * 4, hipMemcpyHostToDevice));
         }
     }
+    if (h->whead_text && h->emb_text && h->vocab_text_head > h->vocab_text) {
+        // the text sampler re-embeds any sampled id < vocab_text_head through emb_text: a larger head would read past the table
+        ctts_set_error("finalize: head_text has %d rows but emb_text only %d", h->vocab_text_head, h->vocab_text);
+        return 1;
+    }
     h->host.clear();
     h->finalized = true;
     return 0;
@@ -496,6 +530,7 @@ static int reset_state(ctts_gpt* h, bool keep_draw, hipStream_t s) {
 extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, const ctts_sampler_cfg* sc, const ctts_gen_io* io, void* stream) {
     if (!h || !h->finalized || !h->kv || !h->rope) { ctts_set_error("begin: handle not ready (finalize / bind_kv / set_rope)"); return 1; }
     if (!mask || !sc || !io || !io->ids || !io->finish || !io->end_idx) { ctts_set_error("begin: null argument"); return 1; }
+    CTTS_RANGE("ctts_gpt_begin");               // reference: nvtx "adjust_buffer" / "set_tensors" (trt_models/predictor.py:142,159)
     if (B < 1 || B > h->cfg.max_batch || T < 1 || T + sc->max_new_token > h->cfg.max_seq) {
         ctts_set_error("begin: B=%d T=%d max_new=%d exceed max_batch=%d / max_seq=%d", B, T, sc->max_new_token, h->cfg.max_batch, h->cfg.max_seq);
         return 1;
@@ -523,6 +558,7 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
 
 extern "C" int ctts_gpt_prefill(ctts_gpt* h, const float* emb, void* stream) {
     if (!h || !emb || h->B == 0) { ctts_set_error("prefill: call begin first"); return 1; }
+    CTTS_RANGE("ctts_gpt_prefill");             // reference: nvtx "forward" (trt_models/llama_trt_model.py:44,74), q_len > 1
     hipStream_t s = (hipStream_t)stream;
     const int R = h->B * h->T;
     std::vector<int> last(h->B);
@@ -550,6 +586,7 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* h, const float* emb, void* stream) {
 
 extern "C" int ctts_gpt_sample(ctts_gpt* h, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("sample: call begin first"); return 1; }
+    CTTS_RANGE("ctts_gpt_sample");
     return run_sample_phase(h, (hipStream_t)stream);
 }
 
@@ -595,6 +632,7 @@ static int ensure_graph(ctts_gpt* h) {
 
 extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("decode: call begin first"); return 1; }
+    CTTS_RANGE("ctts_gpt_decode");              // reference: nvtx "forward" per decode step + "execute" (trt_models/predictor.py:164)
     hipStream_t s = (hipStream_t)stream;
     h->cur_splits = decode_splits(h, h->B, h->T + h->launched + n_steps + 1);
     h->launched += n_steps;

@@ -26,6 +26,7 @@
 #include "common.h"
 
 #include "conv_gemm.h"
+#include "roctx_range.h"
 
 // Stage the batch: copy each utterance's hidden rows ([n][768] == frames [2n][384], dvae.py:277-283) behind a zero guard
 // row and zero the guard rows / channel padding of every conv input (grid = (Fmax + 6, nb), one row per block).
@@ -347,6 +348,7 @@ extern "C" int ctts_dvae_decode(ctts_voc* h, const float* hidden, int n_tokens, 
     if (!h || !h->finalized || !hidden || !mel) { ctts_set_error("dvae_decode: bad argument"); return 1; }
     const int F = 2 * n_tokens;
     if (n_tokens < 1 || F > h->cfg.max_frames) { ctts_set_error("dvae_decode: %d frames exceed max_frames=%d", F, h->cfg.max_frames); return 1; }
+    CTTS_RANGE("ctts_dvae_decode");
     hipStream_t s = (hipStream_t)stream;
     if (set_tables(h, &hidden, &F, nullptr, &mel, 1, s) || stage(h, true, 1, F, s)) return 1;
     return run_dvae(h, 1, F, false, s);
@@ -355,6 +357,7 @@ extern "C" int ctts_dvae_decode(ctts_voc* h, const float* hidden, int n_tokens, 
 extern "C" int ctts_vocos_decode(ctts_voc* h, const float* mel, int F, float* wav, void* stream) {
     if (!h || !h->finalized || !mel || !wav) { ctts_set_error("vocos_decode: bad argument"); return 1; }
     if (F < 2 || F > h->cfg.max_frames) { ctts_set_error("vocos_decode: %d frames exceed max_frames=%d", F, h->cfg.max_frames); return 1; }
+    CTTS_RANGE("ctts_vocos_decode");
     hipStream_t s = (hipStream_t)stream;
     if (set_tables(h, nullptr, &F, &wav, nullptr, 1, s) || stage(h, false, 1, F, s)) return 1;
     hipLaunchKernelGGL(mel_to_cl_kernel, dim3(F), dim3(128), 0, s, mel, h->mcl, h->cfg.n_mels, F, h->mel_ld, 3);
@@ -365,6 +368,7 @@ extern "C" int ctts_vocos_decode(ctts_voc* h, const float* mel, int F, float* wa
 extern "C" int ctts_synth_batch(ctts_voc* h, const float* const* hidden_ptrs, const int32_t* n_tokens, int B, float* const* wav_ptrs, void* stream) {
     if (!h || !h->finalized || !hidden_ptrs || !n_tokens || !wav_ptrs) { ctts_set_error("synth_batch: bad argument"); return 1; }
     if (B < 1 || B > h->cfg.max_batch) { ctts_set_error("synth_batch: B=%d exceeds max_batch=%d", B, h->cfg.max_batch); return 1; }
+    CTTS_RANGE("ctts_synth_batch");
     int Fmax = 0;
     for (int u = 0; u < B; ++u) {
         const int F = 2 * n_tokens[u];

@@ -144,11 +144,18 @@ class GPT:
     def to(self, device=None, dtype=None):
         return self
 
+    def close(self):
+        """Destroys the engine handle (packed weights, workspaces, graphs) now instead of at garbage collection; the KV
+        tensor is released with the last engine that shares it."""
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ctts_gpt_destroy(self._h)
+            self._h = C.c_void_p()
+        self._finalized = False
+        self._kv = None
+
     def __del__(self):
         try:
-            if getattr(self, "_h", None) and self._h.value:
-                self._lib.ctts_gpt_destroy(self._h)
-                self._h = C.c_void_p()
+            self.close()
         except Exception:
             pass
 
@@ -159,7 +166,7 @@ class GPT:
         """peft merge rule W += scale * B @ A (pipeline:420-432) applied before finalize."""
         self._lora.append((layer, target, np.ascontiguousarray(A, dtype=np.float32), np.ascontiguousarray(B, dtype=np.float32), float(scale)))
 
-    def load_state_dict(self, sd, strict: bool = True):
+    def load_state_dict(self, sd, strict: bool = True, _share_kv: Optional[torch.Tensor] = None):
         if self._finalized:
             raise _lib.HipBackendError("weights already loaded")
         keep = []
@@ -176,7 +183,8 @@ class GPT:
             rope = rope_table(self.max_seq)
             _lib.check(self._lib.ctts_gpt_set_rope(self._h, rope.ctypes.data_as(C.c_void_p), self.max_seq), "set_rope")
             nbytes = self._lib.ctts_gpt_kv_bytes(self._h)
-            self._kv = torch.empty(nbytes, dtype=torch.uint8, device=self.device)       # torch owns the KV cache
+            # torch owns the KV cache; LoRA-merged siblings borrow the base engine's (one generate() runs at a time)
+            self._kv = _share_kv if (_share_kv is not None and _share_kv.numel() >= nbytes) else torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self._lib.ctts_gpt_bind_kv(self._h, self._kv.data_ptr(), nbytes), "bind_kv")
         self._finalized = True
         self._ctor = dict(gpt_config=self.gpt_config, num_audio_tokens=self.num_audio_tokens, num_text_tokens=self.num_text_tokens,
@@ -192,7 +200,7 @@ class GPT:
         g = GPT(**self._ctor)
         for (layer, target, A, B, scale) in adapters:
             g.add_lora(layer, target, A, B, scale)
-        g.load_state_dict(self._sd_host)
+        g.load_state_dict(self._sd_host, _share_kv=self._kv)
         return g
 
     # -- get_emb (gpt.py:125-149) ----------------------------------------------------------------
@@ -242,6 +250,19 @@ class GPT:
             raise _lib.HipBackendError("return_attn=True is unsupported (the reference's eager attention path is broken, SURVEY F2)")
         if not self._finalized:
             raise _lib.HipBackendError("weights not loaded")
+        if getattr(self, "_busy", False):
+            # engine state (batch, step counters, noise staging ring, KV cache) belongs to ONE generate() at a time
+            raise _lib.HipBackendError("GPT.generate is already running on this engine: exhaust or close the previous generator first")
+        self._busy = True
+        try:
+            yield from self._generate(emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token, logits_warpers,
+                                      logits_processors, infer_text, return_hidden, stream, ensure_non_empty, stream_batch, context, noise, seed,
+                                      max_restarts)
+        finally:
+            self._busy = False
+
+    def _generate(self, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token, logits_warpers, logits_processors,
+                  infer_text, return_hidden, stream, ensure_non_empty, stream_batch, context, noise, seed, max_restarts):
         context = context or Context()
         lib, h = self._lib, self._h
         B, T = int(inputs_ids.shape[0]), int(inputs_ids.shape[1])

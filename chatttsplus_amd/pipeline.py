@@ -11,9 +11,11 @@ normalisation / splitting (pluggable callables, identity by default).  There is 
 """
 from __future__ import annotations
 
+import dataclasses
 import json
 import logging
 import os
+from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Union
 
@@ -123,7 +125,8 @@ class ChatTTSPlusPipeline:
         self.normalizer: Callable = kwargs.get("normalizer") or (lambda t, *a, **k: t)
         self.text_splitter: Optional[Callable] = kwargs.get("text_splitter")
         self.load_lora = False
-        self._lora_models = {}
+        self._lora_models = OrderedDict()          # lora_path -> merged sibling engine, LRU-bounded (`lora_cache`, default 1)
+        self._lora_cache = max(1, int(kwargs.get("lora_cache", 1)))
         self.load_models(**kwargs)
 
     # -- loading (pipeline:53-155) -----------------------------------------------------------------
@@ -261,7 +264,7 @@ class ChatTTSPlusPipeline:
         """pipeline:286-305: per utterance hidden[n,768] -> DVAE -> mel[1,100,2n] -> Vocos -> wav[256(2n-1)]."""
         if not use_decoder:
             raise _lib.HipBackendError("use_decoder=False (decode codes through dvae_encode) is not served by the hip backend")
-        if len(result_list) > 1 and getattr(self, "synth", None) is not None:
+        if len(result_list) >= 1 and getattr(self, "synth", None) is not None:
             return self.synth.decode_batch(list(result_list))           # one launch sequence for the batch (ctts_synth_batch)
         wavs = []
         decoder, vocos = self.models_dict["dvae_decode"], self.models_dict["vocos"]
@@ -274,11 +277,20 @@ class ChatTTSPlusPipeline:
         return wavs
 
     def _gpt_for_lora(self, lora_path: Optional[str]):
+        """pipeline:420-434,465-470: the reference merges the adapter into a copy of the Llama for the call and restores
+        `gpt_org` afterwards, i.e. it holds ONE merged model at a time.  Here a merged sibling engine (GPT.with_lora: its own
+        packed weights, the base engine's KV cache shared) is cached per adapter path in a small LRU (`lora_cache`, default 1);
+        evicted engines are destroyed, so a service cycling through adapters does not grow HBM."""
         if not lora_path:
             return self.models_dict["gpt"]
-        if lora_path not in self._lora_models:
-            base = self.models_dict["gpt"]
-            self._lora_models[lora_path] = base.with_lora(load_lora_adapter(lora_path))
+        if lora_path in self._lora_models:
+            self._lora_models.move_to_end(lora_path)
+            return self._lora_models[lora_path]
+        while len(self._lora_models) >= self._lora_cache:
+            _, old = self._lora_models.popitem(last=False)
+            old.close()
+        base = self.models_dict["gpt"]
+        self._lora_models[lora_path] = base.with_lora(load_lora_adapter(lora_path))
         return self._lora_models[lora_path]
 
     def _infer(self, text_in, stream=False, lang=None, skip_refine_text=False, refine_text_only=False, use_decoder=True,
@@ -286,6 +298,8 @@ class ChatTTSPlusPipeline:
                params_refine_text=RefineTextParams(), params_infer_code=InferCodeParams(), **kwargs):
         if not isinstance(text_in, list):
             text_in = [text_in]
+        if not use_decoder and not refine_text_only:
+            raise _lib.HipBackendError("use_decoder=False (decode codes through dvae_encode) is not served by the hip backend")
         if do_text_optimization and self.text_splitter is not None:
             text_in = self.text_splitter(text_in)                         # pipeline:353-377 (pluggable; CPU text work)
         text_in = [self.normalizer(t, do_text_normalization, do_homophone_replacement, lang) for t in text_in]
@@ -360,3 +374,53 @@ class ChatTTSPlusPipeline:
             params_infer_code.spk_emb = self.sample_random_speaker()
         return self._infer(text, stream, lang, skip_refine_text, refine_text_only, use_decoder, do_text_normalization,
                            do_text_optimization, do_homophone_replacement, params_refine_text, params_infer_code, **kwargs)
+
+    # -- multi-GPU: utterance sharding (BASELINE configs[3]: batch 256 over 8 GPUs) --------------------------------
+    @torch.no_grad()
+    def infer_sharded(self, texts: List[str], speaker_index: Optional[List[int]] = None, speaker_table: Optional[torch.Tensor] = None,
+                      skip_refine_text: bool = True, params_refine_text=RefineTextParams(), params_infer_code=InferCodeParams(), **kwargs):
+        """One request over all ranks of the initialised torch.distributed group (one process per GPU; world 1 works too).
+        Every rank calls this with the same `texts`; utterances are independent (the reference runs them as sequential slices
+        of 4 with no cross-slice state, pipeline:391-397), so they are split by `dist.partition` (length-balanced snake) and
+        each rank runs its own utterances through the ordinary `_infer` (slices of `max_batch`) + `_decode_to_wavs`.  The only
+        exchange: ONE broadcast of the speaker table [n_spk, 768] from rank 0 (RCCL over xGMI) and one all-reduce of the
+        generated lengths (disjoint supports).  `speaker_index[i]` selects utterance i's row; without a table every utterance
+        uses params_infer_code.spk_emb.
+        Returns (indices of this rank's utterances, their waveforms in that order, generated token counts of ALL utterances).
+        Note SURVEY F8: the reference's repetition penalty skips rows >= 625 of the flattened [B*4] batch; a rank never holds
+        more than max_batch <= 128 sequences (512 rows) per call, so the quirk cannot trigger on any rank."""
+        from . import dist as cdist
+        if not isinstance(texts, list):
+            texts = [texts]
+        params = dataclasses.replace(params_infer_code)
+        n_spk, dim = 1, self.models_dict["gpt"].model_dim
+        if speaker_table is not None or speaker_index is not None:
+            assert speaker_index is not None and len(speaker_index) == len(texts), "speaker_index: one entry per utterance"
+            n_spk = int(max(speaker_index)) + 1
+            if speaker_table is not None:
+                speaker_table = torch.as_tensor(speaker_table, dtype=torch.float32).reshape(-1, dim)
+                assert speaker_table.shape[0] >= n_spk
+                speaker_table = speaker_table[:n_spk]
+        else:
+            speaker_index = [0] * len(texts)
+            if params.spk_emb is None:
+                speaker_table = self._sample_random_speaker().view(1, dim) if (not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0) else None
+            else:
+                speaker_table = codec.speaker_to_vector(params.spk_emb).view(1, dim) if isinstance(params.spk_emb, str) else torch.as_tensor(params.spk_emb, dtype=torch.float32).view(1, dim)
+        slice_size = int(kwargs.pop("slice_size", self.models_dict["gpt"].max_batch))
+        wavs_local: List[torch.Tensor] = []
+
+        def run_local(indices, rows):
+            lens = []
+            for ii in range(0, len(indices), slice_size):
+                sl = indices[ii:ii + slice_size]
+                p = dataclasses.replace(params, spk_emb=rows[ii:ii + len(sl)])
+                for wavs in self._infer([texts[i] for i in sl], False, None, skip_refine_text, False, True, True, False, True,
+                                        params_refine_text, p, slice_size=len(sl), **kwargs):
+                    wavs_local.extend(wavs)
+                    lens.extend([(int(w.shape[0]) // 256 + 1) // 2 if w.shape[0] else 0 for w in wavs])
+            return lens
+
+        mine, all_lens = cdist.sharded_generate([len(t) for t in texts], speaker_index, speaker_table, n_spk, dim, self.device, run_local)
+        return mine, wavs_local, all_lens
+

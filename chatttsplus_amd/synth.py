@@ -73,6 +73,20 @@ def gpt_state_dict(cfg: dict = GPT_REAL, seed: int = 1234) -> Dict[str, np.ndarr
     return sd
 
 
+def stress_gpt_state_dict(sd: Dict[str, np.ndarray], proj_scale: float = 8.0, head_scale: float = 8.0) -> Dict[str, np.ndarray]:
+    """Stress variant of a synthetic GPT checkpoint: every q/k/v/o/gate/up/down projection scaled by `proj_scale` (attention
+    logits x proj_scale^2 -> peaked attention; MLP outputs x proj_scale^3 -> outlier channels in the residual stream) and the
+    weight-norm gains of the code/text heads by `head_scale` (sharpened sampling distributions).  N(0, 0.02^2) weights alone
+    give near-uniform attention and small activations -- the easy case for fp16 weights / KV."""
+    out = {k: v.copy() for k, v in sd.items()}
+    for k in out:
+        if k.endswith("_proj.weight"):
+            out[k] = (out[k] * np.float32(proj_scale)).astype(np.float32)
+        elif k.startswith("head_") and k.endswith("original0"):
+            out[k] = (out[k] * np.float32(head_scale)).astype(np.float32)
+    return out
+
+
 def _conv(seed, name, cout, cin_per_group, k, bias=True):
     fan_in = cin_per_group * k
     out = {name + ".weight": _normal(seed, name + ".w", (cout, cin_per_group, k), 1.0 / np.sqrt(fan_in))}

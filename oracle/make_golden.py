@@ -166,6 +166,53 @@ def golden_gpt_real_ragged(ref):
     raise SystemExit("no staggered-finish case found")
 
 
+def golden_gpt_real_regen(ref):
+    """Real config, first-step EOS -> ensure_non_empty regenerate (gpt.py:496-525): B=2 with left padding, EOS head rows
+    boosted, min_new_token=0.  The torch seed is searched for a run whose first attempt(s) end at step 0 (finish.any()) and a
+    later attempt survives for a few tokens -- the case the HIP path's ctts_gpt_restart / running draw counter must reproduce."""
+    cfg = synth.GPT_REAL
+    pad = [0, 3]
+    ids, mask = synth.prompt_ids(2, 12, cfg["num_text_tokens"], 23, pad_left=pad)
+    old_limit = sys.getrecursionlimit()
+    for boost in (2.6, 3.0, 2.2, 3.5):
+        sd = synth.gpt_state_dict(cfg, 1234)
+        for i in range(4):
+            sd[f"head_code.{i}.parametrizations.weight.original0"][625] *= boost
+        g = build_ref_gpt(ref, cfg, sd)
+        calls = {"n": 0}
+        orig = g.generate
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return orig(*a, **k)
+        g.generate = counting
+        for torch_seed in range(300, 340):
+            calls["n"] = 0
+            sys.setrecursionlimit(400)
+            try:
+                emb, out = run_ref_generate(ref, g, ids, mask, torch_seed, 20, 0)
+            except RecursionError:
+                continue
+            finally:
+                sys.setrecursionlimit(old_limit)
+            lens = [int(i.shape[0]) for i in out.ids]
+            print("  real regen search: boost", boost, "seed", torch_seed, "attempts", calls["n"], "lens", lens)
+            if 2 <= calls["n"] <= 5 and min(lens) >= 2 and max(lens) >= 4:
+                meta = dict(weight_seed=1234, eos_boost=boost, prompt_seed=23, torch_seed=torch_seed, B=2, T=12, pad_left=pad, max_new=20,
+                            min_new=0, attempts=calls["n"], spk_seed=1234, spk_id=21143, spk_pos=-1)
+                # RNG end state of the reference run: the value the CPU generator yields next
+                torch.manual_seed(torch_seed)
+                list(g.generate(emb, torch.from_numpy(ids), temperature=torch.tensor([0.3] * 4), eos_token=625,
+                                attention_mask=torch.from_numpy(mask), max_new_token=20, min_new_token=0,
+                                logits_warpers=ref.processors.gen_logits(num_code=625, top_P=0.7, top_K=20, repetition_penalty=1.05)[0],
+                                logits_processors=ref.processors.gen_logits(num_code=625, top_P=0.7, top_K=20, repetition_penalty=1.05)[1],
+                                return_hidden=True, show_tqdm=False, ensure_non_empty=True))
+                meta["rng_next"] = torch.rand(4).numpy()
+                save_gen("gpt_real_regen", meta, emb, out)
+                return
+    raise RuntimeError("no seed found for the real-config regenerate golden")
+
+
 def golden_refine_text(ref):
     """infer_text=True pass (pipeline:237-277 -> gpt.py infer_text branches): real config, 21178-way text head."""
     cfg = synth.GPT_REAL
@@ -301,6 +348,7 @@ def main():
     golden_dvae_encode(ref)
     golden_gpt_real(ref)
     golden_gpt_real_ragged(ref)
+    golden_gpt_real_regen(ref)
     golden_refine_text(ref)
 
 

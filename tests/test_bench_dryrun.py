@@ -29,3 +29,17 @@ def test_bench_dry_run_single():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "4"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_bench_self_spawns_ranks_without_launcher():
+    """`python bench.py --gpus 2` with no launcher env re-executes itself through torch.distributed.run (a plain
+    --gpus N invocation must work); world size and per-rank rates are visible in the JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and len(d["per_rank_tokens_per_s"]) == 2
+    assert d["per_rank_tokens_per_s"][0] > d["per_rank_tokens_per_s"][1]          # rank 1 sleeps longer

@@ -65,3 +65,118 @@ def test_sharded_generate_world2_gloo():
         assert full == expect
         seen += mine
     assert sorted(seen) == list(range(len(lengths)))
+
+
+# ---- ChatTTSPlusPipeline.infer_sharded: the real _infer/_infer_code/_decode_to_wavs wiring with a fake engine -------------------
+VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "[Stts]", "[Ptts]", "[spk_emb]", "[empty_spk]", "[uv_break]", "[break_0]",
+         "[Ebreak]", "[speed_5]", "a", "b", "c", "d"]
+
+
+class _FakeGPT:
+    """Stands in for hip_models.GPT on CPU: same call surface; the generated length of an utterance is a pure function of its
+    prompt and of its OWN speaker row, so a wrong shard / wrong speaker row / wrong order shows up in the lengths."""
+    num_vq, model_dim, max_batch = 4, 8, 3
+
+    def __init__(self):
+        self.emb_code = [type("E", (), dict(num_embeddings=626))() for _ in range(4)]
+        self.calls = []
+
+    def __call__(self, input_ids, text_mask, spk_emb=None, spk_emb_ids=None):
+        B, T = input_ids.shape[:2]
+        spk = torch.as_tensor(spk_emb, dtype=torch.float32).reshape(-1, self.model_dim).expand(B, -1)
+        emb = torch.zeros(B, T, self.model_dim)
+        emb[:, 0, 0] = text_mask.sum(1).float()           # valid prompt tokens
+        emb[:, 0, 1] = spk[:, 0]                          # first element of this utterance's speaker row
+        return emb
+
+    def generate(self, emb, inputs_ids, temperature, eos_token, attention_mask=None, max_new_token=2048, return_hidden=False, **kw):
+        B = emb.shape[0]
+        self.calls.append(B)
+        assert B <= self.max_batch
+        n = [int(emb[b, 0, 0].item()) + int(emb[b, 0, 1].item()) for b in range(B)]
+        yield type("O", (), dict(ids=[torch.zeros(k, 4, dtype=torch.long) for k in n], attentions=[],
+                                 hiddens=[torch.full((k, 768), float(k)) for k in n]))
+
+
+class _FakeSynth:
+    def decode_batch(self, hiddens):
+        return [torch.full((256 * (2 * h.shape[0] - 1),), float(h.shape[0])) if h.shape[0] else torch.zeros(0) for h in hiddens]
+
+
+def _fake_pipeline(tmpdir):
+    from transformers import BertTokenizerFast
+    from chatttsplus_amd.pipeline import ChatTTSPlusPipeline
+    from chatttsplus_amd.tokenizer import Tokenizer
+    vf = os.path.join(tmpdir, "vocab.txt")
+    with open(vf, "w") as f:
+        f.write("\n".join(VOCAB))
+    bt = BertTokenizerFast(vocab_file=vf, do_lower_case=False)
+    bt.add_special_tokens({"additional_special_tokens": [v for v in VOCAB if v.startswith("[") and v not in ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]")]})
+    pipe = object.__new__(ChatTTSPlusPipeline)
+    pipe.device = torch.device("cpu")
+    pipe.normalizer = lambda t, *a, **k: t
+    pipe.text_splitter = None
+    pipe.models_dict = dict(gpt=_FakeGPT(), tokenizer=Tokenizer(tokenizer=bt))
+    pipe.synth = _FakeSynth()
+    pipe._lora_models, pipe._lora_cache = {}, 1
+    pipe.std = pipe.mean = None
+    return pipe
+
+
+TEXTS = ["a b c d a b c", "a", "b c", "d d d d d d d d d", "a b", "c c c", "b", "a b c d", "d a", "c b a d c b a"]
+SPK_IDX = [0, 1, 2, 1, 0, 2, 2, 1, 0, 1]
+
+
+def _expected_lengths(pipe):
+    tok = pipe.models_dict["tokenizer"]
+    out = []
+    for t, s in zip(TEXTS, SPK_IDX):
+        ids, att, tm = tok.encode([f"[Stts][spk_emb][speed_5]{t} [uv_break][Ptts]"], 4)
+        out.append(int(tm.sum()) + 3 * s + 1)             # speaker table row s = [3 s + 1, ...]
+    return out
+
+
+def _pipe_worker(rank, world, port, q, tmpdir):
+    from chatttsplus_amd.pipeline import InferCodeParams
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pipe = _fake_pipeline(tmpdir)
+        table = (torch.arange(3, dtype=torch.float32)[:, None] * 3 + 1).expand(3, 8).contiguous() if rank == 0 else None
+        mine, wavs, all_lens = pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=table,
+                                                  params_infer_code=InferCodeParams(show_tqdm=False))
+        q.put((rank, mine, [int(w.shape[0]) for w in wavs], all_lens, pipe.models_dict["gpt"].calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipeline_infer_sharded_world2_gloo(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = _expected_lengths(_fake_pipeline(str(tmp_path)))
+    seen = []
+    for rank, mine, wav_samples, all_lens, calls in res:
+        assert all_lens == expect, (rank, all_lens, expect)                       # every rank sees every utterance's length
+        assert wav_samples == [256 * (2 * expect[i] - 1) for i in mine]           # local waveforms, in the order of `mine`
+        assert sum(calls) == len(mine) and max(calls) <= 3                        # sliced at max_batch
+        seen += mine
+    assert sorted(seen) == list(range(len(TEXTS)))
+
+
+def test_pipeline_infer_sharded_single_process(tmp_path):
+    """No process group: world 1, same entry point."""
+    from chatttsplus_amd.pipeline import InferCodeParams
+    pipe = _fake_pipeline(str(tmp_path))
+    table = (torch.arange(3, dtype=torch.float32)[:, None] * 3 + 1).expand(3, 8).contiguous()
+    mine, wavs, all_lens = pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=table, params_infer_code=InferCodeParams(show_tqdm=False))
+    assert mine == list(range(len(TEXTS))) and all_lens == _expected_lengths(pipe)
+    assert [int(w.shape[0]) for w in wavs] == [256 * (2 * n - 1) for n in all_lens]

@@ -35,7 +35,7 @@ def model(wd, seed=1234, boost=None):
     return _models[key]
 
 
-@pytest.mark.parametrize("name", ["gpt_real_b1", "gpt_real_b2_pad", "gpt_real_greedy", "gpt_real_b4_ragged"])
+@pytest.mark.parametrize("name", ["gpt_real_b1", "gpt_real_b2_pad", "gpt_real_greedy", "gpt_real_b4_ragged", "gpt_real_regen"])
 def test_generate_golden_fp32_bit_exact_ids(name):
     z, meta = load_golden(name)
     sd, ids, mask, spk = gen_case_inputs(meta, synth.GPT_REAL)
@@ -56,6 +56,11 @@ def test_generate_golden_fp32_bit_exact_ids(name):
         assert np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64)), f"row {b}: token ids differ"
         err = np.abs(out.hiddens[b].cpu().numpy() - z["hiddens"][b, :n]).max()
         assert err <= 1e-4, f"row {b}: hidden err {err}"
+    if "rng_next" in meta:
+        # ensure_non_empty regenerate (gpt.py:496-525): the first attempt(s) ended at step 0 -> ctts_gpt_restart, draws keep
+        # running; the CPU generator must end where the reference run left it (value minted from the reference)
+        assert int(meta["attempts"]) >= 2
+        np.testing.assert_array_equal(torch.rand(4).numpy(), meta["rng_next"])
 
 
 def test_rng_state_after_generate_matches_reference_consumption():
@@ -169,3 +174,31 @@ def test_embed_kernel_with_speaker_matches_oracle():
     got = g(ids, tm, spk_emb=spk, spk_emb_ids=21143).cpu()
     assert torch.equal(got, ref)
     assert torch.equal(g(ids, tm).cpu(), o.embed(ids, tm))
+
+
+def test_strict_state_dict_keys_and_busy_guard():
+    """Strict load (gpt.py:84-85 load_state_dict default): an unexpected key is refused by ctts_gpt_set_weight; a second
+    generate() on an engine whose previous generator is still alive is refused (one call owns the engine state)."""
+    from chatttsplus_amd import _lib
+    from chatttsplus_amd.hip_models import GPT
+    cfg = dict(LLAMA); cfg["num_hidden_layers"] = 2
+    scfg = dict(synth.GPT_REAL); scfg["num_hidden_layers"] = 2
+    sd = synth.gpt_state_dict(scfg, 3)
+    for bad in ("gpt.layers.2.mlp.up_proj.weight", "gpt.layers.0.self_attn.qq_proj.weight", "emb_code.4.weight", "lm_head.weight",
+                "head_code.0.parametrizations.weight.original2"):
+        g = GPT(cfg, max_batch=1, max_seq_len=32, weight_dtype="fp32")
+        with pytest.raises(_lib.HipBackendError, match="unexpected key"):
+            g.load_state_dict({**sd, bad: np.zeros(4, dtype=np.float32)})
+        g.close()
+    g = GPT(cfg, max_batch=1, max_seq_len=64, weight_dtype="fp32")
+    g.load_state_dict(sd)
+    ids, mask = synth.prompt_ids(1, 6, scfg["num_text_tokens"], 2)
+    emb = g(torch.from_numpy(ids), torch.ones(1, 6, dtype=torch.bool))
+    kw = dict(max_new_token=24, min_new_token=24, logits_warpers=LW, logits_processors=LP, stream=True, stream_batch=8)
+    it = g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, **kw)
+    next(it)                                            # the generator is alive, mid-stream
+    with pytest.raises(_lib.HipBackendError, match="already running"):
+        next(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, **kw))
+    it.close()
+    out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, **kw))[-1]     # released: works again
+    assert out.ids[0].shape[0] == 24
