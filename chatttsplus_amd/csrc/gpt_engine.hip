@@ -87,6 +87,11 @@ struct ctts_gpt {
     DevState* st = nullptr;
     int* last_rows = nullptr;
     int* host_pin = nullptr;
+    void* xh = nullptr;                          // fp16 decode, > split_rows rows: residual stream as packed fp16 B operand (EPI_RESID_XH -> PRO_XH)
+    float *ssq = nullptr, *scale_o = nullptr, *scale_d = nullptr;   //   per-tile sums of squares [rows][48]; per-row power-of-two scales of the xh rows
+    int xh_mode = 1;                             //   env CTTS_XH=0 switches the path off (every block re-normalises fp32 rows: PRO_NORM)
+    int* hist_ring = nullptr;                    // sampler: repetition-penalty window ring [max_B][4][16] (sampler.hip)
+    int2* finend = nullptr;                      // sampler: engine-side mirror of {finish, end_idx} [max_B]
     // per generate()
     int B = 0, T = 0;
     SamplerCfgDev sc;
@@ -131,6 +136,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     if (const char* nr = getenv("CTTS_NBG2_ROWS")) h->nbg2_rows = atoi(nr);
     if (const char* fq = getenv("CTTS_FUSEQKV_ROWS")) { h->fuseqkv_rows = atoi(fq); if (h->fuseqkv_rows > 4) h->fuseqkv_rows = 4; }
     if (const char* fr = getenv("CTTS_FUSE_ROWS")) { h->fuse_rows = atoi(fr); if (h->fuse_rows > 16) h->fuse_rows = 16; }
+    if (const char* xm = getenv("CTTS_XH")) h->xh_mode = atoi(xm);
     if (const char* gs = getenv("CTTS_GRAPH_STEPS")) { h->graph_steps = atoi(gs); if (h->graph_steps < 1) h->graph_steps = 1; }
     if (gemm_configure()) { delete h; return 1; }
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -145,7 +151,8 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
     void* bufs[] = {h->dyn, h->wblob, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
-                    h->act, h->attn_packed, h->norm_packed, h->opart, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows};
+                    h->act, h->attn_packed, h->norm_packed, h->opart, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
+                    h->hist_ring, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -351,7 +358,10 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4) ||
-        dev_alloc((void**)&h->dyn, sizeof(SamplerDyn)))
+        dev_alloc((void**)&h->dyn, sizeof(SamplerDyn)) || dev_alloc((void**)&h->hist_ring, (size_t)CTTS_MAX_B * CTTS_NUM_VQ * 16 * 4) ||
+        dev_alloc((void**)&h->finend, (size_t)CTTS_MAX_B * sizeof(int2)) ||
+        dev_alloc(&h->xh, (size_t)((CTTS_MAX_B + 32) / 16) * (H / 32) * 1024) || dev_alloc((void**)&h->ssq, (size_t)(CTTS_MAX_B + 32) * (H / 16) * 4) ||
+        dev_alloc((void**)&h->scale_o, (size_t)(CTTS_MAX_B + 32) * 4) || dev_alloc((void**)&h->scale_d, (size_t)(CTTS_MAX_B + 32) * 4))
         return 1;
     CTTS_HIP_CHECK(hipHostMalloc((void**)&h->host_pin, 64));
     {
@@ -429,6 +439,9 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     const bool splitd = (st != nullptr) && (R <= h->split_rows) && (nbg == 1) && (h->fuse_rows == 0);
     // prompt pass over more than a few chunks: normalise every row once (norm_pack_kernel) instead of in every GEMM block
     const bool prepack = (st == nullptr) && (nbg == 2) && (R > 64) && !getenv("CTTS_NO_PREPACK");
+    // fp16 decode above the split-K batch sizes: the residual stream travels between kernels as a packed fp16 B operand + per-tile
+    // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself
+    const bool xhm = (dt == CTTS_DTYPE_F16) && (st != nullptr) && h->xh_mode && !splitd && (R > h->fuse_rows) && (R > h->fuseqkv_rows);
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
         a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq;
@@ -454,6 +467,10 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         if (prepack) {
             g1.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s) || launch_gemm(dt, nbg, PRO_PACKED, EPI_QKV, g1, chunks, s)) return 1;
+        } else if (xhm) {
+            g1.scale_out = h->scale_o;
+            if (l > 0) { g1.xh = h->xh; g1.ssq = h->ssq; g1.scale_in = h->scale_d; }
+            if (!(h->ablate & 1) && launch_gemm(dt, nbg, l > 0 ? PRO_XH : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         } else if (!(h->ablate & 1) && launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
@@ -472,7 +489,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g2.xpacked = h->attn_packed;
             g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;
             const bool sp2 = splitd;                       // the down projection's partial sums are folded into x here
-            if (!(h->ablate & 4) && launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, sp2 ? EPI_RESID_P : EPI_RESID, g2, chunks, s)) return 1;
+            if (xhm) { g2.xh = h->xh; g2.ssq = h->ssq; g2.scale_in = h->scale_o; }
+            if (!(h->ablate & 4) && launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (sp2 ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
         }
         }
         // RMSNorm + gate|up + SiLU*up
@@ -481,6 +499,9 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         if (prepack) {
             g3.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s) || launch_gemm(dt, nbg, PRO_PACKED, EPI_SWIGLU, g3, chunks, s)) return 1;
+        } else if (xhm) {
+            g3.xh = h->xh; g3.ssq = h->ssq; g3.scale_in = h->scale_o; g3.scale_out = h->scale_d;
+            if (!(h->ablate & 8) && launch_gemm(dt, nbg, PRO_XH, EPI_SWIGLU, g3, chunks, s)) return 1;
         } else if (!(h->ablate & 8) && launch_gemm(dt, nbg, fused ? PRO_NORM_P : PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
         // down + residual
         GemmArgs g4 = a;
@@ -488,6 +509,9 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         if (splitd) {
             g4.part_out = h->dpart; g4.ktiles_total = h->I / (h->esz == 2 ? 32 : 16);
             if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, EPI_PART, g4, chunks, s)) return 1;
+        } else if (xhm && l + 1 < h->L) {          // the last layer's output goes to the heads, which normalise the fp32 rows themselves
+            g4.xh = h->xh; g4.ssq = h->ssq; g4.scale_in = h->scale_d;
+            if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH, g4, chunks, s)) return 1;
         } else if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, fused ? EPI_RESID_P : EPI_RESID, g4, chunks, s)) return 1;
     }
     return 0;
@@ -512,6 +536,7 @@ static int run_sample_phase(ctts_gpt* h, hipStream_t s) {
     sa.dyn = h->dyn; sa.logits = h->logits; sa.V = h->text_mode ? h->vocab_text_head : h->V; sa.B = h->B; sa.st = h->st;
     sa.text_mode = h->text_mode;
     sa.emb_code = h->text_mode ? h->emb_text : h->emb_code; sa.H = h->H; sa.x_next = h->x_dec; sa.meta = h->meta_dec; sa.rope = h->rope; sa.rope_rows = h->rope_dec;
+    sa.hist_ring = h->hist_ring; sa.finend = h->finend;
     return launch_sampler(sa, h->B, s);
 }
 
@@ -524,6 +549,8 @@ static int reset_state(ctts_gpt* h, bool keep_draw, hipStream_t s) {
     CTTS_HIP_CHECK(hipMemcpyAsync(h->meta_dec, h->meta_dec0, h->B * sizeof(RowMeta), hipMemcpyDeviceToDevice, s));
     CTTS_HIP_CHECK(hipMemsetAsync(h->io.finish, 0, h->B * 4, s));
     CTTS_HIP_CHECK(hipMemsetAsync(h->io.end_idx, 0, h->B * 4, s));
+    CTTS_HIP_CHECK(hipMemsetAsync(h->finend, 0, h->B * sizeof(int2), s));
+    CTTS_HIP_CHECK(hipMemsetAsync(h->hist_ring, 0xFF, (size_t)h->B * CTTS_NUM_VQ * 16 * 4, s));      // -1: no id sampled yet
     return 0;
 }
 
@@ -607,8 +634,8 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows, h->cur_splits,
-             h->fuseqkv_rows);
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows, h->cur_splits,
+             h->fuseqkv_rows, h->xh_mode);
     const std::string key(sig);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }

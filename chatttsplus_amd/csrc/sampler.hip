@@ -11,8 +11,8 @@
 //   next-token embedding = sum of the 4 code embeddings                  gpt.py:403-407
 //
 // Top-p needs the *ascending* cumulative softmax.  Because the removed set is a prefix of the ascending
-// order, and top-k follows, only the largest <= top_k (+ties) candidates are ever kept: they are pulled
-// out one by one with a wave-wide arg-max (6 shuffle steps), and the ascending cumsum at rank r is
+// order, and top-k follows, only the largest <= top_k (+ties) candidates are ever kept: they are found with a
+// value threshold + rank-by-counting (sample_row below), and the ascending cumsum at rank r is
 // total - (sum of the r larger probabilities), accumulated in fp64 exactly like torch's CPU cumsum
 // (acc_type<float> = double) and rounded to fp32 before the `<= 1 - top_p` compare.
 #include "kernels.h"
@@ -31,11 +31,8 @@ __device__ inline uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 
 struct RowIn {
-    const float* logits;     // [V]
     const float* q;          // [V] or null -> Philox
-    const int* hist;         // first id of the penalty window
-    int hist_stride;
-    int nh;                  // ids in the window (<= past_window <= 16)
+    int myid;                // lane hh < 16: id hh of the repetition-penalty window, or -1 (not in the window)
     float T;
     bool penalize;
     int step;
@@ -50,9 +47,23 @@ __device__ inline SampleKnobs knobs_of(SamplerDynPtr d) {
     return k;
 }
 
-// returns the sampled index (identical in every lane)
-// lg: the row's logits, element lane + 64 i, loaded by the caller (ahead of everything it has to wait for)
-__device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& in, int V, int lane, const float (&lg)[VPL]) {
+__device__ inline float exp_noise_of(const RowIn& in, int j) {
+    if (in.q != nullptr) return in.q[j];
+    const uint4 rnd = philox4x32_10(make_uint4((unsigned)j, in.row, in.draw, 0x43545453u), make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
+    const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return -logf(u);
+}
+
+// One row = one wavefront.  Selection of the survivors of top-p / top-k:
+//   Top-p removes a prefix of the ASCENDING order and top-k follows, so the survivors are a prefix of the DESCENDING order, at
+//   most top_k (+ ties with the k-th value) long.  Instead of pulling them out one by one (the former <= 20+ dependent wave-wide
+//   arg-max rounds, ~8 us of a 16 us kernel), a value threshold T0 <= (k-th largest value) is found from the 64 lane maxima
+//   (T0 = their k-th largest: at least k values are >= T0), the candidates {x >= T0} (typically 20-30) are compacted into one
+//   per lane, ranked by counting and permuted into descending order; the ascending cumsum at rank r = total - (sum of the
+//   larger probabilities), accumulated in fp64 in rank order exactly as before, decides the cut for all ranks at once.
+//   Falls back to the serial extraction when top_k > 64 or more than 64 candidates tie at the threshold.
+// `lds64`: 64 x 8 bytes of LDS private to this wave.
+__device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& in, int V, int lane, const float (&lg)[VPL], unsigned long long* lds64) {
     float x[VPL];
     unsigned valid = 0;
 #pragma unroll
@@ -61,23 +72,21 @@ __device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& i
         if (j < V) { x[i] = __fdiv_rn(lg[i], in.T); valid |= 1u << i; }
         else x[i] = -INFINITY;
     }
-    if (in.penalize && in.nh > 0) {
-        int cnt[VPL];
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) cnt[i] = 0;
-        // one parallel load of the <=16 window ids (lane hh holds id hh), then wave-uniform broadcasts: the former
-        // per-id scalar loads were a chain of up to 16 dependent L2 round trips (~11 us of the 24 us kernel)
-        const int myid = (lane < in.nh) ? in.hist[(size_t)lane * in.hist_stride] : -1;
+    if (in.penalize) {
+        // window ids live one per lane (lane hh < 16); each is broadcast and counted into a packed 5-bit counter per slot
+        unsigned long long cntp = 0ull;
 #pragma unroll
         for (int hh = 0; hh < 16; ++hh) {
-            const int id = __builtin_amdgcn_readlane(myid, hh);
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) cnt[i] += (id == lane + 64 * i) ? 1 : 0;
+            const int id = __builtin_amdgcn_readlane(in.myid, hh);
+            const unsigned long long inc = 1ull << (5 * ((unsigned)id >> 6) & 63);      // id == -1 -> owner lane 63, slot >= 10: never read
+            cntp += (id >= 0 && (id & 63) == lane) ? inc : 0ull;
         }
+        if (__builtin_amdgcn_ballot_w64(cntp != 0ull) != 0ull) {
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const float alpha = tab[cnt[i]];
-            x[i] = (x[i] < 0.f) ? __fmul_rn(x[i], alpha) : __fdiv_rn(x[i], alpha);   // processors.py:29-33
+            for (int i = 0; i < VPL; ++i) {
+                const float alpha = tab[(unsigned)(cntp >> (5 * i)) & 31u];
+                x[i] = (x[i] < 0.f) ? __fmul_rn(x[i], alpha) : __fdiv_rn(x[i], alpha);   // processors.py:29-33 (alpha == 1 leaves x unchanged)
+            }
         }
     }
     // softmax over the whole row (TopPLogitsWarper: sorted_logits.softmax(-1))
@@ -95,102 +104,136 @@ __device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& i
     for (int i = 0; i < VPL; ++i) { pr[i] *= inv; tot += (double)pr[i]; }
     tot = wave_sum_d(tot);
 
-    // Each lane sorts its 10 (value,index) keys once (descending, odd-even transposition network); every selection round
-    // then only compares the 64 lane heads (one DPP arg-max) and the winner's lane pops its head.
-    unsigned long long key[VPL];
-#pragma unroll
-    for (int i = 0; i < VPL; ++i)
-        key[i] = ((valid >> i) & 1u) ? (((unsigned long long)f32_key(x[i]) << 32) | (unsigned)(lane + 64 * i)) : 0ull;
-#pragma unroll
-    for (int pass = 0; pass < VPL; ++pass)
-#pragma unroll
-        for (int i = pass & 1; i + 1 < VPL; i += 2) {
-            const unsigned long long a = key[i], b = key[i + 1];
-            key[i] = a > b ? a : b;
-            key[i + 1] = a > b ? b : a;
-        }
-    unsigned kept = 0;
-    double cum_before = 0.0;
-    float vk = 0.f;
     const int topk = (c.top_k > 0) ? c.top_k : V;
-    float myv = -INFINITY;                                         // lane r remembers the r-th selected element (first 64 selections)
+    float myv = -INFINITY;                                         // lane r: the r-th selected element (descending order)
     int myi = 0, nsel = 0;
-    for (int r = 0; r < V; ++r) {
-        const unsigned long long best = wave_max_u64(key[0]);     // larger index wins ties (== reversed stable ascending sort)
-        if (best == 0ull) break;                                   // nothing left
-        const float bv = key_f32((unsigned)(best >> 32));
-        const int bi = (int)(unsigned)best;
-        const int owner = bi & 63, slot = bi >> 6;
-        if (r >= topk && bv != vk) break;                          // beyond top-k and not tied with the k-th value
-        const float cr = (float)(tot - cum_before);               // ascending cumsum at this element
-        if (cr <= c.top_p_threshold && r >= c.min_keep) break;     // removed by top-p (and so is every smaller one)
-        if (lane == owner) {
-            kept |= 1u << slot;
+    unsigned kept = 0;                                             // serial path only
+    bool fast = false;
+    if (topk <= 64) {
+        unsigned vkey[VPL], head = 0u;
 #pragma unroll
-            for (int i = 0; i + 1 < VPL; ++i) key[i] = key[i + 1];
-            key[VPL - 1] = 0ull;
+        for (int i = 0; i < VPL; ++i) { vkey[i] = ((valid >> i) & 1u) ? f32_key(x[i]) : 0u; head = max(head, vkey[i]); }
+        int greater = 0;                                           // lane maxima strictly above mine
+#pragma unroll
+        for (int j = 0; j < 64; ++j) greater += ((unsigned)__builtin_amdgcn_readlane((int)head, j) > head) ? 1 : 0;
+        // k-th largest lane maximum = the smallest one with fewer than k maxima above it
+        const unsigned long long t0k = wave_max_u64((greater < topk) ? (unsigned long long)(~head) : 0ull);
+        const unsigned T0 = ~(unsigned)t0k;
+        int C = 0;
+        int pos[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const bool cand = ((valid >> i) & 1u) && vkey[i] >= T0;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(cand);
+            pos[i] = cand ? C + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) : -1;
+            C += __builtin_popcountll(bal);
         }
-        if (lane == r) { myv = bv; myi = bi; }
-        nsel = r + 1;
-        if (r == topk - 1) vk = bv;
-        cum_before += (double)(expf(bv - mx) * inv);               // the same fp32 expression that produced pr[] for this element
+        if (C <= 64) {
+            fast = true;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (pos[i] >= 0) lds64[pos[i]] = ((unsigned long long)vkey[i] << 32) | (unsigned)(lane + 64 * i);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long ck = (lane < C) ? lds64[lane] : 0ull;
+            int rank = 0;                                          // keys are distinct (index in the low word): ranks = a permutation of 0..C-1
+            for (int j = 0; j < C; ++j) rank += (readlane_u64(ck, j) > ck) ? 1 : 0;
+            // lane r <- the candidate of rank r (lanes >= C push zeros to lane C: harmless)
+            const unsigned lo = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)(unsigned)ck);
+            const unsigned hi = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)(unsigned)(ck >> 32));
+            const float bv = key_f32(hi);
+            const int bi = (int)lo;
+            const float p_r = (lane < C) ? expf(bv - mx) * inv : 0.f;     // the same fp32 expression that produced pr[] for this element
+            const float vk = readlane_f(bv, (topk - 1) & 63);             // only consulted at ranks >= topk, which exist only if C > topk - 1
+            double cum = 0.0, cum_mine = 0.0;                             // cum_mine = sum of the larger probabilities, rank order, fp64
+            for (int r = 0; r < C; ++r) {
+                if (lane == r) cum_mine = cum;
+                cum += (double)readlane_f(p_r, r);
+            }
+            const float cr = (float)(tot - cum_mine);                     // ascending cumsum at this element
+            const bool stop = (lane >= C) || (lane >= topk && bv != vk) || (cr <= c.top_p_threshold && lane >= c.min_keep);
+            const unsigned long long sb = __builtin_amdgcn_ballot_w64(stop);
+            nsel = (sb == 0ull) ? 64 : (int)__builtin_ctzll(sb);
+            myv = bv; myi = bi;
+        }
     }
-    if (in.step < c.min_new) {                                     // gpt.py:477-478
-        if (lane == (c.eos & 63)) kept &= ~(1u << (c.eos >> 6));
+    if (!fast) {
+        // serial extraction: each lane sorts its 10 (value,index) keys once (descending, odd-even transposition network); every
+        // round compares the 64 lane heads (one DPP arg-max) and the winner's lane pops its head
+        unsigned long long key[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            key[i] = ((valid >> i) & 1u) ? (((unsigned long long)f32_key(x[i]) << 32) | (unsigned)(lane + 64 * i)) : 0ull;
+#pragma unroll
+        for (int pass = 0; pass < VPL; ++pass)
+#pragma unroll
+            for (int i = pass & 1; i + 1 < VPL; i += 2) {
+                const unsigned long long a = key[i], b = key[i + 1];
+                key[i] = a > b ? a : b;
+                key[i + 1] = a > b ? b : a;
+            }
+        double cum_before = 0.0;
+        float vk = 0.f;
+        for (int r = 0; r < V; ++r) {
+            const unsigned long long best = wave_max_u64(key[0]);     // larger index wins ties (== reversed stable ascending sort)
+            if (best == 0ull) break;                                   // nothing left
+            const float bv = key_f32((unsigned)(best >> 32));
+            const int bi = (int)(unsigned)best;
+            const int owner = bi & 63, slot = bi >> 6;
+            if (r >= topk && bv != vk) break;                          // beyond top-k and not tied with the k-th value
+            const float cr = (float)(tot - cum_before);               // ascending cumsum at this element
+            if (cr <= c.top_p_threshold && r >= c.min_keep) break;     // removed by top-p (and so is every smaller one)
+            if (lane == owner) {
+                kept |= 1u << slot;
+#pragma unroll
+                for (int i = 0; i + 1 < VPL; ++i) key[i] = key[i + 1];
+                key[VPL - 1] = 0ull;
+            }
+            if (lane == r) { myv = bv; myi = bi; }
+            nsel = r + 1;
+            if (r == topk - 1) vk = bv;
+            cum_before += (double)(expf(bv - mx) * inv);               // the same fp32 expression that produced pr[] for this element
+        }
+        if (in.step < c.min_new) {                                     // gpt.py:477-478
+            if (lane == (c.eos & 63)) kept &= ~(1u << (c.eos >> 6));
+        }
     }
     // final softmax over the kept set and the exponential race
     unsigned long long bkey = 0ull;                                // (ratio, first index wins ties) as one 64-bit key
     if (nsel <= 64) {
         // usual case (top-k / top-p keep a handful): one kept element per lane -- one exp, one noise draw, one division per
-        // lane instead of ten predicated slots of each.  Elements outside the kept set have p == 0 -> ratio 0: element 0
-        // stands in for all of them (smallest index wins ties).
+        // lane.  Elements outside the kept set have p == 0 -> ratio 0: element 0 stands in for all of them (smallest index
+        // wins ties).
         const bool on = (lane < nsel) && !(in.step < c.min_new && myi == c.eos);
         const float m2 = wave_max(on ? myv : -INFINITY);
         const float e = on ? expf(myv - m2) : 0.f;
         const float inv2 = 1.0f / wave_sum(e);
         bkey = ((unsigned long long)f32_key(0.f) << 32) | (unsigned)0x7FFFFFFF;
         if (on) {
-            float q;
-            if (in.q != nullptr) q = in.q[myi];
-            else {
-                const uint4 rnd = philox4x32_10(make_uint4((unsigned)myi, in.row, in.draw, 0x43545453u),
-                                                make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
-                const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
-                q = -logf(u);
-            }
-            const float ratio = __fdiv_rn(e * inv2, q);
+            const float ratio = __fdiv_rn(e * inv2, exp_noise_of(in, myi));
             bkey = umax64(bkey, ((unsigned long long)f32_key(ratio) << 32) | (unsigned)(0x7FFFFFFF - myi));
         }
     } else {
-    float m2 = -INFINITY;
+        float m2 = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) if ((kept >> i) & 1u) m2 = fmaxf(m2, x[i]);
-    m2 = wave_max(m2);
-    float e2[VPL], s2 = 0.f;
+        for (int i = 0; i < VPL; ++i) if ((kept >> i) & 1u) m2 = fmaxf(m2, x[i]);
+        m2 = wave_max(m2);
+        float e2[VPL], s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { e2[i] = ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f; s2 += e2[i]; }
-    s2 = wave_sum(s2);
-    const float inv2 = 1.0f / s2;
+        for (int i = 0; i < VPL; ++i) { e2[i] = ((kept >> i) & 1u) ? expf(x[i] - m2) : 0.f; s2 += e2[i]; }
+        s2 = wave_sum(s2);
+        const float inv2 = 1.0f / s2;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int j = lane + 64 * i;
-        if (j < V) {
-            // elements outside the kept set have p == 0 -> ratio 0 whatever q is: only kept ones draw noise
-            float ratio = 0.f;
-            if ((kept >> i) & 1u) {
-                float q;
-                if (in.q != nullptr) q = in.q[j];
-                else {
-                    const uint4 rnd = philox4x32_10(make_uint4((unsigned)j, in.row, in.draw, 0x43545453u),
-                                                    make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
-                    const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
-                    q = -logf(u);
-                }
-                ratio = __fdiv_rn(e2[i] * inv2, q);
+        for (int i = 0; i < VPL; ++i) {
+            const int j = lane + 64 * i;
+            if (j < V) {
+                // elements outside the kept set have p == 0 -> ratio 0 whatever q is: only kept ones draw noise
+                float ratio = 0.f;
+                if ((kept >> i) & 1u) ratio = __fdiv_rn(e2[i] * inv2, exp_noise_of(in, j));
+                bkey = umax64(bkey, ((unsigned long long)f32_key(ratio) << 32) | (unsigned)(0x7FFFFFFF - j));
             }
-            bkey = umax64(bkey, ((unsigned long long)f32_key(ratio) << 32) | (unsigned)(0x7FFFFFFF - j));
         }
-    }
     }
     bkey = wave_max_u64(bkey);
     const int besti = 0x7FFFFFFF - (int)(unsigned)bkey;
@@ -201,9 +244,10 @@ __device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& i
 // The leading scalars are preloaded into SGPRs (see skinny_gemm.hip): state header, logits and bookkeeping rows are all
 // requested before the first wait of the kernel.
 __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_words, const float* logits_p, const SamplerDyn* dyn_p, const RowMeta* meta_p,
-                                                               const int V_p, const SamplerArgs a) {
+                                                               const int V_p, const int* ring_p, const int2* finend_p, const SamplerArgs a) {
     __shared__ float tab[17];
     __shared__ int idx_s[CTTS_NUM_VQ];
+    __shared__ unsigned long long cand_s[CTTS_NUM_VQ][64];
     DevState* st = a.st;
     const SamplerDynPtr d = (SamplerDynPtr)dyn_p;
     const int tid = threadIdx.x, lane = tid & 63, vq = tid >> 6;
@@ -217,31 +261,36 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
 #pragma unroll
         for (int i = 0; i < VPL; ++i) { const int j = lane + 64 * i; lg[i] = (j < V_p) ? lrow[j] : 0.f; }
     }
+    // Everything the kernel reads lives at addresses known at launch (preloaded kernel arguments), so ALL its loads leave in one
+    // batch: the repetition-penalty window is a 16-entry ring per (sequence, codebook) that this kernel maintains itself (the ids
+    // buffer's address depends on the step and on the per-call block: a second dependent round trip in front of the penalty), and
+    // the finish / end_idx bookkeeping is mirrored in engine memory (the caller's arrays are write-only here).
+    const int ring_v = ring_p[(size_t)(b * CTTS_NUM_VQ + vq) * 16 + (lane & 15)];
+    const int2 fe = finend_p[b];
     if (tid < 17) tab[tid] = d->cfg.penalty_table[tid];
-    // bookkeeping state and the next position's RoPE row are requested now, consumed after the sampling (they used to be
-    // a chain of dependent round trips at the tail of this single-block kernel)
     const RowMeta meta_in = meta_p[b];
     if (__builtin_amdgcn_readfirstlane(hdr.z)) return;            // every sequence finished (gpt.py:545)
     const int step = __builtin_amdgcn_readfirstlane(hdr.x), draw = __builtin_amdgcn_readfirstlane(hdr.y);
-    const int fin_in = d->finish[b], end_in = d->end_idx[b];
+    const int fin_in = fe.x, end_in = fe.y;
     const float rope_next = (tid < 64) ? a.rope[(size_t)(meta_in.pos + 1) * 64 + tid] : 0.f;
     __syncthreads();
     const int row = b * CTTS_NUM_VQ + vq;
     RowIn in;
-    in.logits = a.logits + (size_t)row * a.V;
     in.q = (d->noise != nullptr) ? d->noise + ((size_t)min(draw, d->n_draws - 1) * a.B * CTTS_NUM_VQ + row) * a.V : nullptr;
+    // ring slot p holds the id sampled at the latest step s < `step` with s % 16 == p: it is inside the window of the last
+    // min(step, past_window) ids (processors.py:21-23 with gpt.py:455-457) iff its age step - s is at most that
     const int nh = min(step, d->cfg.past_window);
-    in.hist = d->ids + ((size_t)b * d->cfg.max_new + (step - nh)) * CTTS_NUM_VQ + vq;
-    in.hist_stride = CTTS_NUM_VQ;
-    in.nh = nh;
+    const int age = ((step - 1 - lane) & 15) + 1;
+    in.myid = (lane < 16 && age <= nh) ? ring_v : -1;
     in.T = d->cfg.temperature[vq];
-    in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids);      // quirk SURVEY F8
+    in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids) && nh > 0;      // quirk SURVEY F8
     in.step = step;
     in.seed = d->seed; in.draw = (unsigned)draw; in.row = (unsigned)row;
-    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg);
+    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg, cand_s[vq]);
     if (lane == 0) {
         idx_s[vq] = idx;
         d->ids[((size_t)b * d->cfg.max_new + step) * CTTS_NUM_VQ + vq] = idx;
+        a.hist_ring[(size_t)(b * CTTS_NUM_VQ + vq) * 16 + (step & 15)] = idx;
     }
     __syncthreads();
     // next-token embedding: ((e0 + e1) + e2) + e3   (torch.stack(..., 3).sum(3), gpt.py:403-407)
@@ -255,8 +304,10 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
         const bool was = fin_in != 0;
         bool fin = was;
         for (int v = 0; v < CTTS_NUM_VQ; ++v) fin = fin || (idx_s[v] == d->cfg.eos);   // gpt.py:486-487
+        const int end_out = fin ? end_in : end_in + 1;                               // gpt.py:530-531
         d->finish[b] = fin ? 1 : 0;
-        if (!fin) d->end_idx[b] = end_in + 1;                                        // gpt.py:530-531
+        if (!fin) d->end_idx[b] = end_out;
+        a.finend[b] = make_int2(fin ? 1 : 0, end_out);
         RowMeta m = meta_in;                                                       // next decode row
         m.pos += 1; m.slot += 1;
         a.meta[b] = m;
@@ -467,26 +518,25 @@ __global__ __launch_bounds__(256) void sampler_rows_kernel(const SamplerArgs a) 
     const int rows = a.B;
     const SamplerDynPtr d = (SamplerDynPtr)a.dyn;
     __shared__ float tab[17];
+    __shared__ unsigned long long cand_s[4][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid < 17) tab[tid] = d->cfg.penalty_table[tid];
     __syncthreads();
     const int row = blockIdx.x * 4 + w;
     if (row >= rows) return;
     RowIn in;
-    in.logits = a.logits + (size_t)row * a.V;
+    const float* logits = a.logits + (size_t)row * a.V;
     in.q = d->noise + (size_t)row * a.V;
-    const int nh = min(a.hist_len, d->cfg.past_window);
-    in.hist = a.history + (size_t)row * a.hist_len + (a.hist_len - nh);
-    in.hist_stride = 1;
-    in.nh = nh;
+    const int nh = min(a.hist_len, d->cfg.past_window);              // the last nh ids of the row's history (processors.py:21-23)
+    in.myid = (lane < nh) ? a.history[(size_t)row * a.hist_len + (a.hist_len - nh) + lane] : -1;
     in.T = d->cfg.temperature[row % CTTS_NUM_VQ];
-    in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids);
+    in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids) && nh > 0;
     in.step = a.step_override;
     in.seed = 0; in.draw = 0; in.row = (unsigned)row;
     float lg[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { const int j = lane + 64 * i; lg[i] = (j < a.V) ? in.logits[j] : 0.f; }
-    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg);
+    for (int i = 0; i < VPL; ++i) { const int j = lane + 64 * i; lg[i] = (j < a.V) ? logits[j] : 0.f; }
+    const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg, cand_s[w]);
     if (lane == 0) a.idx_out[row] = idx;
 }
 
@@ -495,7 +545,7 @@ int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s) {
     if (a.st != nullptr && a.text_mode) {
         if (a.V > 1024 * TVPT) { ctts_set_error("text sampler: vocab %d > %d", a.V, 1024 * TVPT); return 1; }
         hipLaunchKernelGGL(sampler_text_kernel, dim3(a.B), dim3(1024), 0, s, a);
-    } else if (a.st != nullptr) hipLaunchKernelGGL(sampler_generate_kernel, dim3(a.B), dim3(256), 0, s, (const int*)a.st, a.logits, a.dyn, (const RowMeta*)a.meta, a.V, a);
+    } else if (a.st != nullptr) hipLaunchKernelGGL(sampler_generate_kernel, dim3(a.B), dim3(256), 0, s, (const int*)a.st, a.logits, a.dyn, (const RowMeta*)a.meta, a.V, (const int*)a.hist_ring, (const int2*)a.finend, a);
     else hipLaunchKernelGGL(sampler_rows_kernel, dim3(blocks), dim3(256), 0, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;

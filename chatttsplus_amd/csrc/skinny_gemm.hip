@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     constexpr int KTILES = WAVES * KPW;
     constexpr int K = KTILES * KT;
     constexpr int NB = 16 * NBG;
-    constexpr int XS_BYTES = (PRO == PRO_PACKED) ? 0 : NBG * KTILES * 1024;   // LDS image of the B operand
+    constexpr int XS_BYTES = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * 1024;   // LDS image of the B operand
     constexpr int PER = K / 256;                      // float4 per lane per row in the prologues
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -104,11 +104,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     //     their L2/HBM round trips overlap the weight stream instead of forming a dependent tail
     constexpr int RITEMS = (16 * NB + WAVES * 64 - 1) / (WAVES * 64);
     float resid_pf[RITEMS];
-    if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
+    float xh_scale_pf[RITEMS];
+    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_RESID_XH) {
 #pragma unroll
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
             const int r = row0 + (t >> 4);
+            // scale_in rides on the leading scalar in1 (free for PRO_PACKED); the rare PRO_ATTN variant reads it from the struct
+            xh_scale_pf[u] = (EPI == EPI_RESID_XH && t < 16 * NB && r < R) ? ((PRO == PRO_ATTN) ? a.scale_in[r] : ((const float*)in1)[r]) : 1.f;
             const int N = a.n_row_tiles * 16, col = rt0 * 16 + (t & 15);
             float v = 0.f;
             if (t < 16 * NB && r < R) {
@@ -193,6 +196,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             for (int i = 0; i < PER; ++i) ss += v[u][i][0] * v[u][i][0] + v[u][i][1] * v[u][i][1] + v[u][i][2] * v[u][i][2] + v[u][i][3] * v[u][i][3];
             ss = wave_sum(ss);
             const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);          // torch.rsqrt(mean(x^2) + eps)
+            if (PRO == PRO_NORM && EPI == EPI_QKV && rt0 == 0 && a.scale_out != nullptr && lane == 0)
+                a.scale_out[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rs) & 0x7F800000u);   // see PRO_XH
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int k = 4 * (lane + 64 * i);
@@ -279,6 +284,48 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     }
 
     if (PRO == PRO_PACKED) { CTTS_ISSUE_WEIGHT_LOADS(); CTTS_EXIT_IF_DONE(); }
+    float* fac_s = (float*)(smem + XS_BYTES + WAVES * NBG * 1024);      // PRO_XH: [NB] rs / scale of each row of the chunk
+    frag bpre[NBG][KPW];                                                 // PRO_XH: this wave's B fragments, requested ahead of the weights
+    if (PRO == PRO_XH) {
+        // the RMSNorm factor of every row from the producer's 48 per-tile sums of squares (fixed order: deterministic); one wave,
+        // 64 / NB lanes per row; its loads are issued before the weight stream and consumed after this wave's MFMAs are queued.
+        // in0 = xh, in1 = ssq, resid_in = scale_in (leading, preloaded scalars: no wait on the argument struct)
+        constexpr int LPR = 64 / NB, PPL = 48 / LPR;               // lanes per row, partials per lane (12 or 24)
+        f32x4 sq[PPL / 4];
+        float sc_in = 1.f;
+        const int n_f = lane / LPR, part = lane % LPR;
+        const bool frow = (wave == WAVES - 1) && (row0 + n_f < R);
+        if (frow) {
+            const f32x4* sp = (const f32x4*)((const float*)in1 + (size_t)(row0 + n_f) * 48 + part * PPL);
+#pragma unroll
+            for (int i = 0; i < PPL / 4; ++i) sq[i] = sp[i];
+            sc_in = resid_in[row0 + n_f];
+        }
+        {
+            const frag* xq = (const frag*)in0 + (size_t)chunk * NBG * KTILES * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < NBG; ++g)
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) bpre[g][i] = xq[(size_t)(g * KTILES + wave * KPW + i) * 64];
+        }
+        CTTS_ISSUE_WEIGHT_LOADS();
+        CTTS_EXIT_IF_DONE();
+        if (wave == WAVES - 1) {
+            float ss = 0.f;
+            if (frow) {
+#pragma unroll
+                for (int i = 0; i < PPL / 4; ++i) ss += (sq[i][0] + sq[i][1]) + (sq[i][2] + sq[i][3]);
+            }
+            ss += dpp_f<DPP_XOR1>(ss);
+            if (LPR == 4) ss += dpp_f<DPP_XOR2>(ss);
+            if (frow && part == 0) {
+                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+                fac_s[n_f] = rs / sc_in;                            // sc_in is a power of two: exact
+                if (rt0 == 0 && a.scale_out != nullptr)             // scale of the rows the next EPI_RESID_XH writes
+                    a.scale_out[row0 + n_f] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rs) & 0x7F800000u);
+            }
+        }
+    }
 
     // 3. MFMA over this wave's K slice
     f32x4 acc[RT][NBG];
@@ -294,7 +341,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 #pragma unroll
         for (int g = 0; g < NBG; ++g) {
             frag b;
-            if (PRO == PRO_PACKED) b = xg[(size_t)(g * kt_all + kt_off + kt) * 64 + lane];
+            if (PRO == PRO_XH) b = bpre[g][i];
+            else if (PRO == PRO_PACKED) b = xg[(size_t)(g * kt_all + kt_off + kt) * 64 + lane];
             else b = xs[(g * KTILES + kt) * 64 + lane];
 #pragma unroll
             for (int ti = 0; ti < RT; ++ti) acc[ti][g] = Mma<WT>::run(wf[ti][i], b, acc[ti][g]);
@@ -317,11 +365,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sum += q[w * NBG * 256];
+        if (PRO == PRO_XH) sum *= fac_s[n];                       // RMSNorm factor (and the xh row scale) applied to the C tile
         return sum;
     };
 
     // 5. fused epilogue
-    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_LOGITS || EPI == EPI_PART) {
+    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_LOGITS || EPI == EPI_PART || EPI == EPI_RESID_XH) {
 #pragma unroll
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
@@ -335,6 +384,17 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 a.part_out[((size_t)r * gridDim.z + blockIdx.z) * (a.n_row_tiles * 16) + col] = v;
             } else if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
                 a.x_out[(size_t)r * (a.n_row_tiles * 16) + col] = resid_pf[u] + v;   // residual + proj (llama.py:731,739)
+            } else if (EPI == EPI_RESID_XH) {
+                // the 16 lanes of a DPP row hold the 16 columns of (row r, tile rt): fp32 residual as before, plus what the next
+                // PRO_XH kernel reads -- the row's sum of squares over this tile and the fp16 (power-of-two scaled) packed copy
+                const float xn = resid_pf[u] + v;
+                a.x_out[(size_t)r * (a.n_row_tiles * 16) + col] = xn;
+                float sq = xn * xn;
+                sq += dpp_f<DPP_XOR1>(sq); sq += dpp_f<DPP_XOR2>(sq); sq += dpp_f<DPP_HALF_MIRROR>(sq); sq += dpp_f<DPP_MIRROR>(sq);
+                if (i == 0) a.ssq[(size_t)r * a.n_row_tiles + rt] = sq;
+                constexpr int KT_OUT = 768 / 32;                  // the stream is H = 768 wide: 24 fp16 k-tiles
+                half_t* dst = (half_t*)a.xh + (size_t)chunk * NBG * KT_OUT * 64 * 8;
+                dst[xfrag_index<half_t>(n, col, KT_OUT)] = (half_t)(xn * xh_scale_pf[u]);
             } else if (col < a.n_valid) {
                 a.logits[(size_t)r * a.n_valid + col] = v;
             }
@@ -380,7 +440,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1>
 static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configure_only) {
     constexpr int KTILES = WAVES * KPW;
-    constexpr int XS = (PRO == PRO_PACKED) ? 0 : NBG * KTILES * 1024;
+    constexpr int XS = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * 1024;
     constexpr int LDS = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4;
     auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI, RT>;
     if (configure_only) {
@@ -397,10 +457,12 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
     }
     if (a.n_row_tiles % RT) { ctts_set_error("skinny_gemm: %d row tiles not a multiple of %d", a.n_row_tiles, RT); return 1; }
     const int* done_p = a.st ? &a.st->all_done : nullptr;
-    const void* in0 = (PRO == PRO_ATTN) ? (const void*)a.part_ml : (PRO == PRO_PACKED) ? (const void*)a.xpacked : (const void*)a.x;
-    const void* in1 = (PRO == PRO_ATTN) ? (const void*)a.part_o : (PRO == PRO_NORM_P) ? (const void*)a.opart : nullptr;
+    const void* in0 = (PRO == PRO_ATTN) ? (const void*)a.part_ml : (PRO == PRO_PACKED) ? (const void*)a.xpacked : (PRO == PRO_XH) ? (const void*)a.xh : (const void*)a.x;
+    const void* in1 = (PRO == PRO_ATTN) ? (const void*)a.part_o : (PRO == PRO_NORM_P) ? (const void*)a.opart : (PRO == PRO_XH) ? (const void*)a.ssq :
+                      (EPI == EPI_RESID_XH) ? (const void*)a.scale_in : nullptr;
+    const float* resid_arg = (PRO == PRO_XH) ? a.scale_in : (const float*)a.x_out;
     const int misc = (a.np & 0xFF) | ((a.S & 0xFF) << 8) | (a.ktiles_total << 16);
-    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, (const float*)a.x_out, a.R, misc, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -411,6 +473,9 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
 #ifndef CTTS_RT_NORM
 #define CTTS_RT_NORM 2
 #endif
+#ifndef CTTS_RT_XH
+#define CTTS_RT_XH 1       // weight row tiles per block of the PRO_XH kernels
+#endif
 template <typename WT, int NBG>
 static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s, bool cfg) {
     constexpr bool F16 = sizeof(WT) == 2;
@@ -418,6 +483,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     constexpr int W768 = F16 ? (NBG == 1 ? 4 : 8) : (NBG == 1 ? 8 : 16), P768 = (NBG == 1) ? 6 : 3;
     // K=3072: fp16 96 k-tiles = 16 x 6, fp32 192 = 16 x 12
     constexpr int W3072 = 16, P3072 = F16 ? 6 : 12;
+    constexpr int RT_XH = CTTS_RT_XH;
     if (cfg) {
         int rc = 0;
         constexpr int RT_NORM_C = (NBG == 2) ? CTTS_RT_NORM : 1;
@@ -431,6 +497,13 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         }
         rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, true);
+        if constexpr (F16) {
+            rc |= launch_one<WT, NBG, W768, P768, PRO_XH, EPI_QKV, RT_XH>(a, chunks, s, true);
+            rc |= launch_one<WT, NBG, W768, P768, PRO_XH, EPI_SWIGLU, RT_XH>(a, chunks, s, true);
+            rc |= launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID_XH>(a, chunks, s, true);
+            rc |= launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
+            rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
+        }
         if constexpr (NBG == 1) {
             rc |= launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_SWIGLU>(a, chunks, s, true);
             rc |= launch_one<WT, 1, W3072, P3072, PRO_PACKED, EPI_RESID_P>(a, chunks, s, true);
@@ -454,6 +527,13 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     if (pro == PRO_PACKED && epi == EPI_RESID && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_PACKED && epi == EPI_RESID) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_NORM && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, false);
+    if constexpr (F16) {
+        if (pro == PRO_XH && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_XH, EPI_QKV, RT_XH>(a, chunks, s, false);
+        if (pro == PRO_XH && epi == EPI_SWIGLU) return launch_one<WT, NBG, W768, P768, PRO_XH, EPI_SWIGLU, RT_XH>(a, chunks, s, false);
+        if (pro == PRO_ATTN && epi == EPI_RESID_XH) return launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID_XH>(a, chunks, s, false);
+        if (pro == PRO_PACKED && epi == EPI_RESID_XH && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, false);
+        if (pro == PRO_PACKED && epi == EPI_RESID_XH) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, false);
+    }
     if constexpr (NBG == 1) {
         if (pro == PRO_NORM_P && epi == EPI_SWIGLU) return launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_SWIGLU>(a, chunks, s, false);
         if (pro == PRO_NORM_P && epi == EPI_QKV) return launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_QKV>(a, chunks, s, false);

@@ -60,10 +60,12 @@ def repetition_penalty(logits_token: torch.Tensor, scores: torch.Tensor, penalty
     return torch.where(scores < 0, scores.multiply(alpha), scores.divide(alpha))
 
 
-def top_p_warp(scores: torch.Tensor, top_p: float, min_keep: int) -> torch.Tensor:
+def top_p_warp(scores: torch.Tensor, top_p: float, min_keep: int, stable: bool = False) -> torch.Tensor:
     """transformers TopPLogitsWarper.__call__ (built at processors.py:45): ascending sort,
-    remove while cumsum(softmax) <= 1 - top_p, always keep the last ``min_keep``."""
-    sorted_logits, sorted_indices = torch.sort(scores, descending=False)
+    remove while cumsum(softmax) <= 1 - top_p, always keep the last ``min_keep``.
+    ``stable``: torch.sort is not stable for large groups of exactly equal logits (the reference's result is then
+    implementation-defined); stable=True pins the tie order the HIP sampler documents (stable ascending)."""
+    sorted_logits, sorted_indices = torch.sort(scores, descending=False, stable=stable)
     cumulative_probs = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
     remove = cumulative_probs <= (1 - top_p)
     remove[..., -min_keep:] = 0
@@ -93,7 +95,7 @@ class SamplerParams:
 
 
 def sample_step(logits: torch.Tensor, logits_token: torch.Tensor, q: torch.Tensor, step: int,
-                sp: SamplerParams, temperature_col: torch.Tensor) -> torch.Tensor:
+                sp: SamplerParams, temperature_col: torch.Tensor, stable_sort: bool = False) -> torch.Tensor:
     """One sampling step for rows [B*num_vq, V]  (gpt.py:469-481).
 
     ``q`` is Exp(1) noise of the same shape; ``argmax(p / q)`` is what
@@ -104,7 +106,7 @@ def sample_step(logits: torch.Tensor, logits_token: torch.Tensor, q: torch.Tenso
     if sp.repetition_penalty is not None and sp.repetition_penalty != 1:
         logits = repetition_penalty(logits_token, logits, sp.repetition_penalty, sp.max_input_ids, sp.past_window)
     if sp.top_p is not None:
-        logits = top_p_warp(logits, sp.top_p, sp.min_keep)             # gpt.py:474-475 (top-p first)
+        logits = top_p_warp(logits, sp.top_p, sp.min_keep, stable=stable_sort)             # gpt.py:474-475 (top-p first)
     if sp.top_k is not None:
         logits = top_k_warp(logits, sp.top_k, sp.min_keep)
     if step < sp.min_new_token:

@@ -156,3 +156,25 @@ def test_fused_qkv_attention_launch_matches_golden(monkeypatch):
     for b, n in enumerate(z["lens"]):
         assert np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64))
         assert np.abs(out.hiddens[b].cpu().numpy() - z["hiddens"][b, :n]).max() <= 1e-4
+
+
+def test_fp16_batch_rows_independent_of_batch_composition():
+    """fp16 mode above the split-K batch sizes (packed fp16 residual stream + per-tile sums of squares between kernels, kernels.h
+    PRO_XH): a sequence's tokens and hiddens do not depend on which other sequences share its batch, nor on its row position --
+    the same sequences decoded as a batch of 32 and as four batches of 8 (rows 8j..8j+7) are bitwise identical."""
+    from chatttsplus_amd.hip_models import GPT
+    g = GPT(LLAMA, max_batch=32, max_seq_len=256, weight_dtype="fp16")
+    g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+    B, T, N = 32, 40, 40
+    rng = np.random.Generator(np.random.Philox(key=4))
+    pads = [int(p) for p in rng.integers(0, 30, size=B)]
+    ids, mask = synth.prompt_ids(B, T, 21178, 79, pad_left=pads)
+    q = torch.from_numpy(np.stack([synth.exp_noise(11, i, 4 * B, 626) for i in range(N)]))
+    _, big = _gen(g, ids, mask, N, q, min_new=N)
+    for j in range(4):
+        sl = slice(8 * j, 8 * j + 8)
+        _, part = _gen(g, ids[sl], mask[sl], N, q[:, 32 * j:32 * j + 32].contiguous(), min_new=N)
+        for b in range(8):
+            assert torch.equal(part.ids[b], big.ids[8 * j + b]), f"row {8 * j + b}: ids depend on the batch composition"
+            assert torch.equal(part.hiddens[b], big.hiddens[8 * j + b]), f"row {8 * j + b}: hiddens depend on the batch composition"
+    g.close()
