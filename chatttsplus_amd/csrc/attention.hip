@@ -9,6 +9,8 @@
 // (coalesced 128-B rows, 8 keys per wave-instruction).  grid = (rows*heads, S key splits) so that a
 // batch-1 step still spreads one head's keys over S CUs; every block writes a flash-decoding partial
 // (running max, running sum, unnormalised output) that the o_proj kernel's prologue combines.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 // one 16-row o_proj tile x one head's 64 input dims on MFMA (B operand = the head's attention output in column 0)
@@ -468,7 +470,8 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     dim3 grid(a.R * a.NH, a.jt > 0 ? a.jt : a.S), block(256);
     const int* done_p = a.st ? &a.st->all_done : nullptr;
     // unsplit rows (large batches): 8 waves per (row, head) keep twice the K/V bytes in flight per CU
-    const bool wide = (a.jt == 0) && (a.S == 1) && (a.st != nullptr);
+    static const int wide_env = getenv("CTTS_ATTN_WIDE") ? atoi(getenv("CTTS_ATTN_WIDE")) : 1;     // diagnostic: 0 = 4-wave blocks for unsplit rows too
+    const bool wide = (a.jt == 0) && (a.S == 1) && (a.st != nullptr) && wide_env;
     if (wide) {
         if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
         else hipLaunchKernelGGL((attn_decode_kernel<float, false, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);

@@ -161,3 +161,80 @@ def test_lora_merge_matches_oracle():
     for b in range(2):
         assert torch.equal(out.ids[b].cpu(), ref.ids[b])
         assert float((out.hiddens[b].cpu() - ref.hiddens[b]).abs().max()) < 1e-4
+
+
+def test_pipeline_lora_path_end_to_end_batch32(tmp_path):
+    """BASELINE configs[4]: a peft adapter directory on disk (adapter_config.json + adapter_model.safetensors, r=8, alpha=16 on
+    q/k/v/o of every layer -- configs/train/train_voice_clone_lora.yaml:72-80) served through pipeline.infer(lora_path=...) at
+    batch 32, against the oracle with algebraically merged weights (peft merge_and_unload: W + (alpha/r) B A, pipeline:420-432;
+    peft itself is absent offline: parity unpinned, pinned algebraically).  fp32 parity mode: identical utterance lengths
+    (== identical token ids) and waveform RMS error <= 1e-3.  Also: the base engine is untouched afterwards and the merged
+    engines are LRU-bounded."""
+    import json
+    from safetensors.numpy import save_file
+    from chatttsplus_amd.pipeline import ChatTTSPlusPipeline, InferCodeParams, load_config
+    cfg = load_config(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "infer", "chattts_plus_hip.yaml"))
+    cfg["MODELS"]["gpt"]["kwargs"].update(weight_dtype="fp32", max_batch=32, max_seq_len=128)
+    os.makedirs(tmp_path / "asset")
+    gsd = synth.gpt_state_dict(synth.GPT_REAL, 1234)
+    dsd = synth.dvae_state_dict(synth.DVAE_REAL, 1234)
+    vsd = synth.vocos_state_dict(synth.VOCOS_REAL, 1234)
+    for name, sd in (("GPT.pt", gsd), ("Decoder.pt", dsd), ("Vocos.pt", vsd)):
+        torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, tmp_path / "asset" / name)
+    # two adapters on disk in peft's layout
+    merged = {}
+    for ai, seed in enumerate((31, 32)):
+        rng = np.random.Generator(np.random.Philox(key=seed))
+        d = tmp_path / f"lora{ai}"
+        os.makedirs(d)
+        tensors = {}
+        m = {k: v.copy() for k, v in gsd.items()}
+        for l in range(20):
+            for t in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                A = (rng.standard_normal((8, 768)) * 0.05).astype(np.float32); Bm = (rng.standard_normal((768, 8)) * 0.05).astype(np.float32)
+                tensors[f"base_model.model.layers.{l}.self_attn.{t}.lora_A.weight"] = A
+                tensors[f"base_model.model.layers.{l}.self_attn.{t}.lora_B.weight"] = Bm
+                m[f"gpt.layers.{l}.self_attn.{t}.weight"] = (m[f"gpt.layers.{l}.self_attn.{t}.weight"] + 2.0 * (Bm @ A)).astype(np.float32)
+        save_file(tensors, str(d / "adapter_model.safetensors"))
+        (d / "adapter_config.json").write_text(json.dumps(dict(r=8, lora_alpha=16, target_modules=["q_proj", "k_proj", "v_proj", "o_proj"], peft_type="LORA")))
+        merged[ai] = m
+    tok = _tokenizer(tmp_path)
+    pipe = ChatTTSPlusPipeline(cfg, device="cuda", tokenizer=tok, checkpoint_dir=str(tmp_path))
+    spk = torch.load(os.path.join(GOLDEN, "speakers", "2222.pt"), weights_only=True)
+    rng = np.random.Generator(np.random.Philox(key=5))
+    texts = [" ".join("abcd"[int(c)] for c in rng.integers(0, 4, size=int(n))) for n in rng.integers(2, 12, size=32)]
+    N = 10
+    params = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=N, min_new_token=N, show_tqdm=False)
+    q = torch.from_numpy(np.stack([synth.exp_noise(21, i, 4 * 32, 626) for i in range(N)]))
+
+    def run(lora):
+        gpt = pipe._gpt_for_lora(lora)
+        g0 = gpt.generate
+        gpt.generate = lambda *a, **k: g0(*a, noise=q, **k)          # fixed noise rows: comparable with the oracle at any batch size
+        try:
+            return list(pipe.infer(list(texts), skip_refine_text=True, do_text_optimization=False, params_infer_code=params, lora_path=lora))[0]
+        finally:
+            gpt.generate = g0
+
+    wrapped = [f"[Stts][spk_emb][speed_5]{t} [uv_break][Ptts]" for t in texts]
+    ids, att, tm = tok.encode(wrapped, 4)
+    for ai in (0, 1):
+        wavs = run(str(tmp_path / f"lora{ai}"))
+        o = ref_cpu.OracleGPT(merged[ai], 12)
+        emb = o.apply_spk_emb(o.embed(ids, tm), torch.from_numpy(codec.decode_spk_emb(spk)), ids, tok.spk_emb_ids)
+        ref = o.generate(emb, ids, ref_cpu.SamplerParams(min_new_token=N), attention_mask=att, max_new_token=N, noise=ref_cpu.ArrayNoise(q))
+        for b in (0, 5, 17, 31):
+            assert wavs[b].shape[0] == 256 * (2 * ref.ids[b].shape[0] - 1)
+            wav_ref = ref_cpu.vocos_decode(vsd, ref_cpu.dvae_decode(dsd, ref.hiddens[b])).numpy()
+            w = wavs[b].cpu().numpy()
+            rms = float(np.sqrt(np.mean((w - wav_ref) ** 2))) / float(np.sqrt(np.mean(wav_ref ** 2)))
+            assert rms <= 1e-3, f"adapter {ai} utterance {b}: waveform rms-rel {rms}"
+    assert len(pipe._lora_models) == 1                               # LRU of one: adapter 0's engine was destroyed when adapter 1 came in
+    # the base engine is untouched: same result as an engine that never saw an adapter
+    base = run(None)
+    o = ref_cpu.OracleGPT(gsd, 12)
+    emb = o.apply_spk_emb(o.embed(ids, tm), torch.from_numpy(codec.decode_spk_emb(spk)), ids, tok.spk_emb_ids)
+    ref = o.generate(emb, ids, ref_cpu.SamplerParams(min_new_token=N), attention_mask=att, max_new_token=N, noise=ref_cpu.ArrayNoise(q))
+    wav_ref = ref_cpu.vocos_decode(vsd, ref_cpu.dvae_decode(dsd, ref.hiddens[3])).numpy()
+    w = base[3].cpu().numpy()
+    assert float(np.sqrt(np.mean((w - wav_ref) ** 2))) / float(np.sqrt(np.mean(wav_ref ** 2))) <= 1e-3
