@@ -466,13 +466,105 @@ int launch_qkv_attention(int dtype, const QkvAttnArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prompt pass: causal attention for QT = 8 consecutive query rows per wavefront (llama.py:590-668 at q_len > 1; mask semantics of
+// llama.py:1073-1087: a row attends to the key slots [kv_start, slot] of its own sequence -- left padding and the future are skipped).
+// The row-by-row kernel above reads a row's whole K/V prefix once per ROW: B*T^2/2 keys per head and layer (12.9 GB per layer at
+// 32 x 512 prompt tokens, 42 % of that prompt pass).  Here a lane group of 8 lanes owns one query (8 of the 64 dims per lane, like
+// the decode kernel) and the 8 groups of a wave walk the keys together, so a K/V row is fetched once per 8 queries (the 8 groups
+// request the same 128 bytes: one line) and no cross-lane merge is needed -- every group carries its query's complete online
+// softmax state.  Keys are taken 4 at a time (one rescale per 4 keys).  Output: the normalised rows, written straight into the
+// o_proj kernel's fragment-major B operand.
+template <typename WT>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const RowMeta* meta_p, const float* q_p, const void* k_p, const void* v_p, const int NHp, const int R,
+                                                         const AttnArgs a) {
+    constexpr int QT = 8, UN = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane >> 3, sub = lane & 7;
+    const int h = blockIdx.y;
+    const int r = (blockIdx.x * 4 + wave) * QT + grp;                    // this lane group's query row
+    const bool live = r < R;
+    RowMeta m = {0, 0, -1, 0};
+    if (live) m = meta_p[r];
+    const int lo = live ? m.kv_start : 0x7FFFFFFF, hi = live ? m.slot : -1;       // attended key slots [lo, hi]
+    // wave-uniform walk over the union of the groups' ranges
+    int wlo = lo, whi = hi;
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) { wlo = min(wlo, __shfl_xor(wlo, off)); whi = max(whi, __shfl_xor(whi, off)); }
+    wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
+    if (whi < 0) return;                                                   // no live row in this wave
+    float q[8];
+    {
+        const float* qp = q_p + ((size_t)(live ? r : 0) * NHp + h) * CTTS_HEAD_DIM + 8 * sub;
+        const f32x4 q0 = *(const f32x4*)qp, q1 = *(const f32x4*)(qp + 4);
+        q[0] = q0[0] * 0.125f; q[1] = q0[1] * 0.125f; q[2] = q0[2] * 0.125f; q[3] = q0[3] * 0.125f;
+        q[4] = q1[0] * 0.125f; q[5] = q1[1] * 0.125f; q[6] = q1[2] * 0.125f; q[7] = q1[3] * 0.125f;
+    }
+    const size_t head_off = ((size_t)m.seq * NHp + h) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
+    const WT* kb = (const WT*)k_p + head_off;
+    const WT* vb = (const WT*)v_p + head_off;
+    float mrun = -INFINITY, lrun = 0.f, o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int p0 = wlo; p0 <= whi; p0 += UN) {
+        float kf[UN][8], vf[UN][8], dot[UN];
+        bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int p = p0 + u;
+            ok[u] = (p >= lo) && (p <= hi);
+            const int pc = ok[u] ? p : (live ? hi : 0);                    // clamp: always a valid slot of this group's sequence
+            KvLoad<WT>::load8(kb + (size_t)pc * CTTS_HEAD_DIM, kf[u]);
+            KvLoad<WT>::load8(vb + (size_t)pc * CTTS_HEAD_DIM, vf[u]);
+        }
+        float mn = mrun;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += q[j] * kf[u][j];
+            d += dpp_f<DPP_XOR1>(d);                                       // 8-lane group sum on DPP
+            d += dpp_f<DPP_XOR2>(d);
+            d += dpp_f<DPP_HALF_MIRROR>(d);
+            dot[u] = ok[u] ? d : -INFINITY;
+            mn = fmaxf(mn, dot[u]);
+        }
+        const float sc = safe_exp_diff(mrun, mn);
+        float pe[UN], ps = 0.f;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { pe[u] = safe_exp_diff(dot[u], mn); ps += pe[u]; }
+        lrun = lrun * sc + ps;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float acc = o[j] * sc;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc += pe[u] * vf[u][j];
+            o[j] = acc;
+        }
+        mrun = mn;
+    }
+    if (!live) return;
+    const float inv = 1.0f / lrun;
+    const int NBr = 16 * a.nbg, K = a.NH * CTTS_HEAD_DIM, kt = K / WTraits<WT>::KT;
+    const int chunk = r / NBr, n = r % NBr, k = h * CTTS_HEAD_DIM + 8 * sub;
+    WT* dst = (WT*)a.packed_out + (size_t)chunk * a.nbg * kt * 64 * WTraits<WT>::EPL;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[xfrag_index<WT>(n, k + j, kt)] = (WT)(o[j] * inv);
+}
+
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     dim3 grid(a.R * a.NH, a.jt > 0 ? a.jt : a.S), block(256);
     const int* done_p = a.st ? &a.st->all_done : nullptr;
     // unsplit rows (large batches): 8 waves per (row, head) keep twice the K/V bytes in flight per CU
     static const int wide_env = getenv("CTTS_ATTN_WIDE") ? atoi(getenv("CTTS_ATTN_WIDE")) : 1;     // diagnostic: 0 = 4-wave blocks for unsplit rows too
     const bool wide = (a.jt == 0) && (a.S == 1) && (a.st != nullptr) && wide_env;
-    if (wide) {
+    static const int tiled_env = getenv("CTTS_PREFILL_ATTN") ? atoi(getenv("CTTS_PREFILL_ATTN")) : 1;    // diagnostic: 0 = row-by-row prompt pass
+    if (a.st == nullptr && a.jt == 0 && a.S == 1 && a.packed_out != nullptr && a.R > 16 && tiled_env) {
+        // prompt pass: 8 query rows per wavefront, 4 wavefronts per block
+        dim3 g2((a.R + 31) / 32, a.NH);
+        if (dtype == 1) hipLaunchKernelGGL(attn_prefill_kernel<half_t>, g2, dim3(256), 0, s, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.R, a);
+        else hipLaunchKernelGGL(attn_prefill_kernel<float>, g2, dim3(256), 0, s, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.R, a);
+    } else if (wide) {
         if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
         else hipLaunchKernelGGL((attn_decode_kernel<float, false, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
     } else if (a.jt > 0) {

@@ -33,7 +33,8 @@ void ctts_set_error(const char* fmt, ...) {
 extern "C" const char* ctts_last_error(void) { return g_err; }
 extern "C" int ctts_version(void) { return 1; }
 
-#define PASS_ROWS 2048
+#define PASS_ROWS 8192     // prompt rows per pass (q / activation workspaces are sized for it; + PASS_PAD rows so whole GEMM blocks stay in bounds)
+#define PASS_PAD 256
 #define SMAX 8        // == ATT_SMAX in skinny_gemm.hip
 
 struct LayerW {
@@ -346,15 +347,15 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
     int rc = (h->cfg.dtype == CTTS_DTYPE_F16) ? finalize_t<half_t>(h) : finalize_t<float>(h);
     if (rc) return rc;
     const int H = h->H, NH = h->NH, MB = h->cfg.max_batch;
-    const size_t act_bytes = (size_t)(PASS_ROWS / 16) * (h->I / (h->esz == 2 ? 32 : 16)) * 1024;
+    const size_t act_bytes = (size_t)((PASS_ROWS + PASS_PAD) / 16) * (h->I / (h->esz == 2 ? 32 : 16)) * 1024;
     if (dev_alloc((void**)&h->x_dec, (size_t)CTTS_MAX_B * H * 4) || dev_alloc((void**)&h->x_last, (size_t)CTTS_MAX_B * H * 4) ||
         dev_alloc((void**)&h->x_pre, (size_t)PASS_ROWS * H * 4) ||
         dev_alloc((void**)&h->q_buf, (size_t)PASS_ROWS * H * 4) ||
-        dev_alloc((void**)&h->part_ml, (size_t)PASS_ROWS * NH * SMAX * 2 * 4) ||
-        dev_alloc((void**)&h->part_o, (size_t)PASS_ROWS * NH * SMAX * CTTS_HEAD_DIM * 4) ||
+        dev_alloc((void**)&h->part_ml, (size_t)(CTTS_MAX_B + 32) * NH * SMAX * 2 * 4) ||          // flash-decoding partials: decode rows only (the prompt pass never splits keys)
+        dev_alloc((void**)&h->part_o, (size_t)(CTTS_MAX_B + 32) * NH * SMAX * CTTS_HEAD_DIM * 4) ||
         dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * (h->NVQ * h->V > h->vocab_text_head ? h->NVQ * h->V : h->vocab_text_head) * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc((void**)&h->rope_pre, (size_t)MB * h->cfg.max_seq * 64 * 4) ||
-        dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->opart, (size_t)16 * NH * H * 4) || dev_alloc((void**)&h->dpart, (size_t)16 * 4 * H * 4) || dev_alloc(&h->attn_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
-        dev_alloc(&h->norm_packed, (size_t)(PASS_ROWS / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
+        dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->opart, (size_t)16 * NH * H * 4) || dev_alloc((void**)&h->dpart, (size_t)16 * 4 * H * 4) || dev_alloc(&h->attn_packed, (size_t)((PASS_ROWS + PASS_PAD) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
+        dev_alloc(&h->norm_packed, (size_t)((PASS_ROWS + PASS_PAD) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4) ||
@@ -439,6 +440,9 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     const bool splitd = (st != nullptr) && (R <= h->split_rows) && (nbg == 1) && (h->fuse_rows == 0);
     // prompt pass over more than a few chunks: normalise every row once (norm_pack_kernel) instead of in every GEMM block
     const bool prepack = (st == nullptr) && (nbg == 2) && (R > 64) && !getenv("CTTS_NO_PREPACK");
+    // prompt pass over >= 128 rows, fp16: LDS-staged 256/128 x 128 MFMA GEMM (prefill_gemm.hip) instead of one weight tile per 32-row block
+    static const int pf_env = getenv("CTTS_PREFILL_GEMM") ? atoi(getenv("CTTS_PREFILL_GEMM")) : 1;
+    const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && (R >= 128) && pf_env;
     // fp16 decode above the split-K batch sizes: the residual stream travels between kernels as a packed fp16 B operand + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself
     const bool xhm = (dt == CTTS_DTYPE_F16) && (st != nullptr) && h->xh_mode && !splitd && (R > h->fuse_rows) && (R > h->fuseqkv_rows);
@@ -466,7 +470,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         g1.opart = h->dpart; g1.np = (splitd && l > 0) ? 4 : 0;
         if (prepack) {
             g1.xpacked = h->norm_packed;
-            if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s) || launch_gemm(dt, nbg, PRO_PACKED, EPI_QKV, g1, chunks, s)) return 1;
+            if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
+            if (pfg ? launch_prefill_gemm(EPI_QKV, g1, s) : launch_gemm(dt, nbg, PRO_PACKED, EPI_QKV, g1, chunks, s)) return 1;
         } else if (xhm) {
             g1.scale_out = h->scale_o;
             if (l > 0) { g1.xh = h->xh; g1.ssq = h->ssq; g1.scale_in = h->scale_d; }
@@ -490,7 +495,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;
             const bool sp2 = splitd;                       // the down projection's partial sums are folded into x here
             if (xhm) { g2.xh = h->xh; g2.ssq = h->ssq; g2.scale_in = h->scale_o; }
-            if (!(h->ablate & 4) && launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (sp2 ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
+            if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
+            else if (!(h->ablate & 4) && launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (sp2 ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
         }
         }
         // RMSNorm + gate|up + SiLU*up
@@ -498,7 +504,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act; g3.opart = h->opart; g3.np = CTTS_NPART;
         if (prepack) {
             g3.xpacked = h->norm_packed;
-            if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s) || launch_gemm(dt, nbg, PRO_PACKED, EPI_SWIGLU, g3, chunks, s)) return 1;
+            if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
+            if (pfg ? launch_prefill_gemm(EPI_SWIGLU, g3, s) : launch_gemm(dt, nbg, PRO_PACKED, EPI_SWIGLU, g3, chunks, s)) return 1;
         } else if (xhm) {
             g3.xh = h->xh; g3.ssq = h->ssq; g3.scale_in = h->scale_o; g3.scale_out = h->scale_d;
             if (!(h->ablate & 8) && launch_gemm(dt, nbg, PRO_XH, EPI_SWIGLU, g3, chunks, s)) return 1;
@@ -506,7 +513,9 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         // down + residual
         GemmArgs g4 = a;
         g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x; g4.opart = h->opart; g4.np = CTTS_NPART;
-        if (splitd) {
+        if (pfg) {
+            if (launch_prefill_gemm(EPI_RESID, g4, s)) return 1;
+        } else if (splitd) {
             g4.part_out = h->dpart; g4.ktiles_total = h->I / (h->esz == 2 ? 32 : 16);
             if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, EPI_PART, g4, chunks, s)) return 1;
         } else if (xhm && l + 1 < h->L) {          // the last layer's output goes to the heads, which normalise the fp32 rows themselves
@@ -588,23 +597,12 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* h, const float* emb, void* stream) {
     CTTS_RANGE("ctts_gpt_prefill");             // reference: nvtx "forward" (trt_models/llama_trt_model.py:44,74), q_len > 1
     hipStream_t s = (hipStream_t)stream;
     const int R = h->B * h->T;
-    std::vector<int> last(h->B);
     for (int r0 = 0; r0 < R; r0 += PASS_ROWS) {
         const int n = (R - r0 < PASS_ROWS) ? R - r0 : PASS_ROWS;
         CTTS_HIP_CHECK(hipMemcpyAsync(h->x_pre, emb + (size_t)r0 * h->H, (size_t)n * h->H * 4, hipMemcpyDeviceToDevice, s));
         if (run_layers(h, h->x_pre, h->meta_pre + r0, h->rope_pre + (size_t)r0 * 64, n, 1, nullptr, s)) return 1;
-        // rows (b, T-1) that live in this pass -> x_dec[b]
-        bool any = false;
-        for (int b = 0; b < h->B; ++b) {
-            const int lr = b * h->T + h->T - 1;
-            last[b] = (lr >= r0 && lr < r0 + n) ? lr - r0 : -1;
-            any = any || last[b] >= 0;
-        }
-        if (any) {
-            CTTS_HIP_CHECK(hipMemcpyAsync(h->last_rows, last.data(), h->B * 4, hipMemcpyHostToDevice, s));
-            CTTS_HIP_CHECK(hipStreamSynchronize(s));     // `last` is a pageable host buffer reused next pass
-            if (launch_gather_rows(h->x_pre, h->x_dec, h->last_rows, h->B, h->H, s)) return 1;
-        }
+        // rows (b, T-1) that live in this pass -> x_dec[b]  (indices computed on the device: the call stays asynchronous)
+        if (launch_gather_last_rows(h->x_pre, h->x_dec, h->B, h->T, r0, n, h->H, s)) return 1;
     }
     // keep a copy of the prompt's last residual rows for ensure_non_empty restarts
     CTTS_HIP_CHECK(hipMemcpyAsync(h->x_last, h->x_dec, (size_t)h->B * h->H * 4, hipMemcpyDeviceToDevice, s));

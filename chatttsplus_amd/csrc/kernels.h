@@ -144,10 +144,11 @@ struct QkvAttnArgs {
 };
 int launch_qkv_attention(int dtype, const QkvAttnArgs& a, hipStream_t s);
 int launch_gemm(int dtype, int nbg, int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s);
+int launch_prefill_gemm(int epi, const GemmArgs& a, hipStream_t s);      // prefill_gemm.hip: fp16 prompt-pass GEMM (QKV / RESID / SWIGLU epilogues)
 int launch_norm_pack(int dtype, const float* x, void* out_packed, int R, int nbg, float eps, hipStream_t s);
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s);
-int launch_gather_rows(const float* src, float* dst, const int* src_rows, int n, int H, hipStream_t s);
+int launch_gather_last_rows(const float* src, float* dst, int B, int T, int r0, int n, int H, hipStream_t s);
 int launch_embed_ids(const int* ids, const float* emb_code, float* x, int B, int V, int H, hipStream_t s);
 int launch_fill_meta(RowMeta* prefill_meta, RowMeta* decode_meta, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre, hipStream_t s);
 int launch_embed_prompt(const int* ids, const int* text_mask, const float* emb_text, const float* emb_code, const float* spk, int spk_id,

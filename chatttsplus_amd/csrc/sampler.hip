@@ -553,15 +553,16 @@ int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s) {
 
 // ---- small helper kernels --------------------------------------------------------------------
 
-__global__ void gather_rows_kernel(const float* src, float* dst, const int* src_rows, int n, int H) {
-    const int r = blockIdx.x;
-    if (r >= n) return;
-    const int sr = src_rows[r];
-    if (sr < 0) return;                        // row not part of this prefill pass
-    for (int k = threadIdx.x; k < H; k += blockDim.x) dst[(size_t)r * H + k] = src[(size_t)sr * H + k];
+// rows (b, T-1) of the prompt that live in the pass [r0, r0 + n) -> dst[b]: the row indices are computed on the device, so the
+// prompt pass needs no host-side index table (and no stream synchronisation between passes)
+__global__ void gather_last_rows_kernel(const float* src, float* dst, int T, int r0, int n, int H) {
+    const int b = blockIdx.x;
+    const int sr = b * T + T - 1 - r0;
+    if (sr < 0 || sr >= n) return;             // row not part of this prefill pass
+    for (int k = threadIdx.x; k < H; k += blockDim.x) dst[(size_t)b * H + k] = src[(size_t)sr * H + k];
 }
-int launch_gather_rows(const float* src, float* dst, const int* src_rows, int n, int H, hipStream_t s) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, s, src, dst, src_rows, n, H);
+int launch_gather_last_rows(const float* src, float* dst, int B, int T, int r0, int n, int H, hipStream_t s) {
+    hipLaunchKernelGGL(gather_last_rows_kernel, dim3(B), dim3(256), 0, s, src, dst, T, r0, n, H);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -489,22 +489,49 @@ def gfsq_indices(x: torch.Tensor, sd, levels=(5, 5, 5, 5), G: int = 2, R: int = 
     loop (`residual = first(self.layers).bound(x)`); later releases replaced that by an optional soft clamp and start from
     `residual = x`.  1.17.8 cannot be inspected offline: True is our best knowledge of that release, both variants are
     implemented (oracle and HIP) and frozen in tests/golden/dvae_encode_real.npz (`ids_pre_bound` / `ids`)."""
+    return gfsq_quantize(x, sd, levels, G, R, pre_bound)[0]
+
+
+def gfsq_quantize(x: torch.Tensor, sd, levels=(5, 5, 5, 5), G: int = 2, R: int = 2, pre_bound: bool = True):
+    """gfsq_indices plus the quantised latent the indices stand for: (indices [G*R, T], latent [G, T, len(levels)]) with
+    latent_g = sum_r codes_r * scale_r in the projected (FSQ) space -- what ResidualFSQ returns before project_out and what
+    get_output_from_indices rebuilds from the indices alone (GFSQ._embed, dvae.py:85-96)."""
     lv = torch.tensor(levels, dtype=torch.float32)
     hw = torch.tensor([l // 2 for l in levels], dtype=torch.float32)
     basis = torch.cumprod(torch.tensor([1] + list(levels[:-1]), dtype=torch.float32), 0)
     per = x.shape[-1] // G
-    out = []
+    out, lat = [], []
     for g in range(G):
         w, b = _t(sd[f"vq_layer.quantizer.rvqs.{g}.project_in.weight"]).float(), _t(sd[f"vq_layer.quantizer.rvqs.{g}.project_in.bias"]).float()
         z = F.linear(x[..., g * per:(g + 1) * per], w, b)
         residual = fsq_bound(z, lv) if pre_bound else z
+        acc = torch.zeros_like(z)
         for r in range(R):
             scale = (lv - 1) ** (-r)
             codes = torch.round(fsq_bound(residual / scale, lv)) / hw
             idx = ((codes * hw + hw) * basis).sum(-1).to(torch.int32)
             residual = residual - codes * scale
+            acc = acc + codes * scale
             out.append(idx)
-    return torch.stack(out, 0)                                                   # [G*R, T], row = g * R + r
+        lat.append(acc)
+    return torch.stack(out, 0), torch.stack(lat, 0)                              # [G*R, T] (row = g * R + r), [G, T, D]
+
+
+def gfsq_latent_from_indices(ids: torch.Tensor, levels=(5, 5, 5, 5), G: int = 2, R: int = 2) -> torch.Tensor:
+    """ResidualFSQ.get_output_from_indices restated up to project_out (GFSQ._embed, dvae.py:85-96): index -> per-dimension level
+    (index // basis) % levels -> code (level - half_width) / half_width, summed over the R quantizers with scale (levels-1)^-r."""
+    lv = torch.tensor(levels, dtype=torch.int64)
+    hw = torch.tensor([l // 2 for l in levels], dtype=torch.float32)
+    basis = torch.cumprod(torch.tensor([1] + list(levels[:-1]), dtype=torch.int64), 0)
+    ids = _t(ids).to(torch.int64)
+    lat = []
+    for g in range(G):
+        acc = 0
+        for r in range(R):
+            level = (ids[g * R + r][:, None] // basis[None, :]) % lv[None, :]
+            acc = acc + ((level.float() - hw) / hw) * (lv.float() - 1) ** (-r)
+        lat.append(acc)
+    return torch.stack(lat, 0)
 
 
 @torch.no_grad()

@@ -128,3 +128,16 @@ def test_batched_synthesis_equals_single_utterance_path(voc):
     for u, h in enumerate(hs):
         alone = s.decode_batch([h])[0]
         assert torch.equal(together[u], alone), f"utterance {u}: max diff {float((together[u] - alone).abs().max())}"
+
+
+@pytest.mark.parametrize("F", [9, 74])
+def test_vocos_vs_second_independent_restatement(voc, F):
+    """HIP Vocos against the second, separately written float64 restatement (tests/vocos_independent.py) -- Vocos is parity-unpinned
+    (third-party, absent offline); two independent readings of the upstream module list and the kernels all agree within 1e-3."""
+    from tests.vocos_independent import vocos_decode_f64
+    s, d, v = voc
+    mel = np.random.Generator(np.random.Philox(key=200 + F)).standard_normal((100, F)).astype(np.float32)
+    ref = vocos_decode_f64(synth.vocos_state_dict(synth.VOCOS_REAL, 1234), mel)
+    wav = v.decode(torch.from_numpy(mel)[None].cuda())[0].cpu().numpy()
+    assert wav.shape == ref.shape
+    assert _rms(wav - ref) <= 1e-3 * _rms(ref), f"F={F}: rms err {_rms(wav - ref)} vs signal {_rms(ref)}"

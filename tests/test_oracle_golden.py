@@ -165,3 +165,41 @@ def test_gfsq_indices_are_nearest_codebook_entries():
                 nearest = torch.cdist(target, grid).argmin(1)
                 assert torch.equal(nearest.to(torch.int32), ids[g * 2 + r]), (pre_bound, g, r)
                 res = res - grid[nearest] * scale
+
+
+@pytest.mark.parametrize("F", [2, 9, 60])
+def test_vocos_second_independent_restatement_agrees(F):
+    """Vocos is third-party and absent offline (parity unpinned).  What can be done offline: a second restatement written separately
+    from the upstream module list (tests/vocos_independent.py, float64 numpy) must agree with the oracle's."""
+    from tests.vocos_independent import vocos_decode_f64
+    vsd = synth.vocos_state_dict(synth.VOCOS_REAL, 1234)
+    mel = np.random.Generator(np.random.Philox(key=900 + F)).standard_normal((100, F)).astype(np.float32)
+    a = ref_cpu.vocos_decode(vsd, torch.from_numpy(mel)).numpy().astype(np.float64)
+    b = vocos_decode_f64(vsd, mel)
+    assert a.shape == b.shape == (256 * (F - 1),)
+    rel = float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    assert rel <= 2e-5, rel
+
+
+@pytest.mark.parametrize("pre_bound", [True, False])
+def test_gfsq_indices_round_trip_to_the_quantised_latent(pre_bound):
+    """The property the reference relies on (GFSQ._embed / get_output_from_indices, dvae.py:85-96): the indices alone rebuild the
+    quantised latent.  Both `pre_bound` variants of the (unpinned) residual-FSQ restatement satisfy it exactly, the indices are
+    valid base-5 numbers (< 625), and the quantiser's reconstruction error stays inside one last-level step."""
+    sd = synth.dvae_encoder_state_dict(synth.DVAE_ENC_REAL, 1234)
+    x = torch.from_numpy(np.random.Generator(np.random.Philox(key=17)).standard_normal((300, 1024)).astype(np.float32)) * 1.5
+    ids, lat = ref_cpu.gfsq_quantize(x, {k: torch.from_numpy(v) for k, v in sd.items()}, pre_bound=pre_bound)
+    assert ids.shape == (4, 300) and int(ids.min()) >= 0 and int(ids.max()) < 625
+    back = ref_cpu.gfsq_latent_from_indices(ids)
+    assert torch.equal(back, lat)                                   # decode(indices) == quantised latent, exactly
+    # every level of every dimension is used somewhere (the synthetic project_in spreads the codes): a wrong basis would not
+    for r in range(4):
+        digits = torch.stack([(ids[r].to(torch.int64) // 5 ** d) % 5 for d in range(4)], 1)
+        assert digits.min() == 0 and digits.max() == 4
+    # reconstruction: |target - latent| <= half a step of the last quantiser (0.25 * 0.5 / 2) wherever the first level did not saturate
+    for g in range(2):
+        w, b = torch.from_numpy(sd[f"vq_layer.quantizer.rvqs.{g}.project_in.weight"]), torch.from_numpy(sd[f"vq_layer.quantizer.rvqs.{g}.project_in.bias"])
+        z = torch.nn.functional.linear(x[:, g * 512:(g + 1) * 512], w, b)
+        target = ref_cpu.fsq_bound(z, torch.tensor([5., 5., 5., 5.])) if pre_bound else z
+        inner = target.abs() < 0.9
+        assert float((target - lat[g])[inner].abs().max()) <= 0.2
