@@ -552,14 +552,159 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const RowMeta* meta_p
     for (int j = 0; j < 8; ++j) dst[xfrag_index<WT>(n, k + j, kt)] = (WT)(o[j] * inv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prompt pass, fp16: flash-style causal attention on MFMA (llama.py:590-668 at q_len > 1, mask semantics of llama.py:1073-1087).
+// The VALU kernels above spend ~8 vector instructions per (query, key) pair whatever the tiling (attn_prefill_kernel reads K/V
+// 8x less often than the row-by-row kernel and is no faster: 42-65 % of a 32 x 512-token prompt pass).  Here
+//   block = (sequence, head, 64 consecutive queries), 4 waves x 16 queries, keys in chunks of 64;
+//   S^T[key][query] = K . Q^T   v_mfma_f32_16x16x32_f16, A = K rows straight from the cache (16 keys x 32 dims = one 16-byte load per
+//                               lane), B = Q (fp16, pre-scaled by 1/8).  In the C layout a lane owns ONE query (lane & 15) and the
+//                               keys 4 * (lane >> 4) + j of the tile -- so the online-softmax state (running max, rescale factor) is a
+//                               per-lane scalar, and P^T in that layout IS the B operand of v_mfma_f32_16x16x16_f16: no transpose of P;
+//   O^T[dim][query] += V^T . P^T   v_mfma_f32_16x16x16_f16, A = V^T: the block stages the chunk's V rows transposed in LDS
+//                               (double-buffered, one barrier per chunk), every wave reads its A fragments with 8-byte LDS loads.
+// The running max is shared by the 4 lanes of a query (lanes 16 apart) with two shuffles per chunk; the row sums stay per-lane
+// partials until the end.  Output: normalised rows in the o_proj kernel's fragment-major B operand, like the other kernels.
+#define FA_PITCH 68        // halfs per V^T row in LDS (64 keys + pad; rows stay 8-byte aligned)
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const RowMeta* meta_p, const float* q_p, const half_t* k_p, const half_t* v_p, const int NHp,
+                                                              const int R, const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) half_t vt[2][CTTS_HEAD_DIM][FA_PITCH];
+    __shared__ int range_s[4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qn = lane & 15, iq = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, T = a.T;
+    const int t = blockIdx.x * 64 + wave * 16 + qn;                       // this lane's query (prompt position)
+    const int r = b * T + t - a.row0;                                     // its row in the current pass
+    const bool live = (t < T) && (r >= 0) && (r < R);
+    RowMeta m = {0, 0, -1, 0};
+    if (live) m = meta_p[r];
+    const int lo = live ? m.kv_start : 0x7FFFFFFF, hi = live ? m.slot : -1;
+    int wlo = lo, whi = hi;                                               // wave-uniform key range
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { wlo = min(wlo, __shfl_xor(wlo, off)); whi = max(whi, __shfl_xor(whi, off)); }
+    if (lane == 0) { range_s[wave][0] = wlo; range_s[wave][1] = whi; }
+    __syncthreads();
+    const int blo = min(min(range_s[0][0], range_s[1][0]), min(range_s[2][0], range_s[3][0]));
+    const int bhi = max(max(range_s[0][1], range_s[1][1]), max(range_s[2][1], range_s[3][1]));
+    if (bhi < 0) return;                                                  // no live query in this block (uniform)
+    wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
+    const size_t head_off = ((size_t)b * NHp + h) * a.Lmax * CTTS_HEAD_DIM;
+    const half_t* kb = k_p + head_off;
+    const half_t* vb = v_p + head_off;
+    // Q fragments (B operand): lane (query qn, kq = iq): dims 8 iq .. + 7 of each 32-dim half, scaled by 1/sqrt(64)
+    half8 qf[2];
+    {
+        const float* qp = q_p + ((size_t)(live ? r : 0) * NHp + h) * CTTS_HEAD_DIM + 8 * iq;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const f32x4 q0 = *(const f32x4*)(qp + 32 * kh), q1 = *(const f32x4*)(qp + 32 * kh + 4);
+            const float sc = live ? 0.125f : 0.f;
+            qf[kh] = (half8){(half_t)(q0[0] * sc), (half_t)(q0[1] * sc), (half_t)(q0[2] * sc), (half_t)(q0[3] * sc),
+                             (half_t)(q1[0] * sc), (half_t)(q1[1] * sc), (half_t)(q1[2] * sc), (half_t)(q1[3] * sc)};
+        }
+    }
+    f32x4 oacc[4];                                                        // O^T: dims 16 db + 4 iq + j of this lane's query
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lpart = 0.f;
+    // V staging: thread -> key (tid >> 2) of the chunk, dims 16 (tid & 3) .. + 15
+    const int skey = tid >> 2, sdim = 16 * (tid & 3);
+    half8 vst[2];
+    auto vload = [&](int c) {
+        const int key = min(c + skey, bhi);                               // clamp: a valid slot of this sequence (masked later)
+        const half8* vp = (const half8*)(vb + (size_t)key * CTTS_HEAD_DIM + sdim);
+        vst[0] = vp[0]; vst[1] = vp[1];
+    };
+    auto vstore = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { vt[buf][sdim + e][skey] = vst[0][e]; vt[buf][sdim + 8 + e][skey] = vst[1][e]; }
+    };
+    const int c0 = blo & ~63;
+    vload(c0);
+    vstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c = c0; c <= bhi; c += 64, buf ^= 1) {
+        const bool more = c + 64 <= bhi;
+        if (more) vload(c + 64);
+        if (c + 63 >= wlo && c <= whi) {                                   // this wave has keys in the chunk
+            f32x4 sT[4];
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                const int key = min(c + 16 * tl + qn, bhi);               // A operand row = key (lane & 15)
+                const half8* kp = (const half8*)(kb + (size_t)key * CTTS_HEAD_DIM + 8 * iq);
+                const half8 k0 = kp[0], k1 = kp[4];                        // dims 8 iq .. and 32 + 8 iq ..
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], acc, 0, 0, 0);
+                sT[tl] = acc;
+            }
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kidx = c + 16 * tl + 4 * iq + j;
+                    const bool ok = (kidx >= lo) && (kidx <= hi);
+                    sT[tl][j] = ok ? sT[tl][j] : -INFINITY;
+                    mloc = fmaxf(mloc, sT[tl][j]);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float mn = fmaxf(mrun, mloc);
+            const float sc = (mrun == -INFINITY) ? 0.f : __expf(mrun - mn);
+            float ps = 0.f;
+            half4 pT[4];
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                float p[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { p[j] = (sT[tl][j] == -INFINITY) ? 0.f : __expf(sT[tl][j] - mn); ps += p[j]; }
+                pT[tl] = (half4){(half_t)p[0], (half_t)p[1], (half_t)p[2], (half_t)p[3]};
+            }
+            lpart = lpart * sc + ps;
+            mrun = mn;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) { oacc[db][0] *= sc; oacc[db][1] *= sc; oacc[db][2] *= sc; oacc[db][3] *= sc; }
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const half4 vf = *(const half4*)&vt[buf][16 * db + qn][16 * tl + 4 * iq];      // A = V^T: row = dim (lane & 15), keys 4 iq ..
+                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pT[tl], oacc[db], 0, 0, 0);
+                }
+        }
+        if (more) vstore(buf ^ 1);
+        __syncthreads();
+    }
+    float ltot = lpart + __shfl_xor(lpart, 16);
+    ltot += __shfl_xor(ltot, 32);
+    if (!live) return;
+    const float inv = 1.0f / ltot;
+    const int NBr = 16 * a.nbg, K = a.NH * CTTS_HEAD_DIM, kt = K / 32;
+    const int chunk = r / NBr, n = r % NBr;
+    half_t* dst = (half_t*)a.packed_out + (size_t)chunk * a.nbg * kt * 64 * 8;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const int k = h * CTTS_HEAD_DIM + 16 * db + 4 * iq;
+        *(half4*)(dst + xfrag_index<half_t>(n, k, kt)) = (half4){(half_t)(oacc[db][0] * inv), (half_t)(oacc[db][1] * inv), (half_t)(oacc[db][2] * inv), (half_t)(oacc[db][3] * inv)};
+    }
+}
+
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     dim3 grid(a.R * a.NH, a.jt > 0 ? a.jt : a.S), block(256);
     const int* done_p = a.st ? &a.st->all_done : nullptr;
-    // unsplit rows (large batches): 8 waves per (row, head) keep twice the K/V bytes in flight per CU
-    static const int wide_env = getenv("CTTS_ATTN_WIDE") ? atoi(getenv("CTTS_ATTN_WIDE")) : 1;     // diagnostic: 0 = 4-wave blocks for unsplit rows too
-    const bool wide = (a.jt == 0) && (a.S == 1) && (a.st != nullptr) && wide_env;
-    static const int tiled_env = getenv("CTTS_PREFILL_ATTN") ? atoi(getenv("CTTS_PREFILL_ATTN")) : 1;    // diagnostic: 0 = row-by-row prompt pass
-    if (a.st == nullptr && a.jt == 0 && a.S == 1 && a.packed_out != nullptr && a.R > 16 && tiled_env) {
+    // unsplit rows: 8 waves per (row, head) keep twice the K/V bytes in flight per CU while there are fewer blocks than CUs; from one
+    // block per CU on, 4-wave blocks balance better (us/step at mean context 312: batch 8 471 vs 479, 16 512 vs 521 | 32 613 vs 598, 64 800 vs 774)
+    static const int wide_env = getenv("CTTS_ATTN_WIDE") ? atoi(getenv("CTTS_ATTN_WIDE")) : -1;     // diagnostic: force 8-wave (1) / 4-wave (0) blocks
+    const bool wide = (a.jt == 0) && (a.S == 1) && (a.st != nullptr) && (wide_env < 0 ? (a.R * a.NH < 256) : wide_env != 0);
+    static const int tiled_env = getenv("CTTS_PREFILL_ATTN") ? atoi(getenv("CTTS_PREFILL_ATTN")) : 1;    // 1 = MFMA flash kernel (fp16, >= 64 rows), 2 = 8-queries-per-wave VALU kernel (diagnostic: no faster than row by row), 0 = row by row
+    if (a.st == nullptr && a.jt == 0 && a.S == 1 && a.packed_out != nullptr && a.R >= 64 && dtype == 1 && a.T > 0 && tiled_env >= 1 && tiled_env != 2) {
+        // prompt pass, fp16: MFMA flash attention, block = (64 queries, head, sequence)
+        const int B = (a.row0 + a.R + a.T - 1) / a.T;                     // sequences 0 .. B-1 may have rows in this pass
+        dim3 g3((a.T + 63) / 64, a.NH, B);
+        hipLaunchKernelGGL(attn_prefill_mfma_kernel, g3, dim3(256), 0, s, a.meta, a.q, (const half_t*)a.k_cache, (const half_t*)a.v_cache, a.NH, a.R, a);
+    } else if (a.st == nullptr && a.jt == 0 && a.S == 1 && a.packed_out != nullptr && a.R > 16 && tiled_env == 2) {
         // prompt pass: 8 query rows per wavefront, 4 wavefronts per block
         dim3 g2((a.R + 31) / 32, a.NH);
         if (dtype == 1) hipLaunchKernelGGL(attn_prefill_kernel<half_t>, g2, dim3(256), 0, s, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.R, a);

@@ -442,7 +442,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     const bool prepack = (st == nullptr) && (nbg == 2) && (R > 64) && !getenv("CTTS_NO_PREPACK");
     // prompt pass over >= 128 rows, fp16: LDS-staged 256/128 x 128 MFMA GEMM (prefill_gemm.hip) instead of one weight tile per 32-row block
     static const int pf_env = getenv("CTTS_PREFILL_GEMM") ? atoi(getenv("CTTS_PREFILL_GEMM")) : 1;
-    const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && (R >= 128) && pf_env;
+    // (measured: 32 x 96 = 3072 rows break even, 1200 rows 4.2 vs 2.7 ms, 512 rows 4.4 vs 1.9 ms, 8192-row passes 19 vs 29 ms)
+    const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && (R >= (pf_env > 1 ? pf_env : 4096)) && pf_env;
     // fp16 decode above the split-K batch sizes: the residual stream travels between kernels as a packed fp16 B operand + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself
     const bool xhm = (dt == CTTS_DTYPE_F16) && (st != nullptr) && h->xh_mode && !splitd && (R > h->fuse_rows) && (R > h->fuseqkv_rows);
@@ -480,6 +481,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
+        if (st == nullptr) { at.T = h->T; at.row0 = (int)(meta - h->meta_pre); }       // prompt pass: position of this pass in the flattened [B][T] prompt
         if (fused) {
             // small batch: attention + per-head o_proj partial in one launch; the residual add is deferred to the
             // consumers (gate|up prologue, down epilogue) which sum the 12 partials in head order

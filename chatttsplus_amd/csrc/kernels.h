@@ -67,6 +67,7 @@ struct AttnArgs {
     int jt;                 //   column groups (grid.y) when fused, 0 otherwise
     void* packed_out;       // S == 1 only: normalised output written straight into the o_proj kernel's fragment-major B operand
     int nbg;                //   rows per chunk = 16*nbg
+    int T, row0;            // prompt pass (MFMA flash kernel): prompt length and the flattened index b*T + t of the pass's first row
 };
 
 struct SamplerCfgDev {      // mirrors ctts_sampler_cfg

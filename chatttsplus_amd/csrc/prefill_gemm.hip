@@ -38,40 +38,44 @@ __global__ __launch_bounds__(WR * 128) void prefill_gemm_kernel(const void* Wq, 
     auto src = [&](int f, int kt) -> const half8* {
         return (f < C::BN_T) ? Wg + ((size_t)(nt0 + f) * ktiles + kt) * 64 + lane : Xg + ((size_t)(g0 + f - C::BN_T) * ktiles + kt) * 64 + lane;
     };
-    half8 stg[C::PER_T];
-#pragma unroll
-    for (int i = 0; i < C::PER_T; ++i) { const int f = wave + i * C::WAVES; if (f < C::FRAGS) stg[i] = *src(f, 0); }
-#pragma unroll
-    for (int i = 0; i < C::PER_T; ++i) { const int f = wave + i * C::WAVES; if (f < C::FRAGS) *(half8*)(lds + f * 1024 + lane * 16) = stg[i]; }
-    __syncthreads();
+    // Software pipeline: LDS double buffer + two register stages, so the global loads of stage kt + 2 are issued before the MFMAs of
+    // stage kt and only have to land by the end of stage kt + 1 (with one register stage every iteration waited for the loads it had
+    // just issued: 17 % of the MFMA peak).
+    half8 st0[C::PER_T], st1[C::PER_T];
     f32x4 acc[4][4];                                       // [n tile][row group]
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const char* cur = lds + (kt & 1) * C::STAGE;
-        char* nxt = lds + ((kt + 1) & 1) * C::STAGE;
-        const bool more = kt + 1 < ktiles;
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < C::PER_T; ++i) { const int f = wave + i * C::WAVES; if (f < C::FRAGS) stg[i] = *src(f, kt + 1); }
-        }
-        half8 af[4], bf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[t] = *(const half8*)(cur + (wn * 4 + t) * 1024 + lane * 16);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bf[g] = *(const half8*)(cur + (C::BN_T + wr * 4 + g) * 1024 + lane * 16);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t], bf[g], acc[t][g], 0, 0, 0);
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < C::PER_T; ++i) { const int f = wave + i * C::WAVES; if (f < C::FRAGS) *(half8*)(nxt + f * 1024 + lane * 16) = stg[i]; }
-        }
-        __syncthreads();
+#define PF_LOAD(dst, kt_)                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < C::PER_T; ++i) { const int f = wave + i * C::WAVES; if (f < C::FRAGS) dst[i] = *src(f, (kt_)); }
+#define PF_STORE(srcr, buf_)                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < C::PER_T; ++i) { const int f = wave + i * C::WAVES; if (f < C::FRAGS) *(half8*)(lds + (buf_) * C::STAGE + f * 1024 + lane * 16) = srcr[i]; }
+#define PF_STEP(kt_, rnext, rfar)                                                                                                    \
+    {                                                                                                                                \
+        const int kt = (kt_);                                                                                                        \
+        if (kt + 2 < ktiles) { PF_LOAD(rfar, kt + 2) }                                                                               \
+        const char* cur = lds + (kt & 1) * C::STAGE;                                                                                 \
+        half8 af[4], bf[4];                                                                                                          \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) af[t] = *(const half8*)(cur + (wn * 4 + t) * 1024 + lane * 16);               \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) bf[g] = *(const half8*)(cur + (C::BN_T + wr * 4 + g) * 1024 + lane * 16);     \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                                \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t], bf[g], acc[t][g], 0, 0, 0); \
+        if (kt + 1 < ktiles) { PF_STORE(rnext, (kt + 1) & 1) }                                                                       \
+        __syncthreads();                                                                                                             \
     }
+    PF_LOAD(st0, 0)
+    PF_STORE(st0, 0)
+    if (ktiles > 1) { PF_LOAD(st1, 1) }
+    __syncthreads();
+    // stage s travels through register set s & 1: at stage kt the "next" set holds stage kt + 1, the "far" set receives stage kt + 2
+    for (int kt2 = 0; kt2 < ktiles; kt2 += 2) {
+        PF_STEP(kt2, st1, st0)
+        if (kt2 + 1 < ktiles) PF_STEP(kt2 + 1, st0, st1)
+    }
+#undef PF_STEP
+#undef PF_STORE
+#undef PF_LOAD
     // ---- epilogue.  C tile layout: lane = (iq = lane >> 4, n = lane & 15): activation row n of the group, weight rows 4 * iq + j (j = register)
     const int iq = lane >> 4, nn = lane & 15;
     constexpr int H = 768, NH = H / CTTS_HEAD_DIM, HT = H / 16;
@@ -93,39 +97,43 @@ __global__ __launch_bounds__(WR * 128) void prefill_gemm_kernel(const void* Wq, 
                 }
             } else {
                 // packed tile rows: [8 "a" rows | 8 "b" rows] (q/k/v: dims d and d + 32 of one head; gate|up: gate row and up row): the
-                // partner half sits 32 lanes away
+                // partner half sits 32 lanes away.  A lane ends up with 4 consecutive outputs (j = 0..3): one vector store each.
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(c[j], 32);
                 const bool lowh = iq < 2;
+                const f32x4 va = lowh ? c : o, vb = lowh ? o : c;
+                const int p0 = 4 * (iq & 1);                                    // outputs p0 .. p0 + 3 of the tile's 8 pairs
+                if (EPI == EPI_SWIGLU) {
+                    if (lowh) {                                                // both lanes of a pair hold it: the low half writes
+                        half4 y = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                        if (rv) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float va = lowh ? c[j] : o[j], vb = lowh ? o[j] : c[j];
-                    const int p = 4 * (iq & 1) + j;
-                    if (EPI == EPI_SWIGLU) {
-                        if (lowh == ((j & 1) == 0)) {            // each pair is held by two lanes: split the work between them
-                            float y = 0.f;
-                            if (rv) y = (va / (1.0f + expf(-va))) * vb;
-                            const int ktiles_out = (a.n_row_tiles * 8) / 32;
-                            half_t* dst = (half_t*)a.act_out;
-                            dst[xfrag_index<half_t>(r, rt * 8 + p, ktiles_out)] = (half_t)y;   // n >> 4 = global 16-row group: the packed image is contiguous over chunks
+                            for (int j = 0; j < 4; ++j) y[j] = (half_t)((va[j] / (1.0f + expf(-va[j]))) * vb[j]);
                         }
-                    } else if (rv) {                             // EPI_QKV
-                        const int which = rt / HT, within = rt % HT;
-                        const int hh = within >> 2, d = ((within & 3) << 3) + p;
-                        float ya = va, yb = vb;
-                        if (which < 2) {
-                            const float cs = a.rope_rows[(size_t)r * 64 + d], sn = a.rope_rows[(size_t)r * 64 + 32 + d];
-                            ya = __fadd_rn(__fmul_rn(va, cs), __fmul_rn(-vb, sn));      // q*cos + rotate_half(q)*sin (llama.py:180-181)
-                            yb = __fadd_rn(__fmul_rn(vb, cs), __fmul_rn(va, sn));
+                        const int ktiles_out = (a.n_row_tiles * 8) / 32;
+                        // n >> 4 = global 16-row group: the packed image is contiguous over chunks; 4 consecutive k share a fragment row
+                        *(half4*)((half_t*)a.act_out + xfrag_index<half_t>(r, rt * 8 + p0, ktiles_out)) = y;
+                    }
+                } else if (rv) {                                             // EPI_QKV
+                    const int which = rt / HT, within = rt % HT;
+                    const int hh = within >> 2, d0 = ((within & 3) << 3) + p0;
+                    f32x4 y;
+                    if (which < 2) {
+                        const f32x4 cs = *(const f32x4*)(a.rope_rows + (size_t)r * 64 + d0), sn = *(const f32x4*)(a.rope_rows + (size_t)r * 64 + 32 + d0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // q*cos + rotate_half(q)*sin (llama.py:180-181), products rounded separately like the reference
+                            const float ya = __fadd_rn(__fmul_rn(va[j], cs[j]), __fmul_rn(-vb[j], sn[j]));
+                            const float yb = __fadd_rn(__fmul_rn(vb[j], cs[j]), __fmul_rn(va[j], sn[j]));
+                            y[j] = lowh ? ya : yb;
                         }
-                        const float y = lowh ? ya : yb;
-                        const int dd = lowh ? d : d + 32;
-                        if (which == 0) a.q_out[((size_t)r * NH + hh) * CTTS_HEAD_DIM + dd] = y;
-                        else {
-                            half_t* cch = (half_t*)(which == 1 ? a.k_cache : a.v_cache) + (((size_t)m.seq * NH + hh) * a.Lmax + m.slot) * CTTS_HEAD_DIM;
-                            cch[dd] = (half_t)y;
-                        }
+                    } else y = lowh ? va : vb;
+                    const int dd = lowh ? d0 : d0 + 32;
+                    if (which == 0) *(f32x4*)(a.q_out + ((size_t)r * NH + hh) * CTTS_HEAD_DIM + dd) = y;
+                    else {
+                        half_t* cch = (half_t*)(which == 1 ? a.k_cache : a.v_cache) + (((size_t)m.seq * NH + hh) * a.Lmax + m.slot) * CTTS_HEAD_DIM;
+                        *(half4*)(cch + dd) = (half4){(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
                     }
                 }
             }
@@ -148,7 +156,8 @@ static int pf_launch(const GemmArgs& a, const void* X, int ktiles, hipStream_t s
 int launch_prefill_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     const void* X = a.xpacked;
     const int ktiles = a.K / 32;
-    const bool big = a.R >= 2048;
+    // 256-row blocks only where the grid still covers the chip a few times over: the N = 768 projections (6 column blocks) take 128-row blocks
+    const bool big = (a.R >= 2048) && (a.n_row_tiles >= 96);
     if (epi == EPI_QKV) return big ? pf_launch<EPI_QKV, 4>(a, X, ktiles, s) : pf_launch<EPI_QKV, 2>(a, X, ktiles, s);
     if (epi == EPI_SWIGLU) return big ? pf_launch<EPI_SWIGLU, 4>(a, X, ktiles, s) : pf_launch<EPI_SWIGLU, 2>(a, X, ktiles, s);
     if (epi == EPI_RESID) return big ? pf_launch<EPI_RESID, 4>(a, X, ktiles, s) : pf_launch<EPI_RESID, 2>(a, X, ktiles, s);
