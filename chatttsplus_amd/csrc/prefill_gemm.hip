@@ -7,10 +7,10 @@
 // 32 x 512 tokens spent 26 of its 48 ms there at ~10 % of the MFMA peak).  Here a block owns a 256 x 128 (or 128 x 128) output tile:
 //   * both operands already live in HBM as MFMA fragment images -- weights [n tile][k tile][lane][16 B] (gpt_engine.hip pack), activations
 //     [16-row group][k tile][lane][16 B] (norm_pack_kernel / the SwiGLU epilogue / the attention kernels) -- so staging a k-tile
-//     is a straight copy of 1-KiB fragments into LDS (one coalesced 16-byte load + one ds_write_b128 per thread) and a wave reads
+//     is a straight copy of 1-KiB fragments into LDS (one global_load_lds_dwordx4 per wave and fragment) and a wave reads
 //     its operands back with conflict-free ds_read_b128;
-//   * 8 (4) waves, each a 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_f16 accumulators, k-tiles double-buffered in LDS (24 KB per
-//     stage), the next stage's global loads in flight under the current stage's 16 MFMAs per wave;
+//   * 8 (4) waves, each a 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_f16 accumulators, k-tiles in a ring of 3 LDS stages (24 KB each)
+//     filled by LDS-DMA loads two stages ahead of the MFMAs;
 //   * every output element is accumulated by one wave in k order: deterministic, no split-K, no atomics.
 // Epilogues restate the same reference lines as the decode kernel: q/k/v projection + RoPE + KV append (llama.py:619-633,151-182),
 // o_proj / down_proj + residual (llama.py:666,731,739), SiLU(gate) * up (llama.py:214).
@@ -27,7 +27,7 @@ struct PfCfg {
 template <int EPI, int WR>
 __global__ __launch_bounds__(WR * 128) void prefill_gemm_kernel(const void* Wq, const void* Xp, const int ktiles, const int R, const GemmArgs a) {
     typedef PfCfg<WR> C;
-    __shared__ __attribute__((aligned(16))) char lds[2 * C::STAGE];
+    __shared__ __attribute__((aligned(16))) char lds[3 * C::STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wn = wave & 1;
     const int nt0 = blockIdx.x * C::BN_T;                  // first n tile of the block
@@ -38,44 +38,48 @@ __global__ __launch_bounds__(WR * 128) void prefill_gemm_kernel(const void* Wq, 
     auto src = [&](int f, int kt) -> const half8* {
         return (f < C::BN_T) ? Wg + ((size_t)(nt0 + f) * ktiles + kt) * 64 + lane : Xg + ((size_t)(g0 + f - C::BN_T) * ktiles + kt) * 64 + lane;
     };
-    // Software pipeline: LDS double buffer + two register stages, so the global loads of stage kt + 2 are issued before the MFMAs of
-    // stage kt and only have to land by the end of stage kt + 1 (with one register stage every iteration waited for the loads it had
-    // just issued: 17 % of the MFMA peak).
-    half8 st0[C::PER_T], st1[C::PER_T];
+    // Software pipeline: a ring of 3 LDS stages filled by LDS-DMA loads (global_load_lds_dwordx4: 1 KiB per wave-instruction straight
+    // into LDS at base + lane * 16 -- exactly the fragment image -- no staging registers, no ds_write).  Staging through registers
+    // cost as many LDS-pipe cycles in ds_write_b128 (13 per wave-instruction) as the MFMAs took: 24 % of the MFMA peak.  The loads
+    // of stage kt + 2 are issued at the top of stage kt; stage kt + 1 must have landed by the barrier that ends stage kt.
     f32x4 acc[4][4];                                       // [n tile][row group]
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#define PF_LOAD(dst, kt_)                                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < C::PER_T; ++i) { const int f = wave + i * C::WAVES; if (f < C::FRAGS) dst[i] = *src(f, (kt_)); }
-#define PF_STORE(srcr, buf_)                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < C::PER_T; ++i) { const int f = wave + i * C::WAVES; if (f < C::FRAGS) *(half8*)(lds + (buf_) * C::STAGE + f * 1024 + lane * 16) = srcr[i]; }
-#define PF_STEP(kt_, rnext, rfar)                                                                                                    \
-    {                                                                                                                                \
-        const int kt = (kt_);                                                                                                        \
-        if (kt + 2 < ktiles) { PF_LOAD(rfar, kt + 2) }                                                                               \
-        const char* cur = lds + (kt & 1) * C::STAGE;                                                                                 \
-        half8 af[4], bf[4];                                                                                                          \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) af[t] = *(const half8*)(cur + (wn * 4 + t) * 1024 + lane * 16);               \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) bf[g] = *(const half8*)(cur + (C::BN_T + wr * 4 + g) * 1024 + lane * 16);     \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                                \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t], bf[g], acc[t][g], 0, 0, 0); \
-        if (kt + 1 < ktiles) { PF_STORE(rnext, (kt + 1) & 1) }                                                                       \
-        __syncthreads();                                                                                                             \
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#define PF_DMA(kt_, buf_)                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < C::PER_T; ++i) {                                                                           \
+        const int f = wave + i * C::WAVES;                                                                                           \
+        if (f < C::FRAGS) __builtin_amdgcn_global_load_lds((gptr_t)src(f, (kt_)), (lptr_t)(lds + (buf_) * C::STAGE + f * 1024), 16, 0, 0); \
     }
-    PF_LOAD(st0, 0)
-    PF_STORE(st0, 0)
-    if (ktiles > 1) { PF_LOAD(st1, 1) }
+    PF_DMA(0, 0)
+    if (ktiles > 1) { PF_DMA(1, 1) }
+    if (ktiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PER_T) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // stage s travels through register set s & 1: at stage kt the "next" set holds stage kt + 1, the "far" set receives stage kt + 2
-    for (int kt2 = 0; kt2 < ktiles; kt2 += 2) {
-        PF_STEP(kt2, st1, st0)
-        if (kt2 + 1 < ktiles) PF_STEP(kt2 + 1, st0, st1)
+    int cb = 0;                                            // ring slot of the current stage
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int nb2 = (cb + 2 >= 3) ? cb - 1 : cb + 2;
+        if (kt + 2 < ktiles) { PF_DMA(kt + 2, nb2) }
+        const char* cur = lds + cb * C::STAGE;
+        half8 af[4], bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = *(const half8*)(cur + (wn * 4 + t) * 1024 + lane * 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bf[g] = *(const half8*)(cur + (C::BN_T + wr * 4 + g) * 1024 + lane * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t], bf[g], acc[t][g], 0, 0, 0);
+        // stage kt + 1 (issued one iteration ago) must be in LDS before anyone reads it: all but the loads just issued have to be back
+        // (a bare s_barrier: __syncthreads() carries a workgroup fence that waits for vmcnt(0), i.e. for the stage just requested too;
+        //  the asm memory clobbers keep the compiler from moving LDS accesses across it)
+        if (kt + 2 < ktiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(C::PER_T) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cb = (cb + 1 == 3) ? 0 : cb + 1;
     }
-#undef PF_STEP
-#undef PF_STORE
-#undef PF_LOAD
+#undef PF_DMA
     // ---- epilogue.  C tile layout: lane = (iq = lane >> 4, n = lane & 15): activation row n of the group, weight rows 4 * iq + j (j = register)
     const int iq = lane >> 4, nn = lane & 15;
     constexpr int H = 768, NH = H / CTTS_HEAD_DIM, HT = H / 16;
@@ -156,8 +160,7 @@ static int pf_launch(const GemmArgs& a, const void* X, int ktiles, hipStream_t s
 int launch_prefill_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     const void* X = a.xpacked;
     const int ktiles = a.K / 32;
-    // 256-row blocks only where the grid still covers the chip a few times over: the N = 768 projections (6 column blocks) take 128-row blocks
-    const bool big = (a.R >= 2048) && (a.n_row_tiles >= 96);
+    const bool big = a.R >= 2048;          // (128-row blocks for the N = 768 projections measured slower: 93 vs 84 us for the down projection at 8192 rows)
     if (epi == EPI_QKV) return big ? pf_launch<EPI_QKV, 4>(a, X, ktiles, s) : pf_launch<EPI_QKV, 2>(a, X, ktiles, s);
     if (epi == EPI_SWIGLU) return big ? pf_launch<EPI_SWIGLU, 4>(a, X, ktiles, s) : pf_launch<EPI_SWIGLU, 2>(a, X, ktiles, s);
     if (epi == EPI_RESID) return big ? pf_launch<EPI_RESID, 4>(a, X, ktiles, s) : pf_launch<EPI_RESID, 2>(a, X, ktiles, s);

@@ -584,34 +584,39 @@ int launch_embed_ids(const int* ids, const float* emb_code, float* x, int B, int
 
 // position ids / cache slots from the left-padded attention mask (gpt.py:238-245):
 //   pos = cumsum(mask) - 1, pad -> 1;   decode rows start at slot T with pos = (#valid tokens)
-__global__ void fill_meta_kernel(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre) {
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) {
-        // lanes 1..63 wait for lane 0's metadata, then the whole wave copies the RoPE rows (below)
-    }
-    if (threadIdx.x == 0) {
-    int cum = 0, pad = 0;
+__global__ __launch_bounds__(64) void fill_meta_kernel(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre) {
+    // one wavefront per sequence: 64 positions per round, cumsum(mask) from ballots (the former single-thread loop over T took
+    // 0.29 ms at T = 512 -- 2 % of a 32 x 512-token prompt pass)
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int cum = 0, pad = 0;                      // uniform: valid tokens before this round; leading zeros (left padding)
     bool seen = false;
-    for (int t = 0; t < T; ++t) {
-        const int mk = mask[b * T + t];
-        cum += mk ? 1 : 0;
-        if (!mk && !seen) pad = t + 1;     // left padding: leading zeros
-        if (mk) seen = true;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const int mk = (t < T) ? (mask[b * T + t] != 0) : 0;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(mk != 0);
+        if (!seen) {                           // first attended position so far
+            if (bal != 0ull) { pad = t0 + (int)__builtin_ctzll(bal); seen = true; }
+            else pad = min(t0 + 64, T);
+        }
+        const int incl = cum + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) + mk;   // cumsum(mask)[t]
         RowMeta m;
         m.seq = b;
-        m.pos = mk ? cum - 1 : 1;
+        m.pos = mk ? incl - 1 : 1;             // gpt.py:238-245: cumsum - 1, pad -> 1
         m.slot = t;
-        m.kv_start = mk ? pad : t;          // pad query rows attend to themselves only (their output is never used)
-        pm[b * T + t] = m;
+        m.kv_start = mk ? pad : t;             // pad query rows attend to themselves only (their output is never used)
+        if (t < T) pm[b * T + t] = m;
+        const int nrow = min(64, T - t0);      // RoPE table rows of this round's positions, one coalesced 256-byte row per iteration
+#pragma unroll 4
+        for (int rr = 0; rr < nrow; ++rr) rope_pre[((size_t)b * T + t0 + rr) * 64 + lane] = rope[(size_t)__shfl(m.pos, rr) * 64 + lane];
+        cum += __builtin_popcountll(bal);
     }
-    RowMeta d;
-    d.seq = b; d.pos = cum - 1; d.slot = T - 1; d.kv_start = pad;   // every sample phase advances pos/slot by one
-    dm[b] = d;
-    st->pad[b] = pad;
-    if (b == 0) { st->step = 0; st->all_done = 0; st->ticket = 0; st->B = B; st->T = T; }
+    if (lane == 0) {
+        RowMeta d;
+        d.seq = b; d.pos = cum - 1; d.slot = T - 1; d.kv_start = pad;   // every sample phase advances pos/slot by one
+        dm[b] = d;
+        st->pad[b] = pad;
+        if (b == 0) { st->step = 0; st->all_done = 0; st->ticket = 0; st->B = B; st->T = T; }
     }
-    __syncthreads();
-    for (int t = 0; t < T; ++t) rope_pre[((size_t)b * T + t) * 64 + threadIdx.x] = rope[(size_t)pm[b * T + t].pos * 64 + threadIdx.x];
 }
 int launch_fill_meta(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre, hipStream_t s) {
     hipLaunchKernelGGL(fill_meta_kernel, dim3(B), dim3(64), 0, s, pm, dm, st, mask, B, T, rope, rope_pre);
