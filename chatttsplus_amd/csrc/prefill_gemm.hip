@@ -30,8 +30,18 @@ __global__ __launch_bounds__(WR * 128) void prefill_gemm_kernel(const void* Wq, 
     __shared__ __attribute__((aligned(16))) char lds[3 * C::STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wn = wave & 1;
-    const int nt0 = blockIdx.x * C::BN_T;                  // first n tile of the block
-    const int g0 = blockIdx.y * C::BM_G;                   // first 16-row group of the block
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own 4-MB L2; in plain
+    // (x, y) order every XCD touches every weight tile AND every activation row block of the launch (22 MB for gate|up at 8192 rows):
+    // the L2s thrash and the GEMM runs at the Infinity-Cache rate.  Remapped, XCD x owns the row blocks y = x (mod 8) and walks the
+    // column blocks in order, so the ~64 workgroups resident on an XCD share 4 activation row blocks and ~16 weight column blocks.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, seq = lin >> 3, rpx = gridDim.y >> 3;
+        bx = seq / rpx;
+        by = (seq % rpx) * 8 + xcd;
+    }
+    const int nt0 = bx * C::BN_T;                          // first n tile of the block
+    const int g0 = by * C::BM_G;                           // first 16-row group of the block
     const half8* Wg = (const half8*)Wq;
     const half8* Xg = (const half8*)Xp;
     // fragment f of a stage: f < BN_T -> weight tile nt0 + f, else activation group g0 + (f - BN_T)

@@ -605,9 +605,6 @@ __global__ __launch_bounds__(64) void fill_meta_kernel(RowMeta* pm, RowMeta* dm,
         m.slot = t;
         m.kv_start = mk ? pad : t;             // pad query rows attend to themselves only (their output is never used)
         if (t < T) pm[b * T + t] = m;
-        const int nrow = min(64, T - t0);      // RoPE table rows of this round's positions, one coalesced 256-byte row per iteration
-#pragma unroll 4
-        for (int rr = 0; rr < nrow; ++rr) rope_pre[((size_t)b * T + t0 + rr) * 64 + lane] = rope[(size_t)__shfl(m.pos, rr) * 64 + lane];
         cum += __builtin_popcountll(bal);
     }
     if (lane == 0) {
@@ -618,8 +615,14 @@ __global__ __launch_bounds__(64) void fill_meta_kernel(RowMeta* pm, RowMeta* dm,
         if (b == 0) { st->step = 0; st->all_done = 0; st->ticket = 0; st->B = B; st->T = T; }
     }
 }
+// per prompt row: its RoPE table row (cos | sin of its position), one wavefront per row, coalesced 256-byte copies
+__global__ __launch_bounds__(256) void rope_rows_kernel(const RowMeta* pm, const float* rope, float* rope_pre, int n) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r < n) rope_pre[(size_t)r * 64 + lane] = rope[(size_t)pm[r].pos * 64 + lane];
+}
 int launch_fill_meta(RowMeta* pm, RowMeta* dm, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre, hipStream_t s) {
     hipLaunchKernelGGL(fill_meta_kernel, dim3(B), dim3(64), 0, s, pm, dm, st, mask, B, T, rope, rope_pre);
+    hipLaunchKernelGGL(rope_rows_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, (const RowMeta*)pm, rope, rope_pre, B * T);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }

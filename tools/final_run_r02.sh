@@ -22,6 +22,7 @@ timeout 250 python tools/pipe_wall.py 2>&1 | tail -1 >> $O/pipe_wall.log
 timeout 250 python tools/pipe_wall.py --n 32 --tokens 256 2>&1 | tail -1 >> $O/pipe_wall.log
 for cfg in "1 48" "1 512" "32 96" "32 512" "8 2000"; do timeout 120 python tools/prefill_probe.py $cfg 2>&1 | grep "prompt pass" | tail -1 >> $O/prefill.log; done
 for cfg in "32 512" "8 2000"; do CTTS_PREFILL_GEMM=0 CTTS_PREFILL_ATTN=0 timeout 120 python tools/prefill_probe.py $cfg 2>&1 | grep "prompt pass" | tail -1 | sed 's/$/  (round-1 kernels: CTTS_PREFILL_GEMM=0 CTTS_PREFILL_ATTN=0)/' >> $O/prefill.log; done
+for cfg in "32 96" "8 300" "4 512"; do for th in 4096 2048; do CTTS_PREFILL_GEMM=$th timeout 120 python tools/prefill_probe.py $cfg 2>&1 | grep "prompt pass" | tail -1 | sed "s/$/  (prompt GEMM from $th rows)/" >> $O/prefill.log; done; done
 timeout 200 python tools/fp16_agreement.py > $O/fp16_token_agreement.json 2>/dev/null
 cat $O/gen_wall.log $O/pipe_wall.log $O/prefill.log
 R=$GRAFT_REPO_ROOT
