@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--cpu-steps", type=int, default=192, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--gen-tokens", type=int, default=GEN_TOKENS, help="length of the generation the timed window is centred in (0: the window starts right after the warm-up; used by the short profiler passes)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (batch 32, mixed prompts, 512-token prompt, LoRA)")
     ap.add_argument("--extra-steps", type=int, default=128, help="timed steps of each extra leg")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank control flow (no HIP work, fake timing); used by tests/test_bench_dryrun.py")
@@ -245,7 +246,7 @@ def main():
     extras = not args.no_extras
     EB, EK = 32, args.extra_steps
     sd = synth.gpt_state_dict(synth.GPT_REAL, 1234)                    # every rank holds a full replica (0.45 GB fp16)
-    need_seq = max(P, 512 if extras else 0) + W + max(GEN_TOKENS, K) + 16
+    need_seq = max(P, 512 if extras else 0) + W + max(GEN_TOKENS, args.gen_tokens, K) + 16
     g = GPT(LLAMA, max_batch=max(B, EB if extras else 1), max_seq_len=need_seq, weight_dtype=args.dtype, device=str(dev))
     g.load_state_dict(sd)
     # speaker table lives on rank 0 and is broadcast over xGMI (the path's only collective)
@@ -254,7 +255,7 @@ def main():
         dist.broadcast(spk, src=0)
     use_graph = 0 if args.no_graph else 1
     leg = Leg(g, dev, rank, world)
-    r = leg.run(B, P, K, W, spk=spk, use_graph=use_graph, keep_hidden=True)
+    r = leg.run(B, P, K, W, spk=spk, use_graph=use_graph, keep_hidden=True, gen_tokens=args.gen_tokens)
     dt, expect, hid = r["dt"], r["expect"], r["hid"]
 
     # RTF leg (outside the timed decode region): DVAE decoder + Vocos on the generated hiddens of every local sequence
@@ -305,6 +306,14 @@ def main():
             e = Leg(gl, dev, rank, world).run(EB, P, EK, W, spk=spk, use_graph=use_graph)
             extra["batch32_lora_merged"] = summarize(e, world)
             gl.close()
+            if args.dtype == "fp16":
+                # the parity-proven mode (fp32 weights / KV, exact-f32 MFMA: token ids bit-exact vs the reference CPU path, mel / waveform
+                # <= 1e-3 -- DESIGN.md section 2) on the headline workload, same window
+                g32 = GPT(LLAMA, max_batch=1, max_seq_len=P + W + max(GEN_TOKENS, K) + 16, weight_dtype="fp32", device=str(dev))
+                g32.load_state_dict(sd)
+                e = Leg(g32, dev, rank, world).run(1, P, min(K, 256), W, spk=spk, use_graph=use_graph)
+                extra["parity_mode_fp32_batch1"] = summarize(e, world)
+                g32.close()
         except SystemExit:
             raise
         except Exception as ex:
@@ -330,14 +339,14 @@ def main():
             "vs_baseline": round(B * K * world / dt / 110.0, 2),   # 110 token/s (TensorRT fp16, RTX 3060)
             "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
             "world_size": world, "per_rank_tokens_per_s": [round(B * K / p, 2) for p in r["per_rank_s"]],
-            "config": {"workload": f"ChatTTS GPT decode, batch {B}/GPU, prompt {P}, steps {r['s0']}..{r['s0'] + K} of a {max(GEN_TOKENS, K)}-token generation "
+            "config": {"workload": f"ChatTTS GPT decode, batch {B}/GPU, prompt {P}, steps {r['s0']}..{r['s0'] + K} of a {max(args.gen_tokens, K)}-token generation "
                                    f"(mean context {r['mean_ctx']:.0f}), top-p 0.7 top-k 20 T 0.3 rep 1.05 (BASELINE configs[{1 if B == 1 else 2}]), "
                                    f"random-init weights of the real 20x768 architecture",
                        "batch_per_gpu": B, "prompt_len": P, "untimed_steps_before_window": r["s0"], "weights": args.dtype, "kv_cache": args.dtype,
                        "accumulate": "f32", "hipgraph": bool(use_graph), "parallelism": f"replicas x{world} (utterance sharding)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_note": "PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE bytes per step from profiles/r0N_pmc_*.json (separate rocprofv3 --pmc passes)",
+                         "traffic_note": "PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE bytes per step from profiles/r0N_pmc_*.json (separate rocprofv3 --pmc passes on a short generation: mean context ~98, i.e. ~14 MB less KV traffic per sequence and step than the timed window's)",
                          "per": "decode step (one hipGraph replay = 4 steps)",
                          "algorithmic_bytes_per_step": int(step_bytes), "step_ms_hip_events": round(step_ms, 5)},
             "rtf_decode_only": round(B * K * world * (512 / 24000.0) / dt, 2),

@@ -69,14 +69,14 @@ __device__ inline float safe_exp_diff(float m, float mn) { return (m == -INFINIT
 // multiplies its head's output with its share of the o_proj rows (weights prefetched at kernel entry), writing a
 // per-head partial sum  opart[row][head][:]  that the next kernels add to the residual stream in head order.
 // Drops one of the five dependent launches per layer in the launch-latency-bound small-batch regime.
-template <typename WT, bool FUSED, int NW>
+template <typename WT, bool FUSED, int NW, int UNR = 4>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const int* done_p, const RowMeta* meta_p, const float* q_p, const void* k_p, const void* v_p,
                                                             const int NHp, const int Sp, const AttnArgs a) {
     // leading scalars = what the first loads need; preloaded into SGPRs at wave launch (see skinny_gemm.hip)
     static_assert(!FUSED || NW == 4, "fused o_proj phase assumes 4 waves");
     int done_v = 0;                                   // requested with the first operand loads, tested once they are in flight (common.h)
     if (done_p != nullptr) done_v = vload_flag(done_p);
-    constexpr int UN = 4;
+    constexpr int UN = UNR;                           // keys per lane group and loop iteration (loads in flight: 2 * UN * 16 B per lane)
     __shared__ float merge[NW][8][10];
     __shared__ float o_s[CTTS_HEAD_DIM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -698,6 +698,7 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     // block per CU on, 4-wave blocks balance better (us/step at mean context 312: batch 8 471 vs 479, 16 512 vs 521 | 32 613 vs 598, 64 800 vs 774)
     static const int wide_env = getenv("CTTS_ATTN_WIDE") ? atoi(getenv("CTTS_ATTN_WIDE")) : -1;     // diagnostic: force 8-wave (1) / 4-wave (0) blocks
     const bool wide = (a.jt == 0) && (a.S == 1) && (a.st != nullptr) && (wide_env < 0 ? (a.R * a.NH < 256) : wide_env != 0);
+    static const int un_env = getenv("CTTS_ATTN_UN") ? atoi(getenv("CTTS_ATTN_UN")) : 4;        // experiment: 8 keys per lane group in flight for unsplit 4-wave blocks
     static const int tiled_env = getenv("CTTS_PREFILL_ATTN") ? atoi(getenv("CTTS_PREFILL_ATTN")) : 1;    // 1 = MFMA flash kernel (fp16, >= 64 rows), 2 = 8-queries-per-wave VALU kernel (diagnostic: no faster than row by row), 0 = row by row
     if (a.st == nullptr && a.jt == 0 && a.S == 1 && a.packed_out != nullptr && a.R >= 64 && dtype == 1 && a.T > 0 && tiled_env >= 1 && tiled_env != 2) {
         // prompt pass, fp16: MFMA flash attention, block = (64 queries, head, sequence)
@@ -716,6 +717,8 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
         if (a.jt * 4 * FUSE_TPW * 16 != a.NH * CTTS_HEAD_DIM) { ctts_set_error("fused attention: jt=%d does not tile H=%d", a.jt, a.NH * CTTS_HEAD_DIM); return 1; }
         if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, true, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
         else hipLaunchKernelGGL((attn_decode_kernel<float, true, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+    } else if (dtype == 1 && a.S == 1 && a.st != nullptr && un_env == 8) {
+        hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 4, 8>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
     } else if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
     else hipLaunchKernelGGL((attn_decode_kernel<float, false, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
     CTTS_HIP_CHECK(hipGetLastError());
