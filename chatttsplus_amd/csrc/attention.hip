@@ -564,7 +564,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const RowMeta* meta_p
 //   O^T[dim][query] += V^T . P^T   v_mfma_f32_16x16x16_f16, A = V^T: the block stages the chunk's V rows transposed in LDS
 //                               (double-buffered, one barrier per chunk), every wave reads its A fragments with 8-byte LDS loads.
 // The running max is shared by the 4 lanes of a query (lanes 16 apart) with two shuffles per chunk; the row sums stay per-lane
-// partials until the end.  Output: normalised rows in the o_proj kernel's fragment-major B operand, like the other kernels.
+// partials until the end.  (Requesting the K fragments one chunk ahead into a second register set measured slower: 59 -> 68 us per
+// launch at 8192 rows -- the extra 32 VGPRs cost more occupancy than the exposed load latency.)  Output: normalised rows in the o_proj kernel's fragment-major B operand, like the other kernels.
 #define FA_PITCH 68        // halfs per V^T row in LDS (64 keys + pad; rows stay 8-byte aligned)
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const RowMeta* meta_p, const float* q_p, const half_t* k_p, const half_t* v_p, const int NHp,
                                                               const int R, const AttnArgs a) {

@@ -119,16 +119,20 @@ __global__ __launch_bounds__(WR * 128) void prefill_gemm_kernel(const void* Wq, 
                 const f32x4 va = lowh ? c : o, vb = lowh ? o : c;
                 const int p0 = 4 * (iq & 1);                                    // outputs p0 .. p0 + 3 of the tile's 8 pairs
                 if (EPI == EPI_SWIGLU) {
-                    if (lowh) {                                                // both lanes of a pair hold it: the low half writes
-                        half4 y = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-                        if (rv) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) y[j] = (half_t)((va[j] / (1.0f + expf(-va[j]))) * vb[j]);
-                        }
-                        const int ktiles_out = (a.n_row_tiles * 8) / 32;
-                        // n >> 4 = global 16-row group: the packed image is contiguous over chunks; 4 consecutive k share a fragment row
-                        *(half4*)((half_t*)a.act_out + xfrag_index<half_t>(r, rt * 8 + p0, ktiles_out)) = y;
+                    // both lanes of a pair hold (gate, up): the low half writes outputs p0, p0 + 1, the high half p0 + 2, p0 + 3.  SiLU with
+                    // the hardware exp / reciprocal (relative error ~1e-6, far below the fp16 rounding of the result): the precise expf +
+                    // IEEE division of the decode epilogue cost as many vector instructions here as the whole 384-MFMA main loop
+                    const int jo = lowh ? 0 : 2;
+                    const float g0 = lowh ? va[0] : va[2], g1 = lowh ? va[1] : va[3], u0 = lowh ? vb[0] : vb[2], u1 = lowh ? vb[1] : vb[3];
+                    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                    half2_t y = {(half_t)0.f, (half_t)0.f};
+                    if (rv) {
+                        y[0] = (half_t)(g0 * __frcp_rn(1.0f + __expf(-g0)) * u0);
+                        y[1] = (half_t)(g1 * __frcp_rn(1.0f + __expf(-g1)) * u1);
                     }
+                    const int ktiles_out = (a.n_row_tiles * 8) / 32;
+                    // n >> 4 = global 16-row group: the packed image is contiguous over chunks; consecutive k share a fragment row
+                    *(half2_t*)((half_t*)a.act_out + xfrag_index<half_t>(r, rt * 8 + p0 + jo, ktiles_out)) = y;
                 } else if (rv) {                                             // EPI_QKV
                     const int which = rt / HT, within = rt % HT;
                     const int hh = within >> 2, d0 = ((within & 3) << 3) + p0;

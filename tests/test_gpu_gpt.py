@@ -29,7 +29,7 @@ def model(wd, seed=1234, boost=None):
         if boost is not None:                      # goldens minted with boosted EOS rows (staggered finishes)
             for i in range(4):
                 sd[f"head_code.{i}.parametrizations.weight.original0"][625] *= float(boost)
-        g = GPT(LLAMA, max_batch=34 if boost is None else 4, max_seq_len=700 if boost is None else 128, weight_dtype=wd)
+        g = GPT(LLAMA, max_batch=34 if boost is None else 4, max_seq_len=840 if boost is None else 128, weight_dtype=wd)
         g.load_state_dict(sd)
         _models[key] = (g, sd)
     return _models[key]
@@ -90,6 +90,8 @@ def test_rng_state_after_generate_matches_reference_consumption():
     # more rows than one prompt pass holds (PASS_ROWS = 8192): 8500 / 8580 rows -> two passes, the second attending to keys the first wrote;
     # fp16 runs the LDS-staged prompt GEMM (prefill_gemm.hip) + the 8-queries-per-wave attention, fp32 the 32-row chunk kernels
     ("fp16", 17, 500, [(37 * i) % 400 for i in range(17)], 2, 2e-3),
+    # 5 rows with > 768 keys: two key splits -> the softmax-combine prologue feeding the packed-fp16 residual epilogue (PRO_ATTN + EPI_RESID_XH)
+    ("fp16", 5, 800, [0, 3, 400, 0, 799], 3, 2e-3),
     ("fp32", 33, 260, [(11 * i) % 200 for i in range(33)], 2, 2e-5),
 ])
 def test_teacher_forced_hiddens_vs_oracle(wd, B, T, pad, N, tol):
