@@ -306,6 +306,15 @@ def main():
             e = Leg(gl, dev, rank, world).run(EB, P, EK, W, spk=spk, use_graph=use_graph)
             extra["batch32_lora_merged"] = summarize(e, world)
             gl.close()
+            # per-utterance adapters: 4 different adapters + "none" spread over the 32 sequences of ONE batch, evaluated as
+            # W x + scale * B (A x) per row (two extra launches per layer); the reference can only merge one adapter per call
+            for slot in range(4):
+                g.load_adapter(slot, [(l, t, (rl.standard_normal((8, 768)) * 0.02).astype(np.float32), (rl.standard_normal((768, 8)) * 0.02).astype(np.float32), 2.0)
+                                      for l in range(LLAMA["num_hidden_layers"]) for t in ("q_proj", "k_proj", "v_proj", "o_proj")])
+            g.set_row_adapters([(b % 5) - 1 for b in range(EB)])
+            e = leg.run(EB, P, EK, W, spk=spk, use_graph=use_graph)
+            g.set_row_adapters(None)
+            extra["batch32_lora_per_utterance"] = summarize(e, world)
             if args.dtype == "fp16":
                 # the parity-proven mode (fp32 weights / KV, exact-f32 MFMA: token ids bit-exact vs the reference CPU path, mel / waveform
                 # <= 1e-3 -- DESIGN.md section 2) on the headline workload, same window

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("CTTS_HIP_LIB", _build.LIB_PATH)      # developer knob
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 MAX_BATCH = 128
+MAX_ADAPTERS = 8
 NUM_VQ = 4
 
 
@@ -67,6 +68,9 @@ SYMBOLS = [
     ("ctts_gpt_destroy", None, [_P]),
     ("ctts_gpt_set_weight", C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),
     ("ctts_gpt_merge_lora", C.c_int, [_P, C.c_int, C.c_char_p, _P, _P, C.c_int, C.c_float]),
+    ("ctts_gpt_set_adapter", C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, _P, _P, C.c_int, C.c_float]),
+    ("ctts_gpt_clear_adapter", C.c_int, [_P, C.c_int]),
+    ("ctts_gpt_set_row_adapters", C.c_int, [_P, _P, C.c_int]),
     ("ctts_gpt_finalize", C.c_int, [_P]),
     ("ctts_gpt_kv_bytes", C.c_size_t, [_P]),
     ("ctts_gpt_bind_kv", C.c_int, [_P, _P, C.c_size_t]),

@@ -88,6 +88,12 @@ struct ctts_gpt {
     DevState* st = nullptr;
     int* last_rows = nullptr;
     int* host_pin = nullptr;
+    // per-utterance LoRA (lora.hip): resident adapters [layer][slot][target][16][768] / [layer][slot][target][768][16] (zero padded to r = 16),
+    // per-sequence slot table, low-rank terms of the rows being processed
+    float *lora_A = nullptr, *lora_B = nullptr, *lora_scale = nullptr, *ln1 = nullptr;
+    int* lora_slot_of_seq = nullptr;
+    float *lora_dqkv = nullptr, *lora_do = nullptr;
+    int lora_rows = 0;                           // 1: the current / next generate() calls carry per-sequence adapters
     void* xh = nullptr;                          // fp16 decode, > split_rows rows: residual stream as packed fp16 B operand (EPI_RESID_XH -> PRO_XH)
     float *ssq = nullptr, *scale_o = nullptr, *scale_d = nullptr;   //   per-tile sums of squares [rows][48]; per-row power-of-two scales of the xh rows
     int xh_mode = 1;                             //   env CTTS_XH=0 switches the path off (every block re-normalises fp32 rows: PRO_NORM)
@@ -153,7 +159,8 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
     void* bufs[] = {h->dyn, h->wblob, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->opart, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
-                    h->hist_ring, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d};
+                    h->hist_ring, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d,
+                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -216,6 +223,71 @@ extern "C" int ctts_gpt_merge_lora(ctts_gpt* h, int layer, const char* target, c
     return 0;
 }
 
+// ---- per-utterance LoRA (lora.hip) ---------------------------------------------------------------
+static int lora_target_index(const char* t) {
+    static const char* names[4] = {"q_proj", "k_proj", "v_proj", "o_proj"};
+    for (int i = 0; i < 4; ++i) if (t && !strcmp(t, names[i])) return i;
+    return -1;
+}
+static int lora_ensure_storage(ctts_gpt* h) {
+    if (h->lora_A) return 0;
+    const size_t per = (size_t)h->L * CTTS_MAX_ADAPTERS * 4 * 16 * h->H;
+    if (dev_alloc((void**)&h->lora_A, per * 4) || dev_alloc((void**)&h->lora_B, per * 4) ||
+        dev_alloc((void**)&h->lora_scale, (size_t)h->L * CTTS_MAX_ADAPTERS * 4 * 4) || dev_alloc((void**)&h->lora_slot_of_seq, CTTS_MAX_B * 4) ||
+        dev_alloc((void**)&h->lora_dqkv, (size_t)PASS_ROWS * 3 * h->H * 4) || dev_alloc((void**)&h->lora_do, (size_t)PASS_ROWS * h->H * 4))
+        return 1;
+    CTTS_HIP_CHECK(hipMemset(h->lora_slot_of_seq, 0xFF, CTTS_MAX_B * 4));
+    return 0;
+}
+extern "C" int ctts_gpt_set_adapter(ctts_gpt* h, int slot, int layer, const char* target, const float* A, const float* B, int r, float scale) {
+    if (!h || !h->finalized || !A || !B) { ctts_set_error("set_adapter: handle not finalized or null argument"); return 1; }
+    const int t = lora_target_index(target);
+    if (slot < 0 || slot >= CTTS_MAX_ADAPTERS || layer < 0 || layer >= h->L || t < 0 || r < 1 || r > 16) {
+        ctts_set_error("set_adapter: slot %d / layer %d / target %s / r %d out of range", slot, layer, target ? target : "(null)", r);
+        return 1;
+    }
+    if (lora_ensure_storage(h)) return 1;
+    const int H = h->H;
+    std::vector<float> a16((size_t)16 * H, 0.f), b16((size_t)H * 16, 0.f);
+    for (int k = 0; k < r; ++k) memcpy(&a16[(size_t)k * H], A + (size_t)k * H, (size_t)H * 4);
+    for (int n = 0; n < H; ++n) for (int k = 0; k < r; ++k) b16[(size_t)n * 16 + k] = B[(size_t)n * r + k];
+    const size_t off = (((size_t)layer * CTTS_MAX_ADAPTERS + slot) * 4 + t) * 16 * H;
+    CTTS_HIP_CHECK(hipMemcpy(h->lora_A + off, a16.data(), a16.size() * 4, hipMemcpyHostToDevice));
+    CTTS_HIP_CHECK(hipMemcpy(h->lora_B + off, b16.data(), b16.size() * 4, hipMemcpyHostToDevice));
+    CTTS_HIP_CHECK(hipMemcpy(h->lora_scale + ((size_t)layer * CTTS_MAX_ADAPTERS + slot) * 4 + t, &scale, 4, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int ctts_gpt_clear_adapter(ctts_gpt* h, int slot) {
+    if (!h || slot < 0 || slot >= CTTS_MAX_ADAPTERS) { ctts_set_error("clear_adapter: bad slot"); return 1; }
+    if (!h->lora_A) return 0;
+    const size_t per = (size_t)4 * 16 * h->H;
+    for (int l = 0; l < h->L; ++l) {
+        const size_t off = ((size_t)l * CTTS_MAX_ADAPTERS + slot) * per;
+        CTTS_HIP_CHECK(hipMemset(h->lora_A + off, 0, per * 4));
+        CTTS_HIP_CHECK(hipMemset(h->lora_B + off, 0, per * 4));
+        CTTS_HIP_CHECK(hipMemset(h->lora_scale + ((size_t)l * CTTS_MAX_ADAPTERS + slot) * 4, 0, 16));
+    }
+    return 0;
+}
+extern "C" int ctts_gpt_set_row_adapters(ctts_gpt* h, const int32_t* slots, int B) {
+    if (!h || !h->finalized) { ctts_set_error("set_row_adapters: handle not finalized"); return 1; }
+    if (!slots || B <= 0) { h->lora_rows = 0; return 0; }
+    if (B > CTTS_MAX_B) { ctts_set_error("set_row_adapters: B=%d > %d", B, CTTS_MAX_B); return 1; }
+    bool any = false;
+    for (int b = 0; b < B; ++b) {
+        if (slots[b] >= CTTS_MAX_ADAPTERS) { ctts_set_error("set_row_adapters: slot %d out of range", slots[b]); return 1; }
+        any = any || slots[b] >= 0;
+    }
+    if (!any) { h->lora_rows = 0; return 0; }
+    if (h->fuse_rows || h->fuseqkv_rows) { ctts_set_error("set_row_adapters: not available with the fused-launch diagnostics (CTTS_FUSE_ROWS / CTTS_FUSEQKV_ROWS)"); return 1; }
+    if (lora_ensure_storage(h)) return 1;
+    std::vector<int> tab(CTTS_MAX_B, -1);
+    for (int b = 0; b < B; ++b) tab[b] = slots[b] < 0 ? -1 : slots[b];
+    CTTS_HIP_CHECK(hipMemcpy(h->lora_slot_of_seq, tab.data(), CTTS_MAX_B * 4, hipMemcpyHostToDevice));
+    h->lora_rows = 1;
+    return 0;
+}
+
 // ---- packing ---------------------------------------------------------------------------------
 template <typename WT> static inline WT cvt(float v);
 template <> inline float cvt<float>(float v) { return v; }
@@ -264,6 +336,8 @@ static int finalize_t(ctts_gpt* h) {
                                 *d = need(h, p + "mlp.down_proj.weight", n_d), *l1 = need(h, p + "input_layernorm.weight", H),
                                 *l2 = need(h, p + "post_attention_layernorm.weight", H);
         if (!q || !k || !v || !o || !g || !u || !d || !l1 || !l2) return 1;
+        if (l == 0 && dev_alloc((void**)&h->ln1, (size_t)L * H * 4)) return 1;       // input_layernorm weights, unfolded: the LoRA path needs w * x_hat itself
+        CTTS_HIP_CHECK(hipMemcpy(h->ln1 + (size_t)l * H, l1->data(), (size_t)H * 4, hipMemcpyHostToDevice));
         WT* base = blob.data() + per_layer * l;
         const int HT = H / 16;
         // QKV: tile rows = dims [8t..8t+7 | 8t+32..8t+39] of one head, so RoPE's (d, d+32) pair sits in one tile
@@ -419,6 +493,7 @@ static inline void* kv_layer(ctts_gpt* h, int l, int which) {
 // in o_proj (S = 1 lets the attention write o_proj's packed operand directly): from 4 rows on, split only when one
 // 8-wave block would otherwise loop over more than ~768 keys.
 static inline int decode_splits(const ctts_gpt* h, int B, int L) {
+    if (h->lora_rows) return 1;                            // per-utterance LoRA reads the attention output from o_proj's packed operand (S = 1 path)
     if (const char* e = getenv("CTTS_SPLITS")) { int v = atoi(e); if (v >= 1 && v <= SMAX) return v; }
     int cap = 256 / (B * h->NH);
     cap = cap < 1 ? 1 : (cap > SMAX ? SMAX : cap);
@@ -437,14 +512,15 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // small decode batches: the down projection is launched as 4 split-K slices (192 blocks instead of 48 x 1024 threads);
     // its partial sums dp[0..3] are added, in order, by the next consumers of the residual stream (QKV RMSNorm, o_proj
     // residual, final heads) -- deterministic, no atomics.  x itself is re-materialised by every o_proj.
-    const bool splitd = (st != nullptr) && (R <= h->split_rows) && (nbg == 1) && (h->fuse_rows == 0);
+    const bool lora = h->lora_rows != 0;                   // per-utterance adapters: the residual stream must be materialised in x (no split-K partials)
+    const bool splitd = (st != nullptr) && (R <= h->split_rows) && (nbg == 1) && (h->fuse_rows == 0) && !lora;
     // prompt pass over more than a few chunks: normalise every row once (norm_pack_kernel) instead of in every GEMM block
     const bool prepack = (st == nullptr) && (nbg == 2) && (R > 64) && !getenv("CTTS_NO_PREPACK");
     // prompt pass over >= 128 rows, fp16: LDS-staged 256/128 x 128 MFMA GEMM (prefill_gemm.hip) instead of one weight tile per 32-row block
     static const int pf_env = getenv("CTTS_PREFILL_GEMM") ? atoi(getenv("CTTS_PREFILL_GEMM")) : 1;
     // (measured, prompt pass ms with / without it: 2048 rows 3.4 / 3.9, 2400 rows 3.3 / 4.4, 3072 rows 3.6 / 5.3, 16384 rows 12.8 / 29;
     //  an earlier version of the kernel lost below ~3000 rows: 1200 rows 4.2 vs 2.7, 512 rows 4.4 vs 1.9)
-    const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && (R >= (pf_env > 1 ? pf_env : 2048)) && pf_env;
+    const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && (R >= (pf_env > 1 ? pf_env : 2048)) && pf_env && !lora;
     // fp16 decode above the split-K batch sizes: the residual stream travels between kernels as a packed fp16 B operand + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself
     const bool xhm = (dt == CTTS_DTYPE_F16) && (st != nullptr) && h->xh_mode && !splitd && (R > h->fuse_rows) && (R > h->fuseqkv_rows);
@@ -470,6 +546,12 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x;
         g1.q_out = h->q_buf; g1.k_cache = kv_layer(h, l, 0); g1.v_cache = kv_layer(h, l, 1); g1.rope_rows = rope_rows;
         g1.opart = h->dpart; g1.np = (splitd && l > 0) ? 4 : 0;
+        const size_t lora_l = (size_t)l * CTTS_MAX_ADAPTERS * 4 * 16 * h->H;
+        if (lora) {
+            if (launch_lora_delta_qkv(x, h->ln1 + (size_t)l * h->H, a.eps, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
+                                      h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_dqkv, R, h->H, s)) return 1;
+            g1.lora_delta = h->lora_dqkv;
+        }
         if (prepack) {
             g1.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
@@ -498,6 +580,12 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;
             const bool sp2 = splitd;                       // the down projection's partial sums are folded into x here
             if (xhm) { g2.xh = h->xh; g2.ssq = h->ssq; g2.scale_in = h->scale_o; }
+            if (lora) {
+                if (S != 1) { ctts_set_error("per-utterance LoRA needs unsplit attention"); return 1; }
+                if (launch_lora_delta_o(dt, h->attn_packed, nbg, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
+                                        h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_do, R, h->H, s)) return 1;
+                g2.lora_delta = h->lora_do;
+            }
             if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
             else if (!(h->ablate & 4) && launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (sp2 ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
         }
@@ -627,7 +715,7 @@ extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
 
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
     if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s)) return 1;
-    h->x_has_parts = (h->B <= h->split_rows && h->B <= 16 && h->fuse_rows == 0) ? 1 : 0;    // same condition as `splitd` in run_layers
+    h->x_has_parts = (h->B <= h->split_rows && h->B <= 16 && h->fuse_rows == 0 && !h->lora_rows) ? 1 : 0;    // same condition as `splitd` in run_layers
     const int rc = run_sample_phase(h, s);          // the heads add dpart[0..3]; the sampler then re-materialises x_dec
     h->x_has_parts = 0;
     return rc;
@@ -635,8 +723,8 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows, h->cur_splits,
-             h->fuseqkv_rows, h->xh_mode);
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows, h->cur_splits,
+             h->fuseqkv_rows, h->xh_mode, h->lora_rows);
     const std::string key(sig);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }

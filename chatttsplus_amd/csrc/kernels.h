@@ -48,6 +48,8 @@ struct GemmArgs {
     float* ssq;             // [rows][48] sum of squares of the fp32 residual row over each 16-column tile (written by EPI_RESID_XH)
     const float* scale_in;  // [rows] power-of-two scale of the xh rows: EPI_RESID_XH multiplies by it, PRO_XH divides the C tile by it
     float* scale_out;       // [rows] PRO_XH / PRO_NORM (block 0): 2^floor(log2(rs)) of this normalisation = the scale of the NEXT xh rows
+    // per-utterance LoRA (lora.hip): low-rank term of every row, added in the epilogue.  EPI_QKV: [rows][3][768]; EPI_RESID*: [rows][768]
+    const float* lora_delta;
 };
 
 struct AttnArgs {
@@ -145,6 +147,10 @@ struct QkvAttnArgs {
 };
 int launch_qkv_attention(int dtype, const QkvAttnArgs& a, hipStream_t s);
 int launch_gemm(int dtype, int nbg, int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s);
+int launch_lora_delta_qkv(const float* x, const float* lnw, float eps, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
+                          const float* scale_l, float* delta, int rows, int H, hipStream_t s);
+int launch_lora_delta_o(int dtype, const void* attn_packed, int nbg, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
+                        const float* scale_l, float* delta, int rows, int H, hipStream_t s);
 int launch_prefill_gemm(int epi, const GemmArgs& a, hipStream_t s);      // prefill_gemm.hip: fp16 prompt-pass GEMM (QKV / RESID / SWIGLU epilogues)
 int launch_norm_pack(int dtype, const float* x, void* out_packed, int R, int nbg, float eps, hipStream_t s);
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s);

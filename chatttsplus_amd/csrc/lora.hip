@@ -1,0 +1,114 @@
+// Per-utterance LoRA: adapters that stay SEPARATE from the packed weights, one (or none) per sequence of a batch.
+//
+// The reference serves an adapter by merging it into a deep copy of the whole Llama for the call (peft merge_and_unload,
+// pipelines/chattts_plus_pipeline.py:420-432: W' = W + (alpha / r) B A on q/k/v/o of every layer) -- one adapter per batch.
+// Here  y = W x + scale * B (A x)  is evaluated per row: a small kernel per projection group computes the low-rank term of every
+// row with the row's own adapter (rows of sequences without one get zeros) and the projection kernels add it in their epilogues
+// (before RoPE / the cache append for q/k/v, with the residual for o_proj).  Two extra launches per layer, paid only by batches
+// that carry adapters; the algebra equals the merged weights up to fp32 rounding.
+#include "kernels.h"
+
+#define LORA_RMAX 16
+
+__device__ inline float block_sum_256(float v, float* red, int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return s;
+}
+
+// q/k/v targets: input = input_layernorm(x) (llama.py:726-731: the projections see the normalised hidden states)
+//   x [rows][768] fp32 residual stream, lnw [768], meta row -> sequence, slot_of_seq [max_batch] (-1 = no adapter),
+//   A_l / B_l: this layer's adapters, [slot][target 0..3][16][768] and [slot][target][768][16] (zero padded to r = 16), scale_l [slot][4]
+//   delta [rows][3][768]
+__global__ __launch_bounds__(256) void lora_delta_qkv_kernel(const float* x, const float* lnw, float eps, const RowMeta* meta, const int* slot_of_seq,
+                                                           const float* A_l, const float* B_l, const float* scale_l, float* delta, int H) {
+    __shared__ float hw[768];
+    __shared__ float u[3][LORA_RMAX];
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = slot_of_seq[meta[r].seq];
+    float* drow = delta + (size_t)r * 3 * H;
+    if (slot < 0) {
+        for (int i = tid; i < 3 * H; i += 256) drow[i] = 0.f;
+        return;
+    }
+    float xv[3], ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { xv[i] = x[(size_t)r * H + tid + 256 * i]; ss += xv[i] * xv[i]; }
+    ss = block_sum_256(ss, red, tid);
+    const float rs = 1.0f / sqrtf(ss / (float)H + eps);                  // LlamaRMSNorm (llama.py:82-87)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hw[tid + 256 * i] = lnw[tid + 256 * i] * (xv[i] * rs);
+    __syncthreads();
+    // u[t][k] = A_t[k] . hw : 48 dot products of length 768, 12 per wave
+    for (int j = wave; j < 3 * LORA_RMAX; j += 4) {
+        const int t = j / LORA_RMAX, k = j % LORA_RMAX;
+        const float* ar = A_l + (((size_t)slot * 4 + t) * LORA_RMAX + k) * H;
+        float acc = 0.f;
+        for (int c = lane; c < H; c += 64) acc += ar[c] * hw[c];
+        acc = wave_sum(acc);
+        if (lane == 0) u[t][k] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * H; i += 256) {
+        const int t = i / H, n = i % H;
+        const float* br = B_l + (((size_t)slot * 4 + t) * H + n) * LORA_RMAX;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < LORA_RMAX; ++k) acc += br[k] * u[t][k];
+        drow[i] = scale_l[slot * 4 + t] * acc;
+    }
+}
+
+// o_proj target: input = the attention output rows, read back from the o_proj kernel's fragment-major B operand (S = 1 path)
+template <typename WT>
+__global__ __launch_bounds__(256) void lora_delta_o_kernel(const void* attn_packed, int nbg, const RowMeta* meta, const int* slot_of_seq, const float* A_l,
+                                                         const float* B_l, const float* scale_l, float* delta, int H) {
+    __shared__ float o[768];
+    __shared__ float u[LORA_RMAX];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = slot_of_seq[meta[r].seq];
+    float* drow = delta + (size_t)r * H;
+    if (slot < 0) {
+        for (int i = tid; i < H; i += 256) drow[i] = 0.f;
+        return;
+    }
+    constexpr int KT = WTraits<WT>::KT, EPL = WTraits<WT>::EPL;
+    const int NB = 16 * nbg, kt = H / KT;
+    const WT* base = (const WT*)attn_packed + (size_t)(r / NB) * nbg * kt * 64 * EPL;
+    for (int c = tid; c < H; c += 256) o[c] = (float)base[xfrag_index<WT>(r % NB, c, kt)];
+    __syncthreads();
+    for (int k = wave; k < LORA_RMAX; k += 4) {
+        const float* ar = A_l + (((size_t)slot * 4 + 3) * LORA_RMAX + k) * H;
+        float acc = 0.f;
+        for (int c = lane; c < H; c += 64) acc += ar[c] * o[c];
+        acc = wave_sum(acc);
+        if (lane == 0) u[k] = acc;
+    }
+    __syncthreads();
+    for (int n = tid; n < H; n += 256) {
+        const float* br = B_l + (((size_t)slot * 4 + 3) * H + n) * LORA_RMAX;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < LORA_RMAX; ++k) acc += br[k] * u[k];
+        drow[n] = scale_l[slot * 4 + 3] * acc;
+    }
+}
+
+int launch_lora_delta_qkv(const float* x, const float* lnw, float eps, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
+                          const float* scale_l, float* delta, int rows, int H, hipStream_t s) {
+    if (H != 768) { ctts_set_error("lora: hidden %d != 768", H); return 1; }
+    hipLaunchKernelGGL(lora_delta_qkv_kernel, dim3(rows), dim3(256), 0, s, x, lnw, eps, meta, slot_of_seq, A_l, B_l, scale_l, delta, H);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_lora_delta_o(int dtype, const void* attn_packed, int nbg, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
+                        const float* scale_l, float* delta, int rows, int H, hipStream_t s) {
+    if (dtype == 1) hipLaunchKernelGGL(lora_delta_o_kernel<half_t>, dim3(rows), dim3(256), 0, s, attn_packed, nbg, meta, slot_of_seq, A_l, B_l, scale_l, delta, H);
+    else hipLaunchKernelGGL(lora_delta_o_kernel<float>, dim3(rows), dim3(256), 0, s, attn_packed, nbg, meta, slot_of_seq, A_l, B_l, scale_l, delta, H);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}

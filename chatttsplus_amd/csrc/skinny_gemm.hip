@@ -379,7 +379,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             const int r = row0 + n;
             if (r >= R) continue;
             const int col = rt * 16 + i;
-            const float v = c_elem(i, n);
+            float v = c_elem(i, n);
+            if ((EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_RESID_XH) && a.lora_delta != nullptr)
+                v += a.lora_delta[(size_t)r * (a.n_row_tiles * 16) + col];          // per-utterance LoRA term of o_proj (lora.hip)
             if (EPI == EPI_PART) {
                 a.part_out[((size_t)r * gridDim.z + blockIdx.z) * (a.n_row_tiles * 16) + col] = v;
             } else if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
@@ -418,10 +420,15 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             const int which = rt / HT, within = rt % HT;
             const int h = within >> 2, d = ((within & 3) << 3) + p;
             float ya = va, yb = vb;
+            if (a.lora_delta != nullptr) {        // per-utterance LoRA term of q/k/v (lora.hip): part of the projection, so before RoPE
+                const float* dl = a.lora_delta + ((size_t)r * 3 + which) * K + h * CTTS_HEAD_DIM + d;
+                ya += dl[0]; yb += dl[32];
+            }
+            const float va2 = ya, vb2 = yb;
             if (which < 2) {
                 // q*cos + rotate_half(q)*sin, products rounded separately like the reference (llama.py:180-181)
-                ya = __fadd_rn(__fmul_rn(va, rope_c[ti]), __fmul_rn(-vb, rope_s[ti]));
-                yb = __fadd_rn(__fmul_rn(vb, rope_c[ti]), __fmul_rn(va, rope_s[ti]));
+                ya = __fadd_rn(__fmul_rn(va2, rope_c[ti]), __fmul_rn(-vb2, rope_s[ti]));
+                yb = __fadd_rn(__fmul_rn(vb2, rope_c[ti]), __fmul_rn(va2, rope_s[ti]));
             }
             if (which == 0) {
                 float* q = a.q_out + ((size_t)r * NH + h) * CTTS_HEAD_DIM;

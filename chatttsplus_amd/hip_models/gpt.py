@@ -203,6 +203,28 @@ class GPT:
         g.load_state_dict(self._sd_host, _share_kv=self._kv)
         return g
 
+    # -- per-utterance LoRA: adapters resident beside the packed weights, one slot (or none) per sequence -------------
+    def load_adapter(self, slot: int, adapters) -> None:
+        """`adapters` = [(layer, target, A[r,in], B[out,r], scale)] as returned by pipeline.load_lora_adapter; replaces whatever the slot held."""
+        if not self._finalized:
+            raise _lib.HipBackendError("weights not loaded")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_gpt_clear_adapter(self._h, int(slot)), "clear_adapter")
+            for (layer, target, A, B, scale) in adapters:
+                A = np.ascontiguousarray(A, dtype=np.float32); B = np.ascontiguousarray(B, dtype=np.float32)
+                _lib.check(self._lib.ctts_gpt_set_adapter(self._h, int(slot), int(layer), target.encode(), A.ctypes.data_as(C.c_void_p),
+                                                          B.ctypes.data_as(C.c_void_p), int(A.shape[0]), float(scale)), "set_adapter")
+
+    def set_row_adapters(self, slots) -> None:
+        """Adapter slot (or -1 / None) per sequence for the following generate() calls; None switches the per-row path off.  With it
+        every q/k/v/o projection evaluates W x + scale * B (A x) per row (two extra launches per layer)."""
+        with torch.cuda.device(self.device):
+            if slots is None:
+                _lib.check(self._lib.ctts_gpt_set_row_adapters(self._h, None, 0), "set_row_adapters")
+                return
+            arr = np.ascontiguousarray([(-1 if s is None else int(s)) for s in slots], dtype=np.int32)
+            _lib.check(self._lib.ctts_gpt_set_row_adapters(self._h, arr.ctypes.data_as(C.c_void_p), int(arr.size)), "set_row_adapters")
+
     # -- get_emb (gpt.py:125-149) ----------------------------------------------------------------
     def __call__(self, input_ids: torch.Tensor, text_mask: torch.Tensor, spk_emb=None, spk_emb_ids: Optional[int] = None) -> torch.Tensor:
         """emb[B,T,H] fp32 on the device, computed by embed_prompt_kernel (ctts_gpt_embed).  With `spk_emb` (a [H] vector, a

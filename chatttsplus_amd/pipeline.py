@@ -116,6 +116,29 @@ def load_lora_adapter(path: str):
     return out
 
 
+def merge_short_sentences(pieces: List[str], min_len: int = 30) -> List[str]:
+    """The merge step of the reference's text optimisation (pipeline:353-377), after whatever splitter produced `pieces`: sentences
+    shorter than `min_len` characters are chained with " [uv_break] " until the chain exceeds `min_len`; a long sentence absorbs the
+    chain in front of it; a left-over chain becomes its own utterance if long enough (or if nothing else exists), else it is
+    appended to the last utterance.  CPU text work in front of the hot path -- kept because it decides the batch the path sees."""
+    out: List[str] = []
+    chain = ""
+    for piece in pieces:
+        if len(piece) < min_len:
+            chain += f"{piece} [uv_break] "
+            if len(chain) > min_len:
+                out.append(chain)
+                chain = ""
+        else:
+            out.append(chain + piece)
+            chain = ""
+    if len(chain) > min_len or not out:
+        out.append(chain)
+    elif chain:
+        out[-1] += f" [uv_break] {chain}"
+    return out
+
+
 class ChatTTSPlusPipeline:
     def __init__(self, cfg, **kwargs):
         self.logger = logging.getLogger(self.__class__.__name__)
@@ -276,6 +299,27 @@ class ChatTTSPlusPipeline:
             wavs.append(vocos.decode(mel)[0])
         return wavs
 
+    def _adapter_slots(self, gpt, paths) -> List[int]:
+        """Slot per utterance for `paths` (adapter directory or None each); adapters are loaded into the engine's resident slots on first
+        use and evicted least-recently-used first (at most _lib.MAX_ADAPTERS distinct adapters per slice)."""
+        if not hasattr(self, "_slot_of_path"):
+            self._slot_of_path = OrderedDict()
+        need = [p for p in dict.fromkeys(paths) if p]
+        if len(need) > _lib.MAX_ADAPTERS:
+            raise _lib.HipBackendError(f"{len(need)} distinct adapters in one slice; the engine holds {_lib.MAX_ADAPTERS}: lower slice_size")
+        for p in need:
+            if p in self._slot_of_path:
+                self._slot_of_path.move_to_end(p)
+                continue
+            if len(self._slot_of_path) >= _lib.MAX_ADAPTERS:
+                victim = next(q for q in self._slot_of_path if q not in need)
+                slot = self._slot_of_path.pop(victim)
+            else:
+                slot = next(i for i in range(_lib.MAX_ADAPTERS) if i not in self._slot_of_path.values())
+            gpt.load_adapter(slot, load_lora_adapter(p))
+            self._slot_of_path[p] = slot
+        return [(-1 if not p else self._slot_of_path[p]) for p in paths]
+
     def _gpt_for_lora(self, lora_path: Optional[str]):
         """pipeline:420-434,465-470: the reference merges the adapter into a copy of the Llama for the call and restores
         `gpt_org` afterwards, i.e. it holds ONE merged model at a time.  Here a merged sibling engine (GPT.with_lora: its own
@@ -301,10 +345,20 @@ class ChatTTSPlusPipeline:
         if not use_decoder and not refine_text_only:
             raise _lib.HipBackendError("use_decoder=False (decode codes through dvae_encode) is not served by the hip backend")
         if do_text_optimization and self.text_splitter is not None:
-            text_in = self.text_splitter(text_in)                         # pipeline:353-377 (pluggable; CPU text work)
+            # pipeline:353-377: split on newlines, hand the lines to the (pluggable) sentence splitter, merge short sentences
+            lines = [t.strip() for text_ in text_in for t in text_.split("\n") if t.strip()]
+            text_in = merge_short_sentences(self.text_splitter(lines))
         text_in = [self.normalizer(t, do_text_normalization, do_homophone_replacement, lang) for t in text_in]
         slice_size = int(kwargs.get("slice_size", self.models_dict["gpt"].max_batch))     # reference: 4 (pipeline:391)
         gpt = self._gpt_for_lora(kwargs.get("lora_path"))
+        # per-utterance adapters (the reference can only merge ONE adapter for a whole call): `lora_paths` = one adapter
+        # directory (or None) per input text; adapters stay resident in up to 8 slots of the base engine, each row selects its own
+        lora_paths = kwargs.get("lora_paths")
+        if lora_paths is not None:
+            if kwargs.get("lora_path"):
+                raise _lib.HipBackendError("lora_path (one merged adapter) and lora_paths (one adapter per utterance) are exclusive")
+            if len(lora_paths) != len(text_in):
+                raise _lib.HipBackendError(f"lora_paths: {len(lora_paths)} entries for {len(text_in)} utterances (after text splitting)")
         tok = self.models_dict["tokenizer"]
         for ii in range(0, len(text_in), slice_size):
             text = list(text_in[ii:ii + slice_size])
@@ -318,7 +372,15 @@ class ChatTTSPlusPipeline:
                 continue
             text = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in text]   # pipeline:414-416
             length, pass_batch_count, last = 0, 0, None
-            for result in self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt):
+            if lora_paths is not None:
+                gpt.set_row_adapters(self._adapter_slots(gpt, lora_paths[ii:ii + slice_size]))
+            try:
+                results = list(self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt)) if lora_paths is not None else \
+                    self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt)
+            finally:
+                if lora_paths is not None:
+                    gpt.set_row_adapters(None)
+            for result in results:
                 if not stream:
                     yield self._decode_to_wavs(result.hiddens, use_decoder)
                     continue

@@ -72,6 +72,17 @@ int ctts_gpt_set_weight(ctts_gpt* h, const char* name, const float* data, size_t
  * ("q_proj","k_proj","v_proj","o_proj") of one layer; A [r, in], B [out, r], host fp32.  Call before finalize. */
 int ctts_gpt_merge_lora(ctts_gpt* h, int layer, const char* target, const float* A, const float* B, int r, float scale);
 
+/* Per-utterance LoRA (no counterpart in the reference, which merges ONE adapter for a whole batch, pipeline:420-432):
+ * up to CTTS_MAX_ADAPTERS adapters stay resident beside the packed weights; every sequence of a batch selects one slot or none and
+ * the projections evaluate  W x + scale * B (A x)  per row.  Call after ctts_gpt_finalize.
+ *   set_adapter      one (layer, target in "q_proj","k_proj","v_proj","o_proj") of adapter `slot`: A [r][hidden], B [hidden][r], host fp32, r <= 16
+ *   clear_adapter    zeroes a slot (all layers / targets)
+ *   set_row_adapters slot (or -1) per sequence for the following ctts_gpt_begin calls; slots == NULL or B == 0 switches the path off */
+#define CTTS_MAX_ADAPTERS 8
+int ctts_gpt_set_adapter(ctts_gpt* h, int slot, int layer, const char* target, const float* A, const float* B, int r, float scale);
+int ctts_gpt_clear_adapter(ctts_gpt* h, int slot);
+int ctts_gpt_set_row_adapters(ctts_gpt* h, const int32_t* slots, int B);
+
 /* folds weight-norm heads (W = g*v/||v||_row, gpt.py:57-77), packs QKV / gate|up, converts to the
  * engine dtype, uploads.  After this the host copies are released. */
 int ctts_gpt_finalize(ctts_gpt* h);

@@ -238,3 +238,72 @@ def test_pipeline_lora_path_end_to_end_batch32(tmp_path):
     wav_ref = ref_cpu.vocos_decode(vsd, ref_cpu.dvae_decode(dsd, ref.hiddens[3])).numpy()
     w = base[3].cpu().numpy()
     assert float(np.sqrt(np.mean((w - wav_ref) ** 2))) / float(np.sqrt(np.mean(wav_ref ** 2))) <= 1e-3
+
+
+@pytest.mark.parametrize("wd", ["fp32", "fp16"])
+def test_per_utterance_lora_matches_per_row_merged_oracle(wd):
+    """several adapters inside ONE batch (the reference can only merge one adapter for a whole call, pipeline:420-432).
+    Rows 0/3 use adapter 0, rows 1/4 adapter 1, rows 2/5 none; every row must equal the oracle run with THAT row's merged weights
+    (W + scale * B A on q/k/v/o).  fp32: token ids identical and hiddens <= 1e-4 (the fused W x + s B (A x) differs from the merged
+    product only by fp32 rounding); fp16: first hiddens within 2e-3 rel-RMS.  Also: switching the per-row path off restores the base model."""
+    from chatttsplus_amd.hip_models import GPT
+    cfg = dict(synth.GPT_REAL); cfg["num_hidden_layers"] = 6
+    llama = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=6)
+    sd = synth.gpt_state_dict(cfg, 1234)
+    rng = np.random.Generator(np.random.Philox(key=77))
+    adapters, merged = [], []
+    for ai in range(2):
+        ad, m = [], {k: v.copy() for k, v in sd.items()}
+        r = 8 if ai == 0 else 4                                            # different ranks
+        for l in range(6):
+            for t in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                A = (rng.standard_normal((r, 768)) * 0.05).astype(np.float32); Bm = (rng.standard_normal((768, r)) * 0.05).astype(np.float32)
+                ad.append((l, t, A, Bm, 2.0))
+                m[f"gpt.layers.{l}.self_attn.{t}.weight"] = (m[f"gpt.layers.{l}.self_attn.{t}.weight"] + 2.0 * (Bm @ A)).astype(np.float32)
+        adapters.append(ad); merged.append(m)
+    B, T, N = 6, 14, 8
+    pads = [0, 3, 0, 5, 1, 2]
+    ids, mask = synth.prompt_ids(B, T, cfg["num_text_tokens"], 19, pad_left=pads)
+    q = torch.from_numpy(np.stack([synth.exp_noise(31, i, 4 * B, 626) for i in range(N)]))
+    slots = [0, 1, -1, 0, 1, -1]
+    lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+    lp = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+    g = GPT(llama, max_batch=B, max_seq_len=64, weight_dtype=wd)
+    g.load_state_dict(sd)
+    g.load_adapter(0, adapters[0]); g.load_adapter(1, adapters[1])
+
+    def run(row_slots):
+        g.set_row_adapters(row_slots)
+        emb = g(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))
+        out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N,
+                              min_new_token=N, logits_warpers=lw, logits_processors=lp, return_hidden=True, noise=q))[-1]
+        g.set_row_adapters(None)
+        return out
+
+    out = run(slots)
+    base = run(None)
+    refs = {}
+    for s_ in (0, 1, -1):
+        rows = [b for b in range(B) if slots[b] == s_]
+        o = ref_cpu.OracleGPT(merged[s_] if s_ >= 0 else sd, 12)
+        emb = o.embed(torch.from_numpy(ids[rows]), torch.ones(len(rows), T, dtype=torch.bool))
+        qr = q.view(N, B, 4, 626)[:, rows].reshape(N, 4 * len(rows), 626).contiguous()
+        ref = o.generate(emb, torch.from_numpy(ids[rows]), ref_cpu.SamplerParams(min_new_token=N), attention_mask=torch.from_numpy(mask[rows]),
+                         max_new_token=N, noise=ref_cpu.ArrayNoise(qr))
+        for j, b in enumerate(rows):
+            refs[b] = (ref.ids[j], ref.hiddens[j])
+    for b in range(B):
+        rid, rh = refs[b]
+        h0 = out.hiddens[b][0].cpu()
+        rel = float((h0 - rh[0]).pow(2).mean().sqrt() / rh[0].pow(2).mean().sqrt())
+        if wd == "fp32":
+            assert torch.equal(out.ids[b].cpu(), rid), f"row {b} (slot {slots[b]}): token ids differ from the merged-weights oracle"
+            assert float((out.hiddens[b].cpu() - rh).abs().max()) <= 1e-4, f"row {b}"
+        else:
+            assert rel <= 2e-3, f"row {b} (slot {slots[b]}): first hidden rel-RMS {rel}"
+    # the adapters matter (rows with an adapter differ from the base model) and switching them off restores the base model exactly
+    assert not torch.equal(out.hiddens[0], base.hiddens[0]) and not torch.equal(out.hiddens[1], base.hiddens[1])
+    if wd == "fp32":
+        for b in (2, 5):
+            assert torch.equal(base.ids[b], out.ids[b])
+    g.close()

@@ -155,3 +155,41 @@ def test_dvae_class_dispatches_to_the_encoder_for_encode_configs():
         hip_models.DVAE(decoder_config=dict(idim=512, odim=512, hidden=256, n_layer=12, bn_dim=128),
                         encoder_config=dict(idim=512, odim=1024, hidden=256, n_layer=12, bn_dim=128),
                         vq_config=dict(dim=1024, levels=[5, 5, 5, 5], G=2, R=2), dim=512)
+
+
+def test_merge_short_sentences_matches_the_reference_rule():
+    """pipeline:353-377: the merge of short sentences behind the (pluggable) splitter -- checked against a direct transcription of
+    the rule's observable behaviour on hand-made cases (the reference function cannot be called in isolation: it is inlined in _infer)."""
+    from chatttsplus_amd.pipeline import merge_short_sentences as m
+    long_a, long_b = "x" * 40, "y" * 31
+    assert m([long_a, long_b]) == [long_a, long_b]
+    assert m(["hi"]) == ["hi [uv_break] "]                                   # nothing else exists: the chain is emitted as is
+    assert m(["hi", long_a]) == ["hi [uv_break] " + long_a]                  # a long sentence absorbs the chain in front of it
+    assert m([long_a, "hi"]) == [long_a + " [uv_break] hi [uv_break] "]      # short left-over appended to the last utterance
+    s12 = "a" * 12
+    out = m([s12, s12, s12, long_a])                                         # the chain exceeds 30 characters after two pieces
+    assert out == [f"{s12} [uv_break] {s12} [uv_break] ", f"{s12} [uv_break] " + long_a]
+    assert m([]) == [""]
+
+
+def test_adapter_slot_cache_lru(tmp_path, monkeypatch):
+    """pipeline._adapter_slots: per-utterance adapters -> resident engine slots, loaded once, least-recently-used evicted first."""
+    import chatttsplus_amd.pipeline as pl
+    from chatttsplus_amd import _lib
+    loaded = []
+    monkeypatch.setattr(pl, "load_lora_adapter", lambda p: [("adapter-of", p)])
+
+    class G:
+        def load_adapter(self, slot, adapters):
+            loaded.append((slot, adapters[0][1]))
+    pipe = object.__new__(pl.ChatTTSPlusPipeline)
+    g = G()
+    assert pipe._adapter_slots(g, ["a", None, "b", "a"]) == [0, -1, 1, 0]
+    assert loaded == [(0, "a"), (1, "b")]
+    assert pipe._adapter_slots(g, ["b", "b"]) == [1, 1] and len(loaded) == 2          # cached
+    many = [f"p{i}" for i in range(_lib.MAX_ADAPTERS - 1)]
+    slots = pipe._adapter_slots(g, many + ["b"])                                        # "a" is the least recently used -> evicted
+    assert len(set(slots)) == _lib.MAX_ADAPTERS and "a" not in pipe._slot_of_path and slots[-1] == 1
+    import pytest
+    with pytest.raises(_lib.HipBackendError):
+        pipe._adapter_slots(g, [f"q{i}" for i in range(_lib.MAX_ADAPTERS + 1)])
