@@ -429,9 +429,83 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
     tot = block_sum_d(red, tot, lane, wave);
 
     unsigned taken = ~valid, kept = 0;
+    const int topk = (d->cfg.top_k > 0) ? d->cfg.top_k : V;
+    // Selection of the top-p / top-k survivors (a prefix of the descending order, <= top_k + ties long).  Fast path, the block-wide
+    // version of sample_row's: a value threshold T0 <= (k-th largest value) from the two largest thread maxima of every wave (32
+    // distinct elements: their k-th largest bounds the k-th largest overall from below, k <= 32), the candidates {x >= T0} compacted
+    // into LDS, ranked and cut by wave 0, and the kept indices handed back to their owner threads -- 4 barriers instead of one
+    // block-wide arg-max round (wave reduction + LDS + barrier) per survivor.  Falls back to the serial rounds below.
+    __shared__ unsigned top2_s[16][2];
+    __shared__ int wtot_s[16];
+    __shared__ unsigned long long cand_s[64];
+    __shared__ int sel_s[64];
+    __shared__ int nsel_s;
+    bool fast = false;
+    if (topk <= 32) {
+        unsigned vkey[TVPT], head = 0u;
+#pragma unroll
+        for (int i = 0; i < TVPT; ++i) { vkey[i] = ((valid >> i) & 1u) ? f32_key(x[i]) : 0u; head = max(head, vkey[i]); }
+        const unsigned long long hk = ((unsigned long long)head << 32) | (unsigned)lane;
+        const unsigned long long b1 = wave_max_u64(hk);
+        const unsigned long long b2 = wave_max_u64(hk == b1 ? 0ull : hk);
+        if (lane == 0) { top2_s[wave][0] = (unsigned)(b1 >> 32); top2_s[wave][1] = (unsigned)(b2 >> 32); }
+        __syncthreads();
+        const unsigned mine32 = (lane < 32) ? top2_s[lane >> 1][lane & 1] : 0u;
+        int greater = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) greater += (top2_s[j >> 1][j & 1] > mine32) ? 1 : 0;
+        const unsigned T0 = ~(unsigned)wave_max_u64((lane < 32 && greater < topk) ? (unsigned long long)(~mine32) : 0ull);
+        unsigned cmask = 0;
+#pragma unroll
+        for (int i = 0; i < TVPT; ++i) cmask |= (((valid >> i) & 1u) && vkey[i] >= T0) ? (1u << i) : 0u;
+        const int cnt = __builtin_popcount(cmask);
+        int incl = cnt;                                              // inclusive prefix over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) wtot_s[wave] = incl;
+        __syncthreads();
+        int base = 0, C = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { base += (w < wave) ? wtot_s[w] : 0; C += wtot_s[w]; }
+        if (C <= 64) {                                               // uniform over the block
+            fast = true;
+            int pos = base + incl - cnt;
+#pragma unroll
+            for (int i = 0; i < TVPT; ++i)
+                if ((cmask >> i) & 1u) cand_s[pos++] = ((unsigned long long)vkey[i] << 32) | (unsigned)(tid + 1024 * i);
+            __syncthreads();
+            if (wave == 0) {
+                const unsigned long long ck = (lane < C) ? cand_s[lane] : 0ull;
+                int rank = 0;
+                for (int j = 0; j < C; ++j) rank += (readlane_u64(ck, j) > ck) ? 1 : 0;
+                const unsigned lo = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)(unsigned)ck);
+                const unsigned hi = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)(unsigned)(ck >> 32));
+                const float bv = key_f32(hi);
+                const float p_r = (lane < C) ? expf(bv - mx) * inv : 0.f;
+                const float vk = readlane_f(bv, (topk - 1) & 63);
+                double cum = 0.0, cum_mine = 0.0;
+                for (int r = 0; r < C; ++r) {
+                    if (lane == r) cum_mine = cum;
+                    cum += (double)readlane_f(p_r, r);
+                }
+                const float cr = (float)(tot - cum_mine);
+                const bool stop = (lane >= C) || (lane >= topk && bv != vk) || (cr <= d->cfg.top_p_threshold && lane >= d->cfg.min_keep);
+                const unsigned long long sb = __builtin_amdgcn_ballot_w64(stop);
+                const int nsel = (sb == 0ull) ? 64 : (int)__builtin_ctzll(sb);
+                if (lane < nsel) sel_s[lane] = (int)lo;
+                if (lane == 0) nsel_s = nsel;
+            }
+            __syncthreads();
+            const int nsel = nsel_s;
+            for (int r = 0; r < nsel; ++r) {
+                const int bi = sel_s[r];
+                if ((bi & 1023) == tid) kept |= 1u << (bi >> 10);
+            }
+        }
+    }
+    if (!fast) {
     double cum_before = 0.0;
     float vk = 0.f;
-    const int topk = (d->cfg.top_k > 0) ? d->cfg.top_k : V;
     // every thread caches the key of its largest untaken value; only the thread whose element was selected rescans its 21 values
     auto my_best = [&]() -> unsigned long long {
         unsigned long long key = 0ull;
@@ -454,6 +528,7 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
         if (tid == (bi & 1023)) { taken |= 1u << (bi >> 10); kept |= 1u << (bi >> 10); mykey = my_best(); }
         if (r == topk - 1) vk = bv;
         cum_before += (double)(expf(bv - mx) * inv);
+    }
     }
     __syncthreads();                                                 // the last round's slot reads are done before `red` is reused
     if (step < d->cfg.min_new && tid == (d->cfg.eos & 1023)) kept &= ~(1u << (d->cfg.eos >> 10));      // gpt.py:477-478

@@ -91,6 +91,20 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
                          speaker_audio_text="a b", params_infer_code=InferCodeParams(max_new_token=12, min_new_token=12, show_tqdm=False)))
     assert len(zs) == 1 and [w.shape[0] for w in zs[0]] == [256 * 23, 256 * 23] and all(bool(torch.isfinite(w).all()) for w in zs[0])
 
+    # infer_sharded with no process group (world 1) on the real engine: per-utterance speaker rows from a table; every utterance must
+    # equal the plain infer() run with its own speaker (same seed: device noise is keyed by row, so compare one utterance at a time)
+    table = torch.stack([codec.speaker_to_vector(spk), torch.from_numpy(synth.speaker_vector(5))], 0)
+    p1 = InferCodeParams(prompt="[speed_5]", max_new_token=10, min_new_token=10, show_tqdm=False)
+    for which in (0, 1):
+        torch.manual_seed(5)
+        mine, sw, lens = pipe.infer_sharded(["a b c d"], speaker_index=[which], speaker_table=table, params_infer_code=p1)
+        torch.manual_seed(5)
+        plain = list(pipe.infer(["a b c d"], skip_refine_text=True, do_text_optimization=False,
+                                params_infer_code=InferCodeParams(prompt="[speed_5]", spk_emb=table[which], max_new_token=10, min_new_token=10, show_tqdm=False)))[0]
+        assert mine == [0] and lens == [10] and torch.equal(sw[0], plain[0]), f"speaker {which}"
+    mine, sw, lens = pipe.infer_sharded(["a b", "c d a", "b"], speaker_index=[1, 0, 1], speaker_table=table, params_infer_code=p1)
+    assert mine == [0, 1, 2] and lens == [10, 10, 10] and [int(w.shape[0]) for w in sw] == [256 * 19] * 3
+
     # default infer() path: refine-text pass first (pipeline:399-411), then code inference on the refined text
     from chatttsplus_amd.pipeline import RefineTextParams
     rp = RefineTextParams(max_new_token=6, show_tqdm=False)
