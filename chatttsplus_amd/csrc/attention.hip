@@ -557,8 +557,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const RowMeta* meta_p
 // The VALU kernels above spend ~8 vector instructions per (query, key) pair whatever the tiling (attn_prefill_kernel reads K/V
 // 8x less often than the row-by-row kernel and is no faster: 42-65 % of a 32 x 512-token prompt pass).  Here
 //   block = (sequence, head, 64 consecutive queries), 4 waves x 16 queries, keys in chunks of 64;
-//   S^T[key][query] = K . Q^T   v_mfma_f32_16x16x32_f16, A = K rows straight from the cache (16 keys x 32 dims = one 16-byte load per
-//                               lane), B = Q (fp16, pre-scaled by 1/8).  In the C layout a lane owns ONE query (lane & 15) and the
+//   S^T[key][query] = K . Q^T   v_mfma_f32_16x16x32_f16, A = K rows (16 keys x 32 dims = one 16-byte LDS read per lane; the block stages
+//                               each 64-key chunk once), B = Q (fp16, pre-scaled by 1/8).  In the C layout a lane owns ONE query (lane & 15) and the
 //                               keys 4 * (lane >> 4) + j of the tile -- so the online-softmax state (running max, rescale factor) is a
 //                               per-lane scalar, and P^T in that layout IS the B operand of v_mfma_f32_16x16x16_f16: no transpose of P;
 //   O^T[dim][query] += V^T . P^T   v_mfma_f32_16x16x16_f16, A = V^T: the block stages the chunk's V rows transposed in LDS
@@ -567,9 +567,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const RowMeta* meta_p
 // partials until the end.  (Requesting the K fragments one chunk ahead into a second register set measured slower: 59 -> 68 us per
 // launch at 8192 rows -- the extra 32 VGPRs cost more occupancy than the exposed load latency.)  Output: normalised rows in the o_proj kernel's fragment-major B operand, like the other kernels.
 #define FA_PITCH 68        // halfs per V^T row in LDS (64 keys + pad; rows stay 8-byte aligned)
+#define FA_KPITCH 72       // halfs per K row in LDS (64 dims + pad; rows stay 16-byte aligned)
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const RowMeta* meta_p, const float* q_p, const half_t* k_p, const half_t* v_p, const int NHp,
                                                               const int R, const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) half_t vt[2][CTTS_HEAD_DIM][FA_PITCH];
+    __shared__ __attribute__((aligned(16))) half_t ks[2][64][FA_KPITCH];          // the chunk's K rows as they lie in the cache (+ pad)
     __shared__ int range_s[4][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qn = lane & 15, iq = lane >> 4;
@@ -610,15 +612,19 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const RowMeta* m
     float mrun = -INFINITY, lpart = 0.f;
     // V staging: thread -> key (tid >> 2) of the chunk, dims 16 (tid & 3) .. + 15
     const int skey = tid >> 2, sdim = 16 * (tid & 3);
-    half8 vst[2];
+    half8 vst[2], kst[2];
     auto vload = [&](int c) {
         const int key = min(c + skey, bhi);                               // clamp: a valid slot of this sequence (masked later)
         const half8* vp = (const half8*)(vb + (size_t)key * CTTS_HEAD_DIM + sdim);
+        const half8* kp = (const half8*)(kb + (size_t)key * CTTS_HEAD_DIM + sdim);
         vst[0] = vp[0]; vst[1] = vp[1];
+        kst[0] = kp[0]; kst[1] = kp[1];
     };
     auto vstore = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { vt[buf][sdim + e][skey] = vst[0][e]; vt[buf][sdim + 8 + e][skey] = vst[1][e]; }
+        *(half8*)&ks[buf][skey][sdim] = kst[0];
+        *(half8*)&ks[buf][skey][sdim + 8] = kst[1];
     };
     const int c0 = blo & ~63;
     vload(c0);
@@ -632,9 +638,9 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const RowMeta* m
             f32x4 sT[4];
 #pragma unroll
             for (int tl = 0; tl < 4; ++tl) {
-                const int key = min(c + 16 * tl + qn, bhi);               // A operand row = key (lane & 15)
-                const half8* kp = (const half8*)(kb + (size_t)key * CTTS_HEAD_DIM + 8 * iq);
-                const half8 k0 = kp[0], k1 = kp[4];                        // dims 8 iq .. and 32 + 8 iq ..
+                // A operand row = key (lane & 15), dims 8 iq .. and 32 + 8 iq ..: from the chunk's K rows staged in LDS by the whole block
+                // (each wave fetching them itself from the cache meant 4x the loads, consumed right after they were issued)
+                const half8 k0 = *(const half8*)&ks[buf][16 * tl + qn][8 * iq], k1 = *(const half8*)&ks[buf][16 * tl + qn][32 + 8 * iq];
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], acc, 0, 0, 0);

@@ -33,8 +33,8 @@ void ctts_set_error(const char* fmt, ...) {
 extern "C" const char* ctts_last_error(void) { return g_err; }
 extern "C" int ctts_version(void) { return 1; }
 
-#define PASS_ROWS 8192     // prompt rows per pass (q / activation workspaces are sized for it; + PASS_PAD rows so whole GEMM blocks stay in bounds)
-#define PASS_PAD 256
+#define PASS_ROWS_MAX 16384   // prompt rows per pass (32 x 512 tokens in one pass); an engine's workspaces are sized for min(this, max_batch * max_seq)
+#define PASS_PAD 256          // + PASS_PAD rows so that whole GEMM blocks stay in bounds
 #define SMAX 8        // == ATT_SMAX in skinny_gemm.hip
 
 struct LayerW {
@@ -94,6 +94,7 @@ struct ctts_gpt {
     int* lora_slot_of_seq = nullptr;
     float *lora_dqkv = nullptr, *lora_do = nullptr;
     int lora_rows = 0;                           // 1: the current / next generate() calls carry per-sequence adapters
+    int pass_rows = PASS_ROWS_MAX;               // prompt rows per pass of this engine (env CTTS_PASS_ROWS lowers it: multi-pass tests)
     void* xh = nullptr;                          // fp16 decode, > split_rows rows: residual stream as packed fp16 B operand (EPI_RESID_XH -> PRO_XH)
     float *ssq = nullptr, *scale_o = nullptr, *scale_d = nullptr;   //   per-tile sums of squares [rows][48]; per-row power-of-two scales of the xh rows
     int xh_mode = 1;                             //   env CTTS_XH=0 switches the path off (every block re-normalises fp32 rows: PRO_NORM)
@@ -234,7 +235,7 @@ static int lora_ensure_storage(ctts_gpt* h) {
     const size_t per = (size_t)h->L * CTTS_MAX_ADAPTERS * 4 * 16 * h->H;
     if (dev_alloc((void**)&h->lora_A, per * 4) || dev_alloc((void**)&h->lora_B, per * 4) ||
         dev_alloc((void**)&h->lora_scale, (size_t)h->L * CTTS_MAX_ADAPTERS * 4 * 4) || dev_alloc((void**)&h->lora_slot_of_seq, CTTS_MAX_B * 4) ||
-        dev_alloc((void**)&h->lora_dqkv, (size_t)PASS_ROWS * 3 * h->H * 4) || dev_alloc((void**)&h->lora_do, (size_t)PASS_ROWS * h->H * 4))
+        dev_alloc((void**)&h->lora_dqkv, (size_t)h->pass_rows * 3 * h->H * 4) || dev_alloc((void**)&h->lora_do, (size_t)h->pass_rows * h->H * 4))
         return 1;
     CTTS_HIP_CHECK(hipMemset(h->lora_slot_of_seq, 0xFF, CTTS_MAX_B * 4));
     return 0;
@@ -421,6 +422,13 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
     int rc = (h->cfg.dtype == CTTS_DTYPE_F16) ? finalize_t<half_t>(h) : finalize_t<float>(h);
     if (rc) return rc;
     const int H = h->H, NH = h->NH, MB = h->cfg.max_batch;
+    {   // prompt rows per pass: never more than the engine can hold at all
+        long cap = (long)MB * h->cfg.max_seq;
+        cap = (cap + 255) / 256 * 256;
+        h->pass_rows = (int)(cap < PASS_ROWS_MAX ? cap : PASS_ROWS_MAX);
+        if (const char* pr = getenv("CTTS_PASS_ROWS")) { const int v = atoi(pr); if (v >= 256 && v < h->pass_rows) h->pass_rows = v / 256 * 256; }
+    }
+    const int PASS_ROWS = h->pass_rows;
     const size_t act_bytes = (size_t)((PASS_ROWS + PASS_PAD) / 16) * (h->I / (h->esz == 2 ? 32 : 16)) * 1024;
     if (dev_alloc((void**)&h->x_dec, (size_t)CTTS_MAX_B * H * 4) || dev_alloc((void**)&h->x_last, (size_t)CTTS_MAX_B * H * 4) ||
         dev_alloc((void**)&h->x_pre, (size_t)PASS_ROWS * H * 4) ||
@@ -688,6 +696,7 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* h, const float* emb, void* stream) {
     CTTS_RANGE("ctts_gpt_prefill");             // reference: nvtx "forward" (trt_models/llama_trt_model.py:44,74), q_len > 1
     hipStream_t s = (hipStream_t)stream;
     const int R = h->B * h->T;
+    const int PASS_ROWS = h->pass_rows;
     for (int r0 = 0; r0 < R; r0 += PASS_ROWS) {
         const int n = (R - r0 < PASS_ROWS) ? R - r0 : PASS_ROWS;
         CTTS_HIP_CHECK(hipMemcpyAsync(h->x_pre, emb + (size_t)r0 * h->H, (size_t)n * h->H * 4, hipMemcpyDeviceToDevice, s));

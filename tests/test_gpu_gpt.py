@@ -4,6 +4,8 @@ fp32 parity mode: token ids bit-exact against the golden vectors minted from the
 (same torch seed -> same Exp(1) draws), hiddens within 1e-4 abs.
 fp16 performance mode: teacher-forced comparison with the oracle; hidden RMS error <= 2e-3 of signal RMS
 (weights and KV rounded to fp16, fp32 accumulate) -- tolerance stated here and in DESIGN.md."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -25,6 +27,7 @@ def model(wd, seed=1234, boost=None):
     from chatttsplus_amd.hip_models import GPT
     key = (wd, seed, boost)
     if key not in _models:
+        os.environ["CTTS_PASS_ROWS"] = "8192"      # prompt rows per pass of these engines (default 16384): the 8500 / 8580-row cases below take two passes
         sd = synth.gpt_state_dict(synth.GPT_REAL, seed)
         if boost is not None:                      # goldens minted with boosted EOS rows (staggered finishes)
             for i in range(4):
@@ -32,6 +35,7 @@ def model(wd, seed=1234, boost=None):
         g = GPT(LLAMA, max_batch=34 if boost is None else 4, max_seq_len=840 if boost is None else 128, weight_dtype=wd)
         g.load_state_dict(sd)
         _models[key] = (g, sd)
+        os.environ.pop("CTTS_PASS_ROWS", None)
     return _models[key]
 
 
@@ -87,7 +91,7 @@ def test_rng_state_after_generate_matches_reference_consumption():
     # prompt pass larger than one 2048-row pass (B*T = 2340): multi-pass prefill + last-row gather across passes
     ("fp32", 9, 260, [0, 1, 17, 100, 259, 3, 0, 200, 64], 4, 2e-5),
     ("fp16", 5, 500, [0, 499, 250, 7, 0], 3, 2e-3),
-    # more rows than one prompt pass holds (PASS_ROWS = 8192): 8500 / 8580 rows -> two passes, the second attending to keys the first wrote;
+    # more rows than one prompt pass holds (8192 for these engines): 8500 / 8580 rows -> two passes, the second attending to keys the first wrote;
     # fp16 runs the LDS-staged prompt GEMM (prefill_gemm.hip) + the 8-queries-per-wave attention, fp32 the 32-row chunk kernels
     ("fp16", 17, 500, [(37 * i) % 400 for i in range(17)], 2, 2e-3),
     # 5 rows with > 768 keys: two key splits -> the softmax-combine prologue feeding the packed-fp16 residual epilogue (PRO_ATTN + EPI_RESID_XH)

@@ -18,11 +18,12 @@ rm -f $O/gen_wall.log $O/pipe_wall.log $O/prefill.log
 for n in torch device; do timeout 200 python tools/gen_wall.py --noise $n 2>&1 | tail -1 >> $O/gen_wall.log; done
 timeout 200 python tools/gen_wall.py --batch 32 --steps 256 --noise device 2>&1 | tail -1 >> $O/gen_wall.log
 timeout 200 python tools/gen_wall.py --text --steps 128 --noise device 2>&1 | tail -1 >> $O/gen_wall.log
+timeout 200 python tools/gen_wall.py --text --steps 128 --noise device --batch 8 2>&1 | tail -1 >> $O/gen_wall.log
 timeout 250 python tools/pipe_wall.py 2>&1 | tail -1 >> $O/pipe_wall.log
 timeout 250 python tools/pipe_wall.py --n 32 --tokens 256 2>&1 | tail -1 >> $O/pipe_wall.log
 for cfg in "1 48" "1 512" "32 96" "32 512" "8 2000"; do timeout 120 python tools/prefill_probe.py $cfg 2>&1 | grep "prompt pass" | tail -1 >> $O/prefill.log; done
 for cfg in "32 512" "8 2000"; do CTTS_PREFILL_GEMM=0 CTTS_PREFILL_ATTN=0 timeout 120 python tools/prefill_probe.py $cfg 2>&1 | grep "prompt pass" | tail -1 | sed 's/$/  (round-1 kernels: CTTS_PREFILL_GEMM=0 CTTS_PREFILL_ATTN=0)/' >> $O/prefill.log; done
-for cfg in "32 96" "8 300" "4 512"; do for th in 4096 2048; do CTTS_PREFILL_GEMM=$th timeout 120 python tools/prefill_probe.py $cfg 2>&1 | grep "prompt pass" | tail -1 | sed "s/$/  (prompt GEMM from $th rows)/" >> $O/prefill.log; done; done
+for cfg in "32 96" "4 512" "2 512"; do for th in 2048 1024; do CTTS_PREFILL_GEMM=$th timeout 120 python tools/prefill_probe.py $cfg 2>&1 | grep "prompt pass" | tail -1 | sed "s/$/  (prompt GEMM from $th rows)/" >> $O/prefill.log; done; done
 timeout 200 python tools/fp16_agreement.py > $O/fp16_token_agreement.json 2>/dev/null
 cat $O/gen_wall.log $O/pipe_wall.log $O/prefill.log
 R=$GRAFT_REPO_ROOT
@@ -39,7 +40,7 @@ for t in b1 b32; do
   [ $t = b1 ] && BA="--batch 1" || BA="--batch 32"
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${t}_$c
-    timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${t}_$c -- python $R/bench.py $BA --steps 64 --warmup 16 --cpu-steps 0 --no-extras > /tmp/pmc_${t}_$c.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${t}_$c -- python $R/bench.py $BA --steps 64 --warmup 16 --gen-tokens 0 --cpu-steps 0 --no-extras > /tmp/pmc_${t}_$c.log 2>&1
     db=$(find /tmp/pmc_${t}_$c -name '*.db' | head -1)
     [ -n "$db" ] && python $R/tools/rocpd_pmc.py $db $c 60 $R/$O/pmc_${t}_$c.json > /dev/null 2>> $R/$O/pmc_errors.log || echo "no db for $t $c" >> $R/$O/pmc_errors.log
   done
