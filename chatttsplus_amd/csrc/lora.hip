@@ -19,20 +19,57 @@ __device__ inline float block_sum_256(float v, float* red, int tid) {
     return s;
 }
 
+// One block = one (row, target): 4 waves x 4 rank components, every lane owns 12 of the 768 input columns.  All loads of a phase are
+// issued together (a first version walked the 16 dot products one after the other, each waiting for its own loads: 20-40 us per
+// launch, 3.7x the step time at batch 32).
+__device__ inline void lora_low_rank(const float* hw, const float* A_t, const float* B_t, float scale, float* drow, int H, float* u, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    float hv[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) hv[i] = hw[lane + 64 * i];
+    float acc[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {                      // rank components 4 * wave + kk
+        const float* ar = A_t + (size_t)(4 * wave + kk) * H + lane;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) a += ar[64 * i] * hv[i];
+        acc[kk] = a;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { const float v = wave_sum(acc[kk]); if (lane == 0) u[4 * wave + kk] = v; }
+    __syncthreads();
+    float uu[LORA_RMAX];
+#pragma unroll
+    for (int k = 0; k < LORA_RMAX; ++k) uu[k] = u[k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int n = tid + 256 * i;
+        const f32x4* br = (const f32x4*)(B_t + (size_t)n * LORA_RMAX);
+        const f32x4 b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
+        float a = 0.f;
+        a += b0[0] * uu[0] + b0[1] * uu[1] + b0[2] * uu[2] + b0[3] * uu[3];
+        a += b1[0] * uu[4] + b1[1] * uu[5] + b1[2] * uu[6] + b1[3] * uu[7];
+        a += b2[0] * uu[8] + b2[1] * uu[9] + b2[2] * uu[10] + b2[3] * uu[11];
+        a += b3[0] * uu[12] + b3[1] * uu[13] + b3[2] * uu[14] + b3[3] * uu[15];
+        drow[n] = scale * a;
+    }
+}
+
 // q/k/v targets: input = input_layernorm(x) (llama.py:726-731: the projections see the normalised hidden states)
 //   x [rows][768] fp32 residual stream, lnw [768], meta row -> sequence, slot_of_seq [max_batch] (-1 = no adapter),
 //   A_l / B_l: this layer's adapters, [slot][target 0..3][16][768] and [slot][target][768][16] (zero padded to r = 16), scale_l [slot][4]
-//   delta [rows][3][768]
+//   delta [rows][3][768];  grid = (rows, 3 targets)
 __global__ __launch_bounds__(256) void lora_delta_qkv_kernel(const float* x, const float* lnw, float eps, const RowMeta* meta, const int* slot_of_seq,
                                                            const float* A_l, const float* B_l, const float* scale_l, float* delta, int H) {
     __shared__ float hw[768];
-    __shared__ float u[3][LORA_RMAX];
+    __shared__ float u[LORA_RMAX];
     __shared__ float red[4];
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const int slot = slot_of_seq[meta[r].seq];
-    float* drow = delta + (size_t)r * 3 * H;
+    float* drow = delta + ((size_t)r * 3 + t) * H;
     if (slot < 0) {
-        for (int i = tid; i < 3 * H; i += 256) drow[i] = 0.f;
+        for (int i = tid; i < H; i += 256) drow[i] = 0.f;
         return;
     }
     float xv[3], ss = 0.f;
@@ -43,24 +80,8 @@ __global__ __launch_bounds__(256) void lora_delta_qkv_kernel(const float* x, con
 #pragma unroll
     for (int i = 0; i < 3; ++i) hw[tid + 256 * i] = lnw[tid + 256 * i] * (xv[i] * rs);
     __syncthreads();
-    // u[t][k] = A_t[k] . hw : 48 dot products of length 768, 12 per wave
-    for (int j = wave; j < 3 * LORA_RMAX; j += 4) {
-        const int t = j / LORA_RMAX, k = j % LORA_RMAX;
-        const float* ar = A_l + (((size_t)slot * 4 + t) * LORA_RMAX + k) * H;
-        float acc = 0.f;
-        for (int c = lane; c < H; c += 64) acc += ar[c] * hw[c];
-        acc = wave_sum(acc);
-        if (lane == 0) u[t][k] = acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < 3 * H; i += 256) {
-        const int t = i / H, n = i % H;
-        const float* br = B_l + (((size_t)slot * 4 + t) * H + n) * LORA_RMAX;
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < LORA_RMAX; ++k) acc += br[k] * u[t][k];
-        drow[i] = scale_l[slot * 4 + t] * acc;
-    }
+    const size_t off = ((size_t)slot * 4 + t) * LORA_RMAX * H;
+    lora_low_rank(hw, A_l + off, B_l + off, scale_l[slot * 4 + t], drow, H, u, tid);
 }
 
 // o_proj target: input = the attention output rows, read back from the o_proj kernel's fragment-major B operand (S = 1 path)
@@ -69,7 +90,7 @@ __global__ __launch_bounds__(256) void lora_delta_o_kernel(const void* attn_pack
                                                          const float* B_l, const float* scale_l, float* delta, int H) {
     __shared__ float o[768];
     __shared__ float u[LORA_RMAX];
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x, tid = threadIdx.x;
     const int slot = slot_of_seq[meta[r].seq];
     float* drow = delta + (size_t)r * H;
     if (slot < 0) {
@@ -79,29 +100,17 @@ __global__ __launch_bounds__(256) void lora_delta_o_kernel(const void* attn_pack
     constexpr int KT = WTraits<WT>::KT, EPL = WTraits<WT>::EPL;
     const int NB = 16 * nbg, kt = H / KT;
     const WT* base = (const WT*)attn_packed + (size_t)(r / NB) * nbg * kt * 64 * EPL;
-    for (int c = tid; c < H; c += 256) o[c] = (float)base[xfrag_index<WT>(r % NB, c, kt)];
-    __syncthreads();
-    for (int k = wave; k < LORA_RMAX; k += 4) {
-        const float* ar = A_l + (((size_t)slot * 4 + 3) * LORA_RMAX + k) * H;
-        float acc = 0.f;
-        for (int c = lane; c < H; c += 64) acc += ar[c] * o[c];
-        acc = wave_sum(acc);
-        if (lane == 0) u[k] = acc;
-    }
-    __syncthreads();
-    for (int n = tid; n < H; n += 256) {
-        const float* br = B_l + (((size_t)slot * 4 + 3) * H + n) * LORA_RMAX;
-        float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < LORA_RMAX; ++k) acc += br[k] * u[k];
-        drow[n] = scale_l[slot * 4 + 3] * acc;
-    }
+    for (int i = 0; i < 3; ++i) { const int c = tid + 256 * i; o[c] = (float)base[xfrag_index<WT>(r % NB, c, kt)]; }
+    __syncthreads();
+    const size_t off = ((size_t)slot * 4 + 3) * LORA_RMAX * H;
+    lora_low_rank(o, A_l + off, B_l + off, scale_l[slot * 4 + 3], drow, H, u, tid);
 }
 
 int launch_lora_delta_qkv(const float* x, const float* lnw, float eps, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
                           const float* scale_l, float* delta, int rows, int H, hipStream_t s) {
     if (H != 768) { ctts_set_error("lora: hidden %d != 768", H); return 1; }
-    hipLaunchKernelGGL(lora_delta_qkv_kernel, dim3(rows), dim3(256), 0, s, x, lnw, eps, meta, slot_of_seq, A_l, B_l, scale_l, delta, H);
+    hipLaunchKernelGGL(lora_delta_qkv_kernel, dim3(rows, 3), dim3(256), 0, s, x, lnw, eps, meta, slot_of_seq, A_l, B_l, scale_l, delta, H);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
