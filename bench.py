@@ -246,7 +246,7 @@ def main():
     extras = not args.no_extras
     EB, EK = 32, args.extra_steps
     sd = synth.gpt_state_dict(synth.GPT_REAL, 1234)                    # every rank holds a full replica (0.45 GB fp16)
-    need_seq = max(P, 512 if extras else 0) + W + max(GEN_TOKENS, args.gen_tokens, K) + 16
+    need_seq = max(P, 512 if (extras and world == 1) else 0) + W + max(GEN_TOKENS, args.gen_tokens, K) + 16
     g = GPT(LLAMA, max_batch=max(B, EB if extras else 1), max_seq_len=need_seq, weight_dtype=args.dtype, device=str(dev))
     g.load_state_dict(sd)
     # speaker table lives on rank 0 and is broadcast over xGMI (the path's only collective)
@@ -286,6 +286,10 @@ def main():
             e = leg.run(EB, P, EK, W, spk=spk, use_graph=use_graph)
             extra["batch32"] = summarize(e, world)
             extra["batch32"]["per_rank_tokens_per_s"] = [round(EB * EK / p, 1) for p in e["per_rank_s"]]
+            if world > 1:
+                # multi-rank runs stop here: the remaining legs characterise one GPU (measured at N = 1) and every leg is a rendezvous --
+                # a rank failing inside one of them would leave the others waiting at its barrier
+                raise StopIteration
             # configs[2] as written: mixed-length utterances, left-padded to the longest prompt (P_b ~ U{16..96}), padded KV
             rng = np.random.Generator(np.random.Philox(key=77 + rank))
             plen = rng.integers(16, 97, size=EB)
@@ -323,9 +327,13 @@ def main():
                 e = Leg(g32, dev, rank, world).run(1, P, min(K, 256), W, spk=spk, use_graph=use_graph)
                 extra["parity_mode_fp32_batch1"] = summarize(e, world)
                 g32.close()
-        except SystemExit:
+        except (SystemExit, KeyboardInterrupt):
             raise
+        except StopIteration:
+            pass
         except Exception as ex:
+            if world > 1:
+                raise                                  # fail loudly rather than desynchronise the ranks
             extra["error"] = f"{type(ex).__name__}: {ex}"
 
     if rank == 0:
