@@ -532,6 +532,11 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // fp16 decode above the split-K batch sizes: the residual stream travels between kernels as a packed fp16 B operand + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself
     const bool xhm = (dt == CTTS_DTYPE_F16) && (st != nullptr) && h->xh_mode && !splitd && (R > h->fuse_rows) && (R > h->fuseqkv_rows);
+    // batches <= 4 keep the split-K down projection (its partial sums feed the next QKV's RMSNorm), but o_proj re-materialises x: it could
+    // hand gate|up the packed fp16 copy + sums of squares too.  Measured SLOWER (us/step with / without: batch 1 393 / 381, 2 415 / 403,
+    // 4 450 / 443 -- one fp32 row normalised by one wave is cheaper than six 1-KiB fragment loads per wave plus the heavier o_proj
+    // epilogue), so it stays a diagnostic switch (env CTTS_XH=3)
+    const bool xhs = (dt == CTTS_DTYPE_F16) && splitd && (h->xh_mode == 3) && (R > h->fuse_rows) && (R > h->fuseqkv_rows);
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
         a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq;
@@ -568,7 +573,10 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g1.scale_out = h->scale_o;
             if (l > 0) { g1.xh = h->xh; g1.ssq = h->ssq; g1.scale_in = h->scale_d; }
             if (!(h->ablate & 1) && launch_gemm(dt, nbg, l > 0 ? PRO_XH : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
-        } else if (!(h->ablate & 1) && launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
+        } else {
+            if (xhs) g1.scale_out = h->scale_o;
+            if (!(h->ablate & 1) && launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
+        }
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
@@ -587,7 +595,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g2.xpacked = h->attn_packed;
             g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;
             const bool sp2 = splitd;                       // the down projection's partial sums are folded into x here
-            if (xhm) { g2.xh = h->xh; g2.ssq = h->ssq; g2.scale_in = h->scale_o; }
+            if (xhm || xhs) { g2.xh = h->xh; g2.ssq = h->ssq; g2.scale_in = h->scale_o; }
             if (lora) {
                 if (S != 1) { ctts_set_error("per-utterance LoRA needs unsplit attention"); return 1; }
                 if (launch_lora_delta_o(dt, h->attn_packed, nbg, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
@@ -605,8 +613,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g3.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
             if (pfg ? launch_prefill_gemm(EPI_SWIGLU, g3, s) : launch_gemm(dt, nbg, PRO_PACKED, EPI_SWIGLU, g3, chunks, s)) return 1;
-        } else if (xhm) {
-            g3.xh = h->xh; g3.ssq = h->ssq; g3.scale_in = h->scale_o; g3.scale_out = h->scale_d;
+        } else if (xhm || xhs) {
+            g3.xh = h->xh; g3.ssq = h->ssq; g3.scale_in = h->scale_o; g3.scale_out = xhm ? h->scale_d : nullptr;
             if (!(h->ablate & 8) && launch_gemm(dt, nbg, PRO_XH, EPI_SWIGLU, g3, chunks, s)) return 1;
         } else if (!(h->ablate & 8) && launch_gemm(dt, nbg, fused ? PRO_NORM_P : PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
         // down + residual

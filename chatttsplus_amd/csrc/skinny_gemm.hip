@@ -111,7 +111,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             const int t = tid + u * WAVES * 64;
             const int r = row0 + (t >> 4);
             // scale_in rides on the leading scalar in1 (free for PRO_PACKED); the rare PRO_ATTN variant reads it from the struct
-            xh_scale_pf[u] = (EPI == EPI_RESID_XH && t < 16 * NB && r < R) ? ((PRO == PRO_ATTN) ? a.scale_in[r] : ((const float*)in1)[r]) : 1.f;
+            xh_scale_pf[u] = (EPI == EPI_RESID_XH && t < 16 * NB && r < R) ? ((PRO == PRO_ATTN) ? a.scale_in[r] : ((const float*)in1)[r])
+                           : (EPI == EPI_RESID_P && a.xh != nullptr && t < 16 * NB && r < R) ? a.scale_in[r] : 1.f;     // split-K batches: see EPI_RESID_P below
             const int N = a.n_row_tiles * 16, col = rt0 * 16 + (t & 15);
             float v = 0.f;
             if (t < 16 * NB && r < R) {
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             for (int i = 0; i < PER; ++i) ss += v[u][i][0] * v[u][i][0] + v[u][i][1] * v[u][i][1] + v[u][i][2] * v[u][i][2] + v[u][i][3] * v[u][i][3];
             ss = wave_sum(ss);
             const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);          // torch.rsqrt(mean(x^2) + eps)
-            if (PRO == PRO_NORM && EPI == EPI_QKV && rt0 == 0 && a.scale_out != nullptr && lane == 0)
+            if ((PRO == PRO_NORM || PRO == PRO_NORM_P) && EPI == EPI_QKV && rt0 == 0 && a.scale_out != nullptr && lane == 0)
                 a.scale_out[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rs) & 0x7F800000u);   // see PRO_XH
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
@@ -385,7 +386,16 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             if (EPI == EPI_PART) {
                 a.part_out[((size_t)r * gridDim.z + blockIdx.z) * (a.n_row_tiles * 16) + col] = v;
             } else if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
-                a.x_out[(size_t)r * (a.n_row_tiles * 16) + col] = resid_pf[u] + v;   // residual + proj (llama.py:731,739)
+                const float xn = resid_pf[u] + v;                                    // residual + proj (llama.py:731,739)
+                a.x_out[(size_t)r * (a.n_row_tiles * 16) + col] = xn;
+                if (EPI == EPI_RESID_P && a.xh != nullptr) {
+                    // batches <= 4 (split-K down projection): o_proj re-materialises x and hands it to gate|up like EPI_RESID_XH does
+                    float sq = xn * xn;
+                    sq += dpp_f<DPP_XOR1>(sq); sq += dpp_f<DPP_XOR2>(sq); sq += dpp_f<DPP_HALF_MIRROR>(sq); sq += dpp_f<DPP_MIRROR>(sq);
+                    if (i == 0) a.ssq[(size_t)r * a.n_row_tiles + rt] = sq;
+                    half_t* dst = (half_t*)a.xh + (size_t)chunk * NBG * 24 * 64 * 8;
+                    dst[xfrag_index<half_t>(n, col, 24)] = (half_t)(xn * xh_scale_pf[u]);
+                }
             } else if (EPI == EPI_RESID_XH) {
                 // the 16 lanes of a DPP row hold the 16 columns of (row r, tile rt): fp32 residual as before, plus what the next
                 // PRO_XH kernel reads -- the row's sum of squares over this tile and the fp16 (power-of-two scaled) packed copy
