@@ -136,7 +136,8 @@ class Leg:
         for b in range(B):                                            # "[Stts][spk_emb]..." (pipeline:187-194): slot 1 of the unpadded text
             ids[b, (pad_left[b] if pad_left is not None else 0) + 1, :] = spk_id
         ids_t = torch.from_numpy(ids).to(dev)
-        emb = g(ids_t, torch.ones(B, P, dtype=torch.bool, device=dev), spk_emb=spk, spk_emb_ids=spk_id)   # get_emb + apply_spk_emb (one HIP launch)
+        rows = spk[torch.arange(B, device=spk.device) % spk.shape[0]] if (spk is not None and spk.dim() == 2) else spk
+        emb = g(ids_t, torch.ones(B, P, dtype=torch.bool, device=dev), spk_emb=rows, spk_emb_ids=spk_id)   # get_emb + apply_spk_emb (one HIP launch)
         lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
         lp = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
         sc = sampler_cfg_from_objects(torch.tensor([0.3] * 4), 625, max_new, max_new, lw, lp, 4)
@@ -249,8 +250,9 @@ def main():
     need_seq = max(P, 512 if (extras and world == 1) else 0) + W + max(GEN_TOKENS, args.gen_tokens, K) + 16
     g = GPT(LLAMA, max_batch=max(B, EB if extras else 1), max_seq_len=need_seq, weight_dtype=args.dtype, device=str(dev))
     g.load_state_dict(sd)
-    # speaker table lives on rank 0 and is broadcast over xGMI (the path's only collective)
-    spk = torch.from_numpy(synth.speaker_vector(1234)).to(dev) if rank == 0 else torch.zeros(768, device=dev)
+    # speaker table (4 distinct speakers) lives on rank 0 and is broadcast over xGMI -- the path's only collective;
+    # sequence b of every batch speaks with speaker b % 4
+    spk = (torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev) if rank == 0 else torch.zeros(4, 768, device=dev))
     if world > 1:
         dist.broadcast(spk, src=0)
     use_graph = 0 if args.no_graph else 1
