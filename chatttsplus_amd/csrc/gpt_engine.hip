@@ -53,6 +53,7 @@ struct ctts_gpt {
     void* whead = nullptr;
     void* whead_text = nullptr;                  // refine-text head (21178 x H), packed like whead; optional
     int x_has_parts = 0;                         // the decode rows' residual stream currently is x_dec + dpart[0..3]
+    int x_has_xh = 0;                            // ... and / or also exists as packed fp16 + sums of squares (xh / ssq / scale_d) for the heads
     int text_mode = 0;                           // current generate() call: infer_text=True
     float* lnf = nullptr;
     float* emb_code = nullptr;
@@ -625,7 +626,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         } else if (splitd) {
             g4.part_out = h->dpart; g4.ktiles_total = h->I / (h->esz == 2 ? 32 : 16);
             if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, EPI_PART, g4, chunks, s)) return 1;
-        } else if (xhm && l + 1 < h->L) {          // the last layer's output goes to the heads, which normalise the fp32 rows themselves
+        } else if (xhm) {                          // (the last layer's copy is for the heads: run_heads)
             g4.xh = h->xh; g4.ssq = h->ssq; g4.scale_in = h->scale_d;
             if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH, g4, chunks, s)) return 1;
         } else if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, fused ? EPI_RESID_P : EPI_RESID, g4, chunks, s)) return 1;
@@ -643,6 +644,10 @@ static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
     a.logits = h->logits; a.n_valid = nv;
     a.dyn = write_hidden ? h->dyn : nullptr;       // the kernel tests dyn->hidden_out itself
     a.opart = h->dpart; a.np = h->x_has_parts ? 4 : 0;
+    if (h->x_has_xh) {       // the last down projection left the rows as packed fp16 + sums of squares (run_layers, PRO_XH): no fp32 re-normalisation per block
+        a.xh = h->xh; a.ssq = h->ssq; a.scale_in = h->scale_d;
+        return launch_gemm(h->cfg.dtype, nbg, PRO_XH, EPI_LOGITS, a, chunks, s);
+    }
     return launch_gemm(h->cfg.dtype, nbg, (nbg == 1 && h->split_rows > 0 && h->fuse_rows == 0) ? PRO_NORM_P : PRO_NORM, EPI_LOGITS, a, chunks, s);
 }
 
@@ -733,8 +738,11 @@ extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
     if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s)) return 1;
     h->x_has_parts = (h->B <= h->split_rows && h->B <= 16 && h->fuse_rows == 0 && !h->lora_rows) ? 1 : 0;    // same condition as `splitd` in run_layers
+    // same condition as `xhm` in run_layers (text mode keeps the fp32 prologue: its head is a different launch shape, not measured)
+    h->x_has_xh = (h->cfg.dtype == CTTS_DTYPE_F16 && h->xh_mode && !h->x_has_parts && h->B > h->fuse_rows && h->B > h->fuseqkv_rows && !h->text_mode &&
+                   !getenv("CTTS_NO_XH_HEADS")) ? 1 : 0;
     const int rc = run_sample_phase(h, s);          // the heads add dpart[0..3]; the sampler then re-materialises x_dec
-    h->x_has_parts = 0;
+    h->x_has_parts = 0; h->x_has_xh = 0;
     return rc;
 }
 

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             if (frow && part == 0) {
                 const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
                 fac_s[n_f] = rs / sc_in;                            // sc_in is a power of two: exact
+                if (EPI == EPI_LOGITS) fac_s[NB + n_f] = rs;        // heads: the hidden rows below need the plain factor
                 if (rt0 == 0 && a.scale_out != nullptr)             // scale of the rows the next EPI_RESID_XH writes
                     a.scale_out[row0 + n_f] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rs) & 0x7F800000u);
             }
@@ -451,6 +452,25 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         }
     }
     }   // row tiles of this block
+    if (PRO == PRO_XH && EPI == EPI_LOGITS) {
+        // heads on the packed-fp16 path: block 0 of every chunk also writes hidden = weight * (x * rs) (llama.py:87, gpt.py:422-423) from the fp32 rows
+        float* const hid_out = (a.dyn != nullptr) ? ((SamplerDynPtr)a.dyn)->hidden_out : nullptr;
+        if (hid_out != nullptr && rt0 == 0) {
+            const int rows = min(NB, R - row0);
+            for (int n = wave; n < rows; n += WAVES) {
+                const int r = row0 + n;
+                const float rs = fac_s[NB + n];
+                const f32x4* xr = (const f32x4*)(a.x + (size_t)r * K);
+                float* hrow = hid_out + (size_t)a.meta[r].seq * ((SamplerDynPtr)a.dyn)->hidden_stride + (size_t)a.st->step * K;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int k = 4 * (lane + 64 * i);
+                    const f32x4 v = xr[lane + 64 * i], w = *(const f32x4*)(a.lnw + k);
+                    *(f32x4*)(hrow + k) = (f32x4){w[0] * (v[0] * rs), w[1] * (v[1] * rs), w[2] * (v[2] * rs), w[3] * (v[3] * rs)};
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -517,6 +537,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         if constexpr (F16) {
             rc |= launch_one<WT, NBG, W768, P768, PRO_XH, EPI_QKV, RT_XH>(a, chunks, s, true);
             rc |= launch_one<WT, NBG, W768, P768, PRO_XH, EPI_SWIGLU, RT_XH>(a, chunks, s, true);
+            rc |= launch_one<WT, NBG, W768, P768, PRO_XH, EPI_LOGITS>(a, chunks, s, true);
             rc |= launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID_XH>(a, chunks, s, true);
             rc |= launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
             rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
@@ -547,6 +568,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     if constexpr (F16) {
         if (pro == PRO_XH && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_XH, EPI_QKV, RT_XH>(a, chunks, s, false);
         if (pro == PRO_XH && epi == EPI_SWIGLU) return launch_one<WT, NBG, W768, P768, PRO_XH, EPI_SWIGLU, RT_XH>(a, chunks, s, false);
+        if (pro == PRO_XH && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_XH, EPI_LOGITS>(a, chunks, s, false);
         if (pro == PRO_ATTN && epi == EPI_RESID_XH) return launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID_XH>(a, chunks, s, false);
         if (pro == PRO_PACKED && epi == EPI_RESID_XH && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, false);
         if (pro == PRO_PACKED && epi == EPI_RESID_XH) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, false);
