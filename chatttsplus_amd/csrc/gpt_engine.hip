@@ -527,9 +527,9 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     const bool prepack = (st == nullptr) && (nbg == 2) && (R > 64) && !getenv("CTTS_NO_PREPACK");
     // prompt pass over >= 128 rows, fp16: LDS-staged 256/128 x 128 MFMA GEMM (prefill_gemm.hip) instead of one weight tile per 32-row block
     static const int pf_env = getenv("CTTS_PREFILL_GEMM") ? atoi(getenv("CTTS_PREFILL_GEMM")) : 1;
-    // (measured, prompt pass ms with / without it: 2048 rows 3.4 / 3.9, 2400 rows 3.3 / 4.4, 3072 rows 3.6 / 5.3, 16384 rows 12.8 / 29;
-    //  an earlier version of the kernel lost below ~3000 rows: 1200 rows 4.2 vs 2.7, 512 rows 4.4 vs 1.9)
-    const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && (R >= (pf_env > 1 ? pf_env : 2048)) && pf_env && !lora;
+    // (measured with 128 x 128 blocks, prompt pass ms with / without it: 512 rows 2.31 / 1.48, 1024 rows 2.47 / 2.29, 1536 rows 2.70 / 3.12,
+    //  2048 rows 2.81 / 3.9, 3072 rows 3.6 / 5.3, 16384 rows 10.3 / 29)
+    const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && (R >= (pf_env > 1 ? pf_env : 1536)) && pf_env && !lora;
     // fp16 decode above the split-K batch sizes: the residual stream travels between kernels as a packed fp16 B operand + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself
     const bool xhm = (dt == CTTS_DTYPE_F16) && (st != nullptr) && h->xh_mode && !splitd && (R > h->fuse_rows) && (R > h->fuseqkv_rows);

@@ -4,16 +4,18 @@
 //
 // The decode-time kernel (skinny_gemm.hip) streams a weight tile per block and multiplies it with <= 32 rows: over a whole prompt
 // that re-reads every weight tile once per 32-row chunk from L2 (885 MB per gate|up launch at 2048 rows; the prompt pass of
-// 32 x 512 tokens spent 26 of its 48 ms there at ~10 % of the MFMA peak).  Here a block owns a 256 x 128 (or 128 x 128) output tile:
+// 32 x 512 tokens spent 26 of its 48 ms there at ~10 % of the MFMA peak).  Here a block owns a 128 x 128 (or 256 x 128) output tile:
 //   * both operands already live in HBM as MFMA fragment images -- weights [n tile][k tile][lane][16 B] (gpt_engine.hip pack), activations
 //     [16-row group][k tile][lane][16 B] (norm_pack_kernel / the SwiGLU epilogue / the attention kernels) -- so staging a k-tile
 //     is a straight copy of 1-KiB fragments into LDS (one global_load_lds_dwordx4 per wave and fragment) and a wave reads
 //     its operands back with conflict-free ds_read_b128;
-//   * 8 (4) waves, each a 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_f16 accumulators, k-tiles in a ring of 3 LDS stages (24 KB each)
+//   * 4 (8) waves, each a 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_f16 accumulators, k-tiles in a ring of 3 LDS stages (24 KB each)
 //     filled by LDS-DMA loads two stages ahead of the MFMAs;
 //   * every output element is accumulated by one wave in k order: deterministic, no split-K, no atomics.
 // Epilogues restate the same reference lines as the decode kernel: q/k/v projection + RoPE + KV append (llama.py:619-633,151-182),
 // o_proj / down_proj + residual (llama.py:666,731,739), SiLU(gate) * up (llama.py:214).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 template <int WR>      // wave rows: block tile = (64 * WR) rows x 128 output features
@@ -174,7 +176,10 @@ static int pf_launch(const GemmArgs& a, const void* X, int ktiles, hipStream_t s
 int launch_prefill_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     const void* X = a.xpacked;
     const int ktiles = a.K / 32;
-    const bool big = a.R >= 2048;          // (128-row blocks for the N = 768 projections measured slower: 93 vs 84 us for the down projection at 8192 rows)
+    static const int wr_env = getenv("CTTS_PF_WR") ? atoi(getenv("CTTS_PF_WR")) : 0;        // diagnostic: 2 / 4 forces 128- / 256-row blocks
+    // 128 x 128 blocks (4 waves, 3 blocks per CU) by default: equal to 256 x 128 at 16384 rows (10.26 ms per 32 x 512 prompt pass either way), faster
+    // at 2048 rows (2.81 vs 3.21 ms)
+    const bool big = wr_env == 4;
     if (epi == EPI_QKV) return big ? pf_launch<EPI_QKV, 4>(a, X, ktiles, s) : pf_launch<EPI_QKV, 2>(a, X, ktiles, s);
     if (epi == EPI_SWIGLU) return big ? pf_launch<EPI_SWIGLU, 4>(a, X, ktiles, s) : pf_launch<EPI_SWIGLU, 2>(a, X, ktiles, s);
     if (epi == EPI_RESID) return big ? pf_launch<EPI_RESID, 4>(a, X, ktiles, s) : pf_launch<EPI_RESID, 2>(a, X, ktiles, s);

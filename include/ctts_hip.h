@@ -144,7 +144,7 @@ int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* attention_mask_dev,
 /* Prompt pass: emb fp32 [B][T][hidden] device (GPT.forward output after apply_spk_emb, gpt.py:125-149,
  * tokenizer.py:150-178).  Fills the KV cache and leaves the last position's residual row per sequence.
  * Asynchronous with respect to the host (enqueues on `stream`, never synchronises); prompts of more than 16384 rows (B * T) run in
- * several passes.  fp16 engines use the MFMA flash-attention kernel from 64 rows and the LDS-staged prompt GEMM from 2048 rows.
+ * several passes.  fp16 engines use the MFMA flash-attention kernel from 64 rows and the LDS-staged prompt GEMM from 1536 rows.
  * replaces the i == 0 iteration's LlamaModel.forward (gpt.py:410-418; llama.py:905-1019). */
 int ctts_gpt_prefill(ctts_gpt* h, const float* emb_dev, void* stream);
 
