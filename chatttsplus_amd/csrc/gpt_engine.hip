@@ -4,8 +4,11 @@
 //   packed weights   per layer  Wqkv [144 tiles][K=768]  Wo [48][768]  Wgu [384][768]  Wd [48][3072]
 //                    + heads [157 tiles][768], each tile = 16 rows x KT cols stored [k-tile][lane][16 B]
 //   KV cache         [layers][2][max_batch][heads][max_seq][64]   (caller-owned, bound with ctts_gpt_bind_kv)
-//   residual stream  x_dec [B][768] fp32 (decode), x_pre [<=2048 rows][768] (prompt pass)
+//   residual stream  x_dec [B][768] fp32 (decode), x_pre [<= 16384 rows][768] (one prompt pass; sized min(16384, max_batch * max_seq))
 //   act              fragment-major SwiGLU output for the down projection
+//   xh / ssq / scale fp16 decode above the split-K batch sizes: the residual stream as packed fp16 B operand + per-tile sums of squares + per-row
+//                    power-of-two scales, handed from the o_proj / down epilogues to the next QKV / gate|up / heads kernels (kernels.h PRO_XH)
+//   lora_*           resident per-utterance adapters and the low-rank terms of the rows being processed (lora.hip)
 //   dpart            [rows <= 16][4][768] ordered split-K partial sums of the down projection (decode batches <= 4)
 //   st / dyn         DevState (per-step counters) and SamplerDyn (per-call buffers and sampling parameters): everything a captured
 //                    decode graph would otherwise bake in is read from these two device blocks
