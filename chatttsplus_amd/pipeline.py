@@ -6,8 +6,9 @@ chattts_plus/pipelines/chattts_plus_pipeline.py for the hot path:
 
 What is kept: constructor kwargs, YAML layout (MODELS.<key>.{name,infer_type,kwargs}), `infer()` /
 `_infer()` / `_infer_code()` / `_decode_to_wavs()` / speaker helpers, the generator-of-wav-lists result,
-InferCodeParams / RefineTextParams.  What is delegated (out of the hot-path scope): text
-normalisation / splitting (pluggable callables, identity by default).  There is no CPU fallback.
+InferCodeParams / RefineTextParams, and the CPU text front-end in front of the path (text_frontend.py: sentence splitting,
+number spelling, short-sentence merging, the Normalizer -- replaceable callables, defaults as in the reference).  The Chinese
+number reader (zh_normalization) and nemo_text_processing are optional plug-ins.  There is no CPU fallback for the models.
 """
 from __future__ import annotations
 
@@ -22,7 +23,7 @@ from typing import Callable, List, Optional, Union
 import numpy as np
 import torch
 
-from . import _lib, codec, hip_models
+from . import _lib, codec, hip_models, text_frontend
 
 
 @dataclass(repr=False, eq=False)
@@ -145,8 +146,11 @@ class ChatTTSPlusPipeline:
         self.cfg = cfg
         self.device = torch.device(kwargs.get("device", "cuda"))
         self.dtype = torch.float32                 # activations / outputs are fp32; weights per `weight_dtype`
-        self.normalizer: Callable = kwargs.get("normalizer") or (lambda t, *a, **k: t)
-        self.text_splitter: Optional[Callable] = kwargs.get("text_splitter")
+        # CPU text front-end in front of the path (pipeline:147-155,353-388): `normalizer(text, do_text_normalization,
+        # do_homophone_replacement, lang)` and `text_splitter(lines) -> sentences`; both replaceable, `text_splitter=None` keeps the
+        # input lines as they are.  Defaults: text_frontend.Normalizer over <checkpoint_dir>/homophones_map.json and text_frontend.split_text
+        self.normalizer: Optional[Callable] = kwargs.get("normalizer")
+        self.text_splitter: Optional[Callable] = kwargs.get("text_splitter", text_frontend.split_text)
         self.load_lora = False
         self._lora_models = OrderedDict()          # lora_path -> merged sibling engine, LRU-bounded (`lora_cache`, default 1)
         self._lora_cache = max(1, int(kwargs.get("lora_cache", 1)))
@@ -218,6 +222,12 @@ class ChatTTSPlusPipeline:
             self.std, self.mean = spk_stat.chunk(2)
         else:
             self.std = self.mean = None
+        if self.normalizer is None:                         # pipeline:147-155 (the reference downloads the map when it is missing)
+            map_path = os.path.join(ckpt_dir, "homophones_map.json")
+            if not os.path.exists(map_path):
+                self.logger.warning("%s not found: homophone replacement is off", map_path)
+                map_path = None
+            self.normalizer = text_frontend.Normalizer(map_path)
 
     # -- speakers (pipeline:306-331) ---------------------------------------------------------------
     @torch.inference_mode()

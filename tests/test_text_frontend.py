@@ -1,0 +1,134 @@
+"""CPU text front-end (chatttsplus_amd/text_frontend.py) against tests/golden/text_frontend.json, the outputs of the imported reference
+functions (oracle/make_golden_text.py; reference chattts_plus/commons/text_utils.py and norm.py)."""
+import json
+import os
+
+import pytest
+
+from chatttsplus_amd import text_frontend as tf
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "text_frontend.json"), encoding="utf-8"))
+
+
+def _raised(expected):
+    return isinstance(expected, dict) and "raises" in expected
+
+
+@pytest.mark.parametrize("name,fn", [("num_to_english", tf.num_to_english), ("get_lang", tf.get_lang), ("num2text", tf.num2text),
+                                     ("remove_brackets", tf.remove_brackets), ("split_text_by_punctuation", tf.split_text_by_punctuation)])
+def test_function_matches_reference(name, fn):
+    n_equal = 0
+    for arg, expected in GOLD[name]:
+        got = fn(arg)
+        if _raised(expected):
+            # the reference aborts here (no word for a group ending in 10 / no scale word above trillion); this module answers
+            assert isinstance(got, str) and got, (name, arg)
+            continue
+        assert got == expected, (name, arg, got, expected)
+        n_equal += 1
+    assert n_equal >= 10
+
+
+def test_reader_fixes_where_the_reference_raises():
+    assert tf.num_to_english(10) == "Ten" and tf.num_to_english(110) == "One hundred and ten"
+    assert tf.num_to_english(10001) == "Ten thousand,  and one"
+    assert tf.num_to_english(1234567890123456).startswith("One quadrillion,  and two hundred and thirty four trillion, ")
+    assert tf.num2text("10 - 3") == "Ten minus  Three" and tf.num2text("10%") == " the pronunciation of  Ten"
+    with pytest.raises(ValueError):
+        tf.num_to_english("12a")                                        # like the reference: int() of a non-digit group
+
+
+def test_split_text_matches_reference():
+    # zh_normalization / nemo_text_processing are absent here as in the minting run: Chinese lines pass through, English through num2text
+    for lines, expected in GOLD["split_text"]:
+        assert tf.split_text(list(lines), zh_reader=lambda s: s) == expected, lines
+    # pluggable readers
+    assert tf.split_text(["价格100元", "pay 5"], zh_reader=lambda s: s.replace("100", "一百"), en_reader=str.upper) == ["价格一百元", "PAY 5"]
+
+
+def test_every_piece_of_a_cut_line_is_a_substring_and_they_concatenate():
+    for text, _ in GOLD["split_text_by_punctuation"]:
+        pieces = tf.split_text_by_punctuation(text)
+        assert "".join(pieces) == text
+        assert all(len(p) > 150 for p in pieces[:-1])
+
+
+def _normalizer(tmp_path):
+    mp = tmp_path / "homophones_map.json"
+    mp.write_text(json.dumps(GOLD["homophones"], ensure_ascii=False), encoding="utf-8")
+    return tf.Normalizer(str(mp))
+
+
+def test_normalizer_matches_reference(tmp_path):
+    n = _normalizer(tmp_path)
+    for args, expected in GOLD["normalizer"]:
+        assert n(*args) == expected, args
+    # same map handed over as a dict; no map at all leaves the homophones alone
+    n2 = tf.Normalizer(dict(GOLD["homophones"]))
+    assert all(n2(*args) == expected for args, expected in GOLD["normalizer"])
+    assert tf.Normalizer()("粘贴一下吗") == "粘贴一下吗"
+
+
+def test_normalizer_register_unregister_match_reference(tmp_path):
+    n = _normalizer(tmp_path)
+    got = [n.register("en", lambda s: s.upper()), n.register("zh", lambda s: s.replace("世界", "地球")), n.register("en", lambda s: s), n.register("fr", lambda s: 3)]
+    assert got == GOLD["register"]
+    assert n.register("de", lambda s: 1 / 0) is False                    # a raising callable is refused too (norm.py:165-172)
+    for args, expected in GOLD["normalizer_registered"]:
+        assert n(*args) == expected, args
+    n.unregister("en")
+    n.unregister("missing")
+    for args, expected in GOLD["normalizer_unregistered_en"]:
+        assert n(*args) == expected, args
+    n.destroy()
+    assert n("粘贴一下吗", True, True, "en") == "粘贴一下吗"
+
+
+def test_goldens_regenerate_from_the_reference_when_it_is_present(tmp_path):
+    from oracle.ref_import import reference_available
+    if not reference_available():
+        pytest.skip("reference tree not present")
+    from oracle import make_golden_text as mg
+    tu, nm = mg.load_text_reference()
+    for arg, expected in GOLD["num2text"]:
+        if not _raised(expected):
+            assert tu.num2text(arg) == expected
+    for arg, expected in GOLD["remove_brackets"]:
+        assert tu.remove_brackets(arg) == expected
+
+
+def test_pipeline_text_path_feeds_the_generator_what_the_reference_would(tmp_path):
+    """`_infer`'s preamble (pipeline:349-388): newline split -> split_text -> short-sentence merge -> Normalizer -> '[uv_break]' suffix.  A
+    pipeline shell without models records what reaches `_infer_code`."""
+    import types
+    from chatttsplus_amd.pipeline import ChatTTSPlusPipeline, InferCodeParams
+    pipe = object.__new__(ChatTTSPlusPipeline)
+    pipe.normalizer = tf.Normalizer(dict(GOLD["homophones"]))
+    pipe.text_splitter = tf.split_text
+    pipe.models_dict = {"gpt": types.SimpleNamespace(max_batch=4), "tokenizer": None}
+    pipe._gpt_for_lora = lambda path: pipe.models_dict["gpt"]
+    seen = []
+    pipe._infer_code = lambda text, stream, use_decoder, params, gpt=None: (seen.append(list(text)) or iter(()))
+    long_line = ("This is a fairly long sentence, with several commas, semicolons; and other marks: it keeps going on and on. " * 3).strip()
+    text = ["I have 2 cats\nand 15 dogs!", "粘贴(一下)吗", long_line]
+    list(pipe._infer(text, skip_refine_text=True, params_infer_code=InferCodeParams()))
+    flat = [t for batch in seen for t in batch]
+    # wiring: the same chain composed by hand from the golden-checked pieces
+    from chatttsplus_amd.pipeline import merge_short_sentences
+    lines = ["I have 2 cats", "and 15 dogs!", "粘贴(一下)吗", long_line]
+    expected = [pipe.normalizer(t, True, True, None) for t in merge_short_sentences(tf.split_text(lines))]
+    expected = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in expected]
+    assert len(seen) == 1 and flat == expected and len(flat) == 3
+    # short lines are chained and numbers spelled; the Chinese line joins the next chain with its homophones replaced; the long line is cut
+    # at punctuation.  Reference quirk kept: once a sentence holds ANY character outside [CJK A-Za-z , . space] the reject filter also
+    # eats the brackets and underscore of the "[uv_break]" joints (norm.py:140-157) -- they arrive as the word "uvbreak"
+    assert flat[0].startswith("I have Two cats uvbreak and Fifteen dogs")
+    assert flat[1].startswith("年贴,一下,嘛 uvbreak This is a fairly long sentence")
+    assert all(t.strip().endswith("[uv_break]") for t in flat)
+    assert "".join(flat).count("This is a fairly long sentence") == 3
+    # text optimisation off: utterances stay 1:1 with the input (what infer_sharded and the per-utterance LoRA path rely on)
+    seen.clear()
+    list(pipe._infer(text, skip_refine_text=True, do_text_optimization=False, params_infer_code=InferCodeParams()))
+    assert [len(b) for b in seen] == [3]
+    # digits are not spelled without the optimisation step: the Normalizer's reject filter drops them, newline included (norm.py:148-157)
+    assert seen[0][0] == "I have  catsand  dogs. [uv_break]"
