@@ -157,17 +157,37 @@ def _default_zh_reader() -> Optional[Callable[[str], str]]:
     return lambda s: "".join(tn.normalize(s))
 
 
+def _default_en_reader() -> Callable[[str], str]:
+    """nemo_text_processing when it is installed and constructs (text_utils.py:139-150), else -- as in the reference -- `num2text`."""
+    try:
+        from nemo_text_processing.text_normalization.normalize import Normalizer as NemoNormalizer
+        nemo = NemoNormalizer(input_case="cased", lang="en")
+    except Exception:  # noqa: BLE001
+        return num2text
+    state = {"failed": False}
+
+    def read(line: str) -> str:
+        if not state["failed"]:
+            try:
+                return nemo.normalize(line, verbose=False, punct_post_process=True)
+            except Exception:  # noqa: BLE001
+                state["failed"] = True                       # the reference latches its fallback after the first failure too
+        return num2text(line)
+
+    return read
+
+
 _MAX_LINE = 200
 
 
 def split_text(text_list: Iterable[str], zh_reader: Optional[Callable[[str], str]] = None, en_reader: Optional[Callable[[str], str]] = None) -> List[str]:
     """Per input line (text_utils.py:127-157): protect the control tags, spell numbers (Chinese lines through `zh_reader` -- by default
     `zh_normalization.TextNormalizer` when that package is installed, else unchanged; English lines through `en_reader`, by default
-    `num2text`, the reference's own fallback when nemo_text_processing is missing), then cut lines longer than 200 characters."""
+    nemo_text_processing when installed, else `num2text`, the reference's own fallback), then cut lines longer than 200 characters."""
     if zh_reader is None:
         zh_reader = _default_zh_reader() or (lambda s: s)
     if en_reader is None:
-        en_reader = num2text
+        en_reader = _default_en_reader()
     out: List[str] = []
     for line in text_list:
         line = remove_brackets(line)
