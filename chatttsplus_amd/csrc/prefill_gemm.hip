@@ -37,11 +37,17 @@ struct PfCfg {
     static constexpr int WAVES_EU = GR == 4 ? 3 : 2;                               // register budget: 168 / 256 per lane
 };
 
+#ifndef PF_RING
+#define PF_RING 3                                          // LDS stages per block (diagnostic builds: 4)
+#endif
+#ifndef PF_LDS_PAD
+#define PF_LDS_PAD 0                                       // diagnostic builds: extra LDS to lower the blocks per CU
+#endif
 template <int EPI, int WR, int WN, int GR>
 __global__ __launch_bounds__(WR * WN * 64) __attribute__((amdgpu_waves_per_eu(PfCfg<WR, WN, GR>::WAVES_EU, 8))) void prefill_gemm_kernel(
     const void* Wq, const void* Xp, const int ktiles, const int R, const GemmArgs a) {
     typedef PfCfg<WR, WN, GR> C;
-    __shared__ __attribute__((aligned(16))) char lds[3 * C::STAGE];
+    __shared__ __attribute__((aligned(16))) char lds[PF_RING * C::STAGE + PF_LDS_PAD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: fragment addresses below stay in scalar registers
     const int wr = wave / WN, wn = wave % WN;
@@ -96,31 +102,32 @@ __global__ __launch_bounds__(WR * WN * 64) __attribute__((amdgpu_waves_per_eu(Pf
     // just left with stage kt + 3, and only then issue the 16 MFMAs of stage kt: the wave's own LDS latency and the DMA issue sit
     // under its MFMAs instead of in front of them.  The waits are the builtin (not inline asm) so that the compiler's own counter
     // tracking knows the register set being multiplied is complete and does not wait for the reads just issued.
-    // s_waitcnt immediate (gfx9): vmcnt[3:0] | expcnt[6:4] = 7 (none) | lgkmcnt[11:8] = 0
-#define PF_WAIT_BAR(n_) { __builtin_amdgcn_s_waitcnt(0x0070 | (n_)); __builtin_amdgcn_s_barrier(); }
+    // s_waitcnt immediate (gfx9): vmcnt[3:0] and [15:14] | expcnt[6:4] = 7 (none) | lgkmcnt[11:8] = 0
+#define PF_WAIT_BAR(n_) { __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15) | (((n_) >> 4) << 14)); __builtin_amdgcn_s_barrier(); }
 #define PF_STEP(kt_, cb_, rd_a, rd_b, nx_a, nx_b, vm_, read_, dma_)                                                                  \
     {                                                                                                                                \
         PF_WAIT_BAR(vm_)                                                                                                             \
-        const int n1 = ((cb_) + 1 == 3) ? 0 : (cb_) + 1;                                                                             \
+        const int n1 = ((cb_) + 1 == PF_RING) ? 0 : (cb_) + 1;                                                                             \
         if (read_) PF_READ(nx_a, nx_b, n1)                                                                                           \
-        if (dma_) { PF_DMA((kt_) + 3, (cb_)) }                                                                                       \
+        if (dma_) { PF_DMA((kt_) + PF_RING, (cb_)) }                                                                                    \
         PF_MFMA(rd_a, rd_b)                                                                                                          \
         cb_ = n1;                                                                                                                    \
     }
-    PF_DMA(0, 0)
-    if (ktiles > 1) { PF_DMA(1, 1) }
-    if (ktiles > 2) { PF_DMA(2, 2) }
-    if (ktiles > 2) PF_WAIT_BAR(2 * C::PER_T) else PF_WAIT_BAR(0)
+#pragma unroll
+    for (int st = 0; st < PF_RING; ++st) { PF_DMA(st, st) }        // ktiles >= PF_RING (checked by the launcher)
+    PF_WAIT_BAR((PF_RING - 1) * C::PER_T)
     half8 af0[4], bf0[GR], af1[4], bf1[GR];
     PF_READ(af0, bf0, 0)
     int cb = 0;                                            // ring slot of the stage held in registers
     int kt = 0;
-    for (; kt + 2 < ktiles; kt += 2) {                     // ktiles is even (K = 768 / 3072): both steps still have a stage in flight behind them
-        PF_STEP(kt, cb, af0, bf0, af1, bf1, C::PER_T, true, true)
-        PF_STEP(kt + 1, cb, af1, bf1, af0, bf0, C::PER_T, true, kt + 4 < ktiles)
+    for (; kt + PF_RING < ktiles; kt += 2) {               // ktiles is even (K = 768 / 3072): PF_RING - 2 later stages stay in flight behind each step
+        PF_STEP(kt, cb, af0, bf0, af1, bf1, (PF_RING - 2) * C::PER_T, true, true)
+        PF_STEP(kt + 1, cb, af1, bf1, af0, bf0, (PF_RING - 2) * C::PER_T, true, kt + 1 + PF_RING < ktiles)
     }
-    PF_STEP(kt, cb, af0, bf0, af1, bf1, 0, true, false)
-    PF_STEP(kt + 1, cb, af1, bf1, af0, bf0, 0, false, false)
+    for (; kt < ktiles; kt += 2) {                         // the last stages: nothing left to request
+        PF_STEP(kt, cb, af0, bf0, af1, bf1, 0, true, false)
+        PF_STEP(kt + 1, cb, af1, bf1, af0, bf0, 0, kt + 2 < ktiles, false)
+    }
 #undef PF_STEP
 #undef PF_WAIT_BAR
 #undef PF_MFMA
@@ -263,7 +270,7 @@ template <int EPI, int WR, int WN, int GR>
 static int pf_launch(const GemmArgs& a, const void* X, int ktiles, hipStream_t s) {
     typedef PfCfg<WR, WN, GR> C;
     if ((a.n_row_tiles % C::BN_T) != 0) { ctts_set_error("prefill_gemm: %d n tiles not a multiple of %d", a.n_row_tiles, C::BN_T); return 1; }
-    if (ktiles < 2 || (ktiles & 1)) { ctts_set_error("prefill_gemm: K = %d is not a multiple of 64", ktiles * 32); return 1; }
+    if (ktiles < PF_RING + 1 || (ktiles & 1)) { ctts_set_error("prefill_gemm: K = %d is not a multiple of 64", ktiles * 32); return 1; }
     dim3 grid(a.n_row_tiles / C::BN_T, (a.R + C::BM_G * 16 - 1) / (C::BM_G * 16));
     hipLaunchKernelGGL((prefill_gemm_kernel<EPI, WR, WN, GR>), grid, dim3(C::WAVES * 64), 0, s, a.W, X, ktiles, a.R, a);
     CTTS_HIP_CHECK(hipGetLastError());
