@@ -132,3 +132,46 @@ def test_pipeline_text_path_feeds_the_generator_what_the_reference_would(tmp_pat
     assert [len(b) for b in seen] == [3]
     # digits are not spelled without the optimisation step: the Normalizer's reject filter drops them, newline included (norm.py:148-157)
     assert seen[0][0] == "I have  catsand  dogs. [uv_break]"
+
+
+def test_random_strings_against_the_imported_reference(tmp_path):
+    """Live comparison (only where /root/reference exists): seeded random numbers and sentences through every function; inputs on which the
+    reference raises (its missing "ten" / scale words) are skipped -- those are answered here instead."""
+    import random
+    from oracle.ref_import import reference_available
+    if not reference_available():
+        pytest.skip("reference tree not present")
+    from oracle import make_golden_text as mg
+    tu, nm = mg.load_text_reference()
+    rng = random.Random(20240927)
+    n_cmp = 0
+    for _ in range(3000):
+        digits = rng.randint(1, 15)
+        num = rng.randint(0, 10 ** digits)
+        try:
+            want = tu.num_to_english(num)
+        except IndexError:
+            continue
+        assert tf.num_to_english(num) == want, num
+        n_cmp += 1
+    assert n_cmp > 1500
+    alphabet = list("abc XYZ 0123456789 .,;:!?%+-*/=x()[]{}<>_'\"~\n\t") + list("你好世界天气今很，。！？；：（）【】《》「」…—　粘吗哦") + ["[uv_break]", "[laugh]", "[lbreak]", "[break]", " 12.5% ", " 3/4 ", "1,000"]
+    mp = tmp_path / "h.json"
+    mp.write_text(json.dumps(GOLD["homophones"], ensure_ascii=False), encoding="utf-8")
+    ref_norm, my_norm = nm.Normalizer(str(mp)), tf.Normalizer(str(mp))
+    n_cmp = 0
+    for _ in range(1500):
+        text = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 60)))
+        assert tf.get_lang(text) == tu.get_lang(text)
+        assert tf.remove_brackets(text) == tu.remove_brackets(text), text
+        long_text = text * rng.randint(1, 8)
+        assert tf.split_text_by_punctuation(long_text) == tu.split_text_by_punctuation(long_text)
+        for flags in ((True, True, None), (False, True, None), (True, False, "zh"), (True, True, "en")):
+            assert my_norm(text, *flags) == ref_norm(text, *flags), (text, flags)
+        try:
+            want = tu.num2text(text)
+        except IndexError:
+            continue
+        assert tf.num2text(text) == want, text
+        n_cmp += 1
+    assert n_cmp > 500
