@@ -48,7 +48,8 @@ def run_ref_generate(ref, g, ids, mask, torch_seed, max_new, min_new, temperatur
     lw, lp = ref.processors.gen_logits(num_code=g.emb_code[0].num_embeddings - 1, top_P=top_p, top_K=top_k,
                                        repetition_penalty=rep)
     torch.manual_seed(torch_seed)
-    out = list(g.generate(emb, ids, temperature=torch.tensor([temperature] * g.num_vq),
+    temps = list(temperature) if isinstance(temperature, (list, tuple)) else [temperature] * g.num_vq
+    out = list(g.generate(emb, ids, temperature=torch.tensor(temps),
                           eos_token=g.emb_code[0].num_embeddings - 1, attention_mask=mask_t,
                           max_new_token=max_new, min_new_token=min_new, logits_warpers=lw, logits_processors=lp,
                           return_hidden=True, show_tqdm=False, ensure_non_empty=ensure_non_empty))[-1]
@@ -164,6 +165,22 @@ def golden_gpt_real_ragged(ref):
                 save_gen("gpt_real_b4_ragged", meta, emb, out)
                 return
     raise SystemExit("no staggered-finish case found")
+
+
+def golden_gpt_real_params(ref):
+    """Real config, B=3 with three left paddings and NON-default sampler settings: one temperature per codebook, top-p 0.9, top-k 8,
+    repetition penalty 1.3 (the webui exposes all of them, webui.py / pipeline:172-199), min_new_token 3, speaker slot at position 1."""
+    cfg = synth.GPT_REAL
+    sd = synth.gpt_state_dict(cfg, 1234)
+    g = build_ref_gpt(ref, cfg, sd)
+    spk = synth.speaker_vector(77)
+    meta = dict(weight_seed=1234, prompt_seed=23, torch_seed=2024, B=3, T=13, pad_left=[0, 4, 2], max_new=28, min_new=3,
+                spk_seed=77, spk_id=21143, spk_pos=6, temperatures=[0.2, 0.35, 0.5, 0.8], top_p=0.9, top_k=8, rep=1.3)
+    ids, mask = synth.prompt_ids(3, 13, cfg["num_text_tokens"], 23, pad_left=meta["pad_left"])
+    ids[:, 6, :] = meta["spk_id"]
+    emb, out = run_ref_generate(ref, g, ids, mask, 2024, 28, 3, temperature=meta["temperatures"], top_p=0.9, top_k=8, rep=1.3,
+                                spk=spk, spk_id=meta["spk_id"])
+    save_gen("gpt_real_params", meta, emb, out)
 
 
 def golden_gpt_real_regen(ref):
@@ -349,6 +366,7 @@ def main():
     golden_gpt_real(ref)
     golden_gpt_real_ragged(ref)
     golden_gpt_real_regen(ref)
+    golden_gpt_real_params(ref)
     golden_refine_text(ref)
 
 

@@ -39,7 +39,7 @@ def model(wd, seed=1234, boost=None):
     return _models[key]
 
 
-@pytest.mark.parametrize("name", ["gpt_real_b1", "gpt_real_b2_pad", "gpt_real_greedy", "gpt_real_b4_ragged", "gpt_real_regen"])
+@pytest.mark.parametrize("name", ["gpt_real_b1", "gpt_real_b2_pad", "gpt_real_greedy", "gpt_real_b4_ragged", "gpt_real_regen", "gpt_real_params"])
 def test_generate_golden_fp32_bit_exact_ids(name):
     z, meta = load_golden(name)
     sd, ids, mask, spk = gen_case_inputs(meta, synth.GPT_REAL)
@@ -50,10 +50,15 @@ def test_generate_golden_fp32_bit_exact_ids(name):
         emb = ref_cpu.OracleGPT.apply_spk_emb(emb.cpu(), torch.from_numpy(spk), ids_t, int(meta["spk_id"])).cuda()
     np.testing.assert_allclose(emb[:, -1].cpu().numpy(), z["emb_last"], atol=0, rtol=0)
     temp = float(meta["temperature"]) if "temperature" in meta else 0.3
+    temps, lw, lp = [temp] * 4, LW, LP
+    if "temperatures" in meta:                      # gpt_real_params: one temperature per codebook, non-default top-p / top-k / penalty
+        temps = [float(t) for t in meta["temperatures"]]
+        lw = [type("P", (), dict(top_p=float(meta["top_p"]), min_tokens_to_keep=3))(), type("K", (), dict(top_k=int(meta["top_k"])))()]
+        lp = [type("R", (), dict(penalty=float(meta["rep"]), past_window=16, max_input_ids=625))()]
     torch.manual_seed(int(meta["torch_seed"]))
-    out = list(g.generate(emb, ids_t, torch.tensor([temp] * 4), 625, attention_mask=torch.from_numpy(mask),
-                          max_new_token=int(meta["max_new"]), min_new_token=int(meta["min_new"]), logits_warpers=LW,
-                          logits_processors=LP, return_hidden=True, noise="torch"))[-1]
+    out = list(g.generate(emb, ids_t, torch.tensor(temps), 625, attention_mask=torch.from_numpy(mask),
+                          max_new_token=int(meta["max_new"]), min_new_token=int(meta["min_new"]), logits_warpers=lw,
+                          logits_processors=lp, return_hidden=True, noise="torch"))[-1]
     lens = z["lens"]
     assert [int(i.shape[0]) for i in out.ids] == lens.tolist()
     for b, n in enumerate(lens):

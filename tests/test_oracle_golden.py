@@ -20,6 +20,9 @@ def _run_oracle(name, cfg):
         emb = o.apply_spk_emb(emb, torch.from_numpy(spk), torch.from_numpy(ids), int(meta["spk_id"]))
     temp = float(meta["temperature"]) if "temperature" in meta else 0.3
     sp = ref_cpu.SamplerParams(temperature=[temp] * 4, min_new_token=int(meta["min_new"]))
+    if "temperatures" in meta:                      # gpt_real_params: one temperature per codebook, non-default top-p / top-k / penalty
+        sp = ref_cpu.SamplerParams(temperature=[float(t) for t in meta["temperatures"]], top_p=float(meta["top_p"]), top_k=int(meta["top_k"]),
+                                   repetition_penalty=float(meta["rep"]), min_new_token=int(meta["min_new"]))
     torch.manual_seed(int(meta["torch_seed"]))
     out = o.generate(emb, torch.from_numpy(ids), sp, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]))
     return z, meta, emb, out
@@ -33,6 +36,7 @@ def _run_oracle(name, cfg):
     ("gpt_real_greedy", synth.GPT_REAL),
     ("gpt_real_b4_ragged", synth.GPT_REAL),
     ("gpt_real_regen", synth.GPT_REAL),
+    ("gpt_real_params", synth.GPT_REAL),
 ])
 def test_generate_matches_reference(name, cfg):
     z, meta, emb, out = _run_oracle(name, cfg)
