@@ -183,6 +183,19 @@ def golden_gpt_real_params(ref):
     save_gen("gpt_real_params", meta, emb, out)
 
 
+def golden_gpt_real_long(ref):
+    """Real config, 160 forced steps (EOS masked by min_new_token, gpt.py:477-478) for two sequences, one left padded by 7: the repetition
+    window slides ten times over, the context grows from 20 to 180 keys, 40 four-step graph replays on the HIP side."""
+    cfg = synth.GPT_REAL
+    sd = synth.gpt_state_dict(cfg, 1234)
+    g = build_ref_gpt(ref, cfg, sd)
+    meta = dict(weight_seed=1234, prompt_seed=31, torch_seed=515, B=2, T=20, pad_left=[0, 7], max_new=160, min_new=160,
+                spk_seed=1234, spk_id=21143, spk_pos=-1)
+    ids, mask = synth.prompt_ids(2, 20, cfg["num_text_tokens"], 31, pad_left=meta["pad_left"])
+    emb, out = run_ref_generate(ref, g, ids, mask, 515, 160, 160)
+    save_gen("gpt_real_long", meta, emb, out)
+
+
 def golden_gpt_real_regen(ref):
     """Real config, first-step EOS -> ensure_non_empty regenerate (gpt.py:496-525): B=2 with left padding, EOS head rows
     boosted, min_new_token=0.  The torch seed is searched for a run whose first attempt(s) end at step 0 (finish.any()) and a
@@ -367,6 +380,7 @@ def main():
     golden_gpt_real_ragged(ref)
     golden_gpt_real_regen(ref)
     golden_gpt_real_params(ref)
+    golden_gpt_real_long(ref)
     golden_refine_text(ref)
 
 

@@ -39,7 +39,7 @@ def model(wd, seed=1234, boost=None):
     return _models[key]
 
 
-@pytest.mark.parametrize("name", ["gpt_real_b1", "gpt_real_b2_pad", "gpt_real_greedy", "gpt_real_b4_ragged", "gpt_real_regen", "gpt_real_params"])
+@pytest.mark.parametrize("name", ["gpt_real_b1", "gpt_real_b2_pad", "gpt_real_greedy", "gpt_real_b4_ragged", "gpt_real_regen", "gpt_real_params", "gpt_real_long"])
 def test_generate_golden_fp32_bit_exact_ids(name):
     z, meta = load_golden(name)
     sd, ids, mask, spk = gen_case_inputs(meta, synth.GPT_REAL)

@@ -37,6 +37,7 @@ def _run_oracle(name, cfg):
     ("gpt_real_b4_ragged", synth.GPT_REAL),
     ("gpt_real_regen", synth.GPT_REAL),
     ("gpt_real_params", synth.GPT_REAL),
+    ("gpt_real_long", synth.GPT_REAL),
 ])
 def test_generate_matches_reference(name, cfg):
     z, meta, emb, out = _run_oracle(name, cfg)
