@@ -115,6 +115,15 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
                            params_infer_code=InferCodeParams(spk_emb=spk, max_new_token=8, min_new_token=8, show_tqdm=False)))
     assert len(full) == 1 and [w.shape[0] for w in full[0]] == [256 * 15, 256 * 15]
 
+    # default text optimisation (text_frontend.split_text + short-sentence merge + Normalizer, pipeline:349-388): two short lines become ONE
+    # utterance joined by [uv_break] -- identical to handing that utterance over with the optimisation switched off
+    p2 = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=12, min_new_token=12, show_tqdm=False)
+    torch.manual_seed(3)
+    merged = list(pipe.infer(["a b c", "d a"], skip_refine_text=True, params_infer_code=p2))
+    torch.manual_seed(3)
+    direct = list(pipe.infer(["a b c [uv_break] d a [uv_break] "], skip_refine_text=True, do_text_optimization=False, params_infer_code=p2))
+    assert len(merged) == 1 and len(merged[0]) == 1 and merged[0][0].shape[0] == 256 * 23 and torch.equal(merged[0][0], direct[0][0])
+
 
 def test_refine_text_generate_golden_bit_exact():
     """infer_text=True on the HIP path (21178-way head, emb_text re-embed, 1024-thread text sampler) reproduces the token ids
