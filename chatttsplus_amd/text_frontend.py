@@ -21,7 +21,7 @@ Two crashes of the reference are NOT kept (they would abort the request): its re
 "quadrillion" / "quintillion".
 
 Third-party readers the reference calls are absent from this image and are plug-ins here: `zh_normalization.TextNormalizer` for Chinese
-numbers / dates (used when importable, else the text passes through unchanged) and `nemo_text_processing` for English (the reference
+numbers / dates (used when importable; else `zh_numbers.py`, the build's own minimal numeral reader) and `nemo_text_processing` for English (the reference
 itself falls back to `num2text` when it is missing; so does this module unless `en_reader` is given).
 """
 from __future__ import annotations
@@ -182,10 +182,13 @@ _MAX_LINE = 200
 
 def split_text(text_list: Iterable[str], zh_reader: Optional[Callable[[str], str]] = None, en_reader: Optional[Callable[[str], str]] = None) -> List[str]:
     """Per input line (text_utils.py:127-157): protect the control tags, spell numbers (Chinese lines through `zh_reader` -- by default
-    `zh_normalization.TextNormalizer` when that package is installed, else unchanged; English lines through `en_reader`, by default
+    `zh_normalization.TextNormalizer` when that package is installed, else the built-in `zh_numbers.read_numbers_zh`; English lines through `en_reader`, by default
     nemo_text_processing when installed, else `num2text`, the reference's own fallback), then cut lines longer than 200 characters."""
     if zh_reader is None:
-        zh_reader = _default_zh_reader() or (lambda s: s)
+        zh_reader = _default_zh_reader()
+        if zh_reader is None:
+            from .zh_numbers import read_numbers_zh     # the build's own minimal reader (not a restatement of zh_normalization)
+            zh_reader = read_numbers_zh
     if en_reader is None:
         en_reader = _default_en_reader()
     out: List[str] = []
