@@ -103,6 +103,7 @@ def _install_stand_ins():
     if "numba" not in sys.modules:
         nb = types.ModuleType("numba")
         nb.jit = lambda f=None, *a, **k: f if callable(f) else (lambda g: g)
+        nb._ctts_stand_in = True
         sys.modules["numba"] = nb
     if "zh_normalization" not in sys.modules:
         zh = types.ModuleType("zh_normalization")
@@ -112,6 +113,7 @@ def _install_stand_ins():
                 return [text]
 
         zh.TextNormalizer = TextNormalizer
+        zh._ctts_stand_in = True
         sys.modules["zh_normalization"] = zh
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
@@ -120,6 +122,14 @@ def _install_stand_ins():
             m = types.ModuleType(pkg)
             m.__path__ = [os.path.join(REFERENCE_ROOT, "chattts_plus", sub)]
             sys.modules[pkg] = m
+
+
+def remove_stand_ins():
+    """Take the stand-in modules out of sys.modules again (tests: later imports must see the packages as absent)."""
+    for name in ("numba", "zh_normalization"):
+        m = sys.modules.get(name)
+        if m is not None and getattr(m, "_ctts_stand_in", False):
+            del sys.modules[name]
 
 
 def load_text_reference():
