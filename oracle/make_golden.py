@@ -334,6 +334,23 @@ def golden_dvae(ref):
     print("dvae_real mel", mel.shape, float(np.sqrt((mel ** 2).mean())))
 
 
+def golden_dvae_lengths(ref):
+    """The DVAE decode branch at the edge lengths the HIP tests use against the oracle (tests/test_gpu_vocoder.py): one token (two mel frames,
+    every conv window mostly padding), five tokens, and 333 tokens (not a multiple of any tile size)."""
+    cfg = synth.DVAE_REAL
+    sd = synth.dvae_state_dict(cfg, 1234)
+    m = ref.dvae.DVAE(decoder_config=dict(idim=cfg["idim"], odim=cfg["odim"], hidden=cfg["hidden"],
+                                          n_layer=cfg["n_layer"], bn_dim=cfg["bn_dim"]), dim=cfg["dim"]).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    out = dict(weight_seed=np.array(1234), lengths=np.array([1, 5, 333]), hidden_seeds=np.array([101, 105, 433]))
+    for n, seed in zip(out["lengths"], out["hidden_seeds"]):
+        hid = np.random.Generator(np.random.Philox(key=int(seed))).standard_normal((int(n), 768)).astype(np.float32)
+        with torch.no_grad():
+            out[f"mel_{int(n)}"] = m(torch.from_numpy(hid).permute(1, 0)[None].clone())[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "dvae_real_lengths.npz"), **out)
+    print("dvae_real_lengths", {k: v.shape for k, v in out.items() if k.startswith("mel_")})
+
+
 def golden_dvae_encode(ref):
     """Zero-shot encode branch.  Pinned by the reference's own modules: downsample_conv + encoder (dvae.py:224-231,263-268)
     on a given mel.  NOT pinned (third-party torchaudio / vector_quantize_pytorch absent): the mel extractor and the GFSQ
@@ -375,6 +392,7 @@ def main():
     golden_gpt_tiny(ref)
     golden_gpt_tiny_regen(ref)
     golden_dvae(ref)
+    golden_dvae_lengths(ref)
     golden_dvae_encode(ref)
     golden_gpt_real(ref)
     golden_gpt_real_ragged(ref)

@@ -73,6 +73,18 @@ def test_dvae_decode_matches_reference():
     assert np.abs(mel - z["mel"]).max() <= 2e-5
 
 
+def test_dvae_decode_matches_reference_at_edge_lengths():
+    """1, 5 and 333 tokens (reference-minted mels): the lengths tests/test_gpu_vocoder.py checks the HIP kernels against this oracle."""
+    z = np.load(os.path.join(GOLDEN, "dvae_real_lengths.npz"))
+    sd = synth.dvae_state_dict(synth.DVAE_REAL, int(z["weight_seed"]))
+    for n, seed in zip(z["lengths"], z["hidden_seeds"]):
+        hid = np.random.Generator(np.random.Philox(key=int(seed))).standard_normal((int(n), 768)).astype(np.float32)
+        mel = ref_cpu.dvae_decode(sd, torch.from_numpy(hid)).numpy()
+        want = z[f"mel_{int(n)}"]
+        assert mel.shape == want.shape == (100, 2 * int(n))
+        assert np.abs(mel - want).max() <= 2e-5, int(n)
+
+
 def test_vocos_istft_self_consistency():
     """Vocos is parity-unpinned (third-party, absent): check the restatement's ISTFT against the direct definition."""
     sd = {k: torch.from_numpy(v) for k, v in synth.vocos_state_dict(synth.VOCOS_REAL, 1234).items()}
