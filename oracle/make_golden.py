@@ -196,6 +196,25 @@ def golden_gpt_real_long(ref):
     save_gen("gpt_real_long", meta, emb, out)
 
 
+def golden_gpt_real_b32(ref):
+    """Batch 32 (eight times the reference pipeline's slice of 4, but `GPT.generate` itself takes any batch): 23 different left paddings, 6
+    forced steps -- the same prompt layout the HIP path is teacher-forced on against the oracle (tests/test_gpu_gpt.py).  Pins the oracle at
+    the batch size of BASELINE configs[2]; all ids are stored, hiddens of four rows only (fixture size)."""
+    cfg = synth.GPT_REAL
+    sd = synth.gpt_state_dict(cfg, 1234)
+    g = build_ref_gpt(ref, cfg, sd)
+    pad = list(range(0, 23)) + [0] * 9
+    meta = dict(weight_seed=1234, prompt_seed=332, torch_seed=88, B=32, T=24, pad_left=pad, max_new=6, min_new=6,
+                spk_seed=1234, spk_id=21143, spk_pos=-1, hidden_rows=[0, 7, 22, 31])
+    ids, mask = synth.prompt_ids(32, 24, cfg["num_text_tokens"], 332, pad_left=pad)
+    emb, out = run_ref_generate(ref, g, ids, mask, 88, 6, 6)
+    lens = np.array([i.shape[0] for i in out.ids], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "gpt_real_b32.npz"), lens=lens, ids=np.stack([i.numpy() for i in out.ids]).astype(np.int16),
+                        hiddens=np.stack([out.hiddens[r].numpy() for r in meta["hidden_rows"]]),
+                        emb_last=emb[:, -1].detach().numpy(), **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
+    print("gpt_real_b32 lens", lens.tolist())
+
+
 def golden_gpt_real_regen(ref):
     """Real config, first-step EOS -> ensure_non_empty regenerate (gpt.py:496-525): B=2 with left padding, EOS head rows
     boosted, min_new_token=0.  The torch seed is searched for a run whose first attempt(s) end at step 0 (finish.any()) and a
@@ -399,6 +418,7 @@ def main():
     golden_gpt_real_regen(ref)
     golden_gpt_real_params(ref)
     golden_gpt_real_long(ref)
+    golden_gpt_real_b32(ref)
     golden_refine_text(ref)
 
 

@@ -220,3 +220,20 @@ def test_gfsq_indices_round_trip_to_the_quantised_latent(pre_bound):
         target = ref_cpu.fsq_bound(z, torch.tensor([5., 5., 5., 5.])) if pre_bound else z
         inner = target.abs() < 0.9
         assert float((target - lat[g])[inner].abs().max()) <= 0.2
+
+
+def test_generate_matches_reference_at_batch_32():
+    """gpt_real_b32: 32 sequences with 23 different left paddings, minted from the reference's own GPT.generate -- the oracle is pinned at the
+    batch size the HIP path is measured at (BASELINE configs[2]); ids of every row, hiddens of four rows."""
+    z, meta = load_golden("gpt_real_b32")
+    sd, ids, mask, _ = gen_case_inputs(meta, synth.GPT_REAL)
+    o = ref_cpu.OracleGPT(sd, 12)
+    emb = o.embed(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
+    np.testing.assert_allclose(emb[:, -1].numpy(), z["emb_last"], atol=0, rtol=0)
+    torch.manual_seed(int(meta["torch_seed"]))
+    out = o.generate(emb, torch.from_numpy(ids), ref_cpu.SamplerParams(min_new_token=int(meta["min_new"])), attention_mask=torch.from_numpy(mask),
+                     max_new_token=int(meta["max_new"]))
+    assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist()
+    assert np.array_equal(np.stack([i.numpy() for i in out.ids]), z["ids"].astype(np.int64))
+    for k, r in enumerate(int(x) for x in meta["hidden_rows"]):
+        assert np.abs(out.hiddens[r].numpy() - z["hiddens"][k]).max() <= 2e-5, r
