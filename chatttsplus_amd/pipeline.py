@@ -425,7 +425,10 @@ class ChatTTSPlusPipeline:
               do_text_normalization=True, do_text_optimization=True, do_homophone_replacement=True,
               params_refine_text=RefineTextParams(), params_infer_code=InferCodeParams(), **kwargs):
         """pipeline:472-579.  Speaker resolution: `speaker_emb_path` (.pt holding a base16384 str or a tensor),
-        else params_infer_code.spk_emb as given, else a random speaker from spk_stat."""
+        else params_infer_code.spk_emb as given (the reference overwrites it with a random speaker whenever no path is passed,
+        pipeline:547-556), else a random speaker from spk_stat.  The params object is copied first: the default argument is one shared
+        instance, and the reference's in-place writes make a zero-shot prompt or a sampled speaker stick to every later default call."""
+        params_infer_code = dataclasses.replace(params_infer_code)
         if kwargs.get("speaker_audio_path"):                                      # zero shot (pipeline:486-499)
             from . import audio
             p = kwargs["speaker_audio_path"]

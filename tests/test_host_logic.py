@@ -193,3 +193,30 @@ def test_adapter_slot_cache_lru(tmp_path, monkeypatch):
     import pytest
     with pytest.raises(_lib.HipBackendError):
         pipe._adapter_slots(g, [f"q{i}" for i in range(_lib.MAX_ADAPTERS + 1)])
+
+
+def test_infer_resolves_the_speaker_on_a_copy_of_the_params(tmp_path):
+    """infer() (pipeline:472-579): speaker_emb_path (.pt with a base16384 string or a tensor) > explicit params.spk_emb > random speaker; the
+    caller's / the shared default params object is never written to."""
+    import torch
+    from chatttsplus_amd import codec
+    from chatttsplus_amd.pipeline import ChatTTSPlusPipeline, InferCodeParams
+    pipe = object.__new__(ChatTTSPlusPipeline)
+    pipe.std, pipe.mean = torch.ones(768), torch.zeros(768)
+    seen = []
+    pipe._infer = lambda text, *a, **k: seen.append(a[9]) or iter(())         # a[9] = params_infer_code
+    default = ChatTTSPlusPipeline.infer.__wrapped__.__defaults__[-1] if hasattr(ChatTTSPlusPipeline.infer, "__wrapped__") else None
+    pipe.infer("a")
+    pipe.infer("a")
+    assert isinstance(seen[0].spk_emb, str) and isinstance(seen[1].spk_emb, str) and seen[0].spk_emb != seen[1].spk_emb    # re-sampled per call
+    if default is not None:
+        assert default.spk_emb is None and default.spk_smp is None                                                     # shared default untouched
+    mine = InferCodeParams(spk_emb="given")
+    pipe.infer("a", params_infer_code=mine)
+    assert seen[2].spk_emb == "given" and seen[2] is not mine
+    vec = torch.randn(768)
+    torch.save(codec.encode_spk_emb(vec), tmp_path / "s.pt")
+    torch.save(vec.view(1, 768), tmp_path / "t.pt")
+    pipe.infer("a", params_infer_code=mine, speaker_emb_path=str(tmp_path / "s.pt"))
+    pipe.infer("a", params_infer_code=mine, speaker_emb_path=str(tmp_path / "t.pt"))
+    assert isinstance(seen[3].spk_emb, str) and torch.equal(torch.as_tensor(seen[4].spk_emb).view(-1), vec) and mine.spk_emb == "given"
