@@ -174,3 +174,58 @@ def test_infer_preamble_and_slicing_match(both, flags):
     assert len(out_ref) == len(out_mine)
     if flags.get("refine_text_only"):
         assert out_ref == out_mine
+
+
+def test_reference_pipeline_end_to_end_equals_the_oracle_chain(both, tmp_path):
+    """The reference pipeline's own `_infer` (text wrapping -> tokenizer -> GPT.generate -> per-utterance DVAE -> Vocos) with the reference's
+    real GPT and DVAE modules on synthetic weights, against the chain the GPU test compares the HIP pipeline with
+    (tests/test_gpu_pipeline.py::test_pipeline_infer_matches_oracle_chain): tokenizer.encode -> OracleGPT -> ref_cpu.dvae_decode ->
+    ref_cpu.vocos_decode.  Vocos is absent from the image: both sides vocode with the oracle's restatement, so the waveform comparison pins
+    everything up to the mel plus the per-utterance loop, not Vocos itself."""
+    import numpy as np
+    from chatttsplus_amd import synth
+    from oracle import make_golden as mgold
+    from oracle import ref_cpu
+    ref, _ = both
+    refmods = load_reference()
+    gsd = synth.gpt_state_dict(synth.GPT_REAL, 1234)
+    dsd = synth.dvae_state_dict(synth.DVAE_REAL, 1234)
+    vsd = synth.vocos_state_dict(synth.VOCOS_REAL, 1234)
+    cfg = synth.DVAE_REAL
+    dvae = refmods.dvae.DVAE(decoder_config=dict(idim=cfg["idim"], odim=cfg["odim"], hidden=cfg["hidden"], n_layer=cfg["n_layer"], bn_dim=cfg["bn_dim"]),
+                             dim=cfg["dim"]).eval()
+    dvae.load_state_dict({k: torch.from_numpy(v) for k, v in dsd.items()}, strict=True)
+
+    class OracleVocos:                                         # stand-in for the absent third-party package (pipeline:93-111,303)
+        def parameters(self):
+            return iter([torch.zeros(1)])
+
+        def decode(self, mel):
+            return ref_cpu.vocos_decode(vsd, mel[0])[None]
+
+    tok = ref.models_dict["tokenizer"]
+    tok._decode_spk_emb = codec.decode_spk_emb                 # pybase16384 is absent; the codec is pinned on the bundled speaker files
+    del tok.apply_spk_emb                                      # the fixture's pass-through: here the reference's own overwrite must run
+    ref.models_dict = {"gpt": mgold.build_ref_gpt(refmods, synth.GPT_REAL, gsd), "tokenizer": tok, "dvae_decode": dvae, "vocos": OracleVocos()}
+    del ref._decode_to_wavs                                    # ... and the reference's own per-utterance loop (pipeline:286-305)
+    spk = torch.load(os.path.join(os.path.dirname(__file__), "golden", "speakers", "2222.pt"), weights_only=True)
+    params = ref_params(ref, "InferCodeParams", dict(prompt="[speed_5]", spk_emb=spk, max_new_token=10, min_new_token=2, show_tqdm=False))
+    texts = ["a b c d a b", "c a"]
+    torch.manual_seed(11)
+    outs = list(ref._infer(list(texts), False, None, True, False, True, True, False, True, ref_params(ref, "RefineTextParams", {}), params))
+    assert len(outs) == 1 and len(outs[0]) == 2
+    # oracle chain on the same inputs
+    mine_tok = Tokenizer(tokenizer=tok._tokenizer)
+    wrapped = [f"[Stts][spk_emb][speed_5]{t} [uv_break][Ptts]" for t in texts]
+    ids, att, tm = mine_tok.encode(wrapped, 4)
+    o = ref_cpu.OracleGPT(gsd, 12)
+    emb = o.apply_spk_emb(o.embed(ids, tm), torch.from_numpy(codec.decode_spk_emb(spk)), ids, mine_tok.spk_emb_ids)
+    torch.manual_seed(11)
+    gen = o.generate(emb, ids, ref_cpu.SamplerParams(min_new_token=2), attention_mask=att, max_new_token=10)
+    for b in range(2):
+        n = gen.ids[b].shape[0]
+        wav_ref = outs[0][b].numpy()
+        assert wav_ref.shape[0] == 256 * (2 * n - 1)
+        wav = ref_cpu.vocos_decode(vsd, ref_cpu.dvae_decode(dsd, gen.hiddens[b])).numpy()
+        rms = float(np.sqrt(np.mean((wav - wav_ref) ** 2))) / float(np.sqrt(np.mean(wav_ref ** 2)))
+        assert rms <= 5e-4, (b, rms)                           # measured 2e-4: fp32 hiddens differ by ~5e-6, Vocos exponentiates magnitudes
