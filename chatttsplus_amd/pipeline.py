@@ -53,6 +53,18 @@ class InferCodeParams(RefineTextParams):     # reference commons/utils.py:25-36
     pass_first_n_batches: int = 2
 
 
+class TorchSeedContext:                        # reference commons/utils.py:48-58: seed torch's CPU generator for one request, restore it afterwards
+    def __init__(self, seed):
+        self.seed, self.state = seed, None
+
+    def __enter__(self):
+        self.state = torch.random.get_rng_state()
+        torch.manual_seed(self.seed)
+
+    def __exit__(self, exc_type, exc, tb):
+        torch.random.set_rng_state(self.state)
+
+
 class _TopP:                                  # scalar carriers with the attribute names the HF warpers expose
     def __init__(self, top_p, min_tokens_to_keep):
         self.top_p, self.min_tokens_to_keep = float(top_p), int(min_tokens_to_keep)

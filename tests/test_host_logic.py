@@ -220,3 +220,16 @@ def test_infer_resolves_the_speaker_on_a_copy_of_the_params(tmp_path):
     pipe.infer("a", params_infer_code=mine, speaker_emb_path=str(tmp_path / "s.pt"))
     pipe.infer("a", params_infer_code=mine, speaker_emb_path=str(tmp_path / "t.pt"))
     assert isinstance(seen[3].spk_emb, str) and torch.equal(torch.as_tensor(seen[4].spk_emb).view(-1), vec) and mine.spk_emb == "given"
+
+
+def test_torch_seed_context_like_the_reference():
+    """commons/utils.py:48-58 -- what demos wrap a request in: the tokens of a request depend on the seed only, the caller's generator state is restored."""
+    import torch
+    from chatttsplus_amd.pipeline import TorchSeedContext
+    torch.manual_seed(123)
+    before = torch.random.get_rng_state()
+    with TorchSeedContext(7):
+        a = torch.rand(3)
+    assert torch.equal(torch.random.get_rng_state(), before)
+    with TorchSeedContext(7):
+        assert torch.equal(torch.rand(3), a)
