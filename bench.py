@@ -3,8 +3,11 @@
 A "step" is one pass of the hot path over one batch: 20 decoder layers + 4 heads + sampler for B sequences,
 i.e. B generated tokens (token = 4 code indices = 21.33 ms of audio).  Default workload =
 BASELINE.json configs[1]: batch 1, 48-token synthetic prompt, top-p 0.7 / top-k 20 / T 0.3 / rep 1.05,
-a 512-token generation (min_new = max_new: EOS masked), fp16 weights+KV with fp32 accumulate (the reference's GPU
-dtype, pipeline:37-41).  Inputs are resident in HBM when the timed region starts.
+a 512-token generation (min_new = max_new: EOS masked).  Default mode = the PARITY mode (`--dtype fp32`: fp32 weights + KV,
+exact-f32 MFMA): the mode in which token ids are bit-exact against the reference CPU path and mel / waveform stay within
+north_star's 1e-3 -- the mode the YAML ships.  `--dtype fp16` = the fast mode (fp16 weights + KV, fp32 accumulate: the reference's own
+GPU dtype, pipeline:37-41; mel / waveform 1.2-1.75e-3); its figures ride in `extra` of the default line.  Inputs are resident in HBM
+when the timed region starts.
 
 The timed window of K steps is placed in the MIDDLE of the 512-token generation whatever K is (the steps before it run
 untimed), so the measured context length -- and with it the KV bytes per step -- is that of the whole generation
@@ -212,7 +215,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--prompt", type=int, default=48)
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp16", "fp32"], help="fp32 = parity mode (default, what the YAML ships); fp16 = fast mode")
     ap.add_argument("--cpu-steps", type=int, default=192, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--gen-tokens", type=int, default=GEN_TOKENS, help="length of the generation the timed window is centred in (0: the window starts right after the warm-up; used by the short profiler passes)")
@@ -329,6 +332,16 @@ def main():
                 e = Leg(g32, dev, rank, world).run(1, P, min(K, 256), W, spk=spk, use_graph=use_graph)
                 extra["parity_mode_fp32_batch1"] = summarize(e, world)
                 g32.close()
+            else:
+                # the fast mode (fp16 weights / KV, fp32 accumulate -- the reference's own GPU dtype, pipeline:37-41): mel / waveform
+                # 1.2-1.75e-3 vs the fp32 CPU path (asserted <= 2e-3, tests/test_gpu_fp16_parity.py), token ids not guaranteed; same windows
+                g16 = GPT(LLAMA, max_batch=EB, max_seq_len=P + W + max(GEN_TOKENS, K) + 16, weight_dtype="fp16", device=str(dev))
+                g16.load_state_dict(sd)
+                l16 = Leg(g16, dev, rank, world)
+                extra["fast_mode_fp16_batch1"] = summarize(l16.run(1, P, min(K, 256), W, spk=spk, use_graph=use_graph), world)
+                extra["fast_mode_fp16_batch32"] = summarize(l16.run(EB, P, EK, W, spk=spk, use_graph=use_graph), world)
+                extra["fast_mode_fp16_note"] = "mel / waveform rel-RMS 1.2-1.75e-3 vs the fp32 CPU path (north_star asks 1e-3): not the shipped default"
+                g16.close()
         except (SystemExit, KeyboardInterrupt):
             raise
         except StopIteration:
@@ -341,7 +354,7 @@ def main():
     if rank == 0:
         traffic = None
         try:      # HBM bytes/step from the committed rocprofv3 PMC passes (profiles/), same kernels and batch; not live
-            for rr in ("r02", "r01"):
+            for rr in ("r03", "r02", "r01"):
                 fp = os.path.join(ROOT, "profiles", f"{rr}_pmc_traffic.json")
                 if os.path.exists(fp):
                     traffic = json.load(open(fp)).get(f"b{B}_{args.dtype}", {}).get("hbm_bytes_per_step")

@@ -46,6 +46,8 @@ class GenIO(C.Structure):
         ("noise", C.c_void_p),
         ("n_draws", C.c_int32),
         ("seed", C.c_uint64),
+        ("utt_ids", C.c_void_p),
+        ("row_limits", C.c_void_p),
     ]
 
 
@@ -83,6 +85,8 @@ SYMBOLS = [
     ("ctts_gpt_decode", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("ctts_gpt_progress", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     ("ctts_gpt_progress_enqueue", C.c_int, [_P, _P, _P]),
+    ("ctts_gpt_rows_enqueue", C.c_int, [_P, _P, _P]),
+    ("ctts_gpt_compact", C.c_int, [_P, _P, C.c_int, _P]),
     ("ctts_gpt_logits", C.c_int, [_P, _P, _P]),
     ("ctts_gpt_force_ids", C.c_int, [_P, _P, _P]),
     ("ctts_sampler_run", C.c_int, [C.POINTER(SamplerCfg), _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

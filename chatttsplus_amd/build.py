@@ -27,7 +27,9 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
+    """`diag=True` (python -m chatttsplus_amd.build --force --diag) compiles the diagnostic switches in (-DCTTS_DIAG: CTTS_SPLITS,
+    CTTS_XH, CTTS_NBG2_ROWS, ... read once at create); the product build ignores the environment apart from CTTS_PASS_ROWS."""
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
@@ -40,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         # kernarg preload: the leading scalar kernel arguments arrive in SGPRs at wave launch instead of through a first s_load
         # round trip (one serial scalar-cache miss per launch; a decode step is ~100 dependent launches)
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=8", "-c", sp, "-o", obj]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=8"] + (["-DCTTS_DIAG"] if diag else []) + ["-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -70,4 +72,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, diag="--diag" in sys.argv)

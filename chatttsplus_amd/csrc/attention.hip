@@ -13,40 +13,6 @@
 
 #include "kernels.h"
 
-// one 16-row o_proj tile x one head's 64 input dims on MFMA (B operand = the head's attention output in column 0)
-template <typename WT> struct HeadMma;
-template <> struct HeadMma<half_t> {
-    static constexpr int FR = 2;                      // 64 dims = 2 k-tiles of 32
-    typedef half8 frag;
-    __device__ static inline f32x4 run(const frag (&w)[FR], const float* o_s, int lane) {
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int f = 0; f < FR; ++f) {
-            half8 b;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = ((lane & 15) == 0) ? (half_t)o_s[f * 32 + 8 * (lane >> 4) + j] : (half_t)0.f;
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f], b, c, 0, 0, 0);
-        }
-        return c;
-    }
-};
-template <> struct HeadMma<float> {
-    static constexpr int FR = 4;                      // 64 dims = 4 k-tiles of 16
-    typedef f32x4 frag;
-    __device__ static inline f32x4 run(const frag (&w)[FR], const float* o_s, int lane) {
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int f = 0; f < FR; ++f)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float b = ((lane & 15) == 0) ? o_s[f * 16 + 4 * (lane >> 4) + j] : 0.f;
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(w[f][j], b, c, 0, 0, 0);
-            }
-        return c;
-    }
-};
-#define FUSE_TPW 3      // o_proj tiles per wave in the fused kernel: 48 tiles = JT(4) x 4 waves x 3
-
 template <typename WT> struct KvLoad;
 template <> struct KvLoad<half_t> {
     __device__ static inline void load8(const half_t* p, float (&o)[8]) {
@@ -65,38 +31,20 @@ template <> struct KvLoad<float> {
 
 __device__ inline float safe_exp_diff(float m, float mn) { return (m == -INFINITY) ? 0.f : expf(m - mn); }
 
-// FUSED: grid.y = JT column groups instead of key splits; every block runs the whole (row, head) attention and then
-// multiplies its head's output with its share of the o_proj rows (weights prefetched at kernel entry), writing a
-// per-head partial sum  opart[row][head][:]  that the next kernels add to the residual stream in head order.
-// Drops one of the five dependent launches per layer in the launch-latency-bound small-batch regime.
-template <typename WT, bool FUSED, int NW, int UNR = 4>
+template <typename WT, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const int* done_p, const RowMeta* meta_p, const float* q_p, const void* k_p, const void* v_p,
                                                             const int NHp, const int Sp, const AttnArgs a) {
     // leading scalars = what the first loads need; preloaded into SGPRs at wave launch (see skinny_gemm.hip)
-    static_assert(!FUSED || NW == 4, "fused o_proj phase assumes 4 waves");
     int done_v = 0;                                   // requested with the first operand loads, tested once they are in flight (common.h)
     if (done_p != nullptr) done_v = vload_flag(done_p);
-    constexpr int UN = UNR;                           // keys per lane group and loop iteration (loads in flight: 2 * UN * 16 B per lane)
+    constexpr int UN = 4;                             // keys per lane group and loop iteration (loads in flight: 2 * UN * 16 B per lane; 8 measured slower)
     __shared__ float merge[NW][8][10];
-    __shared__ float o_s[CTTS_HEAD_DIM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = lane >> 3, sub = lane & 7;
-    const int r = blockIdx.x / NHp, h = blockIdx.x % NHp, s = FUSED ? 0 : blockIdx.y;
-    typedef HeadMma<WT> HM;
-    typename HM::frag wfr[FUSE_TPW][HM::FR];
-    if (FUSED) {        // this wave's o_proj tiles: issued first, consumed after the attention loop
-        const int ktiles = (a.NH * CTTS_HEAD_DIM) / WTraits<WT>::KT;
-#pragma unroll
-        for (int t = 0; t < FUSE_TPW; ++t) {
-            const int rt = (blockIdx.y * 4 + wave) * FUSE_TPW + t;
-#pragma unroll
-            for (int f = 0; f < HM::FR; ++f)
-                wfr[t][f] = __builtin_nontemporal_load((const typename HM::frag*)a.wo + ((size_t)rt * ktiles + h * HM::FR + f) * 64 + lane);
-        }
-    }
+    const int r = blockIdx.x / NHp, h = blockIdx.x % NHp, s = blockIdx.y;
     const RowMeta m = meta_p[r];
     const int kv0 = m.kv_start, kv1 = m.slot + 1;
-    const int nsplit = FUSED ? 1 : Sp;
+    const int nsplit = Sp;
     const int chunk = (kv1 - kv0 + nsplit - 1) / nsplit;
     const int p0 = kv0 + s * chunk;
     const int p1 = min(p0 + chunk, kv1);
@@ -184,11 +132,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const int* done_p,
             for (int j = 0; j < 8; ++j) O[j] = O[j] * s1 + merge[w][tid][2 + j] * s2;
             M = mn;
         }
-        if (FUSED) {
-            const float inv = 1.0f / L;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o_s[8 * tid + j] = O[j] * inv;
-        } else if (a.packed_out != nullptr) {
+        if (a.packed_out != nullptr) {
             // single split: finish the softmax here and hand the o_proj kernel a ready MFMA B operand (no combine prologue)
             const float inv = 1.0f / L;
             const int NBr = 16 * a.nbg, K = a.NH * CTTS_HEAD_DIM, kt = K / WTraits<WT>::KT;
@@ -199,255 +143,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const int* done_p,
             return;
         }
         const size_t pi = ((size_t)r * a.NH + h) * a.S + s;
-        if (!FUSED && tid == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = L; }
-        float* po = a.part_o + pi * CTTS_HEAD_DIM + 8 * tid;
-        if (!FUSED) {
-            *(f32x4*)po = (f32x4){O[0], O[1], O[2], O[3]};
-            *(f32x4*)(po + 4) = (f32x4){O[4], O[5], O[6], O[7]};
-        }
-    }
-    if (FUSED) {
-        __syncthreads();
-        const int H = a.NH * CTTS_HEAD_DIM;
-#pragma unroll
-        for (int t = 0; t < FUSE_TPW; ++t) {
-            const int rt = (blockIdx.y * 4 + wave) * FUSE_TPW + t;
-            const f32x4 c = HM::run(wfr[t], o_s, lane);                 // C[row=(lane>>4)*4+reg][col=lane&15]; col 0 is ours
-            if ((lane & 15) == 0) *(f32x4*)(a.opart + ((size_t)r * a.NH + h) * H + rt * 16 + (lane >> 4) * 4) = c;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused decode launch for one or two rows: llama.py:82-87 (input RMSNorm) + :619-633 (q/k/v projection, RoPE, cache append) +
-// :653-661 (SDPA) in one kernel, so that a layer is 4 dependent launches instead of 5 and q/k/v never round-trip through HBM.
-//   grid.x = (row, head);  grid.y = kind:  kind < S   q projection (4 weight tiles = 96 KB fp16) + attention over split `kind`
-//                                                       of the CACHED keys [kv_start, slot)
-//                                          kind == S   q and k projections of the new token: its score q.k (partial slot S: m = score,
-//                                                       l = 1) and the K append
-//                                          kind == S+1 v projection: V append and the output row of partial slot S
-// Same arithmetic as the separate kernels (norm expression, tile order, RoPE with separately rounded products, K/V rounded to
-// the cache dtype before use); the K dimension is split over NW waves x 3 k-tiles instead of 4 (8) x 6, so sums differ in the
-// last bits from the 5-launch path.
-template <typename WT> struct FragSel;
-template <> struct FragSel<half_t> { typedef half8 type; };
-template <> struct FragSel<float> { typedef f32x4 type; };
-template <typename WT> struct MmaQ;
-template <> struct MmaQ<half_t> { __device__ static inline f32x4 run(half8 a, half8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); } };
-template <> struct MmaQ<float> {
-    __device__ static inline f32x4 run(f32x4 a, f32x4 b, f32x4 c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
-        return c;
-    }
-};
-
-template <typename WT, int NW, int TPP>
-__global__ __launch_bounds__(NW * 64) void qkv_attn_kernel(const int* done_p, const void* Wp, const float* x_p, const RowMeta* meta_p, const int NHp, const int nS,
-                                                          const QkvAttnArgs a) {
-    typedef typename FragSel<WT>::type frag;
-    constexpr int K = 768, KT = WTraits<WT>::KT, EPL = WTraits<WT>::EPL, KTILES = K / KT, KPW = KTILES / NW, UN = 4, HT = K / 16;
-    static_assert(KPW * NW == KTILES, "K split");
-    __shared__ float xn[K];
-    __shared__ float red[NW][8][16];
-    __shared__ float qk[2][CTTS_HEAD_DIM];
-    __shared__ float merge[NW][8][10];
-    int done_v = 0;
-    if (done_p != nullptr) done_v = vload_flag(done_p);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = blockIdx.x / NHp, h = blockIdx.x % NHp, kind = blockIdx.y, S = nS >> 8, np = nS & 0xFF;
-    const bool isK = kind == S, isV = kind == S + 1;
-    const int ntile = isK ? 8 : 4;
-    // weight tiles of this block: q = tiles h*4 .. h*4+3 of the first projection, k / v = the same tiles of the 2nd / 3rd
-    auto tile_of = [&](int t) -> int { return isV ? 2 * HT + h * 4 + t : (t < 4 ? h * 4 + t : HT + h * 4 + (t - 4)); };
-    frag wf[TPP][KPW];
-    auto load_tiles = [&](int t0) {
-#pragma unroll
-        for (int t = 0; t < TPP; ++t)
-            if (t0 + t < ntile) {
-                const frag* w = (const frag*)Wp + ((size_t)tile_of(t0 + t) * KTILES + wave * KPW) * 64 + lane;
-#pragma unroll
-                for (int i = 0; i < KPW; ++i) wf[t][i] = __builtin_nontemporal_load(w + i * 64);
-            }
-    };
-    const RowMeta m = meta_p[r];
-    if (wave == 0) {                                  // the row's RMSNorm, same expression order as the PRO_NORM[_P] prologue
-        const f32x4* xr = (const f32x4*)(x_p + (size_t)r * K);
-        f32x4 v[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) v[i] = xr[lane + 64 * i];
-        if (np > 0) {
-            f32x4 pp[4][3];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    pp[q][i] = (q < np) ? ((const f32x4*)(a.dpart + ((size_t)r * np + q) * K))[lane + 64 * i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < 3; ++i) v[i] += pp[q][i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        load_tiles(0);
-        __builtin_amdgcn_sched_barrier(0);
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-        ss = wave_sum(ss);
-        const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) *(f32x4*)(xn + 4 * (lane + 64 * i)) = (f32x4){v[i][0] * rs, v[i][1] * rs, v[i][2] * rs, v[i][3] * rs};
-    } else {
-        load_tiles(0);
-    }
-    if (__builtin_amdgcn_readfirstlane(done_v)) return;   // every sequence finished: skip on device
-    __syncthreads();
-    for (int t0 = 0; t0 < ntile; t0 += TPP) {
-        if (t0 > 0) load_tiles(t0);                   // parity mode: second phase of the 8-tile block
-        f32x4 acc[TPP];
-#pragma unroll
-        for (int t = 0; t < TPP; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int kt = wave * KPW + i;
-            frag b;
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) b[j] = ((lane & 15) == 0) ? (WT)xn[kt * KT + (lane >> 4) * EPL + j] : (WT)0.f;
-#pragma unroll
-            for (int t = 0; t < TPP; ++t)
-                if (t0 + t < ntile) acc[t] = MmaQ<WT>::run(wf[t][i], b, acc[t]);
-        }
-        if ((lane & 15) == 0) {                       // column 0 of C = this row: lanes 0, 16, 32, 48 hold weight rows (lane / 16) * 4 + reg
-#pragma unroll
-            for (int t = 0; t < TPP; ++t)
-                if (t0 + t < ntile) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) red[wave][t0 + t][(lane >> 4) * 4 + g] = acc[t][g];
-                }
-        }
-    }
-    __syncthreads();
-    const size_t pslot = ((size_t)r * NHp + h) * (S + 1);
-    if (tid < ntile * 8) {
-        const int t = tid >> 3, p = tid & 7, d = (t & 3) * 8 + p;     // tile rows p, p + 8 = head dims d, d + 32
-        float va = 0.f, vb = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { va += red[w][t][p]; vb += red[w][t][p + 8]; }
-        const size_t cslot = (((size_t)m.seq * NHp + h) * a.Lmax + m.slot) * CTTS_HEAD_DIM;
-        if (isV) {
-            const WT ra = (WT)va, rb = (WT)vb;
-            WT* c = (WT*)a.v_cache + cslot;
-            c[d] = ra; c[d + 32] = rb;
-            float* po = a.part_o + (pslot + S) * CTTS_HEAD_DIM;
-            po[d] = (float)ra; po[d + 32] = (float)rb;
-        } else {
-            const float rc = a.rope_rows[(size_t)r * 64 + d], rsn = a.rope_rows[(size_t)r * 64 + 32 + d];
-            const float ya = __fadd_rn(__fmul_rn(va, rc), __fmul_rn(-vb, rsn));   // llama.py:180-181
-            const float yb = __fadd_rn(__fmul_rn(vb, rc), __fmul_rn(va, rsn));
-            if (t < 4) { qk[0][d] = ya; qk[0][d + 32] = yb; }
-            else {
-                const WT ra = (WT)ya, rb = (WT)yb;
-                WT* c = (WT*)a.k_cache + cslot;
-                c[d] = ra; c[d + 32] = rb;
-                qk[1][d] = (float)ra; qk[1][d + 32] = (float)rb;
-            }
-        }
-    }
-    if (isV) return;
-    __syncthreads();
-    const int grp = lane >> 3, sub = lane & 7;
-    float q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = qk[0][8 * sub + j] * 0.125f;
-    if (isK) {                                        // the new token attends to itself: partial (m = score, l = 1, o = v_new)
-        if (wave == 0) {
-            float dot = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dot += q[j] * qk[1][8 * sub + j];
-            dot += dpp_f<DPP_XOR1>(dot);
-            dot += dpp_f<DPP_XOR2>(dot);
-            dot += dpp_f<DPP_HALF_MIRROR>(dot);
-            if (lane == 0) { a.part_ml[(pslot + S) * 2] = dot; a.part_ml[(pslot + S) * 2 + 1] = 1.0f; }
-        }
-        return;
-    }
-    // cached keys of this split
-    const int kv0 = m.kv_start, kv1 = m.slot;
-    const int chunk = (max(kv1 - kv0, 0) + S - 1) / S;
-    const int p0 = kv0 + kind * chunk, p1 = min(p0 + chunk, kv1);
-    const size_t head_off = ((size_t)m.seq * NHp + h) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
-    const WT* kb = (const WT*)a.k_cache + head_off;
-    const WT* vb = (const WT*)a.v_cache + head_off;
-    float mrun = -INFINITY, lrun = 0.f, o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    for (int wb = p0 + 8 * wave; wb < p1; wb += 8 * NW * UN) {
-        const int base = wb + grp;
-        float kf[UN][8], vf[UN][8];
-        bool ok[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int p = base + 8 * NW * u;
-            ok[u] = p < p1;
-            const int pc = ok[u] ? p : kv0;
-            KvLoad<WT>::load8(kb + (size_t)pc * CTTS_HEAD_DIM, kf[u]);
-            KvLoad<WT>::load8(vb + (size_t)pc * CTTS_HEAD_DIM, vf[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            float dot = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dot += q[j] * kf[u][j];
-            dot += dpp_f<DPP_XOR1>(dot);
-            dot += dpp_f<DPP_XOR2>(dot);
-            dot += dpp_f<DPP_HALF_MIRROR>(dot);
-            if (ok[u]) {
-                const float mn = fmaxf(mrun, dot);
-                const float sc = safe_exp_diff(mrun, mn);
-                const float pe = expf(dot - mn);
-                lrun = lrun * sc + pe;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = o[j] * sc + pe * vf[u][j];
-                mrun = mn;
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-        const float m2 = __shfl_xor(mrun, off), l2 = __shfl_xor(lrun, off);
-        const float mn = fmaxf(mrun, m2);
-        const float s1 = safe_exp_diff(mrun, mn), s2 = safe_exp_diff(m2, mn);
-        lrun = lrun * s1 + l2 * s2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float o2 = __shfl_xor(o[j], off);
-            o[j] = o[j] * s1 + o2 * s2;
-        }
-        mrun = mn;
-    }
-    if (grp == 0) {
-        merge[wave][sub][0] = mrun;
-        merge[wave][sub][1] = lrun;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) merge[wave][sub][2 + j] = o[j];
-    }
-    __syncthreads();
-    if (tid < 8) {
-        float M = merge[0][tid][0], L = merge[0][tid][1], O[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) O[j] = merge[0][tid][2 + j];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) {
-            const float m2 = merge[w][tid][0], l2 = merge[w][tid][1];
-            const float mn = fmaxf(M, m2);
-            const float s1 = safe_exp_diff(M, mn), s2 = safe_exp_diff(m2, mn);
-            L = L * s1 + l2 * s2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) O[j] = O[j] * s1 + merge[w][tid][2 + j] * s2;
-            M = mn;
-        }
-        const size_t pi = pslot + kind;
         if (tid == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = L; }
         float* po = a.part_o + pi * CTTS_HEAD_DIM + 8 * tid;
         *(f32x4*)po = (f32x4){O[0], O[1], O[2], O[3]};
@@ -455,107 +150,10 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn_kernel(const int* done_p, co
     }
 }
 
-int launch_qkv_attention(int dtype, const QkvAttnArgs& a, hipStream_t s) {
-    if (a.S < 1 || a.S > 7 || a.np > 4) { ctts_set_error("qkv_attention: S=%d np=%d out of range", a.S, a.np); return 1; }
-    const dim3 grid(a.R * a.NH, a.S + 2);
-    const int* done_p = a.st ? &a.st->all_done : nullptr;
-    const int nS = (a.np & 0xFF) | (a.S << 8);
-    if (dtype == 1) hipLaunchKernelGGL((qkv_attn_kernel<half_t, 8, 8>), grid, dim3(512), 0, s, done_p, a.wqkv, a.x, a.meta, a.NH, nS, a);
-    else hipLaunchKernelGGL((qkv_attn_kernel<float, 16, 4>), grid, dim3(1024), 0, s, done_p, a.wqkv, a.x, a.meta, a.NH, nS, a);
-    CTTS_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Prompt pass: causal attention for QT = 8 consecutive query rows per wavefront (llama.py:590-668 at q_len > 1; mask semantics of
-// llama.py:1073-1087: a row attends to the key slots [kv_start, slot] of its own sequence -- left padding and the future are skipped).
-// The row-by-row kernel above reads a row's whole K/V prefix once per ROW: B*T^2/2 keys per head and layer (12.9 GB per layer at
-// 32 x 512 prompt tokens, 42 % of that prompt pass).  Here a lane group of 8 lanes owns one query (8 of the 64 dims per lane, like
-// the decode kernel) and the 8 groups of a wave walk the keys together, so a K/V row is fetched once per 8 queries (the 8 groups
-// request the same 128 bytes: one line) and no cross-lane merge is needed -- every group carries its query's complete online
-// softmax state.  Keys are taken 4 at a time (one rescale per 4 keys).  Output: the normalised rows, written straight into the
-// o_proj kernel's fragment-major B operand.
-template <typename WT>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const RowMeta* meta_p, const float* q_p, const void* k_p, const void* v_p, const int NHp, const int R,
-                                                         const AttnArgs a) {
-    constexpr int QT = 8, UN = 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = lane >> 3, sub = lane & 7;
-    const int h = blockIdx.y;
-    const int r = (blockIdx.x * 4 + wave) * QT + grp;                    // this lane group's query row
-    const bool live = r < R;
-    RowMeta m = {0, 0, -1, 0};
-    if (live) m = meta_p[r];
-    const int lo = live ? m.kv_start : 0x7FFFFFFF, hi = live ? m.slot : -1;       // attended key slots [lo, hi]
-    // wave-uniform walk over the union of the groups' ranges
-    int wlo = lo, whi = hi;
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) { wlo = min(wlo, __shfl_xor(wlo, off)); whi = max(whi, __shfl_xor(whi, off)); }
-    wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
-    if (whi < 0) return;                                                   // no live row in this wave
-    float q[8];
-    {
-        const float* qp = q_p + ((size_t)(live ? r : 0) * NHp + h) * CTTS_HEAD_DIM + 8 * sub;
-        const f32x4 q0 = *(const f32x4*)qp, q1 = *(const f32x4*)(qp + 4);
-        q[0] = q0[0] * 0.125f; q[1] = q0[1] * 0.125f; q[2] = q0[2] * 0.125f; q[3] = q0[3] * 0.125f;
-        q[4] = q1[0] * 0.125f; q[5] = q1[1] * 0.125f; q[6] = q1[2] * 0.125f; q[7] = q1[3] * 0.125f;
-    }
-    const size_t head_off = ((size_t)m.seq * NHp + h) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
-    const WT* kb = (const WT*)k_p + head_off;
-    const WT* vb = (const WT*)v_p + head_off;
-    float mrun = -INFINITY, lrun = 0.f, o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    for (int p0 = wlo; p0 <= whi; p0 += UN) {
-        float kf[UN][8], vf[UN][8], dot[UN];
-        bool ok[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int p = p0 + u;
-            ok[u] = (p >= lo) && (p <= hi);
-            const int pc = ok[u] ? p : (live ? hi : 0);                    // clamp: always a valid slot of this group's sequence
-            KvLoad<WT>::load8(kb + (size_t)pc * CTTS_HEAD_DIM, kf[u]);
-            KvLoad<WT>::load8(vb + (size_t)pc * CTTS_HEAD_DIM, vf[u]);
-        }
-        float mn = mrun;
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            float d = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) d += q[j] * kf[u][j];
-            d += dpp_f<DPP_XOR1>(d);                                       // 8-lane group sum on DPP
-            d += dpp_f<DPP_XOR2>(d);
-            d += dpp_f<DPP_HALF_MIRROR>(d);
-            dot[u] = ok[u] ? d : -INFINITY;
-            mn = fmaxf(mn, dot[u]);
-        }
-        const float sc = safe_exp_diff(mrun, mn);
-        float pe[UN], ps = 0.f;
-#pragma unroll
-        for (int u = 0; u < UN; ++u) { pe[u] = safe_exp_diff(dot[u], mn); ps += pe[u]; }
-        lrun = lrun * sc + ps;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float acc = o[j] * sc;
-#pragma unroll
-            for (int u = 0; u < UN; ++u) acc += pe[u] * vf[u][j];
-            o[j] = acc;
-        }
-        mrun = mn;
-    }
-    if (!live) return;
-    const float inv = 1.0f / lrun;
-    const int NBr = 16 * a.nbg, K = a.NH * CTTS_HEAD_DIM, kt = K / WTraits<WT>::KT;
-    const int chunk = r / NBr, n = r % NBr, k = h * CTTS_HEAD_DIM + 8 * sub;
-    WT* dst = (WT*)a.packed_out + (size_t)chunk * a.nbg * kt * 64 * WTraits<WT>::EPL;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dst[xfrag_index<WT>(n, k + j, kt)] = (WT)(o[j] * inv);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Prompt pass, fp16: flash-style causal attention on MFMA (llama.py:590-668 at q_len > 1, mask semantics of llama.py:1073-1087).
-// The VALU kernels above spend ~8 vector instructions per (query, key) pair whatever the tiling (attn_prefill_kernel reads K/V
-// 8x less often than the row-by-row kernel and is no faster: 42-65 % of a 32 x 512-token prompt pass).  Here
+// The single-query kernel above spends ~8 vector instructions per (query, key) pair (a VALU variant with 8 queries per wave read K/V
+// 8x less often and was no faster: 42-65 % of a 32 x 512-token prompt pass; removed, see profiles/README.md).  Here
 //   block = (sequence, head, 64 consecutive queries), 4 waves x 16 queries, keys in chunks of 64;
 //   S^T[key][query] = K . Q^T   v_mfma_f32_16x16x32_f16, A = K rows (16 keys x 32 dims = one 16-byte LDS read per lane; the block stages
 //                               each 64-key chunk once), B = Q (fp16, pre-scaled by 1/8).  In the C layout a lane owns ONE query (lane & 15) and the
@@ -699,35 +297,23 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const RowMeta* m
 }
 
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
-    dim3 grid(a.R * a.NH, a.jt > 0 ? a.jt : a.S), block(256);
+    dim3 grid(a.R * a.NH, a.S), block(256);
     const int* done_p = a.st ? &a.st->all_done : nullptr;
     // unsplit rows: 8 waves per (row, head) keep twice the K/V bytes in flight per CU while there are fewer blocks than CUs; from one
     // block per CU on, 4-wave blocks balance better (us/step at mean context 312: batch 8 471 vs 479, 16 512 vs 521 | 32 613 vs 598, 64 800 vs 774)
-    static const int wide_env = getenv("CTTS_ATTN_WIDE") ? atoi(getenv("CTTS_ATTN_WIDE")) : -1;     // diagnostic: force 8-wave (1) / 4-wave (0) blocks
-    const bool wide = (a.jt == 0) && (a.S == 1) && (a.st != nullptr) && (wide_env < 0 ? (a.R * a.NH < 256) : wide_env != 0);
-    static const int un_env = getenv("CTTS_ATTN_UN") ? atoi(getenv("CTTS_ATTN_UN")) : 4;        // experiment: 8 keys per lane group in flight for unsplit 4-wave blocks
-    static const int tiled_env = getenv("CTTS_PREFILL_ATTN") ? atoi(getenv("CTTS_PREFILL_ATTN")) : 1;    // 1 = MFMA flash kernel (fp16, >= 64 rows), 2 = 8-queries-per-wave VALU kernel (diagnostic: no faster than row by row), 0 = row by row
-    if (a.st == nullptr && a.jt == 0 && a.S == 1 && a.packed_out != nullptr && a.R >= 64 && dtype == 1 && a.T > 0 && tiled_env >= 1 && tiled_env != 2) {
+    static const int wide_env = diag_env("CTTS_ATTN_WIDE") ? atoi(diag_env("CTTS_ATTN_WIDE")) : -1;     // diagnostic builds: force 8-wave (1) / 4-wave (0) blocks
+    const bool wide = (a.S == 1) && (a.st != nullptr) && (wide_env < 0 ? (a.R * a.NH < 256) : wide_env != 0);
+    static const int tiled_env = diag_env("CTTS_PREFILL_ATTN") ? atoi(diag_env("CTTS_PREFILL_ATTN")) : 1;    // diagnostic builds: 0 = prompt attention row by row
+    if (a.st == nullptr && a.S == 1 && a.packed_out != nullptr && a.R >= 64 && dtype == 1 && a.T > 0 && tiled_env >= 1) {
         // prompt pass, fp16: MFMA flash attention, block = (64 queries, head, sequence)
         const int B = (a.row0 + a.R + a.T - 1) / a.T;                     // sequences 0 .. B-1 may have rows in this pass
         dim3 g3((a.T + 63) / 64, a.NH, B);
         hipLaunchKernelGGL(attn_prefill_mfma_kernel, g3, dim3(256), 0, s, a.meta, a.q, (const half_t*)a.k_cache, (const half_t*)a.v_cache, a.NH, a.R, a);
-    } else if (a.st == nullptr && a.jt == 0 && a.S == 1 && a.packed_out != nullptr && a.R > 16 && tiled_env == 2) {
-        // prompt pass: 8 query rows per wavefront, 4 wavefronts per block
-        dim3 g2((a.R + 31) / 32, a.NH);
-        if (dtype == 1) hipLaunchKernelGGL(attn_prefill_kernel<half_t>, g2, dim3(256), 0, s, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.R, a);
-        else hipLaunchKernelGGL(attn_prefill_kernel<float>, g2, dim3(256), 0, s, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.R, a);
     } else if (wide) {
-        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
-        else hipLaunchKernelGGL((attn_decode_kernel<float, false, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
-    } else if (a.jt > 0) {
-        if (a.jt * 4 * FUSE_TPW * 16 != a.NH * CTTS_HEAD_DIM) { ctts_set_error("fused attention: jt=%d does not tile H=%d", a.jt, a.NH * CTTS_HEAD_DIM); return 1; }
-        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, true, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
-        else hipLaunchKernelGGL((attn_decode_kernel<float, true, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
-    } else if (dtype == 1 && a.S == 1 && a.st != nullptr && un_env == 8) {
-        hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 4, 8>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
-    } else if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, false, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<float, false, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+        if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<float, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+    } else if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }

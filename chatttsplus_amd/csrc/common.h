@@ -34,6 +34,19 @@ struct DevState {
     int pad[CTTS_MAX_B]; // left-pad count per sequence
 };
 
+// Per decode ROW state the sampler keeps in engine memory (one 32-byte record, fetched with the kernel's first batch of loads):
+// the engine-side mirror of {finish, end_idx} (gpt.py:339-342,486-487,530-531), and what keys the row's device noise stream --
+// the caller's global utterance id, the row's own regenerate attempt (ensure_non_empty, gpt.py:496-525) -- plus the row's own token
+// limit (<= max_new_token).  Rows are re-packed by ctts_gpt_compact; `seq` of RowMeta names the utterance (KV lane, output arrays).
+struct RowState {
+    int fin;             // finished (EOS sampled, or the row's limit reached)
+    int end;             // end_idx
+    int attempt;         // first-step-EOS regenerations of THIS row so far
+    int limit;           // the row stops after this many tokens
+    unsigned uid_lo, uid_hi;   // global utterance id
+    int pad0, pad1;
+};
+
 // fragment-major ("xfrag") activation layout used for every MFMA B operand:
 //   element (n, k) of a [NB rows][K] chunk lives at
 //     fp16: ((g*KT + k/32)*64 + (n%16) + 16*((k/8)%4))*8 + k%8      halfs
@@ -108,6 +121,18 @@ __device__ inline unsigned f32_key(float f) {
 __device__ inline float key_f32(unsigned k) {
     const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
     return __builtin_bit_cast(float, u);
+}
+
+// Diagnostic switches (A/B experiments, kernel-variant overrides) exist only in builds with -DCTTS_DIAG
+// (`python -m chatttsplus_amd.build --diag`); in the product library this is a constant null and no launch path reads the environment.
+#include <stdlib.h>
+static inline const char* diag_env(const char* name) {
+#ifdef CTTS_DIAG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
 }
 
 // host-side error plumbing (gpt_engine.cpp)

@@ -115,7 +115,7 @@ static int launch_gemm_f32_epi(const GemmF32Args& a, int nb, hipStream_t s, bool
 // 128-row tiles need row_pad >= 127 and N % 128 == 0.
 static int launch_gemm_f32(int epi, const GemmF32Args& a, int nb, hipStream_t s, int row_pad = 63) {
     if (a.K % 16 || a.lda % 4 || a.ldw % 4) { ctts_set_error("gemm_f32: K=%d lda=%d ldw=%d alignment", a.K, a.lda, a.ldw); return 1; }
-    static const int force = getenv("CTTS_VOC_TILE") ? atoi(getenv("CTTS_VOC_TILE")) : 0;      // 64 / 128: diagnostic override
+    static const int force = diag_env("CTTS_VOC_TILE") ? atoi(diag_env("CTTS_VOC_TILE")) : 0;      // 64 / 128: diagnostic override
     // measured (32 utterances x 272 tokens): the pointwise-conv GEMMs already run at ~110 TFLOP/s (70 % of the fp32 MFMA peak);
     // 128x128 register tiles 28.8 ms vs 64x64 25.6 ms, an LDS-staged 128x128 variant 25.7 ms (bit-identical, no gain: removed)
     // measured (32 utterances x 272 tokens): 128x128 tiles 28.8 ms vs 64x64 25.6 ms -- the fragment loads (16 rows x 64 B per

@@ -55,8 +55,6 @@ struct ctts_gpt {
     std::vector<LayerW> lw;
     void* whead = nullptr;
     void* whead_text = nullptr;                  // refine-text head (21178 x H), packed like whead; optional
-    int x_has_parts = 0;                         // the decode rows' residual stream currently is x_dec + dpart[0..3]
-    int x_has_xh = 0;                            // ... and / or also exists as packed fp16 + sums of squares (xh / ssq / scale_d) for the heads
     int text_mode = 0;                           // current generate() call: infer_text=True
     float* lnf = nullptr;
     float* emb_code = nullptr;
@@ -72,22 +70,18 @@ struct ctts_gpt {
     void* act = nullptr;
     void* attn_packed = nullptr;
     void* norm_packed = nullptr;                 // prompt pass: RMSNorm'ed rows in the GEMMs' fragment-major operand layout (norm_pack_kernel)
-    float* opart = nullptr;                      // fused path: per-head o_proj partials [rows<=16][12][768]
-    int ablate = 0;                              // diagnostic (env CTTS_ABLATE): bit i set -> skip kernel class i (qkv, attn, o_proj, gate|up, down)
     int split_rows = 4;                          // decode batches up to this size run the down projection as 4 split-K launch slices whose
-                                                 // partial sums the next consumers add (env CTTS_SPLIT_ROWS; 0 = off): 48x1024-thread blocks -> 192x256;
+                                                 // partial sums the next consumers add (0 = off): 48x1024-thread blocks -> 192x256;
                                                  // measured -3 % step time at batch 1-2, -1.7 % at 4, +0.5 % at 8
     float* dpart = nullptr;                      // [rows<=16][4][768]
     int cur_splits = 1;                          // key splits of the decode attention for the steps being launched (decode_splits)
     int launched = 0;                            // decode steps enqueued since begin / restart: host-side bound on the context length
-    int fuseqkv_rows = 0;                        // decode batches up to this size run RMSNorm + q/k/v projection + attention as ONE launch per
-                                                 // layer (attention.hip qkv_attn_kernel; env CTTS_FUSEQKV_ROWS): 4 dependent launches instead of 5
-    int nbg2_rows = 33;                          // decode batches of at least this many rows use 32-row blocks instead of 16-row chunks (env
-                                                 // CTTS_NBG2_ROWS).  Measured: two 16-row chunks beat one 32-row block at batch 24 / 32 (598 vs 624,
+    int nbg2_rows = 33;                          // decode batches of at least this many rows use 32-row blocks instead of 16-row chunks.
+                                                 // Measured: two 16-row chunks beat one 32-row block at batch 24 / 32 (598 vs 624,
                                                  // 640 vs 660 us/step) -- per-block prologue latency, not L2 traffic, is what these launches pay for;
                                                  // the prompt pass keeps 32-row blocks
-    int fuse_rows = 0;                           // decode batches up to this size use the fused attention+o_proj launch (env CTTS_FUSE_ROWS;
-                                                 // measured: 102 -> 82 launches/step but 2 % slower at batch 1, so off by default)
+    int force_splits = 0;                        // diagnostic builds only: key splits of the decode attention (0 = decode_splits policy)
+    int no_prepack = 0, prefill_gemm_rows = 1536, xh_heads = 1;   // diagnostic builds only: see run_layers / run_decode_step
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
     DevState* st = nullptr;
     int* last_rows = nullptr;
@@ -98,12 +92,18 @@ struct ctts_gpt {
     int* lora_slot_of_seq = nullptr;
     float *lora_dqkv = nullptr, *lora_do = nullptr;
     int lora_rows = 0;                           // 1: the current / next generate() calls carry per-sequence adapters
-    int pass_rows = PASS_ROWS_MAX;               // prompt rows per pass of this engine (env CTTS_PASS_ROWS lowers it: multi-pass tests)
+    int pass_rows = PASS_ROWS_MAX;               // prompt rows per pass of this engine (env CTTS_PASS_ROWS, read once at finalize, lowers it: the
+                                                 // one capacity knob of the product library; the multi-pass tests use it)
     void* xh = nullptr;                          // fp16 decode, > split_rows rows: residual stream as packed fp16 B operand (EPI_RESID_XH -> PRO_XH)
     float *ssq = nullptr, *scale_o = nullptr, *scale_d = nullptr;   //   per-tile sums of squares [rows][48]; per-row power-of-two scales of the xh rows
-    int xh_mode = 1;                             //   env CTTS_XH=0 switches the path off (every block re-normalises fp32 rows: PRO_NORM)
+    int xh_mode = 1;                             //   0 (diagnostic builds) switches the path off (every block re-normalises fp32 rows: PRO_NORM)
     int* hist_ring = nullptr;                    // sampler: repetition-penalty window ring [max_B][4][16] (sampler.hip)
-    int2* finend = nullptr;                      // sampler: engine-side mirror of {finish, end_idx} [max_B]
+    RowState* finend = nullptr;                  // sampler: per-row state [max_B] (common.h): mirror of {finish, end_idx}, noise key, token limit
+    std::vector<RowState> rows_host;             //   its initial image for the current generate() (uploaded by begin)
+    // finished-row compaction (ctts_gpt_compact): gather targets + the kept row indices
+    float *cx = nullptr, *crope = nullptr; RowMeta* cmeta = nullptr; int* cring = nullptr; RowState* cfin = nullptr; int* keep_dev = nullptr;
+    std::vector<int> keep_host;
+    int B0 = 0;                                  // sequences the current generate() started with (h->B = rows still in the decode batch)
     // per generate()
     int B = 0, T = 0;
     SamplerCfgDev sc;
@@ -115,7 +115,7 @@ struct ctts_gpt {
     struct GraphEntry { hipGraph_t graph; hipGraphExec_t exec; };
     std::map<std::string, GraphEntry> graphs;
     hipGraphExec_t gexec = nullptr;              // entry selected by the last ensure_graph
-    int graph_steps = 4;                         // decode steps captured per graph (env CTTS_GRAPH_STEPS): a replay costs ~8 us of
+    int graph_steps = 4;                         // decode steps captured per graph: a replay costs ~8 us of
                                                  // GPU-side gap, amortised over 4 x 102 kernel nodes
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -143,13 +143,16 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->cfg = *c;
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
-    if (const char* sr = getenv("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 16) h->split_rows = 16; }
-    if (const char* ab = getenv("CTTS_ABLATE")) h->ablate = atoi(ab);
-    if (const char* nr = getenv("CTTS_NBG2_ROWS")) h->nbg2_rows = atoi(nr);
-    if (const char* fq = getenv("CTTS_FUSEQKV_ROWS")) { h->fuseqkv_rows = atoi(fq); if (h->fuseqkv_rows > 4) h->fuseqkv_rows = 4; }
-    if (const char* fr = getenv("CTTS_FUSE_ROWS")) { h->fuse_rows = atoi(fr); if (h->fuse_rows > 16) h->fuse_rows = 16; }
-    if (const char* xm = getenv("CTTS_XH")) h->xh_mode = atoi(xm);
-    if (const char* gs = getenv("CTTS_GRAPH_STEPS")) { h->graph_steps = atoi(gs); if (h->graph_steps < 1) h->graph_steps = 1; }
+    // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
+    // product library takes no behaviour from the environment on its launch paths (diag_env() is a constant null there).
+    if (const char* sr = diag_env("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 16) h->split_rows = 16; }
+    if (const char* nr = diag_env("CTTS_NBG2_ROWS")) h->nbg2_rows = atoi(nr);
+    if (const char* xm = diag_env("CTTS_XH")) h->xh_mode = atoi(xm) ? 1 : 0;
+    if (const char* gs = diag_env("CTTS_GRAPH_STEPS")) { h->graph_steps = atoi(gs); if (h->graph_steps < 1) h->graph_steps = 1; }
+    if (const char* e = diag_env("CTTS_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= SMAX) h->force_splits = v; }
+    if (diag_env("CTTS_NO_PREPACK")) h->no_prepack = 1;
+    if (const char* e = diag_env("CTTS_PREFILL_GEMM")) { const int v = atoi(e); h->prefill_gemm_rows = v > 1 ? v : (v == 1 ? 1536 : 0); }
+    if (diag_env("CTTS_NO_XH_HEADS")) h->xh_heads = 0;
     if (gemm_configure()) { delete h; return 1; }
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -163,8 +166,8 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
     void* bufs[] = {h->dyn, h->wblob, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
-                    h->act, h->attn_packed, h->norm_packed, h->opart, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
-                    h->hist_ring, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d,
+                    h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
+                    h->hist_ring, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
                     h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
@@ -284,7 +287,6 @@ extern "C" int ctts_gpt_set_row_adapters(ctts_gpt* h, const int32_t* slots, int 
         any = any || slots[b] >= 0;
     }
     if (!any) { h->lora_rows = 0; return 0; }
-    if (h->fuse_rows || h->fuseqkv_rows) { ctts_set_error("set_row_adapters: not available with the fused-launch diagnostics (CTTS_FUSE_ROWS / CTTS_FUSEQKV_ROWS)"); return 1; }
     if (lora_ensure_storage(h)) return 1;
     std::vector<int> tab(CTTS_MAX_B, -1);
     for (int b = 0; b < B; ++b) tab[b] = slots[b] < 0 ? -1 : slots[b];
@@ -440,13 +442,16 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->part_ml, (size_t)(CTTS_MAX_B + 32) * NH * SMAX * 2 * 4) ||          // flash-decoding partials: decode rows only (the prompt pass never splits keys)
         dev_alloc((void**)&h->part_o, (size_t)(CTTS_MAX_B + 32) * NH * SMAX * CTTS_HEAD_DIM * 4) ||
         dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * (h->NVQ * h->V > h->vocab_text_head ? h->NVQ * h->V : h->vocab_text_head) * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc((void**)&h->rope_pre, (size_t)MB * h->cfg.max_seq * 64 * 4) ||
-        dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->opart, (size_t)16 * NH * H * 4) || dev_alloc((void**)&h->dpart, (size_t)16 * 4 * H * 4) || dev_alloc(&h->attn_packed, (size_t)((PASS_ROWS + PASS_PAD) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
+        dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->dpart, (size_t)16 * 4 * H * 4) || dev_alloc(&h->attn_packed, (size_t)((PASS_ROWS + PASS_PAD) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc(&h->norm_packed, (size_t)((PASS_ROWS + PASS_PAD) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4) ||
         dev_alloc((void**)&h->dyn, sizeof(SamplerDyn)) || dev_alloc((void**)&h->hist_ring, (size_t)CTTS_MAX_B * CTTS_NUM_VQ * 16 * 4) ||
-        dev_alloc((void**)&h->finend, (size_t)CTTS_MAX_B * sizeof(int2)) ||
+        dev_alloc((void**)&h->finend, (size_t)CTTS_MAX_B * sizeof(RowState)) ||
+        dev_alloc((void**)&h->cx, (size_t)CTTS_MAX_B * H * 4) || dev_alloc((void**)&h->crope, (size_t)CTTS_MAX_B * 64 * 4) ||
+        dev_alloc((void**)&h->cmeta, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->cring, (size_t)CTTS_MAX_B * CTTS_NUM_VQ * 16 * 4) ||
+        dev_alloc((void**)&h->cfin, (size_t)CTTS_MAX_B * sizeof(RowState)) || dev_alloc((void**)&h->keep_dev, CTTS_MAX_B * 4) ||
         dev_alloc(&h->xh, (size_t)((CTTS_MAX_B + 32) / 16) * (H / 32) * 1024) || dev_alloc((void**)&h->ssq, (size_t)(CTTS_MAX_B + 32) * (H / 16) * 4) ||
         dev_alloc((void**)&h->scale_o, (size_t)(CTTS_MAX_B + 32) * 4) || dev_alloc((void**)&h->scale_d, (size_t)(CTTS_MAX_B + 32) * 4))
         return 1;
@@ -506,7 +511,7 @@ static inline void* kv_layer(ctts_gpt* h, int l, int which) {
 // 8-wave block would otherwise loop over more than ~768 keys.
 static inline int decode_splits(const ctts_gpt* h, int B, int L) {
     if (h->lora_rows) return 1;                            // per-utterance LoRA reads the attention output from o_proj's packed operand (S = 1 path)
-    if (const char* e = getenv("CTTS_SPLITS")) { int v = atoi(e); if (v >= 1 && v <= SMAX) return v; }
+    if (h->force_splits) return h->force_splits;
     int cap = 256 / (B * h->NH);
     cap = cap < 1 ? 1 : (cap > SMAX ? SMAX : cap);
     if (B <= 2) return cap;
@@ -515,8 +520,12 @@ static inline int decode_splits(const ctts_gpt* h, int B, int L) {
     return want < 1 ? 1 : (want > cap ? cap : want);
 }
 
-// 20 decoder layers on R rows starting at row `r0` of residual stream x (llama.py:719-749 per layer)
-static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* rope_rows, int R, int S, const DevState* st, hipStream_t s) {
+// What run_layers decided about the hand-off of the residual stream to whatever reads it next (the heads): one place computes the
+// predicates, the consumer uses what was actually launched.
+struct StreamForm { bool parts; bool xh; };     // x = x_dec + dpart[0..3] (split-K down projection) / packed fp16 copy + sums of squares exist
+
+// 20 decoder layers on R rows of residual stream x (llama.py:719-749 per layer)
+static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* rope_rows, int R, int S, const DevState* st, hipStream_t s, StreamForm* form = nullptr) {
     const int dt = h->cfg.dtype;
     const int nbg = (R <= 16 || (st != nullptr && R < h->nbg2_rows)) ? 1 : 2;     // decode rows: see nbg2_rows
     const int NB = 16 * nbg;
@@ -525,39 +534,21 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // its partial sums dp[0..3] are added, in order, by the next consumers of the residual stream (QKV RMSNorm, o_proj
     // residual, final heads) -- deterministic, no atomics.  x itself is re-materialised by every o_proj.
     const bool lora = h->lora_rows != 0;                   // per-utterance adapters: the residual stream must be materialised in x (no split-K partials)
-    const bool splitd = (st != nullptr) && (R <= h->split_rows) && (nbg == 1) && (h->fuse_rows == 0) && !lora;
+    const bool splitd = (st != nullptr) && (R <= h->split_rows) && (nbg == 1) && !lora;
     // prompt pass over more than a few chunks: normalise every row once (norm_pack_kernel) instead of in every GEMM block
-    const bool prepack = (st == nullptr) && (nbg == 2) && (R > 64) && !getenv("CTTS_NO_PREPACK");
-    // prompt pass over >= 128 rows, fp16: LDS-staged 256/128 x 128 MFMA GEMM (prefill_gemm.hip) instead of one weight tile per 32-row block
-    static const int pf_env = getenv("CTTS_PREFILL_GEMM") ? atoi(getenv("CTTS_PREFILL_GEMM")) : 1;
+    const bool prepack = (st == nullptr) && (nbg == 2) && (R > 64) && !h->no_prepack;
+    // prompt pass over >= 1536 rows, fp16: LDS-staged 256/128 x 128 MFMA GEMM (prefill_gemm.hip) instead of one weight tile per 32-row block
     // (measured with 128 x 128 blocks, prompt pass ms with / without it: 512 rows 2.31 / 1.48, 1024 rows 2.47 / 2.29, 1536 rows 2.70 / 3.12,
     //  2048 rows 2.81 / 3.9, 3072 rows 3.6 / 5.3, 16384 rows 10.3 / 29)
-    const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && (R >= (pf_env > 1 ? pf_env : 1536)) && pf_env && !lora;
+    const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && h->prefill_gemm_rows > 0 && (R >= h->prefill_gemm_rows) && !lora;
     // fp16 decode above the split-K batch sizes: the residual stream travels between kernels as a packed fp16 B operand + per-tile
-    // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself
-    const bool xhm = (dt == CTTS_DTYPE_F16) && (st != nullptr) && h->xh_mode && !splitd && (R > h->fuse_rows) && (R > h->fuseqkv_rows);
-    // batches <= 4 keep the split-K down projection (its partial sums feed the next QKV's RMSNorm), but o_proj re-materialises x: it could
-    // hand gate|up the packed fp16 copy + sums of squares too.  Measured SLOWER (us/step with / without: batch 1 393 / 381, 2 415 / 403,
-    // 4 450 / 443 -- one fp32 row normalised by one wave is cheaper than six 1-KiB fragment loads per wave plus the heavier o_proj
-    // epilogue), so it stays a diagnostic switch (env CTTS_XH=3)
-    const bool xhs = (dt == CTTS_DTYPE_F16) && splitd && (h->xh_mode == 3) && (R > h->fuse_rows) && (R > h->fuseqkv_rows);
+    // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself.  (Handing gate|up
+    // the packed copy at batches <= 4 too was measured slower: batch 1 393 vs 381 us/step, 2 415 vs 403, 4 450 vs 443.)
+    const bool xhm = (dt == CTTS_DTYPE_F16) && (st != nullptr) && h->xh_mode && !splitd;
+    if (form) { form->parts = splitd; form->xh = xhm; }
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
         a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq;
-        const bool fused = (st != nullptr) && (R <= h->fuse_rows);
-        const bool fq = (st != nullptr) && !fused && (R <= h->fuseqkv_rows);
-        if (fq) {
-            // one launch: RMSNorm + q/k/v projection + RoPE + KV append + attention (S splits of the cached keys + the new key)
-            QkvAttnArgs qa = {};
-            qa.x = x; qa.dpart = h->dpart; qa.np = (splitd && l > 0) ? 4 : 0; qa.eps = a.eps; qa.wqkv = h->lw[l].qkv; qa.rope_rows = rope_rows;
-            qa.meta = meta; qa.st = st; qa.k_cache = kv_layer(h, l, 0); qa.v_cache = kv_layer(h, l, 1); qa.Lmax = h->cfg.max_seq; qa.NH = h->NH; qa.R = R;
-            qa.S = S > 7 ? 7 : S; qa.part_ml = h->part_ml; qa.part_o = h->part_o;
-            if (launch_qkv_attention(dt, qa, s)) return 1;
-            GemmArgs g2 = a;
-            g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = qa.S + 1; g2.x_out = x;
-            g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;
-            if (launch_gemm(dt, nbg, PRO_ATTN, splitd ? EPI_RESID_P : EPI_RESID, g2, chunks, s)) return 1;
-        } else {
         // RMSNorm + QKV + RoPE + KV append
         GemmArgs g1 = a;
         g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x;
@@ -576,68 +567,57 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         } else if (xhm) {
             g1.scale_out = h->scale_o;
             if (l > 0) { g1.xh = h->xh; g1.ssq = h->ssq; g1.scale_in = h->scale_d; }
-            if (!(h->ablate & 1) && launch_gemm(dt, nbg, l > 0 ? PRO_XH : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
-        } else {
-            if (xhs) g1.scale_out = h->scale_o;
-            if (!(h->ablate & 1) && launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
-        }
+            if (launch_gemm(dt, nbg, l > 0 ? PRO_XH : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
+        } else if (launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
         if (st == nullptr) { at.T = h->T; at.row0 = (int)(meta - h->meta_pre); }       // prompt pass: position of this pass in the flattened [B][T] prompt
-        if (fused) {
-            // small batch: attention + per-head o_proj partial in one launch; the residual add is deferred to the
-            // consumers (gate|up prologue, down epilogue) which sum the 12 partials in head order
-            at.wo = h->lw[l].o; at.opart = h->opart; at.jt = (h->H / 16) / (4 * 3);
-            if (!(h->ablate & 2) && launch_attention(dt, at, s)) return 1;
-        } else {
-            at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
-            if (!(h->ablate & 2) && launch_attention(dt, at, s)) return 1;
-            // softmax combine + o_proj + residual (S == 1: attention already wrote the normalised, packed B operand)
-            GemmArgs g2 = a;
-            g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = S; g2.x_out = x;
-            g2.xpacked = h->attn_packed;
-            g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;
-            const bool sp2 = splitd;                       // the down projection's partial sums are folded into x here
-            if (xhm || xhs) { g2.xh = h->xh; g2.ssq = h->ssq; g2.scale_in = h->scale_o; }
-            if (lora) {
-                if (S != 1) { ctts_set_error("per-utterance LoRA needs unsplit attention"); return 1; }
-                if (launch_lora_delta_o(dt, h->attn_packed, nbg, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
-                                        h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_do, R, h->H, s)) return 1;
-                g2.lora_delta = h->lora_do;
-            }
-            if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
-            else if (!(h->ablate & 4) && launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (sp2 ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
+        at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
+        if (launch_attention(dt, at, s)) return 1;
+        // softmax combine + o_proj + residual (S == 1: attention already wrote the normalised, packed B operand)
+        GemmArgs g2 = a;
+        g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = S; g2.x_out = x;
+        g2.xpacked = h->attn_packed;
+        g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;      // the down projection's partial sums are folded into x here
+        if (xhm) { g2.xh = h->xh; g2.ssq = h->ssq; g2.scale_in = h->scale_o; }
+        if (lora) {
+            if (S != 1) { ctts_set_error("per-utterance LoRA needs unsplit attention"); return 1; }
+            if (launch_lora_delta_o(dt, h->attn_packed, nbg, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
+                                    h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_do, R, h->H, s)) return 1;
+            g2.lora_delta = h->lora_do;
         }
-        }
+        if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
+        else if (launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (splitd ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
         // RMSNorm + gate|up + SiLU*up
         GemmArgs g3 = a;
-        g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act; g3.opart = h->opart; g3.np = CTTS_NPART;
+        g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act;
         if (prepack) {
             g3.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
             if (pfg ? launch_prefill_gemm(EPI_SWIGLU, g3, s) : launch_gemm(dt, nbg, PRO_PACKED, EPI_SWIGLU, g3, chunks, s)) return 1;
-        } else if (xhm || xhs) {
-            g3.xh = h->xh; g3.ssq = h->ssq; g3.scale_in = h->scale_o; g3.scale_out = xhm ? h->scale_d : nullptr;
-            if (!(h->ablate & 8) && launch_gemm(dt, nbg, PRO_XH, EPI_SWIGLU, g3, chunks, s)) return 1;
-        } else if (!(h->ablate & 8) && launch_gemm(dt, nbg, fused ? PRO_NORM_P : PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
+        } else if (xhm) {
+            g3.xh = h->xh; g3.ssq = h->ssq; g3.scale_in = h->scale_o; g3.scale_out = h->scale_d;
+            if (launch_gemm(dt, nbg, PRO_XH, EPI_SWIGLU, g3, chunks, s)) return 1;
+        } else if (launch_gemm(dt, nbg, PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
         // down + residual
         GemmArgs g4 = a;
-        g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x; g4.opart = h->opart; g4.np = CTTS_NPART;
+        g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x;
         if (pfg) {
             if (launch_prefill_gemm(EPI_RESID, g4, s)) return 1;
         } else if (splitd) {
             g4.part_out = h->dpart; g4.ktiles_total = h->I / (h->esz == 2 ? 32 : 16);
-            if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, EPI_PART, g4, chunks, s)) return 1;
+            if (launch_gemm(dt, nbg, PRO_PACKED, EPI_PART, g4, chunks, s)) return 1;
         } else if (xhm) {                          // (the last layer's copy is for the heads: run_heads)
             g4.xh = h->xh; g4.ssq = h->ssq; g4.scale_in = h->scale_d;
-            if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH, g4, chunks, s)) return 1;
-        } else if (!(h->ablate & 16) && launch_gemm(dt, nbg, PRO_PACKED, fused ? EPI_RESID_P : EPI_RESID, g4, chunks, s)) return 1;
+            if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH, g4, chunks, s)) return 1;
+        } else if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID, g4, chunks, s)) return 1;
     }
     return 0;
 }
 
-static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
+// final RMSNorm + heads on the h->B decode rows; `form` = how the last run_layers left them (all false after a prompt pass / restart)
+static int run_heads(ctts_gpt* h, bool write_hidden, StreamForm form, hipStream_t s) {
     const int nbg = (h->B <= 16 || h->B < h->nbg2_rows) ? 1 : 2;
     const int chunks = (h->B + 16 * nbg - 1) / (16 * nbg);
     GemmArgs a = {};
@@ -646,16 +626,18 @@ static int run_heads(ctts_gpt* h, bool write_hidden, hipStream_t s) {
     a.W = h->text_mode ? h->whead_text : h->whead; a.n_row_tiles = (nv + 15) / 16; a.K = h->H; a.x = h->x_dec; a.lnw = h->lnf;
     a.logits = h->logits; a.n_valid = nv;
     a.dyn = write_hidden ? h->dyn : nullptr;       // the kernel tests dyn->hidden_out itself
-    a.opart = h->dpart; a.np = h->x_has_parts ? 4 : 0;
-    if (h->x_has_xh) {       // the last down projection left the rows as packed fp16 + sums of squares (run_layers, PRO_XH): no fp32 re-normalisation per block
+    a.opart = h->dpart; a.np = form.parts ? 4 : 0;
+    // the last down projection left the rows as packed fp16 + sums of squares (PRO_XH): no fp32 re-normalisation per block.  The text head is a
+    // different launch shape (not measured): it keeps the fp32 prologue
+    if (form.xh && !h->text_mode && h->xh_heads) {
         a.xh = h->xh; a.ssq = h->ssq; a.scale_in = h->scale_d;
         return launch_gemm(h->cfg.dtype, nbg, PRO_XH, EPI_LOGITS, a, chunks, s);
     }
-    return launch_gemm(h->cfg.dtype, nbg, (nbg == 1 && h->split_rows > 0 && h->fuse_rows == 0) ? PRO_NORM_P : PRO_NORM, EPI_LOGITS, a, chunks, s);
+    return launch_gemm(h->cfg.dtype, nbg, (nbg == 1) ? PRO_NORM_P : PRO_NORM, EPI_LOGITS, a, chunks, s);
 }
 
-static int run_sample_phase(ctts_gpt* h, hipStream_t s) {
-    if (run_heads(h, true, s)) return 1;
+static int run_sample_phase(ctts_gpt* h, StreamForm form, hipStream_t s) {
+    if (run_heads(h, true, form, s)) return 1;
     SamplerArgs sa = {};
     sa.dyn = h->dyn; sa.logits = h->logits; sa.V = h->text_mode ? h->vocab_text_head : h->V; sa.B = h->B; sa.st = h->st;
     sa.text_mode = h->text_mode;
@@ -673,7 +655,9 @@ static int reset_state(ctts_gpt* h, bool keep_draw, hipStream_t s) {
     CTTS_HIP_CHECK(hipMemcpyAsync(h->meta_dec, h->meta_dec0, h->B * sizeof(RowMeta), hipMemcpyDeviceToDevice, s));
     CTTS_HIP_CHECK(hipMemsetAsync(h->io.finish, 0, h->B * 4, s));
     CTTS_HIP_CHECK(hipMemsetAsync(h->io.end_idx, 0, h->B * 4, s));
-    CTTS_HIP_CHECK(hipMemsetAsync(h->finend, 0, h->B * sizeof(int2), s));
+    if (!keep_draw) {       // begin: {fin 0, end 0, attempt 0, limit, utterance id} per row (pageable source: staged before the call returns)
+        CTTS_HIP_CHECK(hipMemcpyAsync(h->finend, h->rows_host.data(), h->B * sizeof(RowState), hipMemcpyHostToDevice, s));
+    } else if (launch_restart_rows(h->finend, h->B, s)) return 1;      // ensure_non_empty regenerate: rows that ended at step 0 move on to their next noise attempt
     CTTS_HIP_CHECK(hipMemsetAsync(h->hist_ring, 0xFF, (size_t)h->B * CTTS_NUM_VQ * 16 * 4, s));      // -1: no id sampled yet
     return 0;
 }
@@ -693,7 +677,16 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
         if (sc->eos_token >= h->vocab_text_head) { ctts_set_error("begin: eos out of range"); return 1; }
     } else if (sc->past_window > 16 || sc->eos_token >= h->V) { ctts_set_error("begin: past_window>16 or eos out of range"); return 1; }
     hipStream_t s = (hipStream_t)stream;
-    h->B = B; h->T = T; h->io = *io;
+    h->B = B; h->B0 = B; h->T = T; h->io = *io;
+    h->rows_host.assign(B, RowState{});
+    for (int b = 0; b < B; ++b) {
+        RowState& r = h->rows_host[b];
+        const unsigned long long uid = io->utt_ids ? io->utt_ids[b] : (unsigned long long)b;
+        int lim = io->row_limits ? io->row_limits[b] : sc->max_new_token;
+        r.limit = lim < 1 ? 1 : (lim > sc->max_new_token ? sc->max_new_token : lim);
+        r.uid_lo = (unsigned)uid; r.uid_hi = (unsigned)(uid >> 32);
+    }
+    h->io.utt_ids = nullptr; h->io.row_limits = nullptr;      // host arrays are consumed here, not kept
     memcpy(h->sc.temperature, sc->temperature, sizeof(sc->temperature));
     h->sc.top_p_threshold = sc->top_p_threshold; h->sc.top_k = sc->top_k; h->sc.min_keep = sc->min_tokens_to_keep;
     h->sc.use_penalty = sc->use_penalty; memcpy(h->sc.penalty_table, sc->penalty_table, sizeof(sc->penalty_table));
@@ -702,6 +695,7 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
     SamplerDyn d = {};
     d.cfg = h->sc; d.n_draws = io->n_draws; d.ids = io->ids; d.finish = io->finish; d.end_idx = io->end_idx; d.noise = io->noise;
     d.seed = io->seed; d.hidden_out = io->hiddens; d.hidden_stride = sc->max_new_token * h->H;
+    d.rows0 = B * (h->text_mode ? 1 : CTTS_NUM_VQ);
     CTTS_HIP_CHECK(hipMemcpyAsync(h->dyn, &d, sizeof(d), hipMemcpyHostToDevice, s));       // pageable source: staged before the call returns
     if (launch_fill_meta(h->meta_pre, h->meta_dec0, h->st, mask, B, T, h->rope, h->rope_pre, s)) return 1;
     return reset_state(h, false, s);
@@ -728,35 +722,30 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* h, const float* emb, void* stream) {
 extern "C" int ctts_gpt_sample(ctts_gpt* h, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("sample: call begin first"); return 1; }
     CTTS_RANGE("ctts_gpt_sample");
-    return run_sample_phase(h, (hipStream_t)stream);
+    return run_sample_phase(h, StreamForm{false, false}, (hipStream_t)stream);
 }
 
 extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("restart: call begin first"); return 1; }
+    if (h->B != h->B0) { ctts_set_error("restart: rows were compacted away (a regenerate restarts the whole batch at step 0, gpt.py:496-525)"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     CTTS_HIP_CHECK(hipMemcpyAsync(h->x_dec, h->x_last, (size_t)h->B * h->H * 4, hipMemcpyDeviceToDevice, s));
     return reset_state(h, true, s);
 }
 
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
-    if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s)) return 1;
-    h->x_has_parts = (h->B <= h->split_rows && h->B <= 16 && h->fuse_rows == 0 && !h->lora_rows) ? 1 : 0;    // same condition as `splitd` in run_layers
-    // same condition as `xhm` in run_layers (text mode keeps the fp32 prologue: its head is a different launch shape, not measured)
-    h->x_has_xh = (h->cfg.dtype == CTTS_DTYPE_F16 && h->xh_mode && !h->x_has_parts && h->B > h->fuse_rows && h->B > h->fuseqkv_rows && !h->text_mode &&
-                   !getenv("CTTS_NO_XH_HEADS")) ? 1 : 0;
-    const int rc = run_sample_phase(h, s);          // the heads add dpart[0..3]; the sampler then re-materialises x_dec
-    h->x_has_parts = 0; h->x_has_xh = 0;
-    return rc;
+    StreamForm form = {false, false};
+    if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s, &form)) return 1;
+    return run_sample_phase(h, form, s);            // the heads add dpart[0..3] / read the packed copy; the sampler then re-materialises x_dec
 }
 
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->graph_steps, h->split_rows, h->fuse_rows, h->nbg2_rows, h->cur_splits,
-             h->fuseqkv_rows, h->xh_mode, h->lora_rows);
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows);      // (diagnostic switches are fixed at create)
     const std::string key(sig);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }
-    if (h->graphs.size() >= 16) {                  // bounded: a serving process cycles through few (batch, mode) shapes
+    if (h->graphs.size() >= 48) {                  // bounded: a serving process cycles through few (batch, mode) shapes (compaction adds the sizes of compact_size)
         for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
         h->graphs.clear(); h->gexec = nullptr;
     }
@@ -804,6 +793,27 @@ extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_
 extern "C" int ctts_gpt_progress_enqueue(ctts_gpt* h, int32_t* host_pinned4, void* stream) {
     if (!h || !host_pinned4) { ctts_set_error("progress_enqueue: null argument"); return 1; }
     CTTS_HIP_CHECK(hipMemcpyAsync(host_pinned4, h->st, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int ctts_gpt_rows_enqueue(ctts_gpt* h, int32_t* host_pinned_2B, void* stream) {
+    if (!h || !host_pinned_2B || h->B == 0) { ctts_set_error("rows_enqueue: call begin first"); return 1; }
+    CTTS_HIP_CHECK(hipMemcpy2DAsync(host_pinned_2B, 8, h->finend, sizeof(RowState), 8, h->B, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int ctts_gpt_compact(ctts_gpt* h, const int32_t* keep_rows, int n_keep, void* stream) {
+    if (!h || !keep_rows || h->B == 0) { ctts_set_error("compact: call begin first"); return 1; }
+    if (h->text_mode) { ctts_set_error("compact: code mode only"); return 1; }
+    if (n_keep < 1 || n_keep > h->B) { ctts_set_error("compact: n_keep=%d of %d rows", n_keep, h->B); return 1; }
+    for (int i = 0; i < n_keep; ++i)
+        if (keep_rows[i] < 0 || keep_rows[i] >= h->B || (i > 0 && keep_rows[i] <= keep_rows[i - 1])) { ctts_set_error("compact: keep_rows must be ascending row indices < %d", h->B); return 1; }
+    if (n_keep == h->B) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    h->keep_host.assign(keep_rows, keep_rows + n_keep);
+    CTTS_HIP_CHECK(hipMemcpyAsync(h->keep_dev, h->keep_host.data(), (size_t)n_keep * 4, hipMemcpyHostToDevice, s));
+    if (launch_compact_rows(h->keep_dev, n_keep, h->H, h->x_dec, h->rope_dec, h->meta_dec, h->hist_ring, h->finend, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->st, s)) return 1;
+    h->B = n_keep;
     return 0;
 }
 

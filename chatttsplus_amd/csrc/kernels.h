@@ -2,13 +2,13 @@
 #pragma once
 #include "common.h"
 
-enum { PRO_NORM = 0, PRO_ATTN = 1, PRO_PACKED = 2, PRO_NORM_P = 3, PRO_XH = 4 };     // _P: residual stream = x + sum of per-head o_proj partials
+enum { PRO_NORM = 0, PRO_ATTN = 1, PRO_PACKED = 2, PRO_NORM_P = 3, PRO_XH = 4 };     // _P: residual stream = x + the down projection's split-K partial sums
 // PRO_XH (fp16 decode, > 4 rows): the B operand is the residual stream as the PREVIOUS kernel's epilogue (EPI_RESID_XH) left it -- fp16,
 // fragment-major, scaled by a per-row power of two -- and the RMSNorm factor is applied to the C tile after the MFMAs from the
 // producer's per-tile sums of squares: no block re-reads and re-normalises fp32 rows (16 rows x 3 KB per block, replicated in up to
 // 768 blocks per launch, was the prologue of every QKV / gate|up launch).
 enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_P = 4, EPI_PART = 5, EPI_RESID_XH = 6 };   // PART: write a split-K partial, no residual; RESID_XH: see PRO_XH
-#define CTTS_NPART 12      // o_proj partials per row = attention heads (fused attention+o_proj path)
+#define CTTS_NPART 4       // split-K partial sums of the down projection per row (decode batches <= 4)
 
 // out[R rows][N] = prologue(x)[R][K] . W[N][K]^T  followed by a fused epilogue.
 // W is pre-packed in 16-row x KT-col MFMA-A tiles, [row tile][k tile][lane][16 B] (gpt_engine.cpp).
@@ -23,7 +23,7 @@ struct GemmArgs {
     const float* x;         // PRO_NORM: residual stream [R][K] fp32
     const float* lnw;       // PRO_NORM: RMSNorm weight [K] -- only for hidden_out (the weight is folded into W's columns)
     const float* opart;     // PRO_NORM_P / EPI_RESID_P: partial sums added to the residual stream in index order, [R][np][K] fp32
-    int np;                 //   how many (<= CTTS_NPART): 12 per-head o_proj partials (fused attention) or 4 split-K down partials
+    int np;                 //   how many (<= CTTS_NPART): the 4 split-K partials of the previous down projection, or 0
     int ktiles_total;       // EPI_PART: k-tiles of the whole matrix (the block's slice is blockIdx.z * KTILES); 0 = KTILES
     float* part_out;        // EPI_PART: [R][gridDim.z][N] fp32
     float eps;
@@ -64,9 +64,6 @@ struct AttnArgs {
     const DevState* st;
     float* part_ml;         // [R][NH][S][2]
     float* part_o;          // [R][NH][S][64]
-    const void* wo;         // fused path: packed o_proj weight; each block also computes its head's partial o_proj for n_row_tiles/JT tiles
-    float* opart;           //   [R][NH][H] fp32
-    int jt;                 //   column groups (grid.y) when fused, 0 otherwise
     void* packed_out;       // S == 1 only: normalised output written straight into the o_proj kernel's fragment-major B operand
     int nbg;                //   rows per chunk = 16*nbg
     int T, row0;            // prompt pass (MFMA flash kernel): prompt length and the flattened index b*T + t of the pass's first row
@@ -99,7 +96,8 @@ struct SamplerDyn {
     unsigned long long seed;
     float* hidden_out;      // hiddens[seq][step][H] or null
     int hidden_stride;      //   = max_new_token * H
-    int pad_;
+    int rows0;              // multinomial rows of the batch the call STARTED with (B0 * 4, text mode B0): row stride of `noise`, which stays
+                            //   indexed by utterance when finished rows are compacted away
 };
 #define CTTS_CONST_AS __attribute__((address_space(4)))
 typedef const CTTS_CONST_AS SamplerDyn* SamplerDynPtr;
@@ -119,7 +117,7 @@ struct SamplerArgs {
     const float* rope;      // table [max_seq][64]
     float* rope_rows;       // decode rows' table rows [B][64], refreshed for the next step's positions
     int* hist_ring;         // [B][4][16] the last 16 sampled ids per (sequence, codebook), slot = step % 16, -1 = none yet
-    int2* finend;           // [B] engine-side mirror of {finish, end_idx}
+    RowState* finend;       // [B] per-row state (common.h): mirror of {finish, end_idx}, noise key, token limit
     // stand-alone mode (ctts_sampler_run)
     const int* history;     // [rows][hist_len]
     int hist_len;
@@ -127,25 +125,6 @@ struct SamplerArgs {
     int* idx_out;           // [rows]
 };
 
-// decode rows, very small batches: RMSNorm + the head's q/k/v projection + RoPE + KV append + attention in ONE launch
-// (attention.hip qkv_attn_kernel); per (row, head): S blocks over the cached keys, one block for the new key's score and K append,
-// one for its value and V append -> S + 1 flash-decoding partials for the o_proj prologue.
-struct QkvAttnArgs {
-    const float* x;           // [R][768] residual stream
-    const float* dpart;       // [R][np][768] split-K partial sums of the previous down projection (np = 0: none)
-    int np;
-    float eps;
-    const void* wqkv;         // packed QKV tiles [144][k tiles][64 lanes][16 B] (gpt_engine.hip pack order)
-    const float* rope_rows;   // [R][64] cos | sin of each row's position
-    const RowMeta* meta;
-    const DevState* st;
-    void* k_cache;            // this layer
-    void* v_cache;
-    int Lmax, NH, R, S;       // S >= 1 splits over the cached keys
-    float* part_ml;           // [R][NH][S + 1][2]
-    float* part_o;            // [R][NH][S + 1][64]
-};
-int launch_qkv_attention(int dtype, const QkvAttnArgs& a, hipStream_t s);
 int launch_gemm(int dtype, int nbg, int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s);
 int launch_lora_delta_qkv(const float* x, const float* lnw, float eps, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
                           const float* scale_l, float* delta, int rows, int H, hipStream_t s);
@@ -160,4 +139,7 @@ int launch_embed_ids(const int* ids, const float* emb_code, float* x, int B, int
 int launch_fill_meta(RowMeta* prefill_meta, RowMeta* decode_meta, DevState* st, const int* mask, int B, int T, const float* rope, float* rope_pre, hipStream_t s);
 int launch_embed_prompt(const int* ids, const int* text_mask, const float* emb_text, const float* emb_code, const float* spk, int spk_id,
                         float* out, int rows, int T, int V, int H, hipStream_t s);
+int launch_restart_rows(RowState* rows, int B, hipStream_t s);
+int launch_compact_rows(const int* keep, int n_keep, int H, float* x, float* rope_rows, RowMeta* meta, int* ring, RowState* fin,
+                        float* cx, float* crope, RowMeta* cmeta, int* cring, RowState* cfin, DevState* st, hipStream_t s);
 int gemm_configure();

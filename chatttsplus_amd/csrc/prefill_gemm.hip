@@ -292,7 +292,7 @@ int launch_prefill_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     // block shape per projection: 0 = 128 x 128, 1 = 256 x 128, 2 = 256 x 256.  CTTS_PF_SHAPE = "qkv,gateup,resid" overrides (diagnostic).
     static int shape_env[3] = {-1, -1, -1};
     static const bool parsed = [] {
-        const char* e = getenv("CTTS_PF_SHAPE");
+        const char* e = diag_env("CTTS_PF_SHAPE");
         if (e) sscanf(e, "%d,%d,%d", &shape_env[0], &shape_env[1], &shape_env[2]);
         return true;
     }();

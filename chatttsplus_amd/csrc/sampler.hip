@@ -37,7 +37,8 @@ struct RowIn {
     bool penalize;
     int step;
     unsigned long long seed;
-    unsigned draw, row;
+    unsigned uid_lo, uid_hi;   // Philox stream of the row: (seed | utterance id, codebook, the row's own step and regenerate attempt)
+    unsigned vq, attempt;
 };
 
 struct SampleKnobs { float top_p_threshold; int top_k, min_keep, eos, min_new; };
@@ -49,7 +50,10 @@ __device__ inline SampleKnobs knobs_of(SamplerDynPtr d) {
 
 __device__ inline float exp_noise_of(const RowIn& in, int j) {
     if (in.q != nullptr) return in.q[j];
-    const uint4 rnd = philox4x32_10(make_uint4((unsigned)j, in.row, in.draw, 0x43545453u), make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
+    // counter = (element | codebook << 24, utterance id, step | attempt << 20); nothing in it depends on the row's place in a batch, on
+    // the batch's size or on the batch's draw counter: an utterance draws the same noise in whatever slice / rank it is served
+    const uint4 rnd = philox4x32_10(make_uint4((unsigned)j | (in.vq << 24), in.uid_lo, in.uid_hi, (unsigned)in.step | (in.attempt << 20)),
+                                    make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
     const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
     return -logf(u);
 }
@@ -244,7 +248,7 @@ __device__ int sample_row(const SampleKnobs& c, const float* tab, const RowIn& i
 // The leading scalars are preloaded into SGPRs (see skinny_gemm.hip): state header, logits and bookkeeping rows are all
 // requested before the first wait of the kernel.
 __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_words, const float* logits_p, const SamplerDyn* dyn_p, const RowMeta* meta_p,
-                                                               const int V_p, const int* ring_p, const int2* finend_p, const SamplerArgs a) {
+                                                               const int V_p, const int* ring_p, const RowState* finend_p, const SamplerArgs a) {
     __shared__ float tab[17];
     __shared__ int idx_s[CTTS_NUM_VQ];
     __shared__ unsigned long long cand_s[CTTS_NUM_VQ][64];
@@ -266,17 +270,19 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
     // buffer's address depends on the step and on the per-call block: a second dependent round trip in front of the penalty), and
     // the finish / end_idx bookkeeping is mirrored in engine memory (the caller's arrays are write-only here).
     const int ring_v = ring_p[(size_t)(b * CTTS_NUM_VQ + vq) * 16 + (lane & 15)];
-    const int2 fe = finend_p[b];
+    const int4 fe = ((const int4*)(finend_p + b))[0];              // {fin, end, attempt, limit}
+    const int2 uid = ((const int2*)(finend_p + b))[2];              // {uid_lo, uid_hi}
     if (tid < 17) tab[tid] = d->cfg.penalty_table[tid];
     const RowMeta meta_in = meta_p[b];
     if (__builtin_amdgcn_readfirstlane(hdr.z)) return;            // every sequence finished (gpt.py:545)
     const int step = __builtin_amdgcn_readfirstlane(hdr.x), draw = __builtin_amdgcn_readfirstlane(hdr.y);
     const int fin_in = fe.x, end_in = fe.y;
+    const int seq = meta_in.seq;                                  // utterance of this row: output arrays, noise rows (rows are re-packed by ctts_gpt_compact)
     const float rope_next = (tid < 64) ? a.rope[(size_t)(meta_in.pos + 1) * 64 + tid] : 0.f;
     __syncthreads();
-    const int row = b * CTTS_NUM_VQ + vq;
+    const int row = seq * CTTS_NUM_VQ + vq;                       // row of the [B0 * 4, V] batch the call started with (gpt.py:444-447)
     RowIn in;
-    in.q = (d->noise != nullptr) ? d->noise + ((size_t)min(draw, d->n_draws - 1) * a.B * CTTS_NUM_VQ + row) * a.V : nullptr;
+    in.q = (d->noise != nullptr) ? d->noise + ((size_t)min(draw, d->n_draws - 1) * d->rows0 + row) * a.V : nullptr;
     // ring slot p holds the id sampled at the latest step s < `step` with s % 16 == p: it is inside the window of the last
     // min(step, past_window) ids (processors.py:21-23 with gpt.py:455-457) iff its age step - s is at most that
     const int nh = min(step, d->cfg.past_window);
@@ -285,11 +291,11 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
     in.T = d->cfg.temperature[vq];
     in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids) && nh > 0;      // quirk SURVEY F8
     in.step = step;
-    in.seed = d->seed; in.draw = (unsigned)draw; in.row = (unsigned)row;
+    in.seed = d->seed; in.uid_lo = (unsigned)uid.x; in.uid_hi = (unsigned)uid.y; in.vq = (unsigned)vq; in.attempt = (unsigned)fe.z;
     const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg, cand_s[vq]);
     if (lane == 0) {
         idx_s[vq] = idx;
-        d->ids[((size_t)b * d->cfg.max_new + step) * CTTS_NUM_VQ + vq] = idx;
+        d->ids[((size_t)seq * d->cfg.max_new + step) * CTTS_NUM_VQ + vq] = idx;
         a.hist_ring[(size_t)(b * CTTS_NUM_VQ + vq) * 16 + (step & 15)] = idx;
     }
     __syncthreads();
@@ -305,9 +311,10 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
         bool fin = was;
         for (int v = 0; v < CTTS_NUM_VQ; ++v) fin = fin || (idx_s[v] == d->cfg.eos);   // gpt.py:486-487
         const int end_out = fin ? end_in : end_in + 1;                               // gpt.py:530-531
-        d->finish[b] = fin ? 1 : 0;
-        if (!fin) d->end_idx[b] = end_out;
-        a.finend[b] = make_int2(fin ? 1 : 0, end_out);
+        if (!fin) d->end_idx[seq] = end_out;
+        fin = fin || (end_out >= fe.w);                                              // the row's own token limit: done from the next step on
+        d->finish[seq] = fin ? 1 : 0;
+        ((int2*)(a.finend + b))[0] = make_int2(fin ? 1 : 0, end_out);
         RowMeta m = meta_in;                                                       // next decode row
         m.pos += 1; m.slot += 1;
         a.meta[b] = m;
@@ -403,6 +410,7 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, V = a.V;
     const int step = st->step, draw = st->draw;
+    const RowState rs_in = a.finend[b];
     const float* lg = a.logits + (size_t)b * V;
     const float* q = (d->noise != nullptr) ? d->noise + ((size_t)min(draw, d->n_draws - 1) * a.B + b) * V : nullptr;
     const float T = d->cfg.temperature[0];
@@ -552,7 +560,8 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
             float qq;
             if (q != nullptr) qq = q[j];
             else {
-                const uint4 rnd = philox4x32_10(make_uint4((unsigned)j, (unsigned)b, (unsigned)draw, 0x54585453u),
+                // same keying as the code sampler (utterance id, own step, own attempt); codebook field = 4 marks the text stream
+                const uint4 rnd = philox4x32_10(make_uint4((unsigned)j | (4u << 24), rs_in.uid_lo, rs_in.uid_hi, (unsigned)step | ((unsigned)rs_in.attempt << 20)),
                                                 make_uint2((unsigned)d->seed, (unsigned)(d->seed >> 32)));
                 qq = -logf(((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f));
             }
@@ -570,6 +579,7 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
         const bool fin = was || (idx == d->cfg.eos);                                  // gpt.py:490-491
         d->finish[b] = fin ? 1 : 0;
         if (!fin) d->end_idx[b] += 1;
+        ((int2*)(a.finend + b))[0] = make_int2(fin ? 1 : 0, rs_in.end + (fin ? 0 : 1));   // mirror (read by ctts_gpt_restart's attempt bookkeeping)
         RowMeta m = a.meta[b];
         m.pos += 1; m.slot += 1;
         a.meta[b] = m;
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(256) void sampler_rows_kernel(const SamplerArgs a) 
     in.T = d->cfg.temperature[row % CTTS_NUM_VQ];
     in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids) && nh > 0;
     in.step = a.step_override;
-    in.seed = 0; in.draw = 0; in.row = (unsigned)row;
+    in.seed = 0; in.uid_lo = (unsigned)row; in.uid_hi = 0; in.vq = 0; in.attempt = 0;      // (stand-alone mode always receives q)
     float lg[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { const int j = lane + 64 * i; lg[i] = (j < a.V) ? logits[j] : 0.f; }
@@ -620,13 +630,64 @@ int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s) {
     if (a.st != nullptr && a.text_mode) {
         if (a.V > 1024 * TVPT) { ctts_set_error("text sampler: vocab %d > %d", a.V, 1024 * TVPT); return 1; }
         hipLaunchKernelGGL(sampler_text_kernel, dim3(a.B), dim3(1024), 0, s, a);
-    } else if (a.st != nullptr) hipLaunchKernelGGL(sampler_generate_kernel, dim3(a.B), dim3(256), 0, s, (const int*)a.st, a.logits, a.dyn, (const RowMeta*)a.meta, a.V, (const int*)a.hist_ring, (const int2*)a.finend, a);
+    } else if (a.st != nullptr) hipLaunchKernelGGL(sampler_generate_kernel, dim3(a.B), dim3(256), 0, s, (const int*)a.st, a.logits, a.dyn, (const RowMeta*)a.meta, a.V, (const int*)a.hist_ring, (const RowState*)a.finend, a);
     else hipLaunchKernelGGL(sampler_rows_kernel, dim3(blocks), dim3(256), 0, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 // ---- small helper kernels --------------------------------------------------------------------
+
+// ensure_non_empty regenerate (gpt.py:496-525): every row starts over; a row that itself ended at step 0 moves on to its next noise
+// attempt, the others keep theirs (device noise: they re-draw the very token they drew before -- a row's result does not depend on
+// which other rows shared its batch)
+__global__ void restart_rows_kernel(RowState* rows, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    RowState r = rows[b];
+    r.attempt += r.fin ? 1 : 0;
+    r.fin = 0; r.end = 0;
+    rows[b] = r;
+}
+int launch_restart_rows(RowState* rows, int B, hipStream_t s) {
+    hipLaunchKernelGGL(restart_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, rows, B);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Finished-row compaction (ctts_gpt_compact): per-row decode state of the kept rows -> rows 0..n_keep-1.  Two launches (gather into
+// the c* buffers, copy back): a kept row's new place can be another kept row's old one.  The second one also re-derives the step
+// state that depends on the batch: rows in the batch, how many of them have already finished, all-finished flag.
+__global__ __launch_bounds__(256) void compact_gather_kernel(const int* keep, int H, const float* x, const float* rope_rows, const RowMeta* meta, const int* ring,
+                                                           const RowState* fin, float* cx, float* crope, RowMeta* cmeta, int* cring, RowState* cfin) {
+    const int r = blockIdx.x, src = keep[r], tid = threadIdx.x;
+    for (int k = tid; k < H; k += 256) cx[(size_t)r * H + k] = x[(size_t)src * H + k];
+    if (tid < 64) { crope[r * 64 + tid] = rope_rows[src * 64 + tid]; cring[r * 64 + tid] = ring[src * 64 + tid]; }
+    if (tid == 0) { cmeta[r] = meta[src]; cfin[r] = fin[src]; }
+}
+__global__ __launch_bounds__(256) void compact_scatter_kernel(int n_keep, int H, float* x, float* rope_rows, RowMeta* meta, int* ring, RowState* fin,
+                                                            const float* cx, const float* crope, const RowMeta* cmeta, const int* cring, const RowState* cfin, DevState* st) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < H; k += 256) x[(size_t)r * H + k] = cx[(size_t)r * H + k];
+    if (tid < 64) { rope_rows[r * 64 + tid] = crope[r * 64 + tid]; ring[r * 64 + tid] = cring[r * 64 + tid]; }
+    if (tid == 0) { meta[r] = cmeta[r]; fin[r] = cfin[r]; }
+    if (r == 0 && tid == 0) {
+        int nfin = 0;
+        for (int i = 0; i < n_keep; ++i) nfin += cfin[i].fin ? 1 : 0;
+        st->ticket = nfin << 16;                      // sampler: arrivals (low half) | finished rows of the batch (high half)
+        st->B = n_keep;
+        if (nfin == n_keep) st->all_done = 1;
+    }
+}
+int launch_compact_rows(const int* keep, int n_keep, int H, float* x, float* rope_rows, RowMeta* meta, int* ring, RowState* fin,
+                        float* cx, float* crope, RowMeta* cmeta, int* cring, RowState* cfin, DevState* st, hipStream_t s) {
+    hipLaunchKernelGGL(compact_gather_kernel, dim3(n_keep), dim3(256), 0, s, keep, H, (const float*)x, (const float*)rope_rows, (const RowMeta*)meta, (const int*)ring,
+                       (const RowState*)fin, cx, crope, cmeta, cring, cfin);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(n_keep), dim3(256), 0, s, n_keep, H, x, rope_rows, meta, ring, fin, (const float*)cx, (const float*)crope,
+                       (const RowMeta*)cmeta, (const int*)cring, (const RowState*)cfin, st);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 // rows (b, T-1) of the prompt that live in the pass [r0, r0 + n) -> dst[b]: the row indices are computed on the device, so the
 // prompt pass needs no host-side index table (and no stream synchronisation between passes)

@@ -97,9 +97,26 @@ def sampler_cfg_from_objects(temperature, eos_token, max_new_token, min_new_toke
     return sc
 
 
+def compact_size(n_live: int) -> int:
+    """Decode-batch size used for `n_live` unfinished sequences (finished-row compaction, ctts_gpt_compact): every size up to 8, then
+    multiples of 4 up to 32, of 8 up to 64, of 16 beyond -- a captured decode graph exists per batch size, so the sizes are quantised;
+    the padding rows are finished sequences left in the batch."""
+    n = max(int(n_live), 1)
+    if n <= 8:
+        return n
+    q = 4 if n <= 32 else (8 if n <= 64 else 16)
+    return (n + q - 1) // q * q
+
+
+class _BusyToken:
+    """One generate() at a time per KV cache: shared by every engine bound to the same KV tensor (LoRA-merged siblings, with_lora)."""
+    def __init__(self):
+        self.owner = None
+
+
 class GPT:
     """See module docstring.  Extra kwargs (ride in the YAML `kwargs`):
-    max_batch (<=128), max_seq_len, weight_dtype "fp16" | "fp32", chunk_steps."""
+    max_batch (<=128), max_seq_len, weight_dtype "fp32" (default, parity) | "fp16" (fast), chunk_steps."""
 
     Context = Context
     GenerationOutputs = GenerationOutputs
@@ -114,7 +131,7 @@ class GPT:
         self.emb_code = [_EmbShim(num_audio_tokens) for _ in range(num_vq)]
         self.max_batch = int(kwargs.get("max_batch", 4))
         self.max_seq = int(kwargs.get("max_seq_len", 4096))
-        wd = kwargs.get("weight_dtype", "fp16")
+        wd = kwargs.get("weight_dtype", "fp32")        # parity mode by default; "fp16" = fast mode (Modes)
         self.dtype_code = {"fp16": _lib.DTYPE_F16, "float16": _lib.DTYPE_F16, "fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32}[str(wd)]
         self.chunk_steps = int(kwargs.get("chunk_steps", 32))
         self.use_graph = bool(kwargs.get("use_graph", True))
@@ -132,7 +149,9 @@ class GPT:
             _lib.check(self._lib.ctts_gpt_create(C.byref(cfg), C.byref(self._h)), "ctts_gpt_create")
         self._finalized = False
         self._kv = None
+        self._busy_token = _BusyToken()
         self._lora = []
+        self.compact = bool(kwargs.get("compact", True))      # finished-row compaction at chunk boundaries (batches of >= 8 sequences)
         self.model_path = kwargs.get("model_path", None)
         if self.model_path:
             self.from_pretrained(self.model_path)
@@ -144,9 +163,17 @@ class GPT:
     def to(self, device=None, dtype=None):
         return self
 
-    def close(self):
+    @property
+    def busy(self) -> bool:
+        """A generate() generator is live on this engine or on one that shares its KV cache."""
+        return getattr(self, "_busy_token", None) is not None and self._busy_token.owner is not None
+
+    def close(self, _force: bool = False):
         """Destroys the engine handle (packed weights, workspaces, graphs) now instead of at garbage collection; the KV
-        tensor is released with the last engine that shares it."""
+        tensor is released with the last engine that shares it.  Refused while a generate() generator of THIS engine is live (its
+        native handle is in use): exhaust or close the generator first."""
+        if not _force and getattr(self, "_busy_token", None) is not None and self._busy_token.owner is self:
+            raise _lib.HipBackendError("GPT.close(): a generate() generator is still live on this engine; exhaust or close it first")
         if getattr(self, "_h", None) and self._h.value:
             self._lib.ctts_gpt_destroy(self._h)
             self._h = C.c_void_p()
@@ -155,7 +182,7 @@ class GPT:
 
     def __del__(self):
         try:
-            self.close()
+            self.close(_force=True)
         except Exception:
             pass
 
@@ -166,11 +193,33 @@ class GPT:
         """peft merge rule W += scale * B @ A (pipeline:420-432) applied before finalize."""
         self._lora.append((layer, target, np.ascontiguousarray(A, dtype=np.float32), np.ascontiguousarray(B, dtype=np.float32), float(scale)))
 
-    def load_state_dict(self, sd, strict: bool = True, _share_kv: Optional[torch.Tensor] = None):
+    @staticmethod
+    def _known_key(k: str, layers: int, num_vq: int) -> bool:
+        """The 196 keys of the reference's GPT state dict; the engine's ctts_gpt_set_weight is strict about them."""
+        import re
+        m = re.fullmatch(r"gpt\.layers\.(\d+)\.(self_attn\.[qkvo]_proj|mlp\.(gate|up|down)_proj|input_layernorm|post_attention_layernorm)\.weight", k)
+        if m:
+            return int(m.group(1)) < layers
+        if k in ("gpt.norm.weight", "emb_text.weight", "head_text.parametrizations.weight.original0", "head_text.parametrizations.weight.original1"):
+            return True
+        m = re.fullmatch(r"emb_code\.(\d+)\.weight", k) or re.fullmatch(r"head_code\.(\d+)\.parametrizations\.weight\.original[01]", k)
+        return bool(m) and int(m.group(1)) < num_vq
+
+    def load_state_dict(self, sd, strict: bool = True, _share_kv: Optional[torch.Tensor] = None, _busy_token=None):
+        """strict=True (default, like the reference's load_state_dict, gpt.py:84-85): an unexpected key is an error.  strict=False: keys the
+        engine does not know (e.g. `...rotary_emb.inv_freq` buffers of older transformers exports) are skipped and returned in
+        `self.unexpected_keys`; missing keys are an error either way (the engine cannot run without them)."""
         if self._finalized:
             raise _lib.HipBackendError("weights already loaded")
         keep = []
+        self.unexpected_keys = [k for k in sd if not self._known_key(k, int(self.gpt_config["num_hidden_layers"]), self.num_vq)]
+        if self.unexpected_keys and strict:
+            raise _lib.HipBackendError(f"load_state_dict(strict=True): unexpected key(s) {self.unexpected_keys[:4]}{' ...' if len(self.unexpected_keys) > 4 else ''}")
+        if _busy_token is not None:
+            self._busy_token = _busy_token
         for k, v in sd.items():
+            if k in self.unexpected_keys:
+                continue
             a = v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, dtype=np.float32)
             a = np.ascontiguousarray(a)
             keep.append(a)
@@ -191,7 +240,7 @@ class GPT:
                           num_vq=self.num_vq, max_batch=self.max_batch, max_seq_len=self.max_seq,
                           weight_dtype="fp16" if self.dtype_code == _lib.DTYPE_F16 else "fp32", chunk_steps=self.chunk_steps,
                           use_graph=self.use_graph, device=str(self.device))
-        self._sd_host = {k: v for k, v in sd.items()}        # kept for LoRA-merged siblings (pipeline:420-432)
+        self._sd_host = {k: v for k, v in sd.items() if k not in self.unexpected_keys}        # kept for LoRA-merged siblings (pipeline:420-432)
         return self
 
     def with_lora(self, adapters) -> "GPT":
@@ -200,7 +249,7 @@ class GPT:
         g = GPT(**self._ctor)
         for (layer, target, A, B, scale) in adapters:
             g.add_lora(layer, target, A, B, scale)
-        g.load_state_dict(self._sd_host, _share_kv=self._kv)
+        g.load_state_dict(self._sd_host, _share_kv=self._kv, _busy_token=self._busy_token)     # one KV cache -> one busy token
         return g
 
     # -- per-utterance LoRA: adapters resident beside the packed weights, one slot (or none) per sequence -------------
@@ -260,31 +309,37 @@ class GPT:
                  eos_token: Union[int, torch.Tensor], attention_mask: Optional[torch.Tensor] = None, max_new_token=2048,
                  min_new_token=0, logits_warpers=[], logits_processors=[], infer_text=False, return_attn=False,
                  return_hidden=False, stream=False, show_tqdm=True, ensure_non_empty=True, stream_batch=24,
-                 context=None, noise="auto", seed: Optional[int] = None, max_restarts: int = 64):
+                 context=None, noise="auto", seed: Optional[int] = None, max_restarts: int = 64, utt_ids=None, max_new_tokens_per_row=None):
         """`noise`: "torch" draws q = empty(B*4,V).exponential_() per step from torch's CPU generator -- the very numbers
         torch.multinomial consumes in the reference, so TorchSeedContext(seed) reproduces the CPU path's tokens (costs
         ~21 ns of host time per element: hidden behind the GPU up to batch ~8, 3x the step time at batch 32); "device"
         uses the on-device Philox generator keyed by `seed` (None: one draw from torch's CPU generator, so manual_seed
         still makes the call reproducible); "auto" (default) = "torch" for the batches the reference itself can run
         (<= 4 sequences, pipeline:391-397) as long as a step draws at most 16k numbers (code mode), "device" otherwise
-        (larger batches, the 21178-wide refine-text pass); or an array [n_draws, B*4, V]."""
+        (larger batches, the 21178-wide refine-text pass); or an array [n_draws, B*4, V].
+        `utt_ids` (device noise): one global utterance id per sequence (default 0..B-1) -- the device noise stream of a sequence is keyed by
+        (seed, its utterance id, codebook, its own step and regenerate attempt), not by its batch row, so an utterance samples the same
+        noise in whatever slice / batch position / rank it is served.  `max_new_tokens_per_row`: per-sequence token limits (<= max_new_token)."""
         if return_attn:
             raise _lib.HipBackendError("return_attn=True is unsupported (the reference's eager attention path is broken, SURVEY F2)")
         if not self._finalized:
             raise _lib.HipBackendError("weights not loaded")
-        if getattr(self, "_busy", False):
-            # engine state (batch, step counters, noise staging ring, KV cache) belongs to ONE generate() at a time
-            raise _lib.HipBackendError("GPT.generate is already running on this engine: exhaust or close the previous generator first")
-        self._busy = True
+        if self._busy_token.owner is not None:
+            # engine state (batch, step counters, noise staging ring) and the KV cache -- shared with LoRA-merged sibling engines -- belong
+            # to ONE generate() at a time
+            raise _lib.HipBackendError("GPT.generate is already running on this engine (or on an engine sharing its KV cache): exhaust or close "
+                                       "the previous generator first")
+        self._busy_token.owner = self
         try:
             yield from self._generate(emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token, logits_warpers,
                                       logits_processors, infer_text, return_hidden, stream, ensure_non_empty, stream_batch, context, noise, seed,
-                                      max_restarts)
+                                      max_restarts, utt_ids, max_new_tokens_per_row)
         finally:
-            self._busy = False
+            self._busy_token.owner = None
 
     def _generate(self, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token, logits_warpers, logits_processors,
-                  infer_text, return_hidden, stream, ensure_non_empty, stream_batch, context, noise, seed, max_restarts):
+                  infer_text, return_hidden, stream, ensure_non_empty, stream_batch, context, noise, seed, max_restarts, utt_ids=None,
+                  row_limits=None):
         context = context or Context()
         lib, h = self._lib, self._h
         B, T = int(inputs_ids.shape[0]), int(inputs_ids.shape[1])
@@ -302,8 +357,10 @@ class GPT:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (isinstance(noise, str) and noise == "device") else 0
         mask = torch.ones(B, T, dtype=torch.int32, device=dev) if attention_mask is None else attention_mask.to(dev).to(torch.int32).contiguous()
         emb = emb.to(dev, dtype=torch.float32).contiguous()
-        ids = torch.zeros(B, max_new_token, NVQ, dtype=torch.int32, device=dev)
-        hid = torch.zeros(B, max_new_token, H, dtype=torch.float32, device=dev) if return_hidden else None
+        # uninitialised: only [b, :end_idx[b]] is ever read, and every one of those rows was written by the step that produced it (the
+        # default max_new_token = 2048 made this a 201 MB zero-fill per call at batch 32)
+        ids = torch.empty(B, max_new_token, NVQ, dtype=torch.int32, device=dev)
+        hid = torch.empty(B, max_new_token, H, dtype=torch.float32, device=dev) if return_hidden else None
         finish = torch.zeros(B, dtype=torch.int32, device=dev)
         end_idx = torch.zeros(B, dtype=torch.int32, device=dev)
         n_draws = max_new_token + max_restarts
@@ -318,9 +375,17 @@ class GPT:
             host_q = torch.as_tensor(noise, dtype=torch.float32)
             n_draws = int(host_q.shape[0])
             qbuf = host_q.to(dev).contiguous()
+        uid_arr = lim_arr = None
+        if utt_ids is not None:
+            uid_arr = np.ascontiguousarray([int(u) for u in utt_ids], dtype=np.uint64)
+            assert uid_arr.size == B, "utt_ids: one id per sequence"
+        if row_limits is not None:
+            lim_arr = np.ascontiguousarray([int(u) for u in row_limits], dtype=np.int32)
+            assert lim_arr.size == B, "max_new_tokens_per_row: one limit per sequence"
         io = _lib.GenIO(ids=ids.data_ptr(), hiddens=hid.data_ptr() if hid is not None else None, finish=finish.data_ptr(),
                         end_idx=end_idx.data_ptr(), noise=qbuf.data_ptr() if qbuf is not None else None, n_draws=n_draws,
-                        seed=int(seed))
+                        seed=int(seed), utt_ids=uid_arr.ctypes.data if uid_arr is not None else None,
+                        row_limits=lim_arr.ctypes.data if lim_arr is not None else None)
         drawn = 0
         stage_cap = max(int(self.chunk_steps), int(stream_batch) if stream else 1, 1)
         stage = self._staging(B * rows_per_seq, V, stage_cap) if (isinstance(noise, str) and noise == "torch") else None
@@ -405,6 +470,15 @@ class GPT:
                 evs = [torch.cuda.Event() for _ in range(2)]
                 restarts = used_draws - steps.value            # draws spent on ensure_non_empty regenerations
                 launched, n_chunks, pending = steps.value, 0, []
+                # finished-row compaction (no counterpart in the reference, where finished rows keep computing until the slowest one ends,
+                # gpt.py:527-546): the per-row finish flags travel with the progress words; rows known to have finished are dropped from
+                # the decode batch at the next chunk boundary (ctts_gpt_compact), down to the next size of compact_size()
+                compacting = self.compact and (not infer_text) and B >= 8
+                rowpins = [torch.zeros(2 * B, dtype=torch.int32).pin_memory() for _ in range(2)] if compacting else None
+                row_seq = list(range(B))                       # current decode row -> sequence
+                layouts = [None, None]
+                done_seq = set()
+                self.compactions = []
                 while True:
                     while len(pending) < 2 and launched < max_new_token and not context.get():
                         n = min(chunk, max_new_token - launched)
@@ -417,6 +491,9 @@ class GPT:
                         slot = n_chunks % 2
                         n_chunks += 1
                         _lib.check(lib.ctts_gpt_progress_enqueue(h, pins[slot].data_ptr(), st), "progress_enqueue")
+                        if compacting:
+                            _lib.check(lib.ctts_gpt_rows_enqueue(h, rowpins[slot].data_ptr(), st), "rows_enqueue")
+                            layouts[slot] = list(row_seq)
                         evs[slot].record(torch.cuda.current_stream(dev))
                         pending.append(slot)
                     if not pending:
@@ -427,6 +504,17 @@ class GPT:
                     tick("event_wait")
                     if int(pins[slot][2]) or int(pins[slot][0]) >= max_new_token or context.get():
                         break
+                    if compacting:
+                        flags = rowpins[slot][:2 * len(layouts[slot])].view(-1, 2)[:, 0].tolist()
+                        done_seq.update(sq for sq, f in zip(layouts[slot], flags) if f)
+                        live = [r for r, sq in enumerate(row_seq) if sq not in done_seq]
+                        target = compact_size(len(live))
+                        if live and target < len(row_seq):
+                            fill = [r for r, sq in enumerate(row_seq) if sq in done_seq][:target - len(live)]
+                            keep = np.ascontiguousarray(sorted(live + fill), dtype=np.int32)
+                            _lib.check(lib.ctts_gpt_compact(h, keep.ctypes.data_as(C.c_void_p), int(keep.size), st), "compact")
+                            row_seq = [row_seq[r] for r in keep.tolist()]
+                            self.compactions.append((launched, len(row_seq)))
                 prev = steps.value
                 _lib.check(lib.ctts_gpt_progress(h, C.byref(steps), C.byref(alld), st), "progress")
                 used_draws += steps.value - prev

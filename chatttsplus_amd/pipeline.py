@@ -267,8 +267,9 @@ class ChatTTSPlusPipeline:
 
     # -- hot path callers --------------------------------------------------------------------------
     @torch.no_grad()
-    def _infer_code(self, text, stream: bool, return_hidden: bool, params: InferCodeParams, gpt=None):
-        """pipeline:157-235 -- same argument plumbing; the GPT object is the hip backend."""
+    def _infer_code(self, text, stream: bool, return_hidden: bool, params: InferCodeParams, gpt=None, **gen_kwargs):
+        """pipeline:157-235 -- same argument plumbing; the GPT object is the hip backend.  `gen_kwargs` (noise, seed, utt_ids) ride through to
+        GPT.generate: the device noise stream of an utterance is keyed by the request seed and its global utterance id."""
         gpt = gpt or self.models_dict["gpt"]
         tok = self.models_dict["tokenizer"]
         if not isinstance(text, list):
@@ -289,7 +290,7 @@ class ChatTTSPlusPipeline:
         return gpt.generate(emb, input_ids, temperature=torch.tensor(temperature), eos_token=num_code, attention_mask=attention_mask,
                             max_new_token=params.max_new_token, min_new_token=params.min_new_token, logits_warpers=warpers,
                             logits_processors=processors, infer_text=False, return_hidden=return_hidden, stream=stream,
-                            show_tqdm=params.show_tqdm, ensure_non_empty=params.ensure_non_empty, stream_batch=params.stream_batch)
+                            show_tqdm=params.show_tqdm, ensure_non_empty=params.ensure_non_empty, stream_batch=params.stream_batch, **gen_kwargs)
 
     @torch.no_grad()
     def _refine_text(self, text, params: RefineTextParams):
@@ -353,6 +354,12 @@ class ChatTTSPlusPipeline:
             self._lora_models.move_to_end(lora_path)
             return self._lora_models[lora_path]
         while len(self._lora_models) >= self._lora_cache:
+            victim = next(iter(self._lora_models))
+            if self._lora_models[victim].busy:
+                # a partially consumed infer(stream=True) generator still owns the KV cache its siblings share and, possibly, this
+                # engine's native handle: destroying it now would be a use-after-free when that generator resumes
+                raise _lib.HipBackendError(f"cannot load adapter {lora_path!r}: a generator of an earlier infer() call is still live "
+                                           f"(adapter {victim!r} would have to be evicted); exhaust or close it first")
             _, old = self._lora_models.popitem(last=False)
             old.close()
         base = self.models_dict["gpt"]
@@ -382,6 +389,16 @@ class ChatTTSPlusPipeline:
             if len(lora_paths) != len(text_in):
                 raise _lib.HipBackendError(f"lora_paths: {len(lora_paths)} entries for {len(text_in)} utterances (after text splitting)")
         tok = self.models_dict["tokenizer"]
+        # Device noise is keyed by (request seed, global utterance id): every slice of the request uses the SAME seed and each utterance its
+        # own id, so the result does not depend on slice_size or on which rank serves the utterance (infer_sharded).  `noise="auto"` keeps the
+        # reference-compatible torch-generator noise for slices of <= 4 utterances.
+        noise_mode = kwargs.get("noise", "auto")
+        utt_ids = kwargs.get("utt_ids")
+        if utt_ids is None:
+            utt_ids = list(range(len(text_in)))
+        elif len(utt_ids) != len(text_in):
+            raise _lib.HipBackendError(f"utt_ids: {len(utt_ids)} entries for {len(text_in)} utterances (after text splitting)")
+        noise_seed = kwargs.get("noise_seed")      # None: drawn from torch's CPU generator when the first slice that uses device noise starts
         for ii in range(0, len(text_in), slice_size):
             text = list(text_in[ii:ii + slice_size])
             if not skip_refine_text:                                                   # pipeline:399-411
@@ -396,29 +413,33 @@ class ChatTTSPlusPipeline:
             length, pass_batch_count, last = 0, 0, None
             if lora_paths is not None:
                 gpt.set_row_adapters(self._adapter_slots(gpt, lora_paths[ii:ii + slice_size]))
+            gen_kw = {}
+            if noise_mode != "auto" or len(text) > 4:      # device (or caller-chosen) noise; slices of <= 4 keep the reference-compatible default
+                if noise_seed is None and (noise_mode in ("auto", "device")):
+                    noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # ONE draw per request (torch.manual_seed reproduces it)
+                gen_kw = dict(noise=("device" if noise_mode == "auto" else noise_mode), seed=noise_seed, utt_ids=utt_ids[ii:ii + slice_size])
+            results = self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt, **gen_kw)
             try:
-                results = list(self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt)) if lora_paths is not None else \
-                    self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt)
+                for result in results:
+                    if not stream:
+                        yield self._decode_to_wavs(result.hiddens, use_decoder)
+                        continue
+                    # The reference's stream branch vocodes the whole prefix for every chunk and indexes a python list with
+                    # .shape.  Here every yield is the [length, b) sample window of that same prefix waveform,
+                    # vocoded from the tokens inside the window's receptive field only (Synth.decode_window), zero padded
+                    # like pad_sequence would pad the shorter utterances.
+                    last = result.hiddens
+                    pass_batch_count += 1
+                    if pass_batch_count <= params_infer_code.pass_first_n_batches:
+                        continue
+                    total = max((256 * (2 * int(h.shape[0]) - 1) if h.shape[0] > 0 else 0) for h in last)
+                    b = min(length + params_infer_code.stream_speed, total)
+                    if b > length:
+                        yield self._window(last, length, b)
+                        length = b
             finally:
-                if lora_paths is not None:
-                    gpt.set_row_adapters(None)
-            for result in results:
-                if not stream:
-                    yield self._decode_to_wavs(result.hiddens, use_decoder)
-                    continue
-                # The reference's stream branch vocodes the whole prefix for every chunk and indexes a python list with
-                # .shape.  Here every yield is the [length, b) sample window of that same prefix waveform,
-                # vocoded from the tokens inside the window's receptive field only (Synth.decode_window), zero padded
-                # like pad_sequence would pad the shorter utterances.
-                last = result.hiddens
-                pass_batch_count += 1
-                if pass_batch_count <= params_infer_code.pass_first_n_batches:
-                    continue
-                total = max((256 * (2 * int(h.shape[0]) - 1) if h.shape[0] > 0 else 0) for h in last)
-                b = min(length + params_infer_code.stream_speed, total)
-                if b > length:
-                    yield self._window(last, length, b)
-                    length = b
+                if lora_paths is not None:          # the generator stays lazy (streaming works with per-utterance adapters); the row table is
+                    gpt.set_row_adapters(None)      # reset when the slice is exhausted, closed or fails
             if stream and last is not None:
                 total = max((256 * (2 * int(h.shape[0]) - 1) if h.shape[0] > 0 else 0) for h in last)
                 if total > length:
@@ -482,7 +503,10 @@ class ChatTTSPlusPipeline:
         params = dataclasses.replace(params_infer_code)
         n_spk, dim = 1, self.models_dict["gpt"].model_dim
         if speaker_table is not None or speaker_index is not None:
-            assert speaker_index is not None and len(speaker_index) == len(texts), "speaker_index: one entry per utterance"
+            if speaker_index is None or len(speaker_index) != len(texts):
+                raise _lib.HipBackendError("infer_sharded: speaker_index needs one entry per utterance")
+            if speaker_table is None and (not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0):
+                raise _lib.HipBackendError("infer_sharded: speaker_index given without speaker_table (rank 0 holds the table that is broadcast)")
             n_spk = int(max(speaker_index)) + 1
             if speaker_table is not None:
                 speaker_table = torch.as_tensor(speaker_table, dtype=torch.float32).reshape(-1, dim)
@@ -495,6 +519,10 @@ class ChatTTSPlusPipeline:
             else:
                 speaker_table = codec.speaker_to_vector(params.spk_emb).view(1, dim) if isinstance(params.spk_emb, str) else torch.as_tensor(params.spk_emb, dtype=torch.float32).view(1, dim)
         slice_size = int(kwargs.pop("slice_size", self.models_dict["gpt"].max_batch))
+        # the request's noise seed: the same on every rank (every rank is called with the same arguments, like `texts`); each utterance's
+        # device noise stream is keyed by (seed, its global index), so N ranks produce what one rank would
+        noise_seed = int(kwargs.pop("noise_seed", 0))
+        kwargs.pop("noise", None); kwargs.pop("utt_ids", None)
         wavs_local: List[torch.Tensor] = []
 
         def run_local(indices, rows):
@@ -503,7 +531,7 @@ class ChatTTSPlusPipeline:
                 sl = indices[ii:ii + slice_size]
                 p = dataclasses.replace(params, spk_emb=rows[ii:ii + len(sl)])
                 for wavs in self._infer([texts[i] for i in sl], False, None, skip_refine_text, False, True, True, False, True,
-                                        params_refine_text, p, slice_size=len(sl), **kwargs):
+                                        params_refine_text, p, slice_size=len(sl), utt_ids=list(sl), noise="device", noise_seed=noise_seed, **kwargs):
                     wavs_local.extend(wavs)
                     lens.extend([(int(w.shape[0]) // 256 + 1) // 2 if w.shape[0] else 0 for w in wavs])
             return lens

@@ -78,7 +78,7 @@ def read_number(text: str) -> str:
 
 
 _NUM = r"\d+(?:\.\d+)?"
-_RE_DATE = re.compile(r"(\d{4}|\d{2})年(?:(0?[1-9]|1[0-2])月)?(?:(0?[1-9]|[12]\d|3[01])([日号]))?")
+_RE_DATE = re.compile(r"(?<![\d.])(\d{4}|\d{2})年(?:(0?[1-9]|1[0-2])月)?(?:(0?[1-9]|[12]\d|3[01])([日号]))?")
 _RE_DATE_SEP = re.compile(r"(?<!\d)(\d{4})([-/.])(0?[1-9]|1[0-2])\2(0?[1-9]|[12]\d|3[01])(?!\d)")
 _RE_TIME = re.compile(r"(?<![\d:])([01]?\d|2[0-3]):([0-5]\d)(?::([0-5]\d))?(?![\d:])")
 _RE_TEMP = re.compile(r"(-?)(" + _NUM + r")\s*(°C|℃|度|摄氏度)")
@@ -92,6 +92,8 @@ _RE_NUMBER = re.compile(r"(?<![\d.])-?" + _NUM)
 
 def _date(m: re.Match) -> str:
     year, month, day, suffix = m.groups()
+    # two- and four-digit years are read digit by digit, like the package this stands in for does ("98年" = 九八年; a bare "20年" meaning
+    # "twenty years" is therefore read 二零年 there too); longer numbers never reach this rule (digit lookbehind)
     out = read_digits(year) + "年"
     if month:
         out += read_cardinal(month) + "月"

@@ -117,7 +117,11 @@ typedef struct {
  *   hiddens  fp32  [B][max_new_token][hidden] (gpt.py:422-423, post final norm)
  *   finish   int32 [B], end_idx int32 [B]    (gpt.py:339-342,486-487,530-531)
  * noise: fp32 [n_draws][B*4][vocab_code] Exp(1) draws consumed one per sample step (argmax(p/q) ==
- * torch.multinomial), or NULL for the on-device Philox generator seeded with `seed`. */
+ * torch.multinomial), or NULL for the on-device Philox generator seeded with `seed`.
+ * utt_ids (device noise only): HOST array [B] of caller-chosen global utterance ids, or NULL for 0..B-1.  The Philox stream of a
+ * sequence is keyed by (seed, its utterance id, codebook, its own step, its own regenerate attempt) -- not by its row in the batch and
+ * not by the batch's draw counter -- so a request gives every utterance the same noise whatever slice, batch position or rank it is
+ * served in (the reference's independence argument for slices: pipeline:391-397). */
 typedef struct {
     int32_t* ids;
     float* hiddens;
@@ -126,6 +130,9 @@ typedef struct {
     const float* noise;
     int32_t n_draws;
     uint64_t seed;
+    const uint64_t* utt_ids;
+    const int32_t* row_limits;      /* HOST array [B] or NULL: per-utterance token limit (<= max_new_token): the sequence counts as finished once it
+                                       has produced that many tokens -- the per-row form of the loop bound gpt.py:389 */
 } ctts_gen_io;
 
 /* GPT.forward / get_emb (gpt.py:125-149) fused with Tokenizer.apply_spk_emb (tokenizer.py:150-178):
@@ -167,6 +174,15 @@ int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* stream);
 /* Host-visible progress: number of sample steps executed and whether every row has finished.
  * Synchronises the stream. */
 int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_finished, void* stream);
+
+/* Finished-row compaction (no counterpart in the reference, whose finished rows keep computing until the slowest sequence ends,
+ * gpt.py:527-546): between two ctts_gpt_decode calls the caller may drop rows of the decode batch.
+ *   rows_enqueue  copies {finish, end_idx} of the CURRENT rows (2 int32 each, row order) into pinned host memory, asynchronously
+ *   compact       keep_rows = HOST array of n_keep current row indices, ascending; the engine re-packs its per-row state (residual
+ *                 rows, positions, repetition-penalty windows, noise keys) so that they become rows 0..n_keep-1 and continues with a
+ *                 batch of n_keep.  The KV cache and the output arrays are indexed by utterance and do not move.  Code mode only. */
+int ctts_gpt_rows_enqueue(ctts_gpt* h, int32_t* host_pinned_2B, void* stream);
+int ctts_gpt_compact(ctts_gpt* h, const int32_t* keep_rows, int n_keep, void* stream);
 
 /* Non-blocking variant: enqueues a copy of {steps_done, draws, all_finished, -} into 4 int32 of PINNED host memory; the
  * caller records an event after it and reads the words once the event has completed -- lets the host keep one chunk of

@@ -93,6 +93,9 @@ class _FakeGPT:
         B = emb.shape[0]
         self.calls.append(B)
         assert B <= self.max_batch
+        # what keys each utterance's device noise stream: (noise mode, request seed, global utterance id) -- recorded per utterance
+        assert kw.get("noise") == "device" and len(kw["utt_ids"]) == B
+        self.noise_keys = getattr(self, "noise_keys", []) + [(int(kw["seed"]), int(u)) for u in kw["utt_ids"]]
         n = [int(emb[b, 0, 0].item()) + int(emb[b, 0, 1].item()) for b in range(B)]
         yield type("O", (), dict(ids=[torch.zeros(k, 4, dtype=torch.long) for k in n], attentions=[],
                                  hiddens=[torch.full((k, 768), float(k)) for k in n]))
@@ -144,8 +147,8 @@ def _pipe_worker(rank, world, port, q, tmpdir):
         pipe = _fake_pipeline(tmpdir)
         table = (torch.arange(3, dtype=torch.float32)[:, None] * 3 + 1).expand(3, 8).contiguous() if rank == 0 else None
         mine, wavs, all_lens = pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=table,
-                                                  params_infer_code=InferCodeParams(show_tqdm=False))
-        q.put((rank, mine, [int(w.shape[0]) for w in wavs], all_lens, pipe.models_dict["gpt"].calls))
+                                                  params_infer_code=InferCodeParams(show_tqdm=False), noise_seed=4242)
+        q.put((rank, mine, [int(w.shape[0]) for w in wavs], all_lens, pipe.models_dict["gpt"].calls, pipe.models_dict["gpt"].noise_keys))
     finally:
         dist.destroy_process_group()
 
@@ -164,7 +167,10 @@ def test_pipeline_infer_sharded_world2_gloo(tmp_path):
         assert p.exitcode == 0
     expect = _expected_lengths(_fake_pipeline(str(tmp_path)))
     seen = []
-    for rank, mine, wav_samples, all_lens, calls in res:
+    for rank, mine, wav_samples, all_lens, calls, noise_keys in res:
+        # partition invariance of the sampling noise: utterance i is keyed by (request seed, i) on whatever rank / slice serves it --
+        # exactly the keys a single rank uses (test_pipeline_infer_sharded_single_process)
+        assert noise_keys == [(4242, i) for i in mine], (rank, noise_keys, mine)
         assert all_lens == expect, (rank, all_lens, expect)                       # every rank sees every utterance's length
         assert wav_samples == [256 * (2 * expect[i] - 1) for i in mine]           # local waveforms, in the order of `mine`
         assert sum(calls) == len(mine) and max(calls) <= 3                        # sliced at max_batch
@@ -177,6 +183,10 @@ def test_pipeline_infer_sharded_single_process(tmp_path):
     from chatttsplus_amd.pipeline import InferCodeParams
     pipe = _fake_pipeline(str(tmp_path))
     table = (torch.arange(3, dtype=torch.float32)[:, None] * 3 + 1).expand(3, 8).contiguous()
-    mine, wavs, all_lens = pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=table, params_infer_code=InferCodeParams(show_tqdm=False))
+    mine, wavs, all_lens = pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=table, params_infer_code=InferCodeParams(show_tqdm=False),
+                                              noise_seed=4242)
     assert mine == list(range(len(TEXTS))) and all_lens == _expected_lengths(pipe)
+    assert pipe.models_dict["gpt"].noise_keys == [(4242, i) for i in range(len(TEXTS))]          # same keys as the 2-rank run gives each utterance
+    with pytest.raises(Exception, match="speaker_table"):                                          # index without a table: a clear error, not an AttributeError
+        pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=None)
     assert [int(w.shape[0]) for w in wavs] == [256 * (2 * n - 1) for n in all_lens]

@@ -29,7 +29,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_lib.GptCfg) == 9 * 4
     assert C.sizeof(_lib.SamplerCfg) == 4 * 4 + 4 + 3 * 4 + 17 * 4 + 6 * 4
     assert C.sizeof(_lib.VocCfg) == 12 * 4
-    assert C.sizeof(_lib.GenIO) == 5 * 8 + 8 + 8          # 5 pointers, int32 (+pad), uint64
+    assert C.sizeof(_lib.GenIO) == 5 * 8 + 8 + 8 + 2 * 8  # 5 pointers, int32 (+pad), uint64, 2 pointers
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

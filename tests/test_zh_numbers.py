@@ -56,3 +56,13 @@ def test_split_text_uses_the_reader_when_zh_normalization_is_absent():
     assert out == ["价格一百元，涨了百分之五", "I have Two cats"]
     # what reaches the tokenizer keeps its numbers (the Normalizer would have dropped the digits)
     assert tf.Normalizer()(out[0]) == "价格一百元，涨了百分之五"
+
+
+def test_year_like_durations_and_longer_numbers():
+    """without a digit lookbehind "100年" was read as "1" + "零零年".  Two-digit years stay digit-wise (zh_normalization's own rule)."""
+    from chatttsplus_amd.zh_numbers import read_numbers_zh
+    assert read_numbers_zh("100年") == "一百年"
+    assert read_numbers_zh("过了20年") == "过了二零年"
+    assert read_numbers_zh("98年3月") == "九八年三月"
+    assert read_numbers_zh("2024年") == "二零二四年"
+    assert read_numbers_zh("12345年") == "一万二千三百四十五年"
