@@ -199,6 +199,53 @@ class Leg:
                     per_rank_s=[float(p.item()) for p in per], step_bytes=g.step_bytes(B, mean_ctx))
 
 
+def ragged_leg(g, dev, spk, rank, B=32, seed=2024):
+    """SURVEY 8d C3 as written: batch 32, prompt lengths P_b ~ U{16..96} (left padded), TARGET lengths n_b ~ U{128..512} enforced per row
+    (ctts_gen_io.row_limits: the row counts as finished after n_b tokens, like a sampled EOS).  Host-inclusive wall clock of GPT.generate
+    (prompt pass + decode loop), device noise.  `useful` tokens/s = sum(n_b) / wall -- what a caller gets; `padded` = B * max(n_b) / wall --
+    what the kernels compute when finished rows stay in the batch (the reference's semantics, gpt.py:527-546).  Measured with finished-row
+    compaction off and on (rows dropped from the decode batch at 32-step chunk boundaries, ctts_gpt_compact)."""
+    from chatttsplus_amd import synth
+    cfg = synth.GPT_REAL
+    rng = np.random.Generator(np.random.Philox(key=seed + rank))
+    plen = rng.integers(16, 97, size=B); plen[0] = 96
+    nb = rng.integers(128, 513, size=B); nb[1] = 512
+    P, N = 96, 512
+    pad = [int(P - p) for p in plen]
+    ids, mask = synth.prompt_ids(B, P, cfg["num_text_tokens"], 1234 + rank, pad_left=pad)
+    spk_id = 21143
+    for b in range(B):
+        ids[b, pad[b] + 1, :] = spk_id
+    ids_t = torch.from_numpy(ids).to(dev)
+    rows = spk[torch.arange(B, device=spk.device) % spk.shape[0]]
+    emb = g(ids_t, torch.ones(B, P, dtype=torch.bool, device=dev), spk_emb=rows, spk_emb_ids=spk_id)
+    lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+    lp = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+    res = {}
+    keep = g.compact
+    try:
+        for mode in ("off", "on"):
+            g.compact = (mode == "on")
+            for rep in range(2):                                   # rep 0 captures the decode graphs of the batch sizes the run visits
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                out = list(g.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=N,
+                                      logits_warpers=lw, logits_processors=lp, return_hidden=False, noise="device", seed=7,
+                                      max_new_tokens_per_row=[int(x) for x in nb]))[-1]
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+            lens = [int(i.shape[0]) for i in out.ids]
+            if lens != [int(x) for x in nb]:
+                raise SystemExit(f"ragged leg invalid: generated lengths {lens[:6]}.. != targets {nb[:6].tolist()}..")
+            res[mode] = dict(wall_ms=round(dt * 1e3, 2), useful_tokens_per_s=round(float(nb.sum()) / dt, 1),
+                             padded_tokens_per_s=round(B * float(nb.max()) / dt, 1), batch_sizes=[c[1] for c in getattr(g, "compactions", [])])
+    finally:
+        g.compact = keep
+    return {"batch": B, "prompt_lengths": "U{16..96} left-padded to 96", "target_lengths": "U{128..512}", "useful_tokens": int(nb.sum()),
+            "padded_tokens": int(B * nb.max()), "no_compaction": res["off"], "compaction": res["on"],
+            "useful_speedup": round(res["on"]["useful_tokens_per_s"] / res["off"]["useful_tokens_per_s"], 3)}
+
+
 def summarize(r, world):
     step_ms = r["ev_ms"] / r["K"]
     ach = r["step_bytes"] / (step_ms * 1e-3) / 1e9
@@ -302,6 +349,8 @@ def main():
             e = leg.run(EB, 96, EK, W, pad_left=[int(96 - p) for p in plen], spk=spk, use_graph=use_graph)
             extra["batch32_mixed_prompts"] = summarize(e, world)
             extra["batch32_mixed_prompts"]["prompt_lengths"] = "U{16..96} left-padded to 96"
+            # SURVEY 8d C3 with ragged TARGET lengths: useful vs padded tokens/s, finished-row compaction off / on
+            extra["batch32_ragged_targets"] = ragged_leg(g, dev, spk, rank)
             # north_star: "decode tokens/s on synthetic 512-token prompts", batch 1
             e = leg.run(1, 512, EK, W, spk=spk, use_graph=use_graph)
             extra["prompt512_batch1"] = summarize(e, world)

@@ -53,7 +53,8 @@ class GenIO(C.Structure):
 
 class VocCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dvae_idim", "dvae_hidden", "dvae_bn", "dvae_layers", "n_mels", "vocos_dim",
-                                          "vocos_inter", "vocos_layers", "n_fft", "hop", "max_frames", "max_batch")]
+                                          "vocos_inter", "vocos_layers", "n_fft", "hop", "max_frames", "max_batch",
+                                          "vq_groups", "vq_residuals")] + [("vq_levels", C.c_int32 * 4)]
 
 
 class EncCfg(C.Structure):
@@ -85,6 +86,7 @@ SYMBOLS = [
     ("ctts_gpt_decode", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("ctts_gpt_progress", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     ("ctts_gpt_progress_enqueue", C.c_int, [_P, _P, _P]),
+    ("ctts_gpt_saturations", C.c_int, [_P, C.POINTER(C.c_int32), _P]),
     ("ctts_gpt_rows_enqueue", C.c_int, [_P, _P, _P]),
     ("ctts_gpt_compact", C.c_int, [_P, _P, C.c_int, _P]),
     ("ctts_gpt_logits", C.c_int, [_P, _P, _P]),
@@ -99,6 +101,8 @@ SYMBOLS = [
     ("ctts_dvae_decode", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("ctts_vocos_decode", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("ctts_synth_batch", C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
+    ("ctts_dvae_decode_codes", C.c_int, [_P, _P, C.c_int, _P, _P]),
+    ("ctts_synth_batch_codes", C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
     ("ctts_enc_create", C.c_int, [C.POINTER(EncCfg), C.POINTER(_P)]),
     ("ctts_enc_destroy", None, [_P]),
     ("ctts_enc_set_weight", C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),

@@ -72,6 +72,19 @@ __host__ __device__ inline size_t xfrag_index(int n, int k, int ktiles) {
     return ((size_t)(g * ktiles + k / KT) * 64 + (n & 15) + 16 * ((k / EPL) & 3)) * EPL + (k % EPL);
 }
 
+// fp16 stores of values the model produces without bound (SwiGLU outputs, K / V projections, the scaled residual copy): SATURATE at the
+// largest finite half and REPORT (a device counter the host reads at the end of generate()), instead of the silent +-inf -> NaN a plain
+// conversion gives -- the reference's own .half() path has that failure mode on checkpoints with outlier channels (pipeline:37-41).
+// A NaN input is reported too (it stays NaN).
+__device__ inline half_t sat_half(float v, int* sat) {
+    const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+    if (!(c == v) && sat != nullptr) atomicAdd(sat, 1);
+    return (half_t)((v != v) ? v : c);
+}
+template <typename WT> __device__ inline WT sat_store(float v, int* sat);
+template <> __device__ inline half_t sat_store<half_t>(float v, int* sat) { return sat_half(v, sat); }
+template <> __device__ inline float sat_store<float>(float v, int*) { return v; }
+
 // ---- wave64 reductions on DPP (no LDS crossbar): 4 intra-row steps (quad xor1, quad xor2, half-mirror, mirror)
 // leave the 16-lane row result in every lane; the 4 rows are combined through v_readlane.  ~10x cheaper than a
 // 6-step ds_bpermute butterfly (the sampler's 20+ dependent arg-max rounds were 30 us with __shfl_xor).

@@ -97,6 +97,7 @@ struct ctts_gpt {
     void* xh = nullptr;                          // fp16 decode, > split_rows rows: residual stream as packed fp16 B operand (EPI_RESID_XH -> PRO_XH)
     float *ssq = nullptr, *scale_o = nullptr, *scale_d = nullptr;   //   per-tile sums of squares [rows][48]; per-row power-of-two scales of the xh rows
     int xh_mode = 1;                             //   0 (diagnostic builds) switches the path off (every block re-normalises fp32 rows: PRO_NORM)
+    int* sat = nullptr;                          // fp16 engines: saturated / NaN fp16 stores since begin (common.h sat_half; ctts_gpt_saturations)
     int* hist_ring = nullptr;                    // sampler: repetition-penalty window ring [max_B][4][16] (sampler.hip)
     RowState* finend = nullptr;                  // sampler: per-row state [max_B] (common.h): mirror of {finish, end_idx}, noise key, token limit
     std::vector<RowState> rows_host;             //   its initial image for the current generate() (uploaded by begin)
@@ -167,7 +168,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
     void* bufs[] = {h->dyn, h->wblob, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
-                    h->hist_ring, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
+                    h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
                     h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
@@ -448,7 +449,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4) ||
         dev_alloc((void**)&h->dyn, sizeof(SamplerDyn)) || dev_alloc((void**)&h->hist_ring, (size_t)CTTS_MAX_B * CTTS_NUM_VQ * 16 * 4) ||
-        dev_alloc((void**)&h->finend, (size_t)CTTS_MAX_B * sizeof(RowState)) ||
+        dev_alloc((void**)&h->finend, (size_t)CTTS_MAX_B * sizeof(RowState)) || dev_alloc((void**)&h->sat, 4) ||
         dev_alloc((void**)&h->cx, (size_t)CTTS_MAX_B * H * 4) || dev_alloc((void**)&h->crope, (size_t)CTTS_MAX_B * 64 * 4) ||
         dev_alloc((void**)&h->cmeta, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->cring, (size_t)CTTS_MAX_B * CTTS_NUM_VQ * 16 * 4) ||
         dev_alloc((void**)&h->cfin, (size_t)CTTS_MAX_B * sizeof(RowState)) || dev_alloc((void**)&h->keep_dev, CTTS_MAX_B * 4) ||
@@ -548,7 +549,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     if (form) { form->parts = splitd; form->xh = xhm; }
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
-        a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq;
+        a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq; a.sat = h->sat;
         // RMSNorm + QKV + RoPE + KV append
         GemmArgs g1 = a;
         g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x;
@@ -698,6 +699,7 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
     d.rows0 = B * (h->text_mode ? 1 : CTTS_NUM_VQ);
     CTTS_HIP_CHECK(hipMemcpyAsync(h->dyn, &d, sizeof(d), hipMemcpyHostToDevice, s));       // pageable source: staged before the call returns
     if (launch_fill_meta(h->meta_pre, h->meta_dec0, h->st, mask, B, T, h->rope, h->rope_pre, s)) return 1;
+    CTTS_HIP_CHECK(hipMemsetAsync(h->sat, 0, 4, s));
     return reset_state(h, false, s);
 }
 
@@ -793,6 +795,14 @@ extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_
 extern "C" int ctts_gpt_progress_enqueue(ctts_gpt* h, int32_t* host_pinned4, void* stream) {
     if (!h || !host_pinned4) { ctts_set_error("progress_enqueue: null argument"); return 1; }
     CTTS_HIP_CHECK(hipMemcpyAsync(host_pinned4, h->st, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int ctts_gpt_saturations(ctts_gpt* h, int32_t* count, void* stream) {
+    if (!h || !count || !h->sat) { ctts_set_error("saturations: bad argument"); return 1; }
+    CTTS_HIP_CHECK(hipMemcpyAsync(h->host_pin + 8, h->sat, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CTTS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    *count = h->host_pin[8];
     return 0;
 }
 

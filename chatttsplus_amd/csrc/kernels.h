@@ -50,6 +50,7 @@ struct GemmArgs {
     float* scale_out;       // [rows] PRO_XH / PRO_NORM (block 0): 2^floor(log2(rs)) of this normalisation = the scale of the NEXT xh rows
     // per-utterance LoRA (lora.hip): low-rank term of every row, added in the epilogue.  EPI_QKV: [rows][3][768]; EPI_RESID*: [rows][768]
     const float* lora_delta;
+    int* sat;               // fp16 engines: counter of saturated / NaN fp16 stores (common.h sat_half); null = do not count
 };
 
 struct AttnArgs {

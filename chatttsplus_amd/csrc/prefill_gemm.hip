@@ -196,8 +196,8 @@ __global__ __launch_bounds__(WR * WN * 64) __attribute__((amdgpu_waves_per_eu(Pf
                 const float g0v = lowh ? va[0] : va[2], g1v = lowh ? va[1] : va[3], u0 = lowh ? vb[0] : vb[2], u1 = lowh ? vb[1] : vb[3];
                 half2_t y = {(half_t)0.f, (half_t)0.f};
                 if (rv) {
-                    y[0] = (half_t)(g0v * __frcp_rn(1.0f + __expf(-g0v)) * u0);
-                    y[1] = (half_t)(g1v * __frcp_rn(1.0f + __expf(-g1v)) * u1);
+                    y[0] = sat_half(g0v * __frcp_rn(1.0f + __expf(-g0v)) * u0, a.sat);
+                    y[1] = sat_half(g1v * __frcp_rn(1.0f + __expf(-g1v)) * u1, a.sat);
                 }
                 *(half2_t*)(scr + (nn + 16 * t) * 16 + cp * 4) = y;        // the fragment image: lane' = row + 16 * octet, 8 halfs each
             }
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(WR * WN * 64) __attribute__((amdgpu_waves_per_eu(Pf
                 } else y = lowh ? va : vb;
                 const int dd = t * 8 + p0 + (lowh ? 0 : 32);                 // first of this lane's 4 head dims
                 if (which == 0) *(f32x4*)(scr + nn * P32 + dd * 4) = y;
-                else *(half4*)(scr + nn * P16 + dd * 2) = (half4){(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+                else *(half4*)(scr + nn * P16 + dd * 2) = (half4){sat_half(y[0], a.sat), sat_half(y[1], a.sat), sat_half(y[2], a.sat), sat_half(y[3], a.sat)};
             }
             if (which == 0) {
 #pragma unroll

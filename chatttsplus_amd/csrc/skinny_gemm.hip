@@ -395,7 +395,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                     sq += dpp_f<DPP_XOR1>(sq); sq += dpp_f<DPP_XOR2>(sq); sq += dpp_f<DPP_HALF_MIRROR>(sq); sq += dpp_f<DPP_MIRROR>(sq);
                     if (i == 0) a.ssq[(size_t)r * a.n_row_tiles + rt] = sq;
                     half_t* dst = (half_t*)a.xh + (size_t)chunk * NBG * 24 * 64 * 8;
-                    dst[xfrag_index<half_t>(n, col, 24)] = (half_t)(xn * xh_scale_pf[u]);
+                    dst[xfrag_index<half_t>(n, col, 24)] = sat_half(xn * xh_scale_pf[u], a.sat);
                 }
             } else if (EPI == EPI_RESID_XH) {
                 // the 16 lanes of a DPP row hold the 16 columns of (row r, tile rt): fp32 residual as before, plus what the next
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 if (i == 0) a.ssq[(size_t)r * a.n_row_tiles + rt] = sq;
                 constexpr int KT_OUT = 768 / 32;                  // the stream is H = 768 wide: 24 fp16 k-tiles
                 half_t* dst = (half_t*)a.xh + (size_t)chunk * NBG * KT_OUT * 64 * 8;
-                dst[xfrag_index<half_t>(n, col, KT_OUT)] = (half_t)(xn * xh_scale_pf[u]);
+                dst[xfrag_index<half_t>(n, col, KT_OUT)] = sat_half(xn * xh_scale_pf[u], a.sat);
             } else if (col < a.n_valid) {
                 a.logits[(size_t)r * a.n_valid + col] = v;
             }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             if (r < R) y = (va / (1.0f + expf(-va))) * vb;
             const int ktiles_out = (a.n_row_tiles * 8) / KT;
             WT* dst = (WT*)a.act_out + (size_t)chunk * NBG * ktiles_out * 64 * WTraits<WT>::EPL;
-            dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = (WT)y;
+            dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = sat_store<WT>(y, a.sat);
         } else if (r < R) {  // EPI_QKV: packed rows per tile = dims [8t..8t+7 | 8t+32..8t+39] of one head
             // keep hipcc from scheduling the cache-address arithmetic (and with it a wait on the meta load) at kernel entry
             asm volatile("" : "+v"(meta_pf.seq), "+v"(meta_pf.slot));
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             } else {
                 WT* c = (WT*)(which == 1 ? a.k_cache : a.v_cache) +
                         (((size_t)meta_pf.seq * NH + h) * a.Lmax + meta_pf.slot) * CTTS_HEAD_DIM;
-                c[d] = (WT)ya; c[d + 32] = (WT)yb;
+                c[d] = sat_store<WT>(ya, a.sat); c[d + 32] = sat_store<WT>(yb, a.sat);
             }
         }
     }

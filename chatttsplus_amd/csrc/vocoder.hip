@@ -49,6 +49,36 @@ __global__ void prep_kernel(const float* const* hidden, const int* Fs, float* in
         for (int c = n_mels + tid; c < LD; c += blockDim.x) mcl[(size_t)u * s_mcl + (size_t)r * LD + c] = 0.f;
 }
 
+// GFSQ._embed (dvae.py:85-96) -> GroupedResidualFSQ.get_output_from_indices (vector_quantize_pytorch 1.17.8, restated): frame 2t+g of
+// utterance u = project_out_g( sum_r code(ids[t][g*R + r]) * (levels - 1)^-r ), code_d(i) = ((i / basis_d) % L_d - L_d/2) / (L_d/2);
+// written behind the zero guard row of the decoder's input image exactly where prep_kernel copies the hidden rows in the other mode
+// (the "view(1,2,C/2,n).permute(0,2,3,1).flatten(2)" of dvae.py:277-283 interleaves the two groups frame by frame).
+struct VqCfg { int G, R; int levels[4]; };
+__global__ void embed_codes_kernel(const int* const* ids, const int* Fs, float* in_img, long s_in, int ID, const float* po_w /*[G][ID][4]*/,
+                                   const float* po_b /*[G][ID]*/, VqCfg vq) {
+    const int u = blockIdx.y, f = blockIdx.x, F = Fs[u];
+    if (f >= F) return;
+    const int t = f / vq.G, g = f % vq.G;
+    float lat[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < vq.R; ++r) {
+        int idx = ids[u][(size_t)t * vq.G * vq.R + g * vq.R + r], basis = 1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int L = vq.levels[d], hw = L / 2;
+            const float code = ((float)((idx / basis) % L) - (float)hw) / (float)hw;
+            float sc = 1.f;
+            for (int q = 0; q < r; ++q) sc /= (float)(L - 1);           // (levels - 1)^-r
+            lat[d] += code * sc;
+            basis *= L;
+        }
+    }
+    float* dst = in_img + (size_t)u * s_in + (size_t)(f + 1) * ID;
+    for (int c = threadIdx.x; c < ID; c += blockDim.x) {
+        const float* w = po_w + ((size_t)g * ID + c) * 4;
+        dst[c] = ((w[0] * lat[0] + w[1] * lat[1]) + (w[2] * lat[2] + w[3] * lat[3])) + po_b[(size_t)g * ID + c];
+    }
+}
+
 // mel [n_mels][F] (API layout) -> channels-last rows guard..F+guard-1 of mcl (guards / padding are zeroed by prep_kernel)
 __global__ void mel_to_cl_kernel(const float* mel, float* out, int n_mels, int F, int ldc, int guard) {
     const int f = blockIdx.x, c = threadIdx.x;
@@ -101,6 +131,7 @@ struct ctts_voc {
     std::vector<void*> allocs;
     // DVAE
     float *ci0_w, *ci0_b, *ci2_w, *ci2_b, *co_w, *oc_w, *coef;
+    float *po_w = nullptr, *po_b = nullptr;       // quantiser project_out [G][idim][4] / [G][idim] (vq_groups > 0)
     std::vector<ConvNext> dblocks;
     // Vocos
     float *em_w, *em_b, *n0_w, *n0_b, *nf_w, *nf_b, *hd_w, *hd_b, *win, *basis;
@@ -111,7 +142,7 @@ struct ctts_voc {
     int mel_ld, spec_ld, head_ld, mid_ld;
     // per-call tables: frames per utterance, hidden / wav / mel pointers (device copy + ring of pinned staging slots)
     void* d_tab = nullptr; void* pin = nullptr;
-    int* d_F = nullptr; const float* const* d_hid = nullptr; float* const* d_wav = nullptr; float* const* d_mel = nullptr;
+    int* d_F = nullptr; const float* const* d_hid = nullptr; float* const* d_wav = nullptr; float* const* d_mel = nullptr;      // (d_hid doubles as the table of code-id pointers in the codes mode)
     std::vector<int> frames_host;
     hipEvent_t pin_ev[8]; bool pin_used[8] = {false, false, false, false, false, false, false, false}; int pin_next = 0;
 };
@@ -147,11 +178,14 @@ static int load_convnext(ctts_voc* h, const std::string& p, int dim, int inter, 
 
 extern "C" int ctts_voc_create(const ctts_voc_cfg* c, ctts_voc** out) {
     if (!c || !out) { ctts_set_error("null argument"); return 1; }
-    if (c->dvae_hidden != 512 || c->vocos_dim != 512 || c->dvae_idim % 64 || c->dvae_bn % 64 || c->n_fft != 1024 || c->hop != 256 ||
+    if ((c->dvae_hidden != 512 && c->dvae_hidden != 256) || c->vocos_dim != 512 || c->dvae_idim % 64 || c->dvae_bn % 64 || c->n_fft != 1024 || c->hop != 256 ||
         c->vocos_inter % 64 || c->n_mels > 112 || c->max_frames < 2 || c->max_batch < 1 || c->max_batch > 64) {
         ctts_set_error("unsupported vocoder configuration");
         return 1;
     }
+    if (c->vq_groups < 0 || c->vq_groups > 4 || (c->vq_groups > 0 && (c->vq_residuals < 1 || c->vq_residuals > 4))) { ctts_set_error("unsupported quantiser configuration"); return 1; }
+    for (int d = 0; d < 4 && c->vq_groups > 0; ++d)
+        if (c->vq_levels[d] < 2 || c->vq_levels[d] > 64) { ctts_set_error("unsupported quantiser levels"); return 1; }
     ctts_voc* h = new ctts_voc();
     h->cfg = *c;
     *out = h;
@@ -192,6 +226,17 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
     if (!w || upload(h, &h->oc_w, conv_to_gemm(*w, NM, ID, 3, ID, r64(NM)))) return 1;
     w = vneed(h, "dvae.coef", NM);
     if (!w || upload(h, &h->coef, *w)) return 1;
+    if (c.vq_groups > 0) {      // GroupedResidualFSQ.rvqs[g].project_out: Linear(4 -> idim)
+        std::vector<float> pw((size_t)c.vq_groups * ID * 4), pb((size_t)c.vq_groups * ID);
+        for (int g = 0; g < c.vq_groups; ++g) {
+            const std::string p = "dvae.vq_layer.quantizer.rvqs." + std::to_string(g) + ".project_out.";
+            w = vneed(h, p + "weight", (size_t)ID * 4); b = vneed(h, p + "bias", ID);
+            if (!w || !b) return 1;
+            memcpy(&pw[(size_t)g * ID * 4], w->data(), (size_t)ID * 4 * 4);
+            memcpy(&pb[(size_t)g * ID], b->data(), (size_t)ID * 4);
+        }
+        if (upload(h, &h->po_w, pw) || upload(h, &h->po_b, pb)) return 1;
+    }
     // ---- Vocos
     w = vneed(h, "vocos.backbone.embed.weight", (size_t)VD * NM * 7); b = vneed(h, "vocos.backbone.embed.bias", VD);
     if (!w || !b || upload(h, &h->em_w, conv_to_gemm(*w, VD, NM, 7, h->mel_ld, r64(VD))) || upload(h, &h->em_b, *b)) return 1;
@@ -223,8 +268,9 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
     h->Fp = Fp;
     const size_t MB = c.max_batch;
     h->mid_ld = (HD * 4 > VI) ? HD * 4 : VI;
-    if (valloc(h, &h->in384, MB * Fp * ID) || valloc(h, &h->b128, MB * Fp * BN) || valloc(h, &h->y, MB * Fp * HD) ||
-        valloc(h, &h->ln, MB * Fp * HD) || valloc(h, &h->mid, MB * Fp * h->mid_ld) || valloc(h, &h->co384, MB * Fp * ID) ||
+    const int YD = HD > VD ? HD : VD;                   // y / ln hold the DVAE stream (HD wide) and then the Vocos stream (VD wide)
+    if (valloc(h, &h->in384, MB * Fp * ID) || valloc(h, &h->b128, MB * Fp * BN) || valloc(h, &h->y, MB * Fp * YD) ||
+        valloc(h, &h->ln, MB * Fp * YD) || valloc(h, &h->mid, MB * Fp * h->mid_ld) || valloc(h, &h->co384, MB * Fp * ID) ||
         valloc(h, &h->mcl, MB * Fp * h->mel_ld) || valloc(h, &h->hbuf, MB * Fp * h->head_ld) ||
         valloc(h, &h->spec, MB * Fp * h->spec_ld) || valloc(h, &h->frames, MB * Fp * c.n_fft))
         return 1;
@@ -244,7 +290,8 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
 
 static int run_convnext(ctts_voc* h, const ConvNext& cb, int nb, int Fmax, int dim, int inter, int dil, hipStream_t s) {
     const long sd = (long)h->Fp * dim, sm = (long)h->Fp * h->mid_ld;
-    hipLaunchKernelGGL(dwconv_ln_kernel<8>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln, cb.dw_w, cb.dw_b, cb.ln_w, cb.ln_b, h->d_F, sd, sd, dim, dil, 7);
+    if (dim == 512) hipLaunchKernelGGL(dwconv_ln_kernel<8>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln, cb.dw_w, cb.dw_b, cb.ln_w, cb.ln_b, h->d_F, sd, sd, dim, dil, 7);
+    else hipLaunchKernelGGL(dwconv_ln_kernel<4>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln, cb.dw_w, cb.dw_b, cb.ln_w, cb.ln_b, h->d_F, sd, sd, dim, dil, 7);     // DVAE_full decoder: 256 wide
     CTTS_HIP_CHECK(hipGetLastError());
     GemmF32Args g = {};
     g.A = h->ln; g.lda = dim; g.sA = sd; g.W = cb.w1; g.ldw = dim; g.C = h->mid; g.ldc = inter; g.sC = sm;
@@ -273,11 +320,18 @@ static int set_tables(ctts_voc* h, const float* const* hidden, const int* frames
     return 0;
 }
 
-static int stage(ctts_voc* h, bool with_hidden, int nb, int Fmax, hipStream_t s) {
+static int stage(ctts_voc* h, bool with_hidden, int nb, int Fmax, hipStream_t s, bool codes = false) {
     const ctts_voc_cfg& c = h->cfg;
-    hipLaunchKernelGGL(prep_kernel, dim3(Fmax + 6, nb), dim3(128), 0, s, with_hidden ? h->d_hid : nullptr, h->d_F, h->in384, h->b128, h->co384, h->mcl,
+    hipLaunchKernelGGL(prep_kernel, dim3(Fmax + 6, nb), dim3(128), 0, s, (with_hidden && !codes) ? h->d_hid : nullptr, h->d_F, h->in384, h->b128, h->co384, h->mcl,
                        (long)h->Fp * c.dvae_idim, (long)h->Fp * c.dvae_bn, (long)h->Fp * h->mel_ld, c.dvae_idim, c.dvae_bn, h->mel_ld, c.n_mels);
     CTTS_HIP_CHECK(hipGetLastError());
+    if (codes) {
+        VqCfg vq; vq.G = c.vq_groups; vq.R = c.vq_residuals;
+        for (int d = 0; d < 4; ++d) vq.levels[d] = c.vq_levels[d];
+        hipLaunchKernelGGL(embed_codes_kernel, dim3(Fmax, nb), dim3(128), 0, s, (const int* const*)h->d_hid, h->d_F, h->in384, (long)h->Fp * c.dvae_idim,
+                           c.dvae_idim, h->po_w, h->po_b, vq);
+        CTTS_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -352,6 +406,43 @@ extern "C" int ctts_dvae_decode(ctts_voc* h, const float* hidden, int n_tokens, 
     hipStream_t s = (hipStream_t)stream;
     if (set_tables(h, &hidden, &F, nullptr, &mel, 1, s) || stage(h, true, 1, F, s)) return 1;
     return run_dvae(h, 1, F, false, s);
+}
+
+static int codes_ready(ctts_voc* h, const char* who) {
+    if (!h || !h->finalized) { ctts_set_error("%s: handle not finalized", who); return 1; }
+    if (h->cfg.vq_groups < 1 || !h->po_w) { ctts_set_error("%s: this handle has no quantiser (create it with vq_groups > 0 from the DVAE_full checkpoint)", who); return 1; }
+    if (h->cfg.vq_groups != 2) { ctts_set_error("%s: the decoder input interleaves exactly 2 groups (dvae.py:277-283)", who); return 1; }
+    return 0;
+}
+
+extern "C" int ctts_dvae_decode_codes(ctts_voc* h, const int32_t* ids, int n_tokens, float* mel, void* stream) {
+    if (codes_ready(h, "dvae_decode_codes")) return 1;
+    if (!ids || !mel) { ctts_set_error("dvae_decode_codes: null argument"); return 1; }
+    const int F = 2 * n_tokens;
+    if (n_tokens < 1 || F > h->cfg.max_frames) { ctts_set_error("dvae_decode_codes: %d frames exceed max_frames=%d", F, h->cfg.max_frames); return 1; }
+    CTTS_RANGE("ctts_dvae_decode_codes");
+    hipStream_t s = (hipStream_t)stream;
+    const float* idp = (const float*)ids;                   // pointer table slot shared with the hidden-row pointers
+    if (set_tables(h, &idp, &F, nullptr, &mel, 1, s) || stage(h, true, 1, F, s, true)) return 1;
+    return run_dvae(h, 1, F, false, s);
+}
+
+extern "C" int ctts_synth_batch_codes(ctts_voc* h, const int32_t* const* ids_ptrs, const int32_t* n_tokens, int B, float* const* wav_ptrs, void* stream) {
+    if (codes_ready(h, "synth_batch_codes")) return 1;
+    if (!ids_ptrs || !n_tokens || !wav_ptrs) { ctts_set_error("synth_batch_codes: null argument"); return 1; }
+    if (B < 1 || B > h->cfg.max_batch) { ctts_set_error("synth_batch_codes: B=%d exceeds max_batch=%d", B, h->cfg.max_batch); return 1; }
+    CTTS_RANGE("ctts_synth_batch_codes");
+    int Fmax = 0;
+    for (int u = 0; u < B; ++u) {
+        const int F = 2 * n_tokens[u];
+        if (n_tokens[u] < 1 || F > h->cfg.max_frames) { ctts_set_error("synth_batch_codes: utterance %d has %d frames (max_frames=%d)", u, F, h->cfg.max_frames); return 1; }
+        h->frames_host[u] = F;
+        Fmax = F > Fmax ? F : Fmax;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (set_tables(h, (const float* const*)ids_ptrs, h->frames_host.data(), wav_ptrs, nullptr, B, s) || stage(h, true, B, Fmax, s, true)) return 1;
+    if (run_dvae(h, B, Fmax, true, s)) return 1;
+    return run_vocos(h, B, Fmax, s);
 }
 
 extern "C" int ctts_vocos_decode(ctts_voc* h, const float* mel, int F, float* wav, void* stream) {

@@ -520,6 +520,17 @@ class GPT:
                 used_draws += steps.value - prev
                 tick("final_progress")
             self._restore_rng(rng_states, used_draws)
+            self.saturations = 0
+            if self.dtype_code == _lib.DTYPE_F16:
+                # fp16 stores (SwiGLU outputs, K / V, packed residual) saturate instead of overflowing to inf; a non-zero count means the
+                # checkpoint drives activations past the fp16 range -- the result is finite but clipped: say so (fp32 mode has no such limit)
+                nsat = C.c_int32(0)
+                _lib.check(lib.ctts_gpt_saturations(h, C.byref(nsat), st), "saturations")
+                self.saturations = int(nsat.value)
+                if self.saturations:
+                    import warnings
+                    warnings.warn(f"hip GPT (weight_dtype fp16): {self.saturations} fp16 stores saturated or were NaN during this generate(); "
+                                  f"use weight_dtype='fp32' for this checkpoint", RuntimeWarning)
             out = self._outputs(ids, hid, end_idx, infer_text)
             tick("outputs")
             yield out

@@ -24,7 +24,9 @@ def _np(v) -> np.ndarray:
 class Synth:
     """Owner of the native DVAE-decoder + Vocos handle."""
 
-    def __init__(self, dvae_cfg: dict, vocos_cfg: dict, max_frames: int = 4096, device="cuda", max_batch: int = 1):
+    def __init__(self, dvae_cfg: dict, vocos_cfg: dict, max_frames: int = 4096, device="cuda", max_batch: int = 1, vq_cfg: Optional[dict] = None):
+        """`vq_cfg` (the YAML's dvae_encode.vq_config: dim, levels, G, R) makes this the "decode codes" model of use_decoder=False
+        (pipeline:292): dvae_cfg is then DVAE_full's decoder_config and the input of decode_batch / dvae_decode_codes are code ids."""
         self.device = torch.device(device)
         self.max_batch = int(max_batch)
         self._lib = _lib.load()
@@ -36,6 +38,15 @@ class Synth:
                                vocos_inter=int(vocos_cfg.get("intermediate_dim", 1536)), vocos_layers=int(vocos_cfg.get("num_layers", 8)),
                                n_fft=int(vocos_cfg.get("n_fft", 1024)), hop=int(vocos_cfg.get("hop_length", 256)), max_frames=int(max_frames),
                                max_batch=int(max_batch))
+        self.vq = None
+        if vq_cfg is not None:
+            lv = [int(x) for x in vq_cfg.get("levels", (5, 5, 5, 5))]
+            if len(lv) != 4:
+                raise _lib.HipBackendError("hip DVAE: the quantiser restatement covers 4-dimensional FSQ codes (levels: [5, 5, 5, 5])")
+            self.vq = dict(G=int(vq_cfg.get("G", 2)), R=int(vq_cfg.get("R", 2)), levels=lv)
+            self.cfg.vq_groups, self.cfg.vq_residuals = self.vq["G"], self.vq["R"]
+            for i, l in enumerate(lv):
+                self.cfg.vq_levels[i] = l
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ctts_voc_create(C.byref(self.cfg), C.byref(self._h)), "ctts_voc_create")
@@ -54,8 +65,9 @@ class Synth:
         for k, v in sd.items():
             if prefix == "vocos." and k.startswith("feature_extractor."):
                 continue                                     # mel extractor: encode path only
-            if prefix == "dvae." and not (k.startswith("decoder.") or k in ("out_conv.weight", "coef")):
-                continue                                     # encoder / vq / downsample_conv: zero-shot path (next)
+            if prefix == "dvae." and not (k.startswith("decoder.") or k in ("out_conv.weight", "coef") or
+                                          (self.vq is not None and ".project_out." in k and k.startswith("vq_layer.quantizer.rvqs."))):
+                continue                                     # encoder / downsample_conv / project_in: the zero-shot encode path (hip_models.DVAEEncoder)
             a = _np(v)
             _lib.check(self._lib.ctts_voc_set_weight(self._h, (prefix + k).encode(), a.ctypes.data_as(C.c_void_p), a.size), f"set_weight({prefix + k})")
         self._loaded.add(prefix)
@@ -76,6 +88,18 @@ class Synth:
         mel = torch.empty(self.cfg.n_mels, 2 * n, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ctts_dvae_decode(self._h, hidden.data_ptr(), n, mel.data_ptr(), self._stream()), "dvae_decode")
+        return mel
+
+    def dvae_decode_codes(self, ids: torch.Tensor) -> torch.Tensor:
+        """ids [n, G*R] (GPT.generate's ids rows) -> mel [100, 2n]: DVAE_full's decode branch (dvae.py:272-291 with vq_layer)."""
+        if not self._finalized or self.vq is None:
+            raise _lib.HipBackendError("decode-codes model not loaded (Synth(vq_cfg=...) + DVAE_full / Vocos weights)")
+        ids = ids.to(self.device, dtype=torch.int32).contiguous()
+        n = int(ids.shape[0])
+        assert ids.dim() == 2 and ids.shape[1] == self.vq["G"] * self.vq["R"]
+        mel = torch.empty(self.cfg.n_mels, 2 * n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_dvae_decode_codes(self._h, ids.data_ptr(), n, mel.data_ptr(), self._stream()), "dvae_decode_codes")
         return mel
 
     def vocos_decode(self, mel: torch.Tensor) -> torch.Tensor:
@@ -103,13 +127,15 @@ class Synth:
         with torch.cuda.device(self.device):
             for c0 in range(0, len(todo), self.max_batch):
                 idx = todo[c0:c0 + self.max_batch]
-                hs = [hiddens[i].to(self.device, dtype=torch.float32).contiguous() for i in idx]
+                # the decode-codes model (use_decoder=False) takes the generated ids [n, 4] instead of hidden rows [n, 768]
+                hs = [hiddens[i].to(self.device, dtype=torch.int32 if self.vq is not None else torch.float32).contiguous() for i in idx]
                 ns = [int(h.shape[0]) for h in hs]
                 wavs = [torch.empty(self.cfg.hop * (2 * n - 1), dtype=torch.float32, device=self.device) for n in ns]
                 hp = (C.c_void_p * len(idx))(*[h.data_ptr() for h in hs])
                 wp = (C.c_void_p * len(idx))(*[w.data_ptr() for w in wavs])
                 nt = (C.c_int32 * len(idx))(*ns)
-                _lib.check(self._lib.ctts_synth_batch(self._h, hp, nt, len(idx), wp, self._stream()), "synth_batch")
+                fn = self._lib.ctts_synth_batch_codes if self.vq is not None else self._lib.ctts_synth_batch
+                _lib.check(fn(self._h, hp, nt, len(idx), wp, self._stream()), "synth_batch")
                 for i, w in zip(idx, wavs):
                     outs[i] = w
         return outs

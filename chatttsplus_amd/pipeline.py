@@ -195,6 +195,8 @@ class ChatTTSPlusPipeline:
                 continue
             if model_name == "dvae_encode":                 # zero-shot speaker prompt (pipeline:279-284): optional checkpoint
                 if itype == "hip" and kw.get("model_path") and os.path.exists(kw["model_path"]):
+                    # the same checkpoint's decoder + quantiser serve use_decoder=False (pipeline:292): built on first use (_codes_synth)
+                    self._full_ckpt = dict(path=kw["model_path"], decoder_config=dict(kw.get("decoder_config") or {}), vq_config=dict(kw.get("vq_config") or {}))
                     path = kw.pop("model_path")
                     enc = hip_models.DVAEEncoder(device=str(self.device), **kw)
                     sd = dict(torch.load(path, weights_only=True, mmap=True))
@@ -216,6 +218,7 @@ class ChatTTSPlusPipeline:
             if model_name == "vocos":                       # pipeline:93-111
                 model_ = hip_models.Vocos(synth)
                 model_.load_state_dict(torch.load(kw["model_path"], weights_only=True, mmap=True))
+                self._vocos_ckpt = dict(path=kw["model_path"], cfg=vcfg)
             elif model_name == "dvae_decode":
                 kw["coef"] = coef
                 path = kw.pop("model_path")
@@ -305,11 +308,32 @@ class ChatTTSPlusPipeline:
                                  logits_warpers=warpers, logits_processors=processors, infer_text=True, stream=False,
                                  show_tqdm=params.show_tqdm, ensure_non_empty=params.ensure_non_empty))
 
+    def _codes_synth(self):
+        """The "decode codes" model of use_decoder=False (pipeline:292: decoder = models_dict["dvae_encode"], i.e. the DVAE_full checkpoint
+        run in decode mode on the generated ids, dvae.py:272-291): its decoder stack + the quantiser's project_out + a second copy of the
+        Vocos weights in one native handle, created on first use."""
+        if getattr(self, "synth_codes", None) is not None:
+            return self.synth_codes
+        full, voc = getattr(self, "_full_ckpt", None), getattr(self, "_vocos_ckpt", None)
+        if full is None or voc is None:
+            raise _lib.HipBackendError("use_decoder=False needs the dvae_encode checkpoint (DVAE_full.pt, infer_type 'hip') and vocos configured")
+        dcfg = dict(full["decoder_config"]); dcfg["n_mels"] = 100
+        sc = hip_models.Synth(dcfg, voc["cfg"], max_frames=int(self.synth.cfg.max_frames), device=self.device, max_batch=int(self.synth.max_batch),
+                              vq_cfg=full["vq_config"])
+        sd = dict(torch.load(full["path"], weights_only=True, mmap=True))
+        if "coef" not in sd:
+            sd["coef"] = torch.from_numpy(codec.coef_from_string(self.dave_coef)).view(1, -1, 1)
+        sc.load("dvae.", sd)
+        sc.load("vocos.", torch.load(voc["path"], weights_only=True, mmap=True))
+        self.synth_codes = sc
+        return sc
+
     @torch.inference_mode()
     def _decode_to_wavs(self, result_list, use_decoder: bool = True):
-        """pipeline:286-305: per utterance hidden[n,768] -> DVAE -> mel[1,100,2n] -> Vocos -> wav[256(2n-1)]."""
+        """pipeline:286-305: per utterance hidden[n,768] -> DVAE -> mel[1,100,2n] -> Vocos -> wav[256(2n-1)]; with use_decoder=False the
+        inputs are the generated ids [n,4] and the decoder is the DVAE_full model (pipeline:292,435-439)."""
         if not use_decoder:
-            raise _lib.HipBackendError("use_decoder=False (decode codes through dvae_encode) is not served by the hip backend")
+            return self._codes_synth().decode_batch(list(result_list))
         if len(result_list) >= 1 and getattr(self, "synth", None) is not None:
             return self.synth.decode_batch(list(result_list))           # one launch sequence for the batch (ctts_synth_batch)
         wavs = []
@@ -371,8 +395,6 @@ class ChatTTSPlusPipeline:
                params_refine_text=RefineTextParams(), params_infer_code=InferCodeParams(), **kwargs):
         if not isinstance(text_in, list):
             text_in = [text_in]
-        if not use_decoder and not refine_text_only:
-            raise _lib.HipBackendError("use_decoder=False (decode codes through dvae_encode) is not served by the hip backend")
         if do_text_optimization and self.text_splitter is not None:
             # pipeline:353-377: split on newlines, hand the lines to the (pluggable) sentence splitter, merge short sentences
             lines = [t.strip() for text_ in text_in for t in text_.split("\n") if t.strip()]
@@ -422,20 +444,20 @@ class ChatTTSPlusPipeline:
             try:
                 for result in results:
                     if not stream:
-                        yield self._decode_to_wavs(result.hiddens, use_decoder)
+                        yield self._decode_to_wavs(result.hiddens if use_decoder else result.ids, use_decoder)      # pipeline:435-439
                         continue
                     # The reference's stream branch vocodes the whole prefix for every chunk and indexes a python list with
                     # .shape.  Here every yield is the [length, b) sample window of that same prefix waveform,
                     # vocoded from the tokens inside the window's receptive field only (Synth.decode_window), zero padded
                     # like pad_sequence would pad the shorter utterances.
-                    last = result.hiddens
+                    last = result.hiddens if use_decoder else result.ids
                     pass_batch_count += 1
                     if pass_batch_count <= params_infer_code.pass_first_n_batches:
                         continue
                     total = max((256 * (2 * int(h.shape[0]) - 1) if h.shape[0] > 0 else 0) for h in last)
                     b = min(length + params_infer_code.stream_speed, total)
                     if b > length:
-                        yield self._window(last, length, b)
+                        yield self._window(last, length, b, use_decoder)
                         length = b
             finally:
                 if lora_paths is not None:          # the generator stays lazy (streaming works with per-utterance adapters); the row table is
@@ -443,11 +465,12 @@ class ChatTTSPlusPipeline:
             if stream and last is not None:
                 total = max((256 * (2 * int(h.shape[0]) - 1) if h.shape[0] > 0 else 0) for h in last)
                 if total > length:
-                    yield self._window(last, length, total)
+                    yield self._window(last, length, total, use_decoder)
 
-    def _window(self, hiddens, s0: int, s1: int) -> torch.Tensor:
+    def _window(self, hiddens, s0: int, s1: int, use_decoder: bool = True) -> torch.Tensor:
         """[B, s1-s0] samples s0..s1 of the padded batch of prefix waveforms."""
-        parts = self.synth.decode_window(list(hiddens), [s0] * len(hiddens), [s1] * len(hiddens))
+        syn = self.synth if use_decoder else self._codes_synth()
+        parts = syn.decode_window(list(hiddens), [s0] * len(hiddens), [s1] * len(hiddens))
         out = torch.zeros(len(parts), s1 - s0, device=self.device)
         for u, w in enumerate(parts):
             out[u, :w.shape[0]] = w

@@ -150,6 +150,19 @@ def dvae_encoder_state_dict(cfg: dict = DVAE_ENC_REAL, seed: int = 1234) -> Dict
     return sd
 
 
+# decode side of DVAE_full.pt (configs/infer/chattts_plus.yaml dvae_encode: decoder_config idim 512 / hidden 256, dim 512) + the quantiser's
+# project_out: what use_decoder=False runs (pipeline:292; dvae.py:272-291 with vq_layer, :85-96 GFSQ._embed)
+DVAE_FULL_DEC = dict(idim=512, odim=512, hidden=256, n_layer=12, bn_dim=128, dim=512, n_mels=100, vq_levels=(5, 5, 5, 5), vq_G=2, vq_R=2)
+
+
+def dvae_full_decoder_state_dict(cfg: dict = DVAE_FULL_DEC, seed: int = 1234) -> Dict[str, np.ndarray]:
+    """decoder.* / out_conv / coef of a DVAE_full-shaped checkpoint + `vq_layer.quantizer.rvqs.{g}.project_out` (Linear 4 -> dim)."""
+    sd = dict(dvae_state_dict(cfg, seed + 77))
+    for g in range(cfg["vq_G"]):
+        sd.update(_linear(seed, f"vq_layer.quantizer.rvqs.{g}.project_out", cfg["dim"], len(cfg["vq_levels"]), gain=1.0))
+    return sd
+
+
 def speaker_wave(seed: int, n_samples: int) -> np.ndarray:
     """Synthetic 24 kHz speech-like test signal in [-1, 1]: a few drifting harmonics plus noise."""
     t = np.arange(n_samples, dtype=np.float64) / 24000.0

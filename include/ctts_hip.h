@@ -175,6 +175,11 @@ int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* stream);
  * Synchronises the stream. */
 int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_finished, void* stream);
 
+/* fp16 engines store SwiGLU outputs, K / V and the packed residual copy as fp16: values beyond the fp16 range are SATURATED at +-65504 and
+ * counted (the reference's .half() path would produce inf -> NaN silently on such a checkpoint, pipeline:37-41); `count` = saturated or NaN
+ * stores since ctts_gpt_begin.  Synchronises the stream.  Always 0 for fp32 engines. */
+int ctts_gpt_saturations(ctts_gpt* h, int32_t* count, void* stream);
+
 /* Finished-row compaction (no counterpart in the reference, whose finished rows keep computing until the slowest sequence ends,
  * gpt.py:527-546): between two ctts_gpt_decode calls the caller may drop rows of the decode batch.
  *   rows_enqueue  copies {finish, end_idx} of the CURRENT rows (2 int32 each, row order) into pinned host memory, asynchronously
@@ -226,12 +231,19 @@ typedef struct {
     int32_t hop;            /* 256 */
     int32_t max_frames;     /* capacity in mel frames (2 per generated token) per utterance */
     int32_t max_batch;      /* utterances synthesised by one ctts_synth_batch call (<= 64) */
+    /* optional quantiser of the DVAE_full model (configs/infer/chattts_plus.yaml dvae_encode.vq_config: G=2, R=2, levels 5,5,5,5):
+     * vq_groups > 0 makes the handle a "decode codes" model (use_decoder=False, pipeline:292) -- dvae_idim = vq dim / G (512),
+     * dvae_hidden 256; vq_groups == 0: the plain decoder (Decoder.pt) */
+    int32_t vq_groups;
+    int32_t vq_residuals;
+    int32_t vq_levels[4];
 } ctts_voc_cfg;
 
 /* replaces DVAE.__init__ (dvae.py:203-239) + vocos.Vocos construction (pipeline:93-111) */
 int ctts_voc_create(const ctts_voc_cfg* cfg, ctts_voc** out);
 void ctts_voc_destroy(ctts_voc* h);
-/* `name` = "dvae." + DVAE state-dict key  or  "vocos." + Vocos state-dict key; host fp32 */
+/* `name` = "dvae." + DVAE state-dict key  or  "vocos." + Vocos state-dict key; host fp32.  With vq_groups > 0 also
+ * "dvae.vq_layer.quantizer.rvqs.{g}.project_out.{weight,bias}" (GroupedResidualFSQ, vector_quantize_pytorch). */
 int ctts_voc_set_weight(ctts_voc* h, const char* name, const float* data, size_t numel);
 int ctts_voc_finalize(ctts_voc* h);
 
@@ -244,6 +256,14 @@ int ctts_vocos_decode(ctts_voc* h, const float* mel_dev, int frames, float* wav_
  * hidden_ptrs[u] fp32 [n_tokens[u]][768] device -> wav_ptrs[u] fp32 [hop*(2*n_tokens[u]-1)] device; the two pointer
  * arrays and n_tokens are HOST arrays of length B (<= max_batch).  Same arithmetic as dvae_decode + vocos_decode. */
 int ctts_synth_batch(ctts_voc* h, const float* const* hidden_ptrs, const int32_t* n_tokens, int B, float* const* wav_ptrs, void* stream);
+
+/* use_decoder=False branch (pipeline:292,435-439: the DVAE_full model decodes the generated CODE IDS instead of the hidden states):
+ * DVAE.forward decode with a quantiser (dvae.py:272-291) = GFSQ._embed (dvae.py:85-96: ids -> implicit FSQ codes, summed over the R
+ * residual levels with scale (levels-1)^-r -> project_out, groups concatenated) + the same decoder stack.  Needs a handle created with
+ * vq_groups > 0.  ids int32 [n][G*R] device (GPT.generate's ids rows, gpt.py:295-297) -> mel fp32 [100][2n]. */
+int ctts_dvae_decode_codes(ctts_voc* h, const int32_t* ids_dev, int n_tokens, float* mel_dev, void* stream);
+/* ... and _decode_to_wavs(result.ids, use_decoder=False) for B utterances in one launch sequence; ids_ptrs[u] int32 [n_tokens[u]][G*R]. */
+int ctts_synth_batch_codes(ctts_voc* h, const int32_t* const* ids_ptrs, const int32_t* n_tokens, int B, float* const* wav_ptrs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Zero-shot speaker prompt: waveform -> audio-prompt codes.

@@ -215,6 +215,43 @@ def golden_gpt_real_b32(ref):
     print("gpt_real_b32 lens", lens.tolist())
 
 
+def golden_gpt_real_b32_ragged(ref, only_search=False):
+    """BASELINE configs[2] pinned against the reference ITSELF with a ragged finish: 32 sequences, the same 23 left paddings, free-running
+    for up to 96 steps with the EOS rows of the heads boosted so that the rows end at many different steps (gpt.py:483-494,527-546: finish /
+    end_idx bookkeeping while finished rows keep computing).  All ids are stored; hiddens of three rows (fixture size)."""
+    cfg = synth.GPT_REAL
+    pad = list(range(0, 23)) + [0] * 9
+    ids, mask = synth.prompt_ids(32, 24, cfg["num_text_tokens"], 332, pad_left=pad)
+    for boost in (1.45, 1.55, 1.35, 1.65):
+        sd = synth.gpt_state_dict(cfg, 1234)
+        for i in range(4):
+            sd[f"head_code.{i}.parametrizations.weight.original0"][625] *= boost
+        g = build_ref_gpt(ref, cfg, sd)
+        for torch_seed in (88, 89):
+            emb, out = run_ref_generate(ref, g, ids, mask, torch_seed, 96, 2)
+            lens = np.array([i.shape[0] for i in out.ids], dtype=np.int32)
+            print("  b32 ragged search: boost", boost, "seed", torch_seed, "lens", sorted(lens.tolist()), flush=True)
+            if only_search:
+                continue
+            if lens.max() >= 64 and len(set(lens.tolist())) >= 12 and lens.min() <= 16:
+                rows = [int(np.argmin(lens)), int(np.argsort(lens)[16]), int(np.argmax(lens))]
+                meta = dict(weight_seed=1234, eos_boost=boost, prompt_seed=332, torch_seed=torch_seed, B=32, T=24, pad_left=pad, max_new=96, min_new=2,
+                            spk_seed=1234, spk_id=21143, spk_pos=-1, hidden_rows=rows)
+                n = int(lens.max())
+                allids = np.full((32, n, 4), -1, dtype=np.int16)
+                for b in range(32):
+                    allids[b, :lens[b]] = out.ids[b].numpy()
+                hid = np.zeros((3, n, 768), dtype=np.float32)
+                for j, r in enumerate(rows):
+                    hid[j, :lens[r]] = out.hiddens[r].numpy()
+                np.savez_compressed(os.path.join(OUT, "gpt_real_b32_ragged.npz"), lens=lens, ids=allids, hiddens=hid,
+                                    emb_last=emb[:, -1].detach().numpy(), **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
+                print("gpt_real_b32_ragged lens", lens.tolist())
+                return
+    if not only_search:
+        raise SystemExit("no ragged batch-32 case found")
+
+
 def golden_gpt_real_regen(ref):
     """Real config, first-step EOS -> ensure_non_empty regenerate (gpt.py:496-525): B=2 with left padding, EOS head rows
     boosted, min_new_token=0.  The torch seed is searched for a run whose first attempt(s) end at step 0 (finish.any()) and a
@@ -370,6 +407,33 @@ def golden_dvae_lengths(ref):
     print("dvae_real_lengths", {k: v.shape for k, v in out.items() if k.startswith("mel_")})
 
 
+def golden_dvae_full_decode(ref):
+    """use_decoder=False (pipeline:292): the DECODER STACK of the DVAE_full-shaped model (idim 512, hidden 256) on the reference's own
+    module, fed with the latent our restatement of GFSQ._embed builds from random code ids (the quantiser itself is third-party code
+    absent offline: parity unpinned; the stack behind it is pinned here).  Stores the ids, a digest of the latent and the mel."""
+    cfg = synth.DVAE_FULL_DEC
+    sd = synth.dvae_full_decoder_state_dict(cfg, 1234)
+    dec = {k: v for k, v in sd.items() if k.startswith("decoder.") or k in ("out_conv.weight", "coef")}
+    m = ref.dvae.DVAE(decoder_config=dict(idim=cfg["idim"], odim=cfg["odim"], hidden=cfg["hidden"], n_layer=cfg["n_layer"], bn_dim=cfg["bn_dim"]),
+                      dim=cfg["dim"]).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in dec.items()}, strict=True)
+    from oracle import ref_cpu
+    out = dict(weight_seed=np.array(1234), lengths=np.array([1, 41, 200]), id_seeds=np.array([301, 341, 500]))
+    for n, seed in zip(out["lengths"], out["id_seeds"]):
+        ids = np.random.Generator(np.random.Philox(key=int(seed))).integers(0, 625, size=(int(n), 4)).astype(np.int64)
+        lat = ref_cpu.gfsq_latent_from_indices(torch.from_numpy(ids).t().contiguous())
+        feat = torch.cat([torch.nn.functional.linear(lat[g], torch.from_numpy(sd[f"vq_layer.quantizer.rvqs.{g}.project_out.weight"]),
+                                                     torch.from_numpy(sd[f"vq_layer.quantizer.rvqs.{g}.project_out.bias"])) for g in range(2)], -1)   # [n, 1024]
+        with torch.no_grad():
+            mel = m(feat.permute(1, 0)[None].clone())[0].numpy()                        # the reference's decode branch, vq_layer=None: inp = vq_feats [1, 1024, n]
+        mine = ref_cpu.dvae_decode_codes(sd, torch.from_numpy(ids)).numpy()
+        print("dvae_full_decode n", int(n), "mel", mel.shape, "oracle-vs-reference max err", float(np.abs(mine - mel).max()))
+        out[f"ids_{int(n)}"] = ids.astype(np.int16)
+        out[f"mel_{int(n)}"] = mel
+        out[f"feat_absmean_{int(n)}"] = np.array(float(feat.abs().mean()))
+    np.savez_compressed(os.path.join(OUT, "dvae_full_decode_real.npz"), **out)
+
+
 def golden_dvae_encode(ref):
     """Zero-shot encode branch.  Pinned by the reference's own modules: downsample_conv + encoder (dvae.py:224-231,263-268)
     on a given mel.  NOT pinned (third-party torchaudio / vector_quantize_pytorch absent): the mel extractor and the GFSQ
@@ -407,18 +471,24 @@ def main():
     ref = load_reference()
     import importlib
     ref.tokenizer = importlib.import_module("chattts_plus.models.tokenizer")
+    if len(sys.argv) > 1:          # python -m oracle.make_golden golden_gpt_real_b32_ragged [...]: mint the named fixtures only
+        for name in sys.argv[1:]:
+            globals()[name](ref)
+        return
     golden_sampler(ref)
     golden_gpt_tiny(ref)
     golden_gpt_tiny_regen(ref)
     golden_dvae(ref)
     golden_dvae_lengths(ref)
     golden_dvae_encode(ref)
+    golden_dvae_full_decode(ref)
     golden_gpt_real(ref)
     golden_gpt_real_ragged(ref)
     golden_gpt_real_regen(ref)
     golden_gpt_real_params(ref)
     golden_gpt_real_long(ref)
     golden_gpt_real_b32(ref)
+    golden_gpt_real_b32_ragged(ref)
     golden_refine_text(ref)
 
 

@@ -535,6 +535,21 @@ def gfsq_latent_from_indices(ids: torch.Tensor, levels=(5, 5, 5, 5), G: int = 2,
 
 
 @torch.no_grad()
+def dvae_decode_codes(sd: Dict[str, np.ndarray], ids: torch.Tensor, levels=(5, 5, 5, 5), G: int = 2, R: int = 2) -> torch.Tensor:
+    """DVAE.forward decode WITH a quantiser (dvae.py:272-291; the use_decoder=False branch, pipeline:292,435-439): ids [n, G*R] (one
+    utterance's generated code ids) -> GFSQ._embed (dvae.py:85-96 -> GroupedResidualFSQ.get_output_from_indices, vector_quantize_pytorch
+    1.17.8, third party: parity unpinned) = per group project_out(sum of the R residual codes), groups concatenated -> the decoder
+    stack (pinned on the reference's module: tests/golden/dvae_full_decode_real.npz) -> mel [100, 2n]."""
+    ids = _t(ids).to(torch.int64)
+    lat = gfsq_latent_from_indices(ids.t().contiguous(), levels, G, R)                  # [G, n, 4]; row g*R + r of ids.T = codebook r of group g
+    feats = [F.linear(lat[g], _t(sd[f"vq_layer.quantizer.rvqs.{g}.project_out.weight"]).float(),
+                      _t(sd[f"vq_layer.quantizer.rvqs.{g}.project_out.bias"]).float()) for g in range(G)]
+    feat = torch.cat(feats, dim=-1)                                                     # [n, dim * G] (= feat.transpose(1, 2) of _embed, per frame)
+    dec = {k: v for k, v in sd.items() if k.startswith("decoder.") or k in ("out_conv.weight", "coef")}
+    return dvae_decode(dec, feat)
+
+
+@torch.no_grad()
 def dvae_encoder_features(sd: Dict[str, np.ndarray], mel: torch.Tensor) -> torch.Tensor:
     """mel [100, F] -> encoder output [1024, F // 2]: div by coef, downsample_conv, DVAEDecoder-as-encoder (dvae.py:263-268)."""
     sd = {k: _t(v).float() for k, v in sd.items()}

@@ -137,3 +137,41 @@ def test_stress_weights_fp32_ids_bit_exact_and_fp16_hiddens():
     worst = max(_rel_rms(hid[b].cpu().numpy(), ref.hiddens[b].numpy()) for b in range(B))
     print(f"stress weights fp16 teacher-forced hidden rel-RMS {worst:.2e}")
     assert worst <= 3e-2, worst
+
+
+@pytest.mark.parametrize("B", [2, 12])
+def test_fp16_overflow_saturates_and_is_reported(B):
+    """a checkpoint whose SwiGLU outputs leave the fp16 range.  The reference's GPU path (`model.half()`, pipeline:37-41)
+    turns such a value into inf and the row into NaN; the fp16 engine SATURATES the store at +-65504 and REPORTS it (ctts_gpt_saturations,
+    RuntimeWarning from generate()) -- finite hiddens, valid token ids, no silent NaN.  The fp32 engine is unaffected.  Batch 2 runs the
+    split-K path, batch 12 the packed-fp16 residual path."""
+    import warnings
+    from chatttsplus_amd.hip_models import GPT
+    sd = synth.gpt_state_dict(synth.GPT_REAL, 1234)
+    for l in (3, 11):
+        for k in ("gate_proj", "up_proj"):
+            sd[f"gpt.layers.{l}.mlp.{k}.weight"] = sd[f"gpt.layers.{l}.mlp.{k}.weight"] * 600.0
+    # the emulated .half() path overflows: act = silu(gate(x)) * up(x) on a unit-RMS row, rounded to fp16
+    xh = torch.from_numpy(np.random.Generator(np.random.Philox(key=5)).standard_normal((4, 768)).astype(np.float32))
+    xh = xh / xh.pow(2).mean(-1, keepdim=True).sqrt()
+    act = torch.nn.functional.silu(xh @ torch.from_numpy(sd["gpt.layers.3.mlp.gate_proj.weight"]).t()) * (xh @ torch.from_numpy(sd["gpt.layers.3.mlp.up_proj.weight"]).t())
+    assert bool(torch.isinf(act.half()).any()), "test premise: the fp16 rounding of this checkpoint's SwiGLU output overflows"
+    ids, mask = synth.prompt_ids(B, 10, 21178, 91)
+    out = {}
+    for wd in ("fp16", "fp32"):
+        g = GPT(LLAMA, max_batch=B, max_seq_len=64, weight_dtype=wd)
+        g.load_state_dict(sd)
+        emb = g(torch.from_numpy(ids), torch.ones(B, 10, dtype=torch.bool))
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            o = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=6,
+                                min_new_token=6, logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="device", seed=3))[-1]
+        out[wd] = (o, g.saturations, [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)])
+        g.close()
+    o16, nsat16, warn16 = out["fp16"]
+    o32, nsat32, warn32 = out["fp32"]
+    assert nsat16 > 0 and any("saturated" in w for w in warn16), (nsat16, warn16)
+    assert nsat32 == 0 and not warn32
+    for o in (o16, o32):
+        assert all(bool(torch.isfinite(h).all()) for h in o.hiddens), "NaN / inf reached the hidden states"
+        assert all(int(i.min()) >= 0 and int(i.max()) < 626 and i.shape[0] == 6 for i in o.ids)

@@ -23,16 +23,16 @@ LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, nu
 _models = {}
 
 
-def model(wd, seed=1234, boost=None):
+def model(wd, seed=1234, boost=None, max_batch=None):
     from chatttsplus_amd.hip_models import GPT
-    key = (wd, seed, boost)
+    key = (wd, seed, boost, max_batch)
     if key not in _models:
         os.environ["CTTS_PASS_ROWS"] = "8192"      # prompt rows per pass of these engines (default 16384): the 8500 / 8580-row cases below take two passes
         sd = synth.gpt_state_dict(synth.GPT_REAL, seed)
         if boost is not None:                      # goldens minted with boosted EOS rows (staggered finishes)
             for i in range(4):
                 sd[f"head_code.{i}.parametrizations.weight.original0"][625] *= float(boost)
-        g = GPT(LLAMA, max_batch=34 if boost is None else 4, max_seq_len=840 if boost is None else 128, weight_dtype=wd)
+        g = GPT(LLAMA, max_batch=max_batch or (34 if boost is None else 4), max_seq_len=840 if boost is None else 128, weight_dtype=wd)
         g.load_state_dict(sd)
         _models[key] = (g, sd)
         os.environ.pop("CTTS_PASS_ROWS", None)
@@ -70,6 +70,38 @@ def test_generate_golden_fp32_bit_exact_ids(name):
         # running; the CPU generator must end where the reference run left it (value minted from the reference)
         assert int(meta["attempts"]) >= 2
         np.testing.assert_array_equal(torch.rand(4).numpy(), meta["rng_next"])
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_generate_golden_b32_ragged_fp32_bit_exact_ids(compact):
+    """BASELINE configs[2] against the reference directly: gpt_real_b32_ragged was minted by the reference's own
+    GPT.generate -- 32 sequences, 23 left paddings, EOS rows boosted, rows ending at 2 .. 96 tokens.  fp32 mode with the torch-generator
+    noise reproduces every row's ids and length bit for bit, with finished rows kept in the batch (the reference's semantics) and with
+    finished-row compaction (rows dropped at chunk boundaries: 32 -> 28 -> ... rows)."""
+    z, meta = load_golden("gpt_real_b32_ragged")
+    sd, ids, mask, _ = gen_case_inputs(meta, synth.GPT_REAL)
+    g, _ = model("fp32", boost=float(meta["eos_boost"]), max_batch=32)
+    ids_t = torch.from_numpy(ids)
+    emb = g(ids_t, torch.ones(ids.shape[:2], dtype=torch.bool))
+    np.testing.assert_allclose(emb[:, -1].cpu().numpy(), z["emb_last"], atol=0, rtol=0)
+    g.compact = compact
+    torch.manual_seed(int(meta["torch_seed"]))
+    try:
+        out = list(g.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]),
+                              min_new_token=int(meta["min_new"]), logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="torch"))[-1]
+    finally:
+        g.compact = True
+    lens = z["lens"]
+    assert [int(i.shape[0]) for i in out.ids] == lens.tolist()
+    for b, n in enumerate(lens):
+        assert np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64)), f"row {b}: token ids differ"
+    for k, r in enumerate(int(x) for x in meta["hidden_rows"]):
+        n = int(lens[r])
+        assert np.abs(out.hiddens[r].cpu().numpy() - z["hiddens"][k, :n]).max() <= 1e-4, r
+    if compact:
+        assert g.compactions and g.compactions[-1][1] < 32, g.compactions       # rows really left the batch
+    else:
+        assert not g.compactions
 
 
 def test_rng_state_after_generate_matches_reference_consumption():

@@ -36,6 +36,7 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
     dsd = synth.dvae_state_dict(synth.DVAE_REAL, 1234)
     vsd = synth.vocos_state_dict(synth.VOCOS_REAL, 1234)
     esd = synth.dvae_encoder_state_dict(synth.DVAE_ENC_REAL, 1234)
+    esd.update(synth.dvae_full_decoder_state_dict(synth.DVAE_FULL_DEC, 1234))        # DVAE_full.pt = encode side + decode side + quantiser (one coef)
     for name, sd in (("GPT.pt", gsd), ("Decoder.pt", dsd), ("Vocos.pt", vsd), ("DVAE_full.pt", esd)):
         torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, tmp_path / "asset" / name)
     tok = _tokenizer(tmp_path)
@@ -62,6 +63,18 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
         wav_ref = ref_cpu.vocos_decode(vsd, mel).numpy()
         rms = float(np.sqrt(np.mean((wavs[b] - wav_ref) ** 2))) / float(np.sqrt(np.mean(wav_ref ** 2)))
         assert rms <= 1e-3, f"utterance {b}: waveform rms-rel {rms}"
+
+    # use_decoder=False (pipeline:292,435-439): the DVAE_full model decodes the generated CODE IDS (GFSQ._embed + its own decoder stack)
+    torch.manual_seed(11)
+    outs_c = list(pipe.infer(list(texts), skip_refine_text=True, do_text_optimization=False, use_decoder=False, params_infer_code=params))
+    assert len(outs_c) == 1 and len(outs_c[0]) == 2
+    for b in range(2):
+        wav_ref = ref_cpu.vocos_decode(vsd, ref_cpu.dvae_decode_codes(esd, ref.ids[b])).numpy()
+        w = outs_c[0][b].cpu().numpy()
+        assert w.shape == wav_ref.shape, f"use_decoder=False, utterance {b}: {w.shape} vs {wav_ref.shape}"
+        rms = float(np.sqrt(np.mean((w - wav_ref) ** 2))) / float(np.sqrt(np.mean(wav_ref ** 2)))
+        assert rms <= 1e-3, f"use_decoder=False, utterance {b}: waveform rms-rel {rms}"
+        assert not np.allclose(w, wavs[b], atol=1e-3)                      # really a different decoder
 
     # stream=True: the yields are consecutive sample windows of the prefix waveform; their total length is the final length
     sp = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=40, min_new_token=2, show_tqdm=False, stream_batch=8,
@@ -92,18 +105,39 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
     assert len(zs) == 1 and [w.shape[0] for w in zs[0]] == [256 * 23, 256 * 23] and all(bool(torch.isfinite(w).all()) for w in zs[0])
 
     # infer_sharded with no process group (world 1) on the real engine: per-utterance speaker rows from a table; every utterance must
-    # equal the plain infer() run with its own speaker (same seed: device noise is keyed by row, so compare one utterance at a time)
+    # equal the plain infer() run with its own speaker and the same noise key (request seed, utterance id 0)
     table = torch.stack([codec.speaker_to_vector(spk), torch.from_numpy(synth.speaker_vector(5))], 0)
     p1 = InferCodeParams(prompt="[speed_5]", max_new_token=10, min_new_token=10, show_tqdm=False)
     for which in (0, 1):
         torch.manual_seed(5)
         mine, sw, lens = pipe.infer_sharded(["a b c d"], speaker_index=[which], speaker_table=table, params_infer_code=p1)
         torch.manual_seed(5)
-        plain = list(pipe.infer(["a b c d"], skip_refine_text=True, do_text_optimization=False,
+        plain = list(pipe.infer(["a b c d"], skip_refine_text=True, do_text_optimization=False, noise="device", noise_seed=0,
                                 params_infer_code=InferCodeParams(prompt="[speed_5]", spk_emb=table[which], max_new_token=10, min_new_token=10, show_tqdm=False)))[0]
         assert mine == [0] and lens == [10] and torch.equal(sw[0], plain[0]), f"speaker {which}"
     mine, sw, lens = pipe.infer_sharded(["a b", "c d a", "b"], speaker_index=[1, 0, 1], speaker_table=table, params_infer_code=p1)
     assert mine == [0, 1, 2] and lens == [10, 10, 10] and [int(w.shape[0]) for w in sw] == [256 * 19] * 3
+
+    # Partition invariance (what an N-rank infer_sharded needs to equal the 1-rank result): the device noise of an
+    # utterance is keyed by (request seed, global utterance id, its own step / attempt), so slices of 2, 4 or all 7 utterances -- different
+    # batch rows, different left padding, different kernels (split-K path at <= 4 rows) -- produce the same tokens; waveforms agree to
+    # rounding.  The sharded entry point (world 1) gives the same again.
+    many = ["a b c d a b", "c a", "b", "d d c", "a b", "c c c c a", "b a d"]
+    pv = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=24, min_new_token=3, show_tqdm=False)
+    runs = {}
+    for ss in (2, 4, 32):
+        got = []
+        for w in pipe.infer(list(many), skip_refine_text=True, do_text_optimization=False, params_infer_code=pv, noise="device", noise_seed=77, slice_size=ss):
+            got.extend(w)
+        runs[ss] = [w.cpu().numpy() for w in got]
+    _, sw, lens = pipe.infer_sharded(list(many), params_infer_code=pv, noise_seed=77, slice_size=3)
+    runs["sharded"] = [w.cpu().numpy() for w in sw]
+    assert len(set(lens)) >= 2, lens                                          # ragged lengths: the rows really finish at different steps
+    for key in (4, 32, "sharded"):
+        for u in range(len(many)):
+            a, b2 = runs[2][u], runs[key][u]
+            assert a.shape == b2.shape, f"slice {key}, utterance {u}: {a.shape} vs {b2.shape} samples (token count differs)"
+            assert float(np.sqrt(np.mean((a - b2) ** 2))) <= 1e-4 * float(np.sqrt(np.mean(a ** 2))), f"slice {key}, utterance {u}"
 
     # default infer() path: refine-text pass first (pipeline:399-411), then code inference on the refined text
     from chatttsplus_amd.pipeline import RefineTextParams

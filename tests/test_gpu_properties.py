@@ -138,24 +138,48 @@ def test_stream_mode_yields_growing_prefixes(gpt32):
         assert torch.equal(o.ids[0], outs[-1].ids[0][:o.ids[0].shape[0]])
 
 
-def test_fused_qkv_attention_launch_matches_golden(monkeypatch):
-    """CTTS_FUSEQKV_ROWS: RMSNorm + q/k/v projection + RoPE + KV append + attention as one launch per layer (kept as a switch:
-    measured slower than the two separate launches, profiles/README.md).  Same token ids as the reference golden."""
-    from chatttsplus_amd.hip_models import GPT
-    from tests.helpers import gen_case_inputs, load_golden
-    monkeypatch.setenv("CTTS_FUSEQKV_ROWS", "2")
-    z, meta = load_golden("gpt_real_b2_pad")
-    sd, ids, mask, spk = gen_case_inputs(meta, synth.GPT_REAL)
-    g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=2, max_seq_len=64, weight_dtype="fp32")
-    g.load_state_dict(sd)
+def test_row_limits_and_compaction_keep_every_row_identical(gpt32):
+    """Per-row token limits (ctts_gen_io.row_limits) + finished-row compaction (ctts_gpt_compact): 24 sequences with limits 3 .. 70 and
+    device noise keyed by utterance id.  Every row stops exactly at its limit, its tokens are the prefix of the unlimited run's, and the
+    run with rows dropped from the batch at chunk boundaries (24 -> 20 -> ... rows; at <= 4 rows the split-K kernels take over) produces
+    the same ids as the run that keeps finished rows in the batch (the reference's semantics, gpt.py:527-546); hiddens agree to rounding."""
+    g = gpt32
+    B, T, N = 24, 40, 70
+    rng = np.random.Generator(np.random.Philox(key=8))
+    pads = [int(p) for p in rng.integers(0, 30, size=B)]
+    limits = [int(x) for x in rng.integers(3, N + 1, size=B)]
+    limits[0], limits[1], limits[2] = N, 3, 33
+    ids, mask = synth.prompt_ids(B, T, 21178, 81, pad_left=pads)
     emb = g(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
-    torch.manual_seed(int(meta["torch_seed"]))
-    out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]),
-                          min_new_token=int(meta["min_new"]), logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="torch"))[-1]
-    assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist()
-    for b, n in enumerate(z["lens"]):
-        assert np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64))
-        assert np.abs(out.hiddens[b].cpu().numpy() - z["hiddens"][b, :n]).max() <= 1e-4
+
+    def run(compact, lim):
+        g.compact = compact
+        try:
+            return list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N,
+                                   min_new_token=N, logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="device", seed=21,
+                                   utt_ids=[100 + b for b in range(B)], max_new_tokens_per_row=lim))[-1]
+        finally:
+            g.compact = True
+
+    full = run(False, None)
+    kept = run(False, limits)
+    assert not g.compactions
+    comp = run(True, limits)
+    assert g.compactions and g.compactions[-1][1] <= 8, g.compactions
+    for b in range(B):
+        n = limits[b]
+        assert kept.ids[b].shape[0] == n and comp.ids[b].shape[0] == n and full.ids[b].shape[0] == N, (b, n, kept.ids[b].shape, comp.ids[b].shape)
+        assert torch.equal(kept.ids[b], full.ids[b][:n]), f"row {b}: a limit changed the tokens before it"
+        assert torch.equal(comp.ids[b], kept.ids[b]), f"row {b}: compaction changed the tokens"
+        assert float((comp.hiddens[b] - kept.hiddens[b]).abs().max()) <= 5e-5, b
+    # the same utterances served alone (batch 1, own utterance id): same noise stream -> same tokens
+    for b in (1, 2, 23):
+        p = pads[b]
+        e1 = g(torch.from_numpy(ids[b:b + 1, p:]), torch.ones(1, T - p, dtype=torch.bool))
+        one = list(g.generate(e1, torch.from_numpy(ids[b:b + 1, p:]), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask[b:b + 1, p:]),
+                              max_new_token=N, min_new_token=N, logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="device", seed=21,
+                              utt_ids=[100 + b], max_new_tokens_per_row=[limits[b]]))[-1]
+        assert torch.equal(one.ids[0], kept.ids[b]), f"utterance {b}: batch row vs served alone"
 
 
 def test_fp16_batch_rows_independent_of_batch_composition():

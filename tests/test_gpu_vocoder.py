@@ -141,3 +141,32 @@ def test_vocos_vs_second_independent_restatement(voc, F):
     wav = v.decode(torch.from_numpy(mel)[None].cuda())[0].cpu().numpy()
     assert wav.shape == ref.shape
     assert _rms(wav - ref) <= 1e-3 * _rms(ref), f"F={F}: rms err {_rms(wav - ref)} vs signal {_rms(ref)}"
+
+
+def test_dvae_full_decode_codes_golden_and_oracle():
+    """use_decoder=False (pipeline:292): ids -> GFSQ._embed -> DVAE_full decoder stack -> mel.  Golden = the reference's own DVAE module on the
+    latent our GFSQ restatement builds (tests/golden/dvae_full_decode_real.npz); lengths 1 / 41 / 200 tokens; then the batched
+    codes -> waveform entry point against the oracle chain."""
+    from chatttsplus_amd.hip_models import Synth
+    cfg = synth.DVAE_FULL_DEC
+    sd = synth.dvae_full_decoder_state_dict(cfg, 1234)
+    vsd = synth.vocos_state_dict(synth.VOCOS_REAL, 1234)
+    s = Synth(dict(cfg), dict(synth.VOCOS_REAL), max_frames=1024, max_batch=4, vq_cfg=dict(dim=1024, levels=[5, 5, 5, 5], G=2, R=2))
+    s.load("dvae.", sd)
+    s.load("vocos.", vsd)
+    z = np.load(os.path.join(GOLDEN, "dvae_full_decode_real.npz"))
+    for n in (int(x) for x in z["lengths"]):
+        ids = z[f"ids_{n}"].astype(np.int64)
+        mel = s.dvae_decode_codes(torch.from_numpy(ids).cuda()).cpu().numpy()
+        gold = z[f"mel_{n}"]
+        assert mel.shape == gold.shape == (100, 2 * n)
+        assert _rms(mel - gold) <= 1e-3 * _rms(gold) and np.abs(mel - gold).max() <= 5e-4, f"n={n}: max err {np.abs(mel - gold).max()}"
+    batch = [torch.from_numpy(z[f"ids_{n}"].astype(np.int64)) for n in (41, 1, 200)]
+    wavs = s.decode_batch([b.cuda() for b in batch])
+    for b, w in zip(batch, wavs):
+        ref = ref_cpu.vocos_decode(vsd, ref_cpu.dvae_decode_codes(sd, b)).numpy()
+        assert w.shape[0] == ref.shape[0] == 256 * (2 * b.shape[0] - 1)
+        assert _rms(w.cpu().numpy() - ref) <= 1e-3 * _rms(ref), f"n={b.shape[0]}"
+    plain = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=64)
+    with pytest.raises(Exception, match="quantiser|not loaded"):
+        plain.dvae_decode_codes(batch[1].cuda())

@@ -28,7 +28,7 @@ def test_struct_layouts_match_header_sizes():
     import ctypes as C
     assert C.sizeof(_lib.GptCfg) == 9 * 4
     assert C.sizeof(_lib.SamplerCfg) == 4 * 4 + 4 + 3 * 4 + 17 * 4 + 6 * 4
-    assert C.sizeof(_lib.VocCfg) == 12 * 4
+    assert C.sizeof(_lib.VocCfg) == 12 * 4 + 2 * 4 + 4 * 4
     assert C.sizeof(_lib.GenIO) == 5 * 8 + 8 + 8 + 2 * 8  # 5 pointers, int32 (+pad), uint64, 2 pointers
 
 

@@ -237,3 +237,41 @@ def test_generate_matches_reference_at_batch_32():
     assert np.array_equal(np.stack([i.numpy() for i in out.ids]), z["ids"].astype(np.int64))
     for k, r in enumerate(int(x) for x in meta["hidden_rows"]):
         assert np.abs(out.hiddens[r].numpy() - z["hiddens"][k]).max() <= 2e-5, r
+
+
+def test_generate_matches_reference_at_batch_32_ragged_finish():
+    """gpt_real_b32_ragged: BASELINE configs[2] free-running through the reference's own GPT.generate with boosted EOS rows -- 32 sequences, 23
+    left paddings, rows ending at 2 .. 96 tokens (gpt.py:483-494,527-546: finish / end_idx bookkeeping while finished rows keep computing)."""
+    z, meta = load_golden("gpt_real_b32_ragged")
+    assert len(set(z["lens"].tolist())) >= 12 and z["lens"].max() >= 64
+    sd, ids, mask, _ = gen_case_inputs(meta, synth.GPT_REAL)              # (applies the EOS boost of the fixture)
+    o = ref_cpu.OracleGPT(sd, 12)
+    emb = o.embed(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
+    np.testing.assert_allclose(emb[:, -1].numpy(), z["emb_last"], atol=0, rtol=0)
+    torch.manual_seed(int(meta["torch_seed"]))
+    out = o.generate(emb, torch.from_numpy(ids), ref_cpu.SamplerParams(min_new_token=int(meta["min_new"])), attention_mask=torch.from_numpy(mask),
+                     max_new_token=int(meta["max_new"]))
+    assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist()
+    for b, n in enumerate(z["lens"]):
+        assert np.array_equal(out.ids[b].numpy(), z["ids"][b, :n].astype(np.int64)), b
+    for k, r in enumerate(int(x) for x in meta["hidden_rows"]):
+        n = int(z["lens"][r])
+        assert np.abs(out.hiddens[r].numpy() - z["hiddens"][k, :n]).max() <= 2e-5, r
+
+
+def test_dvae_full_decode_codes_matches_reference_decoder_stack():
+    """use_decoder=False (pipeline:292): the oracle's ids -> GFSQ._embed -> decoder chain against the mel the REFERENCE's DVAE module produced
+    from the same latent (dvae_full_decode_real.npz); the embed itself (third-party quantiser) is checked against its defining property:
+    the latent of a code id is the implicit FSQ codebook entry."""
+    z = np.load(os.path.join(GOLDEN, "dvae_full_decode_real.npz"))
+    sd = synth.dvae_full_decoder_state_dict(synth.DVAE_FULL_DEC, int(z["weight_seed"]))
+    for n in (int(x) for x in z["lengths"]):
+        ids = torch.from_numpy(z[f"ids_{n}"].astype(np.int64))
+        mel = ref_cpu.dvae_decode_codes(sd, ids).numpy()
+        assert np.abs(mel - z[f"mel_{n}"]).max() <= 2e-5, n
+    # implicit codebook: id = sum_d level_d * 5^d  ->  code_d = (level_d - 2) / 2; second residual level scaled by 1/4
+    ids = torch.tensor([[0, 0, 0, 0], [624, 0, 312, 0], [1, 5, 25, 125]])
+    lat = ref_cpu.gfsq_latent_from_indices(ids.t().contiguous())
+    assert torch.equal(lat[0][0], torch.tensor([-1.25, -1.25, -1.25, -1.25]))          # id 0: all levels 0 -> -1, + (-1) / 4
+    assert torch.equal(lat[0][1], torch.tensor([0.75, 0.75, 0.75, 0.75]))              # 624 -> +1 on every dim, second id 0 -> -1 / 4
+    assert torch.equal(lat[1][2], torch.tensor([-1.0, -1.0, -0.5, -1.0]) + torch.tensor([-1.0, -1.0, -1.0, -0.5]) / 4)
