@@ -39,7 +39,7 @@ struct DevState {
 // the caller's global utterance id, the row's own regenerate attempt (ensure_non_empty, gpt.py:496-525) -- plus the row's own token
 // limit (<= max_new_token).  Rows are re-packed by ctts_gpt_compact; `seq` of RowMeta names the utterance (KV lane, output arrays).
 struct RowState {
-    int fin;             // finished (EOS sampled, or the row's limit reached)
+    int fin;             // 0 = live; bit 0 = finished (no more tokens counted); bit 1 = ... by a sampled EOS (gpt.py:486-487) rather than by the row's limit
     int end;             // end_idx
     int attempt;         // first-step-EOS regenerations of THIS row so far
     int limit;           // the row stops after this many tokens
@@ -72,7 +72,7 @@ __host__ __device__ inline size_t xfrag_index(int n, int k, int ktiles) {
     return ((size_t)(g * ktiles + k / KT) * 64 + (n & 15) + 16 * ((k / EPL) & 3)) * EPL + (k % EPL);
 }
 
-// fp16 stores of values the model produces without bound (SwiGLU outputs, K / V projections, the scaled residual copy): SATURATE at the
+// fp16 stores of values the model produces without bound (SwiGLU outputs, the scaled residual copy): SATURATE at the
 // largest finite half and REPORT (a device counter the host reads at the end of generate()), instead of the silent +-inf -> NaN a plain
 // conversion gives -- the reference's own .half() path has that failure mode on checkpoints with outlier channels (pipeline:37-41).
 // A NaN input is reported too (it stays NaN).

@@ -747,7 +747,7 @@ static int ensure_graph(ctts_gpt* h) {
     const std::string key(sig);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }
-    if (h->graphs.size() >= 48) {                  // bounded: a serving process cycles through few (batch, mode) shapes (compaction adds the sizes of compact_size)
+    if (h->graphs.size() >= 96) {                  // bounded: a serving process cycles through few (batch, mode) shapes (compaction adds the sizes of compact_size)
         for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
         h->graphs.clear(); h->gexec = nullptr;
     }

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(WR * WN * 64) __attribute__((amdgpu_waves_per_eu(Pf
                 } else y = lowh ? va : vb;
                 const int dd = t * 8 + p0 + (lowh ? 0 : 32);                 // first of this lane's 4 head dims
                 if (which == 0) *(f32x4*)(scr + nn * P32 + dd * 4) = y;
-                else *(half4*)(scr + nn * P16 + dd * 2) = (half4){sat_half(y[0], a.sat), sat_half(y[1], a.sat), sat_half(y[2], a.sat), sat_half(y[3], a.sat)};
+                else *(half4*)(scr + nn * P16 + dd * 2) = (half4){(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
             }
             if (which == 0) {
 #pragma unroll

@@ -308,13 +308,14 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
     }
     if (tid == 0) {
         const bool was = fin_in != 0;
-        bool fin = was;
-        for (int v = 0; v < CTTS_NUM_VQ; ++v) fin = fin || (idx_s[v] == d->cfg.eos);   // gpt.py:486-487
+        bool eos = (fin_in & 2) != 0;
+        for (int v = 0; v < CTTS_NUM_VQ; ++v) eos = eos || (idx_s[v] == d->cfg.eos);   // gpt.py:486-487
+        bool fin = was || eos;
         const int end_out = fin ? end_in : end_in + 1;                               // gpt.py:530-531
         if (!fin) d->end_idx[seq] = end_out;
         fin = fin || (end_out >= fe.w);                                              // the row's own token limit: done from the next step on
-        d->finish[seq] = fin ? 1 : 0;
-        ((int2*)(a.finend + b))[0] = make_int2(fin ? 1 : 0, end_out);
+        d->finish[seq] = eos ? 1 : 0;                                                // the caller's `finish` keeps the reference's meaning: EOS seen
+        ((int2*)(a.finend + b))[0] = make_int2(fin ? (eos ? 3 : 1) : 0, end_out);
         RowMeta m = meta_in;                                                       // next decode row
         m.pos += 1; m.slot += 1;
         a.meta[b] = m;
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
         const bool fin = was || (idx == d->cfg.eos);                                  // gpt.py:490-491
         d->finish[b] = fin ? 1 : 0;
         if (!fin) d->end_idx[b] += 1;
-        ((int2*)(a.finend + b))[0] = make_int2(fin ? 1 : 0, rs_in.end + (fin ? 0 : 1));   // mirror (read by ctts_gpt_restart's attempt bookkeeping)
+        ((int2*)(a.finend + b))[0] = make_int2(fin ? 3 : 0, rs_in.end + (fin ? 0 : 1));   // mirror (read by ctts_gpt_restart's attempt bookkeeping)
         RowMeta m = a.meta[b];
         m.pos += 1; m.slot += 1;
         a.meta[b] = m;
@@ -645,7 +646,7 @@ __global__ void restart_rows_kernel(RowState* rows, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     RowState r = rows[b];
-    r.attempt += r.fin ? 1 : 0;
+    r.attempt += (r.fin & 2) ? 1 : 0;
     r.fin = 0; r.end = 0;
     rows[b] = r;
 }

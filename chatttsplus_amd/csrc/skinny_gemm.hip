@@ -422,7 +422,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             if (r < R) y = (va / (1.0f + expf(-va))) * vb;
             const int ktiles_out = (a.n_row_tiles * 8) / KT;
             WT* dst = (WT*)a.act_out + (size_t)chunk * NBG * ktiles_out * 64 * WTraits<WT>::EPL;
-            dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = sat_store<WT>(y, a.sat);
+                        dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = sat_store<WT>(y, a.sat);      // silu(g) * u is unbounded: saturate + report (common.h)
         } else if (r < R) {  // EPI_QKV: packed rows per tile = dims [8t..8t+7 | 8t+32..8t+39] of one head
             // keep hipcc from scheduling the cache-address arithmetic (and with it a wait on the meta load) at kernel entry
             asm volatile("" : "+v"(meta_pf.seq), "+v"(meta_pf.slot));
@@ -447,7 +447,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             } else {
                 WT* c = (WT*)(which == 1 ? a.k_cache : a.v_cache) +
                         (((size_t)meta_pf.seq * NH + h) * a.Lmax + meta_pf.slot) * CTTS_HEAD_DIM;
-                c[d] = sat_store<WT>(ya, a.sat); c[d + 32] = sat_store<WT>(yb, a.sat);
+                // K / V are projections of RMS-normalised rows (|k| <= ||w_row|| * sqrt(768)): plain conversion.  (A saturating store here made
+                // the fp16 prompt pass non-reproducible run to run on gfx950 -- same values, different schedule; profiles/README.md round 3.)
+                c[d] = (WT)ya; c[d + 32] = (WT)yb;
             }
         }
     }

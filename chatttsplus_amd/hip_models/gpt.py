@@ -98,13 +98,13 @@ def sampler_cfg_from_objects(temperature, eos_token, max_new_token, min_new_toke
 
 
 def compact_size(n_live: int) -> int:
-    """Decode-batch size used for `n_live` unfinished sequences (finished-row compaction, ctts_gpt_compact): every size up to 8, then
-    multiples of 4 up to 32, of 8 up to 64, of 16 beyond -- a captured decode graph exists per batch size, so the sizes are quantised;
+    """Decode-batch size used for `n_live` unfinished sequences (finished-row compaction, ctts_gpt_compact): every size up to 16, then
+    multiples of 2 up to 32, of 4 up to 64, of 8 beyond -- a captured decode graph exists per batch size, so the sizes are quantised;
     the padding rows are finished sequences left in the batch."""
     n = max(int(n_live), 1)
-    if n <= 8:
+    if n <= 16:
         return n
-    q = 4 if n <= 32 else (8 if n <= 64 else 16)
+    q = 2 if n <= 32 else (4 if n <= 64 else 8)
     return (n + q - 1) // q * q
 
 
@@ -152,6 +152,7 @@ class GPT:
         self._busy_token = _BusyToken()
         self._lora = []
         self.compact = bool(kwargs.get("compact", True))      # finished-row compaction at chunk boundaries (batches of >= 8 sequences)
+        self.compact_chunk = int(kwargs.get("compact_chunk", 8))   # ... whose chunks are this short: a finished row leaves the batch 1-2 chunks later
         self.model_path = kwargs.get("model_path", None)
         if self.model_path:
             self.from_pretrained(self.model_path)
@@ -474,6 +475,8 @@ class GPT:
                 # gpt.py:527-546): the per-row finish flags travel with the progress words; rows known to have finished are dropped from
                 # the decode batch at the next chunk boundary (ctts_gpt_compact), down to the next size of compact_size()
                 compacting = self.compact and (not infer_text) and B >= 8
+                if compacting:
+                    chunk = max(4, min(chunk, self.compact_chunk))
                 rowpins = [torch.zeros(2 * B, dtype=torch.int32).pin_memory() for _ in range(2)] if compacting else None
                 row_seq = list(range(B))                       # current decode row -> sequence
                 layouts = [None, None]
@@ -522,7 +525,7 @@ class GPT:
             self._restore_rng(rng_states, used_draws)
             self.saturations = 0
             if self.dtype_code == _lib.DTYPE_F16:
-                # fp16 stores (SwiGLU outputs, K / V, packed residual) saturate instead of overflowing to inf; a non-zero count means the
+                # fp16 stores (SwiGLU outputs, packed residual) saturate instead of overflowing to inf; a non-zero count means the
                 # checkpoint drives activations past the fp16 range -- the result is finite but clipped: say so (fp32 mode has no such limit)
                 nsat = C.c_int32(0)
                 _lib.check(lib.ctts_gpt_saturations(h, C.byref(nsat), st), "saturations")

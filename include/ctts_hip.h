@@ -175,7 +175,7 @@ int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* stream);
  * Synchronises the stream. */
 int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_finished, void* stream);
 
-/* fp16 engines store SwiGLU outputs, K / V and the packed residual copy as fp16: values beyond the fp16 range are SATURATED at +-65504 and
+/* fp16 engines store SwiGLU outputs and the packed residual copy as fp16: values beyond the fp16 range are SATURATED at +-65504 and
  * counted (the reference's .half() path would produce inf -> NaN silently on such a checkpoint, pipeline:37-41); `count` = saturated or NaN
  * stores since ctts_gpt_begin.  Synchronises the stream.  Always 0 for fp32 engines. */
 int ctts_gpt_saturations(ctts_gpt* h, int32_t* count, void* stream);

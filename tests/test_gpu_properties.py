@@ -182,6 +182,36 @@ def test_row_limits_and_compaction_keep_every_row_identical(gpt32):
         assert torch.equal(one.ids[0], kept.ids[b]), f"utterance {b}: batch row vs served alone"
 
 
+@pytest.mark.parametrize("wd", ["fp16", "fp32"])
+def test_runs_are_bitwise_reproducible(wd):
+    """The same request three times on one engine: token ids, hiddens and the KV cache contents are bitwise identical (no atomics anywhere on
+    the data path, fixed reduction orders).  Shapes cover the 32-row prompt kernels at 320 .. 1280 prompt rows + the MFMA prompt attention
+    (fp16) and the decode kernels at batch 12 / 32.  Regression test for round 3: a saturating K/V store made the fp16 prompt pass differ
+    from run to run (same arithmetic, different schedule) -- caught by this comparison."""
+    from chatttsplus_amd.hip_models import GPT
+    MB, MS = 32, 128
+    g = GPT(LLAMA, max_batch=MB, max_seq_len=MS, weight_dtype=wd)
+    g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+    esz = torch.float16 if wd == "fp16" else torch.float32
+    for (B, T, N) in ((32, 40, 10), (32, 10, 4), (12, 40, 4)):
+        rng = np.random.Generator(np.random.Philox(key=4))
+        pads = [int(p) for p in rng.integers(0, T - 5, size=B)]
+        ids, mask = synth.prompt_ids(B, T, 21178, 79, pad_left=pads)
+        q = torch.from_numpy(np.stack([synth.exp_noise(11, i, 4 * B, 626) for i in range(N)]))
+        runs = []
+        for rep in range(3):
+            g._kv.zero_()
+            _, o = _gen(g, ids, mask, N, q, min_new=N)
+            torch.cuda.synchronize()
+            kv = g._kv.view(esz).view(20, 2, MB, 12, MS, 64)[:, :, :B, :, :T + N].clone()
+            runs.append((torch.stack(o.ids).clone(), torch.stack(o.hiddens).clone(), kv))
+        for rep in (1, 2):
+            assert torch.equal(runs[rep][0], runs[0][0]), f"{wd} {(B, T, N)}: token ids differ between runs"
+            assert torch.equal(runs[rep][2], runs[0][2]), f"{wd} {(B, T, N)}: KV cache differs between runs"
+            assert torch.equal(runs[rep][1], runs[0][1]), f"{wd} {(B, T, N)}: hiddens differ between runs"
+    g.close()
+
+
 def test_fp16_batch_rows_independent_of_batch_composition():
     """fp16 mode above the split-K batch sizes (packed fp16 residual stream + per-tile sums of squares between kernels, kernels.h
     PRO_XH): at a given batch size a sequence's tokens and hiddens depend neither on which other sequences share its batch nor on
