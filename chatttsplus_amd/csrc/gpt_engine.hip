@@ -9,7 +9,7 @@
 //   xh / ssq / scale fp16 decode above the split-K batch sizes: the residual stream as packed fp16 B operand + per-tile sums of squares + per-row
 //                    power-of-two scales, handed from the o_proj / down epilogues to the next QKV / gate|up / heads kernels (kernels.h PRO_XH)
 //   lora_*           resident per-utterance adapters and the low-rank terms of the rows being processed (lora.hip)
-//   dpart            [rows <= 16][4][768] ordered split-K partial sums of the down projection (decode batches <= 4)
+//   dpart            [rows <= 32][4][768] ordered split-K partial sums of the down projection (decode batches <= split_rows)
 //   st / dyn         DevState (per-step counters) and SamplerDyn (per-call buffers and sampling parameters): everything a captured
 //                    decode graph would otherwise bake in is read from these two device blocks
 #include <stdarg.h>
@@ -71,9 +71,13 @@ struct ctts_gpt {
     void* attn_packed = nullptr;
     void* norm_packed = nullptr;                 // prompt pass: RMSNorm'ed rows in the GEMMs' fragment-major operand layout (norm_pack_kernel)
     int split_rows = 4;                          // decode batches up to this size run the down projection as 4 split-K launch slices whose
-                                                 // partial sums the next consumers add (0 = off): 48x1024-thread blocks -> 192x256;
-                                                 // measured -3 % step time at batch 1-2, -1.7 % at 4, +0.5 % at 8
-    float* dpart = nullptr;                      // [rows<=16][4][768]
+                                                 // partial sums the next consumers add (0 = off): 48 x 1024-thread blocks -> 192 x 256/512.
+                                                 // fp16: 8 (us/step with the threshold at 4 / 16: batch 5 474 / 458, 8 477 / 470, 16 515 / 585 -- above 8 the
+                                                 // packed-fp16 residual hand-off wins); fp32: 16 = every single-chunk batch (batch 5 633 -> 572, 8 674 -> 612,
+                                                 // 16 766 -> 712: 48 blocks pulling 9.4 MB of fp32 weights + as many bytes of fp32 activations through 48 CUs were
+                                                 // the slowest launch of the layer; with two 16-row chunks the partial sums cost the next QKV prologue what the
+                                                 // split saves: batch 20 / 24 / 28 / 32 835 / 892 / 914 / 941 either way)
+    float* dpart = nullptr;                      // [rows<=32][4][768]
     int cur_splits = 1;                          // key splits of the decode attention for the steps being launched (decode_splits)
     int launched = 0;                            // decode steps enqueued since begin / restart: host-side bound on the context length
     int nbg2_rows = 33;                          // decode batches of at least this many rows use 32-row blocks instead of 16-row chunks.
@@ -144,9 +148,10 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->cfg = *c;
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
+    h->split_rows = (c->dtype == CTTS_DTYPE_F16) ? 8 : 16;
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
     // product library takes no behaviour from the environment on its launch paths (diag_env() is a constant null there).
-    if (const char* sr = diag_env("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 16) h->split_rows = 16; }
+    if (const char* sr = diag_env("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 32) h->split_rows = 32; }
     if (const char* nr = diag_env("CTTS_NBG2_ROWS")) h->nbg2_rows = atoi(nr);
     if (const char* xm = diag_env("CTTS_XH")) h->xh_mode = atoi(xm) ? 1 : 0;
     if (const char* gs = diag_env("CTTS_GRAPH_STEPS")) { h->graph_steps = atoi(gs); if (h->graph_steps < 1) h->graph_steps = 1; }
@@ -443,7 +448,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->part_ml, (size_t)(CTTS_MAX_B + 32) * NH * SMAX * 2 * 4) ||          // flash-decoding partials: decode rows only (the prompt pass never splits keys)
         dev_alloc((void**)&h->part_o, (size_t)(CTTS_MAX_B + 32) * NH * SMAX * CTTS_HEAD_DIM * 4) ||
         dev_alloc((void**)&h->logits, (size_t)CTTS_MAX_B * (h->NVQ * h->V > h->vocab_text_head ? h->NVQ * h->V : h->vocab_text_head) * 4) || dev_alloc(&h->act, act_bytes) || dev_alloc((void**)&h->rope_pre, (size_t)MB * h->cfg.max_seq * 64 * 4) ||
-        dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->dpart, (size_t)16 * 4 * H * 4) || dev_alloc(&h->attn_packed, (size_t)((PASS_ROWS + PASS_PAD) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
+        dev_alloc((void**)&h->rope_dec, (size_t)CTTS_MAX_B * 64 * 4) || dev_alloc((void**)&h->dpart, (size_t)32 * 4 * H * 4) || dev_alloc(&h->attn_packed, (size_t)((PASS_ROWS + PASS_PAD) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc(&h->norm_packed, (size_t)((PASS_ROWS + PASS_PAD) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) ||
         dev_alloc((void**)&h->meta_pre, (size_t)MB * h->cfg.max_seq * sizeof(RowMeta)) ||
         dev_alloc((void**)&h->meta_dec, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->meta_dec0, CTTS_MAX_B * sizeof(RowMeta)) ||
