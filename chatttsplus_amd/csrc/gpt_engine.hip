@@ -458,7 +458,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->cx, (size_t)CTTS_MAX_B * H * 4) || dev_alloc((void**)&h->crope, (size_t)CTTS_MAX_B * 64 * 4) ||
         dev_alloc((void**)&h->cmeta, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->cring, (size_t)CTTS_MAX_B * CTTS_NUM_VQ * 16 * 4) ||
         dev_alloc((void**)&h->cfin, (size_t)CTTS_MAX_B * sizeof(RowState)) || dev_alloc((void**)&h->keep_dev, CTTS_MAX_B * 4) ||
-        dev_alloc(&h->xh, (size_t)((CTTS_MAX_B + 32) / 16) * (H / 32) * 1024) || dev_alloc((void**)&h->ssq, (size_t)(CTTS_MAX_B + 32) * (H / 16) * 4) ||
+        dev_alloc(&h->xh, (size_t)((CTTS_MAX_B + 32) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) || dev_alloc((void**)&h->ssq, (size_t)(CTTS_MAX_B + 32) * (H / 16) * 4) ||
         dev_alloc((void**)&h->scale_o, (size_t)(CTTS_MAX_B + 32) * 4) || dev_alloc((void**)&h->scale_d, (size_t)(CTTS_MAX_B + 32) * 4))
         return 1;
     CTTS_HIP_CHECK(hipHostMalloc((void**)&h->host_pin, 64));
@@ -547,10 +547,12 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // (measured with 128 x 128 blocks, prompt pass ms with / without it: 512 rows 2.31 / 1.48, 1024 rows 2.47 / 2.29, 1536 rows 2.70 / 3.12,
     //  2048 rows 2.81 / 3.9, 3072 rows 3.6 / 5.3, 16384 rows 10.3 / 29)
     const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && h->prefill_gemm_rows > 0 && (R >= h->prefill_gemm_rows) && !lora;
-    // fp16 decode above the split-K batch sizes: the residual stream travels between kernels as a packed fp16 B operand + per-tile
+    // decode above the split-K batch sizes: the residual stream travels between kernels as a packed B operand in the engine dtype + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself.  (Handing gate|up
-    // the packed copy at batches <= 4 too was measured slower: batch 1 393 vs 381 us/step, 2 415 vs 403, 4 450 vs 443.)
-    const bool xhm = (dt == CTTS_DTYPE_F16) && (st != nullptr) && h->xh_mode && !splitd;
+    // the packed copy at batches <= 4 too was measured slower in fp16: batch 1 393 vs 381 us/step, 2 415 vs 403, 4 450 vs 443.)
+    // fp32: the RMSNorm factor then multiplies the C tile instead of the operand -- (sum w x) rs instead of sum w (x rs), one rounding
+    // apart; token ids stay bit-exact on every golden (tests/test_gpu_gpt.py)
+    const bool xhm = (st != nullptr) && h->xh_mode && !splitd;
     if (form) { form->parts = splitd; form->xh = xhm; }
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};

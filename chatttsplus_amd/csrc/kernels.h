@@ -3,8 +3,8 @@
 #include "common.h"
 
 enum { PRO_NORM = 0, PRO_ATTN = 1, PRO_PACKED = 2, PRO_NORM_P = 3, PRO_XH = 4 };     // _P: residual stream = x + the down projection's split-K partial sums
-// PRO_XH (fp16 decode, > 4 rows): the B operand is the residual stream as the PREVIOUS kernel's epilogue (EPI_RESID_XH) left it -- fp16,
-// fragment-major, scaled by a per-row power of two -- and the RMSNorm factor is applied to the C tile after the MFMAs from the
+// PRO_XH (decode above the split-K batch sizes): the B operand is the residual stream as the PREVIOUS kernel's epilogue (EPI_RESID_XH) left
+// it -- engine dtype, fragment-major, scaled by a per-row power of two -- and the RMSNorm factor is applied to the C tile after the MFMAs from the
 // producer's per-tile sums of squares: no block re-reads and re-normalises fp32 rows (16 rows x 3 KB per block, replicated in up to
 // 768 blocks per launch, was the prologue of every QKV / gate|up launch).
 enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_P = 4, EPI_PART = 5, EPI_RESID_XH = 6 };   // PART: write a split-K partial, no residual; RESID_XH: see PRO_XH
@@ -44,7 +44,7 @@ struct GemmArgs {
     float* logits;          // EPI_LOGITS: [R][n_valid]
     int n_valid;            // valid output rows (2504)
     // PRO_XH / EPI_RESID_XH (see the enum comment)
-    void* xh;               // fp16 fragment-major residual stream [chunk][g][24 k-tiles][lane][16 B]: written by EPI_RESID_XH, read by PRO_XH (as in0)
+    void* xh;               // fragment-major residual stream [chunk][g][24 / 48 k-tiles][lane][16 B] (engine dtype): written by EPI_RESID_XH, read by PRO_XH (as in0)
     float* ssq;             // [rows][48] sum of squares of the fp32 residual row over each 16-column tile (written by EPI_RESID_XH)
     const float* scale_in;  // [rows] power-of-two scale of the xh rows: EPI_RESID_XH multiplies by it, PRO_XH divides the C tile by it
     float* scale_out;       // [rows] PRO_XH / PRO_NORM (block 0): 2^floor(log2(rs)) of this normalisation = the scale of the NEXT xh rows

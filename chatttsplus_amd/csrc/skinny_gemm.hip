@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             const int r = row0 + (t >> 4);
             // scale_in rides on the leading scalar in1 (free for PRO_PACKED); the rare PRO_ATTN variant reads it from the struct
             xh_scale_pf[u] = (EPI == EPI_RESID_XH && t < 16 * NB && r < R) ? ((PRO == PRO_ATTN) ? a.scale_in[r] : ((const float*)in1)[r])
-                           : (EPI == EPI_RESID_P && a.xh != nullptr && t < 16 * NB && r < R) ? a.scale_in[r] : 1.f;     // split-K batches: see EPI_RESID_P below
+                           : 1.f;
             const int N = a.n_row_tiles * 16, col = rt0 * 16 + (t & 15);
             float v = 0.f;
             if (t < 16 * NB && r < R) {
@@ -389,14 +389,6 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             } else if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
                 const float xn = resid_pf[u] + v;                                    // residual + proj (llama.py:731,739)
                 a.x_out[(size_t)r * (a.n_row_tiles * 16) + col] = xn;
-                if (EPI == EPI_RESID_P && a.xh != nullptr) {
-                    // batches <= 4 (split-K down projection): o_proj re-materialises x and hands it to gate|up like EPI_RESID_XH does
-                    float sq = xn * xn;
-                    sq += dpp_f<DPP_XOR1>(sq); sq += dpp_f<DPP_XOR2>(sq); sq += dpp_f<DPP_HALF_MIRROR>(sq); sq += dpp_f<DPP_MIRROR>(sq);
-                    if (i == 0) a.ssq[(size_t)r * a.n_row_tiles + rt] = sq;
-                    half_t* dst = (half_t*)a.xh + (size_t)chunk * NBG * 24 * 64 * 8;
-                    dst[xfrag_index<half_t>(n, col, 24)] = sat_half(xn * xh_scale_pf[u], a.sat);
-                }
             } else if (EPI == EPI_RESID_XH) {
                 // the 16 lanes of a DPP row hold the 16 columns of (row r, tile rt): fp32 residual as before, plus what the next
                 // PRO_XH kernel reads -- the row's sum of squares over this tile and the fp16 (power-of-two scaled) packed copy
@@ -405,9 +397,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 float sq = xn * xn;
                 sq += dpp_f<DPP_XOR1>(sq); sq += dpp_f<DPP_XOR2>(sq); sq += dpp_f<DPP_HALF_MIRROR>(sq); sq += dpp_f<DPP_MIRROR>(sq);
                 if (i == 0) a.ssq[(size_t)r * a.n_row_tiles + rt] = sq;
-                constexpr int KT_OUT = 768 / 32;                  // the stream is H = 768 wide: 24 fp16 k-tiles
-                half_t* dst = (half_t*)a.xh + (size_t)chunk * NBG * KT_OUT * 64 * 8;
-                dst[xfrag_index<half_t>(n, col, KT_OUT)] = sat_half(xn * xh_scale_pf[u], a.sat);
+                constexpr int KT_OUT = 768 / KT;                  // the stream is H = 768 wide: 24 fp16 / 48 fp32 k-tiles
+                WT* dst = (WT*)a.xh + (size_t)chunk * NBG * KT_OUT * 64 * WTraits<WT>::EPL;
+                dst[xfrag_index<WT>(n, col, KT_OUT)] = sat_store<WT>(xn * xh_scale_pf[u], a.sat);
             } else if (col < a.n_valid) {
                 a.logits[(size_t)r * a.n_valid + col] = v;
             }
@@ -536,7 +528,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         }
         rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, true);
         rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, true);
-        if constexpr (F16) {
+        {
             rc |= launch_one<WT, NBG, W768, P768, PRO_XH, EPI_QKV, RT_XH>(a, chunks, s, true);
             rc |= launch_one<WT, NBG, W768, P768, PRO_XH, EPI_SWIGLU, RT_XH>(a, chunks, s, true);
             rc |= launch_one<WT, NBG, W768, P768, PRO_XH, EPI_LOGITS>(a, chunks, s, true);
@@ -567,7 +559,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     if (pro == PRO_PACKED && epi == EPI_RESID && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_PACKED && epi == EPI_RESID) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_NORM && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_LOGITS>(a, chunks, s, false);
-    if constexpr (F16) {
+    {
         if (pro == PRO_XH && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_XH, EPI_QKV, RT_XH>(a, chunks, s, false);
         if (pro == PRO_XH && epi == EPI_SWIGLU) return launch_one<WT, NBG, W768, P768, PRO_XH, EPI_SWIGLU, RT_XH>(a, chunks, s, false);
         if (pro == PRO_XH && epi == EPI_LOGITS) return launch_one<WT, NBG, W768, P768, PRO_XH, EPI_LOGITS>(a, chunks, s, false);
