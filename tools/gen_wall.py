@@ -11,11 +11,12 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--steps", type=int, default=512)
 ap.add_argument("--noise", default="torch")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--dtype", default="fp32")
 ap.add_argument("--text", action="store_true", help="refine-text pass: infer_text=True on the 21178-way head (top-p 0.7, top-k 20, T 0.7)")
 a = ap.parse_args()
 cfg = synth.GPT_REAL
 g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=max(a.batch, 1),
-        max_seq_len=48 + a.steps + 8)
+        max_seq_len=48 + a.steps + 8, weight_dtype=a.dtype)
 g.load_state_dict(synth.gpt_state_dict(cfg, 7))
 ids = torch.from_numpy(synth.prompt_ids(a.batch, 48, cfg["num_text_tokens"], 3)[0]).cuda()
 emb = g(ids, torch.ones(a.batch, 48, dtype=torch.bool, device="cuda"))
@@ -40,5 +41,5 @@ for r in range(a.reps + 1):
 n = int(res[-1].ids[0].shape[0])
 best = min(out)
 print(json.dumps({k: round(v, 2) for k, v in g.host_timing.items()}))
-print(json.dumps({"batch": a.batch, "steps": n, "noise": a.noise, "wall_ms": round(best * 1e3, 2),
+print(json.dumps({"batch": a.batch, "dtype": a.dtype, "steps": n, "noise": a.noise, "wall_ms": round(best * 1e3, 2),
                   "us_per_step_wall": round(best / n * 1e6, 1), "tokens_per_s_wall": round(a.batch * n / best, 1)}))

@@ -1,5 +1,5 @@
 """Per-kernel register / LDS / scratch usage of the gfx950 code objects, from the compiler's own metadata (no GPU needed):
-    python tools/kernel_resources.py > profiles/r02_kernel_resources.md
+    python tools/kernel_resources.py > profiles/r03_kernel_resources.md
 Waves per SIMD follow MI355X_MICROARCH.md (512 registers per lane and SIMD, allocation granule 8, at most 8 waves)."""
 import os
 import re

@@ -1,5 +1,5 @@
 """Host-inclusive wall clock of ChatTTSPlusPipeline.infer() (tokenize -> embed -> generate -> DVAE/Vocos), synthetic
-checkpoints and a toy vocabulary.  python tools/pipe_wall.py [--n 1] [--tokens 512] [--dtype fp16]"""
+checkpoints and a toy vocabulary.  python tools/pipe_wall.py [--n 1] [--tokens 512] [--dtype fp32|fp16]"""
 import argparse, json, os, sys, tempfile, time, pathlib
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "[Stts]", "[Ptts]", "[spk
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1, help="texts per infer() call")
 ap.add_argument("--tokens", type=int, default=512)
-ap.add_argument("--dtype", default="fp16")
+ap.add_argument("--dtype", default="fp32")
 ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
