@@ -42,6 +42,8 @@ extern "C" int ctts_version(void) { return 1; }
 
 struct LayerW {
     void *qkv, *o, *gu, *d;      // RMSNorm weights are folded into qkv / gu columns
+    // fp32 engines that can see a prompt pass of >= 1536 rows: head / tail fp16 images of 64 * W (prefill_split.hip), same tile order
+    void *qkv_hi = nullptr, *qkv_lo = nullptr, *o_hi = nullptr, *o_lo = nullptr, *gu_hi = nullptr, *gu_lo = nullptr, *d_hi = nullptr, *d_lo = nullptr;
 };
 
 struct ctts_gpt {
@@ -52,6 +54,9 @@ struct ctts_gpt {
     bool finalized = false;
     // device
     char* wblob = nullptr;
+    char* wsplit = nullptr;                      // fp32 engines: the split images of every layer matrix (2 x 2 bytes per weight), or null
+    void *sp_x_hi = nullptr, *sp_x_lo = nullptr, *sp_act_hi = nullptr, *sp_act_lo = nullptr;   //   ... and of the prompt rows' operands
+    int split_rows_min = 1536;                   //   prompt passes of at least this many rows use them (diagnostic builds: CTTS_PREFILL_SPLIT, 0 = never)
     std::vector<LayerW> lw;
     void* whead = nullptr;
     void* whead_text = nullptr;                  // refine-text head (21178 x H), packed like whead; optional
@@ -159,6 +164,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     if (diag_env("CTTS_NO_PREPACK")) h->no_prepack = 1;
     if (const char* e = diag_env("CTTS_PREFILL_GEMM")) { const int v = atoi(e); h->prefill_gemm_rows = v > 1 ? v : (v == 1 ? 1536 : 0); }
     if (diag_env("CTTS_NO_XH_HEADS")) h->xh_heads = 0;
+    if (const char* e = diag_env("CTTS_PREFILL_SPLIT")) h->split_rows_min = atoi(e);
     if (gemm_configure()) { delete h; return 1; }
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -171,7 +177,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
 extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
-    void* bufs[] = {h->dyn, h->wblob, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
+    void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
                     h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do};
@@ -323,6 +329,28 @@ static void pack_tiles(WT* dst, int n_row_tiles, int K, RowFn rows, const float*
         }
 }
 
+// head / tail fp16 images of 64 * W in the fp16 tile layout (prefill_split.hip): hi = fp16(v), lo = fp16(v - hi)
+template <typename RowFn>
+static void pack_tiles_split(half_t* hi, half_t* lo, int n_row_tiles, int K, RowFn rows, const float* colscale = nullptr) {
+    constexpr int KT = 32, EPL = 8;
+    const int ktiles = K / KT;
+    for (int rt = 0; rt < n_row_tiles; ++rt)
+        for (int i = 0; i < 16; ++i) {
+            const float* src = rows(rt * 16 + i);
+            for (int kt = 0; kt < ktiles; ++kt)
+                for (int kq = 0; kq < 4; ++kq) {
+                    const size_t o = (((size_t)rt * ktiles + kt) * 64 + i + 16 * kq) * EPL;
+                    const int k0 = kt * KT + kq * EPL;
+                    for (int j = 0; j < EPL; ++j) {
+                        const float v = 64.0f * (colscale ? src[k0 + j] * colscale[k0 + j] : src[k0 + j]);       // == SP_WSCALE; the product rounds exactly like pack_tiles'
+                        const half_t h = (half_t)v;
+                        hi[o + j] = h;
+                        lo[o + j] = (half_t)(v - (float)h);
+                    }
+                }
+        }
+}
+
 static const std::vector<float>* need(ctts_gpt* h, const std::string& k, size_t numel) {
     auto it = h->host.find(k);
     if (it == h->host.end()) { ctts_set_error("missing weight %s", k.c_str()); return nullptr; }
@@ -341,6 +369,13 @@ static int finalize_t(ctts_gpt* h) {
     std::vector<WT> blob(total);
     h->lw.resize(L);
     if (dev_alloc((void**)&h->wblob, total * sizeof(WT))) return 1;
+    // fp32 engine whose prompt passes can reach the split-GEMM threshold: head / tail fp16 images of the layer matrices too
+    const bool want_split = (sizeof(WT) == 4) && h->split_rows_min > 0 && (long)h->cfg.max_batch * h->cfg.max_seq >= h->split_rows_min;
+    std::vector<half_t> sblob;
+    if (want_split) {
+        sblob.resize(per_layer * 2);
+        if (dev_alloc((void**)&h->wsplit, per_layer * L * 2 * sizeof(half_t))) return 1;
+    }
     for (int l = 0; l < L; ++l) {
         const std::string p = "gpt.layers." + std::to_string(l) + ".";
         const std::vector<float>*q = need(h, p + "self_attn.q_proj.weight", n_o), *k = need(h, p + "self_attn.k_proj.weight", n_o),
@@ -368,6 +403,30 @@ static int finalize_t(ctts_gpt* h) {
             return (i < 8) ? g->data() + (size_t)(rt * 8 + i) * H : u->data() + (size_t)(rt * 8 + i - 8) * H;
         }, l2->data());
         pack_tiles<WT>(base + n_qkv + n_o + n_gu, HT, I, [&](int pr) { return d->data() + (size_t)pr * I; });
+        if (want_split) {
+            const int HT2 = H / 16;
+            half_t *shi = sblob.data(), *slo = sblob.data() + per_layer;
+            pack_tiles_split(shi, slo, 3 * HT2, H, [&](int pr) -> const float* {
+                const int rt = pr / 16, i = pr % 16;
+                const int which = rt / HT2, within = rt % HT2, hh = within / 4, tq = within % 4;
+                const int dd = (i < 8) ? 8 * tq + i : 8 * tq + (i - 8) + 32;
+                const std::vector<float>* src = which == 0 ? q : (which == 1 ? k : v);
+                return src->data() + (size_t)(hh * CTTS_HEAD_DIM + dd) * H;
+            }, l1->data());
+            pack_tiles_split(shi + n_qkv, slo + n_qkv, HT2, H, [&](int pr) { return o->data() + (size_t)pr * H; });
+            pack_tiles_split(shi + n_qkv + n_o, slo + n_qkv + n_o, 2 * I / 16, H, [&](int pr) -> const float* {
+                const int rt = pr / 16, i = pr % 16;
+                return (i < 8) ? g->data() + (size_t)(rt * 8 + i) * H : u->data() + (size_t)(rt * 8 + i - 8) * H;
+            }, l2->data());
+            pack_tiles_split(shi + n_qkv + n_o + n_gu, slo + n_qkv + n_o + n_gu, HT2, I, [&](int pr) { return d->data() + (size_t)pr * I; });
+            char* sv = h->wsplit + per_layer * l * 2 * sizeof(half_t);
+            CTTS_HIP_CHECK(hipMemcpy(sv, sblob.data(), per_layer * 2 * sizeof(half_t), hipMemcpyHostToDevice));
+            char* lov = sv + per_layer * sizeof(half_t);
+            h->lw[l].qkv_hi = sv; h->lw[l].qkv_lo = lov;
+            h->lw[l].o_hi = sv + n_qkv * 2; h->lw[l].o_lo = lov + n_qkv * 2;
+            h->lw[l].gu_hi = sv + (n_qkv + n_o) * 2; h->lw[l].gu_lo = lov + (n_qkv + n_o) * 2;
+            h->lw[l].d_hi = sv + (n_qkv + n_o + n_gu) * 2; h->lw[l].d_lo = lov + (n_qkv + n_o + n_gu) * 2;
+        }
         char* dv = h->wblob + per_layer * l * sizeof(WT);
         h->lw[l].qkv = dv;
         h->lw[l].o = dv + n_qkv * sizeof(WT);
@@ -461,6 +520,10 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc(&h->xh, (size_t)((CTTS_MAX_B + 32) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) || dev_alloc((void**)&h->ssq, (size_t)(CTTS_MAX_B + 32) * (H / 16) * 4) ||
         dev_alloc((void**)&h->scale_o, (size_t)(CTTS_MAX_B + 32) * 4) || dev_alloc((void**)&h->scale_d, (size_t)(CTTS_MAX_B + 32) * 4))
         return 1;
+    if (h->wsplit) {     // operand images of the prompt rows for the split GEMMs: heads / tails of the normalised rows | attention outputs (K = 768) and of the SwiGLU outputs (K = 3072)
+        const size_t rows = (size_t)PASS_ROWS + PASS_PAD;
+        if (dev_alloc(&h->sp_x_hi, rows * H * 2) || dev_alloc(&h->sp_x_lo, rows * H * 2) || dev_alloc(&h->sp_act_hi, rows * h->I * 2) || dev_alloc(&h->sp_act_lo, rows * h->I * 2)) return 1;
+    }
     CTTS_HIP_CHECK(hipHostMalloc((void**)&h->host_pin, 64));
     {
         auto it = h->host.find("emb_text.weight");
@@ -547,6 +610,10 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // (measured with 128 x 128 blocks, prompt pass ms with / without it: 512 rows 2.31 / 1.48, 1024 rows 2.47 / 2.29, 1536 rows 2.70 / 3.12,
     //  2048 rows 2.81 / 3.9, 3072 rows 3.6 / 5.3, 16384 rows 10.3 / 29)
     const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && h->prefill_gemm_rows > 0 && (R >= h->prefill_gemm_rows) && !lora;
+    // prompt pass over >= 1536 rows, fp32 engine: the same tiling on the fp16 pipes with head / tail operands -- 3 MFMAs per product instead of 16,
+    // fp32-level accuracy (prefill_split.hip); the attention stays the fp32 row kernel
+    const bool pfs = prepack && (dt == CTTS_DTYPE_F32) && h->wsplit != nullptr && h->split_rows_min > 0 && (R >= h->split_rows_min) && !lora;
+    const float sp_scale = 1.0f / 64.0f;
     // decode above the split-K batch sizes: the residual stream travels between kernels as a packed B operand in the engine dtype + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself.  (Handing gate|up
     // the packed copy at batches <= 4 too was measured slower in fp16: batch 1 393 vs 381 us/step, 2 415 vs 403, 4 450 vs 443.)
@@ -568,7 +635,10 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
                                       h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_dqkv, R, h->H, s)) return 1;
             g1.lora_delta = h->lora_dqkv;
         }
-        if (prepack) {
+        if (pfs) {
+            if (launch_norm_pack_split(x, h->sp_x_hi, h->sp_x_lo, R, a.eps, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_QKV, g1, h->lw[l].qkv_hi, h->lw[l].qkv_lo, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, s)) return 1;
+        } else if (prepack) {
             g1.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
             if (pfg ? launch_prefill_gemm(EPI_QKV, g1, s) : launch_gemm(dt, nbg, PRO_PACKED, EPI_QKV, g1, chunks, s)) return 1;
@@ -582,7 +652,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
         if (st == nullptr) { at.T = h->T; at.row0 = (int)(meta - h->meta_pre); }       // prompt pass: position of this pass in the flattened [B][T] prompt
         at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
-        if (launch_attention(dt, at, s)) return 1;
+        if (pfs && S == 1) { if (launch_attention_split(at, h->sp_x_hi, h->sp_x_lo, s)) return 1; }      // writes o_proj's head / tail operand images directly
+        else if (launch_attention(dt, at, s)) return 1;
         // softmax combine + o_proj + residual (S == 1: attention already wrote the normalised, packed B operand)
         GemmArgs g2 = a;
         g2.W = h->lw[l].o; g2.n_row_tiles = h->H / 16; g2.K = h->H; g2.part_ml = h->part_ml; g2.part_o = h->part_o; g2.S = S; g2.x_out = x;
@@ -595,12 +666,17 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
                                     h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_do, R, h->H, s)) return 1;
             g2.lora_delta = h->lora_do;
         }
-        if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
+        if (pfs && S == 1) {
+            if (launch_prefill_split_gemm(EPI_RESID, g2, h->lw[l].o_hi, h->lw[l].o_lo, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, s)) return 1;
+        } else if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
         else if (launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (splitd ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
         // RMSNorm + gate|up + SiLU*up
         GemmArgs g3 = a;
         g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act;
-        if (prepack) {
+        if (pfs) {
+            if (launch_norm_pack_split(x, h->sp_x_hi, h->sp_x_lo, R, a.eps, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_SWIGLU, g3, h->lw[l].gu_hi, h->lw[l].gu_lo, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, sp_scale, s)) return 1;
+        } else if (prepack) {
             g3.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
             if (pfg ? launch_prefill_gemm(EPI_SWIGLU, g3, s) : launch_gemm(dt, nbg, PRO_PACKED, EPI_SWIGLU, g3, chunks, s)) return 1;
@@ -611,7 +687,9 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         // down + residual
         GemmArgs g4 = a;
         g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x;
-        if (pfg) {
+        if (pfs) {      // the SwiGLU images hold silu(g) * u / 16
+            if (launch_prefill_split_gemm(EPI_RESID, g4, h->lw[l].d_hi, h->lw[l].d_lo, h->sp_act_hi, h->sp_act_lo, nullptr, nullptr, sp_scale * 16.0f, s)) return 1;
+        } else if (pfg) {
             if (launch_prefill_gemm(EPI_RESID, g4, s)) return 1;
         } else if (splitd) {
             g4.part_out = h->dpart; g4.ktiles_total = h->I / (h->esz == 2 ? 32 : 16);

@@ -1,0 +1,443 @@
+// Prompt-pass projections of the PARITY (fp32) engine on the fp16 MFMA pipes: a 3-term split GEMM with fp32-level accuracy (gfx950).
+//
+//   C[rows][N] = X[rows][K] . W[N][K]^T,   X = Xhi + Xlo,  W = (Whi + Wlo) / 64,   every part an fp16 image,
+//   C = (Xhi.Whi + Xhi.Wlo + Xlo.Whi) / 64      (the dropped Xlo.Wlo term is 2^-22 of a product: below fp32 rounding of the sum)
+//
+// Why: the fp32 engine's prompt pass ran the decode kernels over 32-row chunks (every weight tile re-read from L2 once per chunk) on
+// v_mfma_f32_16x16x4_f32, whose peak is 1/16 of the fp16 pipe's: 110 ms for 32 x 512 prompt tokens against 9.6 ms in the fp16 engine.
+// fp16 products are exact in the fp32 accumulator, so splitting both operands into a 11-bit head and a 11-bit tail gives ~22-bit operands
+// for three MFMAs instead of sixteen.  The heads / tails are plain fp16 (no block exponents): weights are pre-scaled by 64 at pack time so
+// that their tails stay normal numbers (|w| ~ 0.02 -> tail ~ 6e-4); activations are O(1) rows (RMSNorm output, attention output) whose
+// tails lose nothing that matters (absolute error <= 2^-24); the SwiGLU output is stored divided by 16 (range +-1e6).
+// Same fusions and reference lines as prefill_gemm.hip: q/k/v projection + RoPE + KV append (llama.py:619-633,151-182), o_proj / down_proj +
+// residual (llama.py:666,731,739), SiLU(gate) * up (llama.py:214, precise expf + division like the decode kernels).
+//
+// Structure: block = 128 rows x 128 features, 4 waves (2 x 2) of 64 x 64 = 4 x 4 accumulators; a k-tile stage = 32 one-KiB fragments
+// (8 Whi, 8 Wlo, 8 Xhi, 8 Xlo) copied by LDS-DMA into a ring of 3 stages (96 KB: one block per CU, 48 MFMAs per wave and stage).
+#include "kernels.h"
+
+#define SP_WSCALE 64.0f
+#define SP_ACT_SCALE 16.0f
+#define SP_RING 3
+#define SP_STAGE (32 * 1024)
+
+__device__ inline void split_h4(const f32x4 v, half4& hi, half4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float c = fminf(fmaxf(v[j], -65504.f), 65504.f);
+        hi[j] = (half_t)c;
+        lo[j] = (half_t)(c - (float)hi[j]);
+    }
+}
+
+// RMSNorm once per row (llama.py:82-87; the weight is folded into W's columns) -> head / tail fp16 fragment images [16-row group][24 k-tiles][lane][16 B]
+__global__ __launch_bounds__(256) void norm_pack_split_kernel(const float* x, half_t* hi, half_t* lo, int R, float eps) {
+    constexpr int K = 768, KTILES = K / 32, PER = K / 256;
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const f32x4* xr = (const f32x4*)(x + (size_t)r * K);
+    f32x4 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = xr[lane + 64 * i];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)K + eps);
+    const size_t base = (size_t)(r >> 4) * KTILES * 64 * 8;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = 4 * (lane + 64 * i);
+        half4 h, l;
+        split_h4((f32x4){v[i][0] * rs, v[i][1] * rs, v[i][2] * rs, v[i][3] * rs}, h, l);
+        const size_t o = base + xfrag_index<half_t>(r & 15, k, KTILES);
+        *(half4*)(hi + o) = h;
+        *(half4*)(lo + o) = l;
+    }
+}
+
+// fp32 fragment image (the attention kernel's output, [16-row group][48 k-tiles][lane][4 floats]) -> head / tail fp16 images
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* src, half_t* hi, half_t* lo, int R) {
+    constexpr int K = 768;
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // (row, 4 consecutive k)
+    const int r = idx / (K / 4), k = 4 * (idx % (K / 4));
+    if (r >= R) return;
+    const f32x4 v = *(const f32x4*)(src + (size_t)(r >> 4) * (K / 16) * 64 * 4 + xfrag_index<float>(r & 15, k, K / 16));
+    half4 h, l;
+    split_h4(v, h, l);
+    const size_t o = (size_t)(r >> 4) * (K / 32) * 64 * 8 + xfrag_index<half_t>(r & 15, k, K / 32);
+    *(half4*)(hi + o) = h;
+    *(half4*)(lo + o) = l;
+}
+
+struct SplitGemm {
+    const half_t *Whi, *Wlo, *Xhi, *Xlo;   // fragment images: W [n tile][k tile][lane][8], X [16-row group][k tile][lane][8]
+    int ktiles, R;
+    float scale;                            // applied to the accumulators: 1 / SP_WSCALE (x SP_ACT_SCALE for the down projection)
+    half_t *act_hi, *act_lo;                // EPI_SWIGLU: output images [16-row group][96 k-tiles][lane][8] of silu(g) * u / SP_ACT_SCALE
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void prefill_split_gemm_kernel(const SplitGemm p, const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order (see prefill_gemm.hip): XCD x owns the row blocks y = x (mod 8) and walks the column blocks in order
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, seq = lin >> 3, rpx = gridDim.y >> 3;
+        bx = seq / rpx;
+        by = (seq % rpx) * 8 + xcd;
+    }
+    const int nt0 = bx * 8, g0 = by * 8;                   // first n tile / first 16-row group of the block
+    const int ktiles = p.ktiles;
+    // fragment f of a stage: 0..7 Whi tiles, 8..15 Wlo tiles, 16..23 Xhi groups, 24..31 Xlo groups
+    auto src = [&](int f, int kt) -> const char* {
+        const half_t* img = (f < 8) ? p.Whi : (f < 16) ? p.Wlo : (f < 24) ? p.Xhi : p.Xlo;
+        const int unit = (f < 16) ? nt0 + (f & 7) : g0 + (f & 7);
+        return (const char*)img + ((size_t)unit * ktiles + kt) * 1024 + (unsigned)(lane * 16);
+    };
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#define SP_DMA(kt_, buf_)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                     \
+        const int f = wave + 4 * i;                                                                                      \
+        __builtin_amdgcn_global_load_lds((gptr_t)src(f, (kt_)), (lptr_t)(lds + (buf_) * SP_STAGE + f * 1024), 16, 0, 0); \
+    }
+    // s_waitcnt immediate (gfx9): vmcnt[3:0] and [15:14] | expcnt[6:4] = 7 (none) | lgkmcnt[11:8] = 0; a bare s_barrier (no vmcnt(0) fence)
+#define SP_WAIT_BAR(n_) { __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15) | (((n_) >> 4) << 14)); __builtin_amdgcn_s_barrier(); }
+    f32x4 acc[4][4];                                       // [n tile][row group]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    SP_DMA(0, 0)
+    SP_DMA(1, 1)                                           // ktiles >= 2 (checked by the launcher)
+    int cb = 0;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        // stage kt has landed for every wave (its 8 loads per wave retire before the 8 of stage kt + 1), and every wave is done with the
+        // slot stage kt + 2 is about to overwrite (it held stage kt - 1, whose fragments were consumed before this barrier)
+        if (kt + 1 < ktiles) SP_WAIT_BAR(8) else SP_WAIT_BAR(0)
+        const char* cur = lds + cb * SP_STAGE;
+        half8 wh[4], wl[4], xh[4], xl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            wh[t] = *(const half8*)(cur + (wn * 4 + t) * 1024 + lane * 16);
+            wl[t] = *(const half8*)(cur + (8 + wn * 4 + t) * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            xh[g] = *(const half8*)(cur + (16 + wr * 4 + g) * 1024 + lane * 16);
+            xl[g] = *(const half8*)(cur + (24 + wr * 4 + g) * 1024 + lane * 16);
+        }
+        if (kt + 2 < ktiles) {
+            const int nb = (cb + 2 >= SP_RING) ? cb + 2 - SP_RING : cb + 2;
+            SP_DMA(kt + 2, nb)
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // tails first, head product last: the small terms meet while the accumulator's low bits still see them
+                acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], xh[g], acc[t][g], 0, 0, 0);
+                acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xl[g], acc[t][g], 0, 0, 0);
+                acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xh[g], acc[t][g], 0, 0, 0);
+            }
+        cb = (cb + 1 == SP_RING) ? 0 : cb + 1;
+    }
+#undef SP_DMA
+#undef SP_WAIT_BAR
+    // ---- epilogue.  C tile layout: lane = (iq = lane >> 4, n = lane & 15): activation row n of the group, weight rows 4 * iq + j (j = register)
+    const int iq = lane >> 4, nn = lane & 15;
+    constexpr int H = 768, NH = H / CTTS_HEAD_DIM, HT = H / 16;
+    const int rt0 = nt0 + wn * 4;                          // the wave's 4 n tiles: one head of q / k / v (tile t = dims 8t.. | 8t + 32..), or 32 outputs of gate|up
+    const bool lowh = iq < 2;
+    const float sc = p.scale;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int G = g0 + wr * 4 + g;                     // 16-row group
+        const int row = G * 16 + nn;
+        const bool rv = row < p.R;
+        if (EPI == EPI_RESID) {
+            const int N = a.n_row_tiles * 16;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!rv) continue;
+                float* xo = a.x_out + (size_t)row * N + (rt0 + t) * 16 + 4 * iq;
+                const f32x4 x = *(const f32x4*)xo, c = acc[t][g];
+                *(f32x4*)xo = (f32x4){x[0] + c[0] * sc, x[1] + c[1] * sc, x[2] + c[2] * sc, x[3] + c[3] * sc};      // residual + proj (llama.py:731,739)
+            }
+        } else if (EPI == EPI_SWIGLU) {
+            // tile rows [8 gate | 8 up]: lanes iq 0,1 hold gate rows 4 iq + j, lanes iq 2,3 the matching up rows
+            const int ktiles_out = (a.n_row_tiles * 8) / 32;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 c = acc[t][g];
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(c[j], 32);
+                if (lowh && rv) {
+                    f32x4 y;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gv = c[j] * sc, uv = o[j] * sc;
+                        y[j] = (gv / (1.0f + expf(-gv))) * uv * (1.0f / SP_ACT_SCALE);
+                    }
+                    half4 h, l;
+                    split_h4(y, h, l);
+                    const size_t off = (size_t)G * ktiles_out * 64 * 8 + xfrag_index<half_t>(nn, (rt0 + t) * 8 + 4 * iq, ktiles_out);
+                    *(half4*)(p.act_hi + off) = h;
+                    *(half4*)(p.act_lo + off) = l;
+                }
+            }
+        } else {                                           // EPI_QKV
+            const int which = rt0 / HT, hh = (rt0 % HT) >> 2;
+            RowMeta m = {0, 0, 0, 0};
+            if (rv && which != 0) m = a.meta[row];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 c = acc[t][g];
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(c[j], 32);
+                if (!rv) continue;
+                const int d0 = t * 8 + 4 * (iq & 1);         // first of this lane's 4 frequency indices
+                f32x4 y;
+                if (which < 2) {
+                    const f32x4 cs = *(const f32x4*)(a.rope_rows + (size_t)row * 64 + d0), sn = *(const f32x4*)(a.rope_rows + (size_t)row * 64 + 32 + d0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float va = (lowh ? c[j] : o[j]) * sc, vb = (lowh ? o[j] : c[j]) * sc;
+                        // q*cos + rotate_half(q)*sin (llama.py:180-181), products rounded separately like the reference
+                        const float ya = __fadd_rn(__fmul_rn(va, cs[j]), __fmul_rn(-vb, sn[j]));
+                        const float yb = __fadd_rn(__fmul_rn(vb, cs[j]), __fmul_rn(va, sn[j]));
+                        y[j] = lowh ? ya : yb;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = c[j] * sc;
+                }
+                const int dd = d0 + (lowh ? 0 : 32);
+                if (which == 0) *(f32x4*)(a.q_out + ((size_t)row * NH + hh) * CTTS_HEAD_DIM + dd) = y;
+                else *(f32x4*)((float*)(which == 1 ? a.k_cache : a.v_cache) + (((size_t)m.seq * NH + hh) * a.Lmax + m.slot) * CTTS_HEAD_DIM + dd) = y;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prompt attention of the parity engine: the flash-style MFMA kernel of attention.hip (attn_prefill_mfma_kernel: block = (sequence, head, 64 queries),
+// S^T = K.Q^T with the lane owning ONE query so that P^T is already the B operand of the P.V product) on head / tail operands.  K and V come from
+// the fp32 cache and are split while a 64-key chunk is staged in LDS; Q (pre-scaled by 1/8, exact) and P (<= 1) are split in registers; every
+// product is 3 MFMAs (tail x head, head x tail, head x head).  exp is the precise expf (parity mode).  llama.py:590-668 at q_len > 1, mask semantics
+// of llama.py:1073-1087 (a row attends to the key slots [kv_start, slot] of its own sequence).  The fp32 row-by-row kernel this replaces took
+// 1.2 ms per layer for 32 x 512 prompt tokens (half of the prompt pass once the projections ran on the split GEMM).
+// Output: the normalised rows as head / tail fp16 images = the X operand of the o_proj split GEMM (no separate conversion pass).
+#define FS_PITCH 68        // halfs per V^T row in LDS (64 keys + pad; rows stay 8-byte aligned)
+#define FS_KPITCH 72       // halfs per K row in LDS (64 dims + pad; rows stay 16-byte aligned)
+#define FS_LDS (2 * (2 * 64 * FS_PITCH + 2 * 64 * FS_KPITCH) * 2)
+__global__ __launch_bounds__(256) void attn_prefill_split_kernel(const RowMeta* meta_p, const float* q_p, const float* k_p, const float* v_p, const int NHp, const int R,
+                                                               const AttnArgs a, half_t* out_hi, half_t* out_lo) {
+    extern __shared__ __attribute__((aligned(16))) char fs_lds[];
+    typedef half_t (*vt_t)[64][FS_PITCH];
+    typedef half_t (*ks_t)[64][FS_KPITCH];
+    vt_t vth = (vt_t)fs_lds, vtl = (vt_t)(fs_lds + 2 * 64 * FS_PITCH * 2);
+    ks_t ksh = (ks_t)(fs_lds + 4 * 64 * FS_PITCH * 2), ksl = (ks_t)(fs_lds + 4 * 64 * FS_PITCH * 2 + 2 * 64 * FS_KPITCH * 2);
+    __shared__ int range_s[4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qn = lane & 15, iq = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, T = a.T;
+    const int t = blockIdx.x * 64 + wave * 16 + qn;                       // this lane's query (prompt position)
+    const int r = b * T + t - a.row0;                                     // its row in the current pass
+    const bool live = (t < T) && (r >= 0) && (r < R);
+    RowMeta m = {0, 0, -1, 0};
+    if (live) m = meta_p[r];
+    const int lo = live ? m.kv_start : 0x7FFFFFFF, hi = live ? m.slot : -1;
+    int wlo = lo, whi = hi;                                               // wave-uniform key range
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { wlo = min(wlo, __shfl_xor(wlo, off)); whi = max(whi, __shfl_xor(whi, off)); }
+    if (lane == 0) { range_s[wave][0] = wlo; range_s[wave][1] = whi; }
+    __syncthreads();
+    const int blo = min(min(range_s[0][0], range_s[1][0]), min(range_s[2][0], range_s[3][0]));
+    const int bhi = max(max(range_s[0][1], range_s[1][1]), max(range_s[2][1], range_s[3][1]));
+    if (bhi < 0) return;                                                  // no live query in this block (uniform)
+    wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
+    const size_t head_off = ((size_t)b * NHp + h) * a.Lmax * CTTS_HEAD_DIM;
+    const float* kb = k_p + head_off;
+    const float* vb = v_p + head_off;
+    // Q fragments (B operand): lane (query qn, kq = iq): dims 8 iq .. + 7 of each 32-dim half, scaled by 1/sqrt(64), head / tail
+    half8 qh[2], ql[2];
+    {
+        const float* qp = q_p + ((size_t)(live ? r : 0) * NHp + h) * CTTS_HEAD_DIM + 8 * iq;
+        const float sc = live ? 0.125f : 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const f32x4 q0 = *(const f32x4*)(qp + 32 * kh), q1 = *(const f32x4*)(qp + 32 * kh + 4);
+            half4 h0, l0, h1, l1;
+            split_h4((f32x4){q0[0] * sc, q0[1] * sc, q0[2] * sc, q0[3] * sc}, h0, l0);
+            split_h4((f32x4){q1[0] * sc, q1[1] * sc, q1[2] * sc, q1[3] * sc}, h1, l1);
+            qh[kh] = (half8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            ql[kh] = (half8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        }
+    }
+    f32x4 oacc[4];                                                        // O^T: dims 16 db + 4 iq + j of this lane's query
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lpart = 0.f;
+    // staging: thread -> key (tid >> 2) of the chunk, dims 16 (tid & 3) .. + 15
+    const int skey = tid >> 2, sdim = 16 * (tid & 3);
+    f32x4 vst[4], kst[4];
+    auto vload = [&](int c) {
+        const int key = min(c + skey, bhi);                               // clamp: a valid slot of this sequence (masked later)
+        const f32x4* vp = (const f32x4*)(vb + (size_t)key * CTTS_HEAD_DIM + sdim);
+        const f32x4* kp = (const f32x4*)(kb + (size_t)key * CTTS_HEAD_DIM + sdim);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { vst[i] = vp[i]; kst[i] = kp[i]; }
+    };
+    auto vstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            half4 vh, vl, kh, kl;
+            split_h4(vst[i], vh, vl);
+            split_h4(kst[i], kh, kl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vth[buf][sdim + 4 * i + e][skey] = vh[e]; vtl[buf][sdim + 4 * i + e][skey] = vl[e]; }
+            *(half4*)&ksh[buf][skey][sdim + 4 * i] = kh;
+            *(half4*)&ksl[buf][skey][sdim + 4 * i] = kl;
+        }
+    };
+    const int c0 = blo & ~63;
+    vload(c0);
+    vstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c = c0; c <= bhi; c += 64, buf ^= 1) {
+        const bool more = c + 64 <= bhi;
+        if (more) vload(c + 64);
+        if (c + 63 >= wlo && c <= whi) {                                   // this wave has keys in the chunk
+            f32x4 sT[4];
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                // A operand row = key (lane & 15), dims 8 iq .. and 32 + 8 iq ..
+                const half8 k0h = *(const half8*)&ksh[buf][16 * tl + qn][8 * iq], k1h = *(const half8*)&ksh[buf][16 * tl + qn][32 + 8 * iq];
+                const half8 k0l = *(const half8*)&ksl[buf][16 * tl + qn][8 * iq], k1l = *(const half8*)&ksl[buf][16 * tl + qn][32 + 8 * iq];
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0l, qh[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1l, qh[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, ql[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, ql[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qh[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, qh[1], acc, 0, 0, 0);
+                sT[tl] = acc;
+            }
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kidx = c + 16 * tl + 4 * iq + j;
+                    const bool ok = (kidx >= lo) && (kidx <= hi);
+                    sT[tl][j] = ok ? sT[tl][j] : -INFINITY;
+                    mloc = fmaxf(mloc, sT[tl][j]);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float mn = fmaxf(mrun, mloc);
+            const float sc = (mrun == -INFINITY) ? 0.f : expf(mrun - mn);
+            float ps = 0.f;
+            half4 pTh[4], pTl[4];
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                f32x4 pv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pv[j] = (sT[tl][j] == -INFINITY) ? 0.f : expf(sT[tl][j] - mn); ps += pv[j]; }
+                split_h4(pv, pTh[tl], pTl[tl]);
+            }
+            lpart = lpart * sc + ps;
+            mrun = mn;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) { oacc[db][0] *= sc; oacc[db][1] *= sc; oacc[db][2] *= sc; oacc[db][3] *= sc; }
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const half4 vh = *(const half4*)&vth[buf][16 * db + qn][16 * tl + 4 * iq];      // A = V^T: row = dim (lane & 15), keys 4 iq ..
+                    const half4 vl = *(const half4*)&vtl[buf][16 * db + qn][16 * tl + 4 * iq];
+                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vl, pTh[tl], oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, pTl[tl], oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, pTh[tl], oacc[db], 0, 0, 0);
+                }
+        }
+        if (more) vstore(buf ^ 1);
+        __syncthreads();
+    }
+    float ltot = lpart + __shfl_xor(lpart, 16);
+    ltot += __shfl_xor(ltot, 32);
+    if (!live) return;
+    const float inv = 1.0f / ltot;
+    constexpr int KT = 768 / 32;
+    const size_t base = (size_t)(r >> 4) * KT * 64 * 8;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const int k = h * CTTS_HEAD_DIM + 16 * db + 4 * iq;
+        half4 oh, ol;
+        split_h4((f32x4){oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv}, oh, ol);
+        const size_t o = base + xfrag_index<half_t>(r & 15, k, KT);
+        *(half4*)(out_hi + o) = oh;
+        *(half4*)(out_lo + o) = ol;
+    }
+}
+
+// prompt attention of one pass on the split operands: a.q fp32 [R][NH][64], fp32 K / V cache of this layer -> head / tail images of the normalised output rows
+int launch_attention_split(const AttnArgs& a, void* out_hi, void* out_lo, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)attn_prefill_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS));
+        configured = true;
+    }
+    if (a.T <= 0 || a.S != 1) { ctts_set_error("attention_split: prompt pass only"); return 1; }
+    const int B = (a.row0 + a.R + a.T - 1) / a.T;                         // sequences 0 .. B-1 may have rows in this pass
+    dim3 g3((a.T + 63) / 64, a.NH, B);
+    hipLaunchKernelGGL(attn_prefill_split_kernel, g3, dim3(256), FS_LDS, s, a.meta, a.q, (const float*)a.k_cache, (const float*)a.v_cache, a.NH, a.R, a, (half_t*)out_hi, (half_t*)out_lo);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_norm_pack_split(const float* x, void* hi, void* lo, int R, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(norm_pack_split_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, (half_t*)hi, (half_t*)lo, R, eps);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_split_pack(const float* src, void* hi, void* lo, int R, hipStream_t s) {
+    hipLaunchKernelGGL(split_pack_kernel, dim3((R * (768 / 4) + 255) / 256), dim3(256), 0, s, src, (half_t*)hi, (half_t*)lo, R);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int EPI>
+static int sp_launch(const SplitGemm& p, const GemmArgs& a, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_RING * SP_STAGE));
+        configured = true;
+    }
+    dim3 grid(a.n_row_tiles / 8, (p.R + 127) / 128);
+    hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI>), grid, dim3(256), SP_RING * SP_STAGE, s, p, a);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// W / X: head and tail images; the operand buffers must cover whole 128-row blocks (gpt_engine.hip allocates PASS_ROWS + 256 rows).
+int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Whi, const void* Wlo, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,
+                              float scale, hipStream_t s) {
+    SplitGemm p;
+    p.Whi = (const half_t*)Whi; p.Wlo = (const half_t*)Wlo; p.Xhi = (const half_t*)Xhi; p.Xlo = (const half_t*)Xlo;
+    p.ktiles = a.K / 32; p.R = a.R; p.scale = scale; p.act_hi = (half_t*)act_hi; p.act_lo = (half_t*)act_lo;
+    if ((a.n_row_tiles % 8) != 0 || p.ktiles < 2) { ctts_set_error("prefill_split_gemm: %d n tiles / K = %d not supported", a.n_row_tiles, a.K); return 1; }
+    if (epi == EPI_QKV) return sp_launch<EPI_QKV>(p, a, s);
+    if (epi == EPI_SWIGLU) return sp_launch<EPI_SWIGLU>(p, a, s);
+    if (epi == EPI_RESID) return sp_launch<EPI_RESID>(p, a, s);
+    ctts_set_error("prefill_split_gemm: unsupported epilogue %d", epi);
+    return 1;
+}
