@@ -20,6 +20,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ctts_hip.h"
@@ -56,7 +57,8 @@ struct ctts_gpt {
     char* wblob = nullptr;
     char* wsplit = nullptr;                      // fp32 engines: the split images of every layer matrix (2 x 2 bytes per weight), or null
     void *sp_x_hi = nullptr, *sp_x_lo = nullptr, *sp_act_hi = nullptr, *sp_act_lo = nullptr;   //   ... and of the prompt rows' operands
-    int split_rows_min = 1536;                   //   prompt passes of at least this many rows use them (diagnostic builds: CTTS_PREFILL_SPLIT, 0 = never)
+    int split_rows_min = 384;                    //   prompt passes of at least this many rows use them (prompt pass ms old / split: 192 rows 2.0 / 3.0, 384 rows 3.1 / 3.0,
+                                                 //   768 rows 5.3 / 3.6, 1152 rows 7.5 / 3.7; diagnostic builds: CTTS_PREFILL_SPLIT, 0 = never)
     std::vector<LayerW> lw;
     void* whead = nullptr;
     void* whead_text = nullptr;                  // refine-text head (21178 x H), packed like whead; optional
@@ -373,66 +375,77 @@ static int finalize_t(ctts_gpt* h) {
     const bool want_split = (sizeof(WT) == 4) && h->split_rows_min > 0 && (long)h->cfg.max_batch * h->cfg.max_seq >= h->split_rows_min;
     std::vector<half_t> sblob;
     if (want_split) {
-        sblob.resize(per_layer * 2);
+        sblob.resize(per_layer * 2 * L);
         if (dev_alloc((void**)&h->wsplit, per_layer * L * 2 * sizeof(half_t))) return 1;
     }
+    if (dev_alloc((void**)&h->ln1, (size_t)L * H * 4)) return 1;       // input_layernorm weights, unfolded: the LoRA path needs w * x_hat itself
+    struct LayerSrc { const std::vector<float>*q, *k, *v, *o, *g, *u, *d, *l1, *l2; };
+    std::vector<LayerSrc> ls(L);
     for (int l = 0; l < L; ++l) {
         const std::string p = "gpt.layers." + std::to_string(l) + ".";
-        const std::vector<float>*q = need(h, p + "self_attn.q_proj.weight", n_o), *k = need(h, p + "self_attn.k_proj.weight", n_o),
-                                *v = need(h, p + "self_attn.v_proj.weight", n_o), *o = need(h, p + "self_attn.o_proj.weight", n_o),
-                                *g = need(h, p + "mlp.gate_proj.weight", (size_t)I * H), *u = need(h, p + "mlp.up_proj.weight", (size_t)I * H),
-                                *d = need(h, p + "mlp.down_proj.weight", n_d), *l1 = need(h, p + "input_layernorm.weight", H),
-                                *l2 = need(h, p + "post_attention_layernorm.weight", H);
-        if (!q || !k || !v || !o || !g || !u || !d || !l1 || !l2) return 1;
-        if (l == 0 && dev_alloc((void**)&h->ln1, (size_t)L * H * 4)) return 1;       // input_layernorm weights, unfolded: the LoRA path needs w * x_hat itself
-        CTTS_HIP_CHECK(hipMemcpy(h->ln1 + (size_t)l * H, l1->data(), (size_t)H * 4, hipMemcpyHostToDevice));
-        WT* base = blob.data() + per_layer * l;
+        LayerSrc& t = ls[l];
+        t.q = need(h, p + "self_attn.q_proj.weight", n_o); t.k = need(h, p + "self_attn.k_proj.weight", n_o);
+        t.v = need(h, p + "self_attn.v_proj.weight", n_o); t.o = need(h, p + "self_attn.o_proj.weight", n_o);
+        t.g = need(h, p + "mlp.gate_proj.weight", (size_t)I * H); t.u = need(h, p + "mlp.up_proj.weight", (size_t)I * H);
+        t.d = need(h, p + "mlp.down_proj.weight", n_d); t.l1 = need(h, p + "input_layernorm.weight", H);
+        t.l2 = need(h, p + "post_attention_layernorm.weight", H);
+        if (!t.q || !t.k || !t.v || !t.o || !t.g || !t.u || !t.d || !t.l1 || !t.l2) return 1;
+        CTTS_HIP_CHECK(hipMemcpy(h->ln1 + (size_t)l * H, t.l1->data(), (size_t)H * 4, hipMemcpyHostToDevice));
+    }
+    // host-side packing of the 20 layers on a few threads (pure CPU work on disjoint slices of the blobs)
+    auto pack_layer = [&](int l) {
+        const LayerSrc& t = ls[l];
         const int HT = H / 16;
-        // QKV: tile rows = dims [8t..8t+7 | 8t+32..8t+39] of one head, so RoPE's (d, d+32) pair sits in one tile
-        pack_tiles<WT>(base, 3 * HT, H, [&](int pr) -> const float* {
+        auto qkv_row = [&](int pr) -> const float* {      // QKV: tile rows = dims [8t..8t+7 | 8t+32..8t+39] of one head, so RoPE's (d, d+32) pair sits in one tile
             const int rt = pr / 16, i = pr % 16;
             const int which = rt / HT, within = rt % HT, hh = within / 4, tq = within % 4;
             const int dd = (i < 8) ? 8 * tq + i : 8 * tq + (i - 8) + 32;
-            const std::vector<float>* src = which == 0 ? q : (which == 1 ? k : v);
+            const std::vector<float>* src = which == 0 ? t.q : (which == 1 ? t.k : t.v);
             return src->data() + (size_t)(hh * CTTS_HEAD_DIM + dd) * H;
-        }, l1->data());      // RMSNorm weight folded into the columns: W (w * xn) == (W diag(w)) xn  (llama.py:87,619-621)
-        pack_tiles<WT>(base + n_qkv, HT, H, [&](int pr) { return o->data() + (size_t)pr * H; });
-        // gate|up: tile rows = [8 gate rows | the matching 8 up rows]
-        pack_tiles<WT>(base + n_qkv + n_o, 2 * I / 16, H, [&](int pr) -> const float* {
+        };
+        auto o_row = [&](int pr) { return t.o->data() + (size_t)pr * H; };
+        auto gu_row = [&](int pr) -> const float* {       // gate|up: tile rows = [8 gate rows | the matching 8 up rows]
             const int rt = pr / 16, i = pr % 16;
-            return (i < 8) ? g->data() + (size_t)(rt * 8 + i) * H : u->data() + (size_t)(rt * 8 + i - 8) * H;
-        }, l2->data());
-        pack_tiles<WT>(base + n_qkv + n_o + n_gu, HT, I, [&](int pr) { return d->data() + (size_t)pr * I; });
+            return (i < 8) ? t.g->data() + (size_t)(rt * 8 + i) * H : t.u->data() + (size_t)(rt * 8 + i - 8) * H;
+        };
+        auto d_row = [&](int pr) { return t.d->data() + (size_t)pr * I; };
+        WT* base = blob.data() + per_layer * l;
+        // RMSNorm weights folded into the columns: W (w * xn) == (W diag(w)) xn  (llama.py:87,619-621)
+        pack_tiles<WT>(base, 3 * HT, H, qkv_row, t.l1->data());
+        pack_tiles<WT>(base + n_qkv, HT, H, o_row);
+        pack_tiles<WT>(base + n_qkv + n_o, 2 * I / 16, H, gu_row, t.l2->data());
+        pack_tiles<WT>(base + n_qkv + n_o + n_gu, HT, I, d_row);
         if (want_split) {
-            const int HT2 = H / 16;
-            half_t *shi = sblob.data(), *slo = sblob.data() + per_layer;
-            pack_tiles_split(shi, slo, 3 * HT2, H, [&](int pr) -> const float* {
-                const int rt = pr / 16, i = pr % 16;
-                const int which = rt / HT2, within = rt % HT2, hh = within / 4, tq = within % 4;
-                const int dd = (i < 8) ? 8 * tq + i : 8 * tq + (i - 8) + 32;
-                const std::vector<float>* src = which == 0 ? q : (which == 1 ? k : v);
-                return src->data() + (size_t)(hh * CTTS_HEAD_DIM + dd) * H;
-            }, l1->data());
-            pack_tiles_split(shi + n_qkv, slo + n_qkv, HT2, H, [&](int pr) { return o->data() + (size_t)pr * H; });
-            pack_tiles_split(shi + n_qkv + n_o, slo + n_qkv + n_o, 2 * I / 16, H, [&](int pr) -> const float* {
-                const int rt = pr / 16, i = pr % 16;
-                return (i < 8) ? g->data() + (size_t)(rt * 8 + i) * H : u->data() + (size_t)(rt * 8 + i - 8) * H;
-            }, l2->data());
-            pack_tiles_split(shi + n_qkv + n_o + n_gu, slo + n_qkv + n_o + n_gu, HT2, I, [&](int pr) { return d->data() + (size_t)pr * I; });
+            half_t *shi = sblob.data() + per_layer * 2 * l, *slo = shi + per_layer;
+            pack_tiles_split(shi, slo, 3 * HT, H, qkv_row, t.l1->data());
+            pack_tiles_split(shi + n_qkv, slo + n_qkv, HT, H, o_row);
+            pack_tiles_split(shi + n_qkv + n_o, slo + n_qkv + n_o, 2 * I / 16, H, gu_row, t.l2->data());
+            pack_tiles_split(shi + n_qkv + n_o + n_gu, slo + n_qkv + n_o + n_gu, HT, I, d_row);
+        }
+    };
+    {
+        const int nthreads = L < 8 ? L : 8;
+        std::vector<std::thread> pool;
+        for (int w = 0; w < nthreads; ++w)
+            pool.emplace_back([&, w]() { for (int l = w; l < L; l += nthreads) pack_layer(l); });
+        for (auto& th : pool) th.join();
+    }
+    for (int l = 0; l < L; ++l) {
+        char* dv = h->wblob + per_layer * l * sizeof(WT);
+        h->lw[l].qkv = dv;
+        h->lw[l].o = dv + n_qkv * sizeof(WT);
+        h->lw[l].gu = dv + (n_qkv + n_o) * sizeof(WT);
+        h->lw[l].d = dv + (n_qkv + n_o + n_gu) * sizeof(WT);
+        if (want_split) {
             char* sv = h->wsplit + per_layer * l * 2 * sizeof(half_t);
-            CTTS_HIP_CHECK(hipMemcpy(sv, sblob.data(), per_layer * 2 * sizeof(half_t), hipMemcpyHostToDevice));
             char* lov = sv + per_layer * sizeof(half_t);
             h->lw[l].qkv_hi = sv; h->lw[l].qkv_lo = lov;
             h->lw[l].o_hi = sv + n_qkv * 2; h->lw[l].o_lo = lov + n_qkv * 2;
             h->lw[l].gu_hi = sv + (n_qkv + n_o) * 2; h->lw[l].gu_lo = lov + (n_qkv + n_o) * 2;
             h->lw[l].d_hi = sv + (n_qkv + n_o + n_gu) * 2; h->lw[l].d_lo = lov + (n_qkv + n_o + n_gu) * 2;
         }
-        char* dv = h->wblob + per_layer * l * sizeof(WT);
-        h->lw[l].qkv = dv;
-        h->lw[l].o = dv + n_qkv * sizeof(WT);
-        h->lw[l].gu = dv + (n_qkv + n_o) * sizeof(WT);
-        h->lw[l].d = dv + (n_qkv + n_o + n_gu) * sizeof(WT);
     }
+    if (want_split) CTTS_HIP_CHECK(hipMemcpy(h->wsplit, sblob.data(), sblob.size() * sizeof(half_t), hipMemcpyHostToDevice));
     // heads: fold weight norm, W = v * (g / ||v||_row)  (gpt.py:57-77; torch._weight_norm dim=0)
     std::vector<float> folded((size_t)h->NVQ * V * H);
     for (int i = 0; i < h->NVQ; ++i) {
@@ -610,7 +623,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // (measured with 128 x 128 blocks, prompt pass ms with / without it: 512 rows 2.31 / 1.48, 1024 rows 2.47 / 2.29, 1536 rows 2.70 / 3.12,
     //  2048 rows 2.81 / 3.9, 3072 rows 3.6 / 5.3, 16384 rows 10.3 / 29)
     const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && h->prefill_gemm_rows > 0 && (R >= h->prefill_gemm_rows) && !lora;
-    // prompt pass over >= 1536 rows, fp32 engine: the same tiling on the fp16 pipes with head / tail operands -- 3 MFMAs per product instead of 16,
+    // prompt pass over >= 384 rows, fp32 engine: the same tiling on the fp16 pipes with head / tail operands -- 3 MFMAs per product instead of 16,
     // fp32-level accuracy (prefill_split.hip); the attention stays the fp32 row kernel
     const bool pfs = prepack && (dt == CTTS_DTYPE_F32) && h->wsplit != nullptr && h->split_rows_min > 0 && (R >= h->split_rows_min) && !lora;
     const float sp_scale = 1.0f / 64.0f;
