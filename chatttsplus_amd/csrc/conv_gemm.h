@@ -28,7 +28,9 @@ struct GemmF32Args {
     const float* resid; int ldr; long sR;
     const float* scale;                 // [N]   EP_SCALE / EP_SCALE_T
     float* const* Cptrs;                // EP_SCALE_T: per-utterance output base (written transposed C[n*M_z + m]); null -> C
+    const half_t *Whi, *Wlo;            // head / tail fp16 images of VOC_WSCALE * W, same [Npad][ldw] layout (null: the fp32 MFMA kernel)
 };
+#define VOC_WSCALE 256.0f
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -103,8 +105,107 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args a) {
         }
 }
 
+// The same GEMM on the fp16 pipes with fp32-level accuracy (round 3; the idea of prefill_split.hip): operands split into an 11-bit head and an
+// 11-bit tail, C = (Ah.Wh + Ah.Wl + Al.Wh) / VOC_WSCALE -- 3 v_mfma_f32_16x16x32_f16 (48 pipe cycles per 32-deep step and 16 x 16 tile) instead of
+// 8 v_mfma_f32_16x16x4_f32 (256 cycles).  The fp32 kernel above sits at 37 % of the fp32 MFMA peak whatever the tile shape, the staging (LDS or
+// straight from L2) or the prefetch depth (2 / 3 / 4 / 6 register sets: 23.6 / 23.8 / 24.0 / 24.8 ms per 32 x 272 tokens): the pipe itself is the limit.
+// Weights are split once at load time (scaled by 256 so that the tails stay normal fp16 numbers); activation fragments -- 8 consecutive k of one row
+// per lane, the A layout of the 32-deep MFMA -- are split in registers.  K % 16 == 0: the upper half of a last, half-filled step is zeroed.
+// Every output element still accumulates its K range in the same order whatever M, the tiling or the batch.
+template <int EPI, int MI, int NJ>
+__global__ __launch_bounds__(256) void gemm_split_kernel(const GemmF32Args a) {
+    const int z = blockIdx.z;
+    const int M = a.Ms ? a.Ms[z] : a.M;
+    if ((int)blockIdx.y * (32 * MI) >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * (32 * MI) + (wave >> 1) * (16 * MI), n0 = blockIdx.x * (32 * NJ) + (wave & 1) * (16 * NJ);
+    const int kq = lane >> 4;                                         // this lane's 8-wide k group of a 32-deep step
+    const float* Ap = a.A + (size_t)z * a.sA + (size_t)(m0 + (lane & 15)) * a.lda + 8 * kq;
+    const size_t woff = (size_t)(n0 + (lane & 15)) * a.ldw + 8 * kq;
+    const half_t *Wh = a.Whi + woff, *Wl = a.Wlo + woff;
+    const size_t a16 = (size_t)16 * a.lda, w16 = (size_t)16 * a.ldw;
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    struct Frags { f32x4 a0[MI], a1[MI]; half8 wh[NJ], wl[NJ]; };
+    auto load = [&](Frags& f, int k0) {
+        const bool on = (k0 + 8 * kq) < a.K;                           // K % 32 == 16: lanes of the upper half step hold zeros
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            f.a0[i] = on ? *(const f32x4*)(Ap + i * a16 + k0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            f.a1[i] = on ? *(const f32x4*)(Ap + i * a16 + k0 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f.wh[j] = on ? *(const half8*)(Wh + j * w16 + k0) : (half8){0, 0, 0, 0, 0, 0, 0, 0};
+            f.wl[j] = on ? *(const half8*)(Wl + j * w16 + k0) : (half8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto step = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            half8 ah, al;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (e < 4) ? f.a0[i][e] : f.a1[i][e - 4];
+                const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+                ah[e] = (half_t)c;
+                al[e] = (half_t)(c - (float)ah[e]);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, f.wh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.wl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.wh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    Frags f0, f1;
+    load(f0, 0);
+    for (int k0 = 0; k0 < a.K; k0 += 64) {
+        if (k0 + 32 < a.K) load(f1, k0 + 32);
+        __builtin_amdgcn_sched_barrier(0);
+        step(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 32 >= a.K) break;
+        if (k0 + 64 < a.K) load(f0, k0 + 64);
+        __builtin_amdgcn_sched_barrier(0);
+        step(f1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float* Cb = (EPI == EP_SCALE_T && a.Cptrs) ? a.Cptrs[z] : a.C + (size_t)z * a.sC;
+    const float* Rb = (EPI == EP_GAMMA_RESID) ? a.resid + (size_t)z * a.sR : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NJ; ++ni) {
+            const int n = n0 + ni * 16 + (lane & 15);
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + mi * 16 + (lane >> 4) * 4 + r;
+                if (m >= M) continue;
+                float v = acc[mi][ni][r] * (1.0f / VOC_WSCALE);
+                if (EPI == EP_BIAS || EPI == EP_BIAS_GELU || EPI == EP_GAMMA_RESID) v += a.bias[n];
+                if (EPI == EP_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EP_GAMMA_RESID) v = __fadd_rn(__fmul_rn(v, a.gamma[n]), Rb[(size_t)m * a.ldr + n]);
+                if (EPI == EP_SCALE_T) { Cb[(size_t)n * M + m] = v * a.scale[n]; continue; }     // mel [n_mels][F_z]
+                if (EPI == EP_SCALE) v *= a.scale[n];
+                if (EPI == EP_LOGCLIP_DIV) v = logf(fmaxf(v, 1e-5f)) / a.scale[n];
+                Cb[(size_t)m * a.ldc + n] = v;
+            }
+        }
+}
+
 template <int EPI>
 static int launch_gemm_f32_epi(const GemmF32Args& a, int nb, hipStream_t s, bool big) {
+    if (a.Whi != nullptr) {
+        hipLaunchKernelGGL((gemm_split_kernel<EPI, 2, 2>), dim3((a.N + 63) / 64, (a.M + 63) / 64, nb), dim3(256), 0, s, a);
+        CTTS_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (big) hipLaunchKernelGGL((gemm_f32_kernel<EPI, 4, 4>), dim3((a.N + 127) / 128, (a.M + 127) / 128, nb), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_f32_kernel<EPI, 2, 2>), dim3((a.N + 63) / 64, (a.M + 63) / 64, nb), dim3(256), 0, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
@@ -114,7 +215,7 @@ static int launch_gemm_f32_epi(const GemmF32Args& a, int nb, hipStream_t s, bool
 // `row_pad`: rows the caller guarantees to be readable past M in A (the weights are padded to a multiple of 64 rows): the
 // 128-row tiles need row_pad >= 127 and N % 128 == 0.
 static int launch_gemm_f32(int epi, const GemmF32Args& a, int nb, hipStream_t s, int row_pad = 63) {
-    if (a.K % 16 || a.lda % 4 || a.ldw % 4) { ctts_set_error("gemm_f32: K=%d lda=%d ldw=%d alignment", a.K, a.lda, a.ldw); return 1; }
+    if (a.K % 16 || a.lda % 4 || a.ldw % 4 || (a.Whi != nullptr && a.ldw % 8)) { ctts_set_error("gemm_f32: K=%d lda=%d ldw=%d alignment", a.K, a.lda, a.ldw); return 1; }
     static const int force = diag_env("CTTS_VOC_TILE") ? atoi(diag_env("CTTS_VOC_TILE")) : 0;      // 64 / 128: diagnostic override
     // measured (32 utterances x 272 tokens): the pointwise-conv GEMMs already run at ~110 TFLOP/s (70 % of the fp32 MFMA peak);
     // 128x128 register tiles 28.8 ms vs 64x64 25.6 ms, an LDS-staged 128x128 variant 25.7 ms (bit-identical, no gain: removed)
@@ -199,4 +300,14 @@ static inline std::vector<float> pad_rows(const std::vector<float>& w, int rows,
     return o;
 }
 static inline int r64(int n) { return (n + 63) / 64 * 64; }
+// head / tail fp16 images of VOC_WSCALE * w (gemm_split_kernel)
+static inline void split_weights(const std::vector<float>& w, std::vector<half_t>& hi, std::vector<half_t>& lo) {
+    hi.resize(w.size()); lo.resize(w.size());
+    for (size_t i = 0; i < w.size(); ++i) {
+        const float v = VOC_WSCALE * w[i];
+        const half_t h = (half_t)v;
+        hi[i] = h;
+        lo[i] = (half_t)(v - (float)h);
+    }
+}
 

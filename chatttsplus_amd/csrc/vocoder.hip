@@ -26,6 +26,7 @@
 #include "common.h"
 
 #include "conv_gemm.h"
+#include "cnx_gemm.h"
 #include "roctx_range.h"
 
 // Stage the batch: copy each utterance's hidden rows ([n][768] == frames [2n][384], dvae.py:277-283) behind a zero guard
@@ -122,7 +123,8 @@ __global__ void overlap_add_kernel(const float* frames, const float* win, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-struct ConvNext { float *dw_w, *dw_b, *ln_w, *ln_b, *w1, *b1, *w2, *b2, *gamma; };
+struct SplitW { half_t *hi = nullptr, *lo = nullptr; };       // head / tail fp16 images of a GEMM weight (conv_gemm.h gemm_split_kernel)
+struct ConvNext { float *dw_w, *dw_b, *ln_w, *ln_b, *b1, *b2, *gamma; SplitW s1, s2; };      // s1 / s2: head / tail FRAGMENT images of pwconv1 / pwconv2 (cnx_gemm.h)
 
 struct ctts_voc {
     ctts_voc_cfg cfg;
@@ -132,12 +134,14 @@ struct ctts_voc {
     // DVAE
     float *ci0_w, *ci0_b, *ci2_w, *ci2_b, *co_w, *oc_w, *coef;
     float *po_w = nullptr, *po_b = nullptr;       // quantiser project_out [G][idim][4] / [G][idim] (vq_groups > 0)
+    SplitW s_ci0, s_ci2, s_co, s_oc, s_em, s_hd, s_basis;
     std::vector<ConvNext> dblocks;
     // Vocos
     float *em_w, *em_b, *n0_w, *n0_b, *nf_w, *nf_b, *hd_w, *hd_b, *win, *basis;
     std::vector<ConvNext> vblocks;
     // workspaces
     float *in384, *b128, *y, *ln, *mid, *co384, *mcl, *hbuf, *spec, *frames;
+    half_t *ln_hi = nullptr, *ln_lo = nullptr, *mid_hi = nullptr, *mid_lo = nullptr;      // ConvNeXt operands as head / tail fragment images (cnx_gemm.h)
     int Fp;
     int mel_ld, spec_ld, head_ld, mid_ld;
     // per-call tables: frames per utterance, hidden / wav / mel pointers (device copy + ring of pinned staging slots)
@@ -158,6 +162,27 @@ static int upload(ctts_voc* h, float** p, const std::vector<float>& v) {
     CTTS_HIP_CHECK(hipMemcpy(*p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
     return 0;
 }
+// a GEMM weight: the fp32 array (kept for reference / the fp32 kernel) + its head / tail fp16 images
+static int upload_w(ctts_voc* h, float** p, SplitW* sw, const std::vector<float>& v) {
+    if (upload(h, p, v)) return 1;
+    std::vector<half_t> hi, lo;
+    split_weights(v, hi, lo);
+    CTTS_HIP_CHECK(hipMalloc((void**)&sw->hi, hi.size() * 2)); h->allocs.push_back(sw->hi);
+    CTTS_HIP_CHECK(hipMalloc((void**)&sw->lo, lo.size() * 2)); h->allocs.push_back(sw->lo);
+    CTTS_HIP_CHECK(hipMemcpy(sw->hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+    CTTS_HIP_CHECK(hipMemcpy(sw->lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+// a ConvNeXt pointwise weight [N][K]: head / tail fragment images for cnx_gemm_kernel
+static int upload_frag(ctts_voc* h, SplitW* sw, const std::vector<float>& w, int N, int K) {
+    std::vector<half_t> hi, lo;
+    cnx_pack_weights(w, N, K, hi, lo);
+    CTTS_HIP_CHECK(hipMalloc((void**)&sw->hi, hi.size() * 2)); h->allocs.push_back(sw->hi);
+    CTTS_HIP_CHECK(hipMalloc((void**)&sw->lo, lo.size() * 2)); h->allocs.push_back(sw->lo);
+    CTTS_HIP_CHECK(hipMemcpy(sw->hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+    CTTS_HIP_CHECK(hipMemcpy(sw->lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    return 0;
+}
 static const std::vector<float>* vneed(ctts_voc* h, const std::string& k, size_t n) {
     auto it = h->host.find(k);
     if (it == h->host.end()) { ctts_set_error("missing weight %s", k.c_str()); return nullptr; }
@@ -172,14 +197,14 @@ static int load_convnext(ctts_voc* h, const std::string& p, int dim, int inter, 
                             *g = vneed(h, p + "gamma", dim);
     if (!dw || !db || !lw || !lb || !w1 || !b1 || !w2 || !b2 || !g) return 1;
     return upload(h, &cb->dw_w, *dw) || upload(h, &cb->dw_b, *db) || upload(h, &cb->ln_w, *lw) || upload(h, &cb->ln_b, *lb) ||
-           upload(h, &cb->w1, *w1) || upload(h, &cb->b1, *b1) || upload(h, &cb->w2, *w2) || upload(h, &cb->b2, *b2) ||
+           upload_frag(h, &cb->s1, *w1, inter, dim) || upload(h, &cb->b1, *b1) || upload_frag(h, &cb->s2, *w2, dim, inter) || upload(h, &cb->b2, *b2) ||
            upload(h, &cb->gamma, *g);
 }
 
 extern "C" int ctts_voc_create(const ctts_voc_cfg* c, ctts_voc** out) {
     if (!c || !out) { ctts_set_error("null argument"); return 1; }
     if ((c->dvae_hidden != 512 && c->dvae_hidden != 256) || c->vocos_dim != 512 || c->dvae_idim % 64 || c->dvae_bn % 64 || c->n_fft != 1024 || c->hop != 256 ||
-        c->vocos_inter % 64 || c->n_mels > 112 || c->max_frames < 2 || c->max_batch < 1 || c->max_batch > 64) {
+        c->vocos_inter % 128 || c->n_mels > 112 || c->max_frames < 2 || c->max_batch < 1 || c->max_batch > 64) {
         ctts_set_error("unsupported vocoder configuration");
         return 1;
     }
@@ -214,16 +239,16 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
     h->mel_ld = 112; h->spec_ld = (2 * NB + 15) / 16 * 16; h->head_ld = r64(2 * NB);
     // ---- DVAE
     const std::vector<float>*w = vneed(h, "dvae.decoder.conv_in.0.weight", (size_t)BN * ID * 3), *b = vneed(h, "dvae.decoder.conv_in.0.bias", BN);
-    if (!w || !b || upload(h, &h->ci0_w, conv_to_gemm(*w, BN, ID, 3, ID, r64(BN))) || upload(h, &h->ci0_b, *b)) return 1;
+    if (!w || !b || upload_w(h, &h->ci0_w, &h->s_ci0, conv_to_gemm(*w, BN, ID, 3, ID, r64(BN))) || upload(h, &h->ci0_b, *b)) return 1;
     w = vneed(h, "dvae.decoder.conv_in.2.weight", (size_t)HD * BN * 3); b = vneed(h, "dvae.decoder.conv_in.2.bias", HD);
-    if (!w || !b || upload(h, &h->ci2_w, conv_to_gemm(*w, HD, BN, 3, BN, r64(HD))) || upload(h, &h->ci2_b, *b)) return 1;
+    if (!w || !b || upload_w(h, &h->ci2_w, &h->s_ci2, conv_to_gemm(*w, HD, BN, 3, BN, r64(HD))) || upload(h, &h->ci2_b, *b)) return 1;
     h->dblocks.resize(c.dvae_layers);
     for (int i = 0; i < c.dvae_layers; ++i)
         if (load_convnext(h, "dvae.decoder.decoder_block." + std::to_string(i) + ".", HD, HD * 4, &h->dblocks[i])) return 1;
     w = vneed(h, "dvae.decoder.conv_out.weight", (size_t)ID * HD);
-    if (!w || upload(h, &h->co_w, pad_rows(*w, ID, HD, r64(ID)))) return 1;
+    if (!w || upload_w(h, &h->co_w, &h->s_co, pad_rows(*w, ID, HD, r64(ID)))) return 1;
     w = vneed(h, "dvae.out_conv.weight", (size_t)NM * ID * 3);
-    if (!w || upload(h, &h->oc_w, conv_to_gemm(*w, NM, ID, 3, ID, r64(NM)))) return 1;
+    if (!w || upload_w(h, &h->oc_w, &h->s_oc, conv_to_gemm(*w, NM, ID, 3, ID, r64(NM)))) return 1;
     w = vneed(h, "dvae.coef", NM);
     if (!w || upload(h, &h->coef, *w)) return 1;
     if (c.vq_groups > 0) {      // GroupedResidualFSQ.rvqs[g].project_out: Linear(4 -> idim)
@@ -239,7 +264,7 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
     }
     // ---- Vocos
     w = vneed(h, "vocos.backbone.embed.weight", (size_t)VD * NM * 7); b = vneed(h, "vocos.backbone.embed.bias", VD);
-    if (!w || !b || upload(h, &h->em_w, conv_to_gemm(*w, VD, NM, 7, h->mel_ld, r64(VD))) || upload(h, &h->em_b, *b)) return 1;
+    if (!w || !b || upload_w(h, &h->em_w, &h->s_em, conv_to_gemm(*w, VD, NM, 7, h->mel_ld, r64(VD))) || upload(h, &h->em_b, *b)) return 1;
     w = vneed(h, "vocos.backbone.norm.weight", VD); b = vneed(h, "vocos.backbone.norm.bias", VD);
     if (!w || !b || upload(h, &h->n0_w, *w) || upload(h, &h->n0_b, *b)) return 1;
     h->vblocks.resize(c.vocos_layers);
@@ -248,7 +273,7 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
     w = vneed(h, "vocos.backbone.final_layer_norm.weight", VD); b = vneed(h, "vocos.backbone.final_layer_norm.bias", VD);
     if (!w || !b || upload(h, &h->nf_w, *w) || upload(h, &h->nf_b, *b)) return 1;
     w = vneed(h, "vocos.head.out.weight", (size_t)2 * NB * VD); b = vneed(h, "vocos.head.out.bias", 2 * NB);
-    if (!w || !b || upload(h, &h->hd_w, pad_rows(*w, 2 * NB, VD, h->head_ld)) || upload(h, &h->hd_b, *b)) return 1;
+    if (!w || !b || upload_w(h, &h->hd_w, &h->s_hd, pad_rows(*w, 2 * NB, VD, h->head_ld)) || upload(h, &h->hd_b, *b)) return 1;
     const std::vector<float>* win = vneed(h, "vocos.head.istft.window", c.n_fft);
     if (!win || upload(h, &h->win, *win)) return 1;
     {   // windowed inverse real-DFT basis: frame[n] = w[n]/N * sum_k c_k (Re_k cos(2 pi k n/N) - Im_k sin(2 pi k n/N))
@@ -261,7 +286,7 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
                 B[(size_t)n * LD + k] = (float)((*win)[n] * ck * cos(ang) / N);
                 B[(size_t)n * LD + NB + k] = (float)(-(double)(*win)[n] * ck * sin(ang) / N);
             }
-        if (upload(h, &h->basis, B)) return 1;
+        if (upload_w(h, &h->basis, &h->s_basis, B)) return 1;
     }
     // ---- workspaces: max_batch regions of Fp rows (rows padded so every 64-row GEMM tile stays in bounds)
     const int Fp = r64(c.max_frames) + 192;             // 128-row GEMM tiles + conv guard rows stay in bounds
@@ -274,6 +299,11 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
         valloc(h, &h->mcl, MB * Fp * h->mel_ld) || valloc(h, &h->hbuf, MB * Fp * h->head_ld) ||
         valloc(h, &h->spec, MB * Fp * h->spec_ld) || valloc(h, &h->frames, MB * Fp * c.n_fft))
         return 1;
+    {
+        float *a = nullptr, *b2 = nullptr, *c2 = nullptr, *d2 = nullptr;                 // (valloc counts floats: half as many for fp16 images)
+        if (valloc(h, &a, MB * Fp * YD / 2) || valloc(h, &b2, MB * Fp * YD / 2) || valloc(h, &c2, MB * Fp * h->mid_ld / 2) || valloc(h, &d2, MB * Fp * h->mid_ld / 2)) return 1;
+        h->ln_hi = (half_t*)a; h->ln_lo = (half_t*)b2; h->mid_hi = (half_t*)c2; h->mid_lo = (half_t*)d2;
+    }
     const size_t tab_bytes = MB * 4 + MB * 24;
     CTTS_HIP_CHECK(hipMalloc(&h->d_tab, tab_bytes));
     CTTS_HIP_CHECK(hipHostMalloc(&h->pin, tab_bytes * 8));
@@ -289,18 +319,19 @@ extern "C" int ctts_voc_finalize(ctts_voc* h) {
 }
 
 static int run_convnext(ctts_voc* h, const ConvNext& cb, int nb, int Fmax, int dim, int inter, int dil, hipStream_t s) {
-    const long sd = (long)h->Fp * dim, sm = (long)h->Fp * h->mid_ld;
-    if (dim == 512) hipLaunchKernelGGL(dwconv_ln_kernel<8>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln, cb.dw_w, cb.dw_b, cb.ln_w, cb.ln_b, h->d_F, sd, sd, dim, dil, 7);
-    else hipLaunchKernelGGL(dwconv_ln_kernel<4>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln, cb.dw_w, cb.dw_b, cb.ln_w, cb.ln_b, h->d_F, sd, sd, dim, dil, 7);     // DVAE_full decoder: 256 wide
+    // dw-conv + LayerNorm -> head / tail fragment images; Linear + GELU -> images of mid; Linear, gamma, + residual -> y (cnx_gemm.h)
+    const long sd = (long)h->Fp * dim, sm = (long)h->Fp * inter;
+    if (dim == 512) hipLaunchKernelGGL(dwconv_ln_split_kernel<8>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln_hi, h->ln_lo, cb.dw_w, cb.dw_b, cb.ln_w, cb.ln_b, h->d_F, sd, sd, dim, dil, 7);
+    else hipLaunchKernelGGL(dwconv_ln_split_kernel<4>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->y, h->ln_hi, h->ln_lo, cb.dw_w, cb.dw_b, cb.ln_w, cb.ln_b, h->d_F, sd, sd, dim, dil, 7);     // DVAE_full decoder: 256 wide
     CTTS_HIP_CHECK(hipGetLastError());
-    GemmF32Args g = {};
-    g.A = h->ln; g.lda = dim; g.sA = sd; g.W = cb.w1; g.ldw = dim; g.C = h->mid; g.ldc = inter; g.sC = sm;
-    g.M = Fmax; g.Ms = h->d_F; g.N = inter; g.K = dim; g.bias = cb.b1;
-    if (launch_gemm_f32(EP_BIAS_GELU, g, nb, s, 127)) return 1;
-    GemmF32Args g2 = {};
-    g2.A = h->mid; g2.lda = inter; g2.sA = sm; g2.W = cb.w2; g2.ldw = inter; g2.C = h->y; g2.ldc = dim; g2.sC = sd;
-    g2.M = Fmax; g2.Ms = h->d_F; g2.N = dim; g2.K = inter; g2.bias = cb.b2; g2.gamma = cb.gamma; g2.resid = h->y; g2.ldr = dim; g2.sR = sd;
-    return launch_gemm_f32(EP_GAMMA_RESID, g2, nb, s, 127);
+    CnxGemm g = {};
+    g.Whi = cb.s1.hi; g.Wlo = cb.s1.lo; g.Xhi = h->ln_hi; g.Xlo = h->ln_lo; g.sX = sd; g.ktiles = dim / 32; g.N = inter; g.Ms = h->d_F; g.bias = cb.b1;
+    g.Ohi = h->mid_hi; g.Olo = h->mid_lo; g.sO = sm; g.ktiles_out = inter / 32;
+    if (launch_cnx_gemm(CNX_PW1, g, Fmax, nb, s)) return 1;
+    CnxGemm g2 = {};
+    g2.Whi = cb.s2.hi; g2.Wlo = cb.s2.lo; g2.Xhi = h->mid_hi; g2.Xlo = h->mid_lo; g2.sX = sm; g2.ktiles = inter / 32; g2.N = dim; g2.Ms = h->d_F; g2.bias = cb.b2;
+    g2.gamma = cb.gamma; g2.y = h->y; g2.sY = sd;
+    return launch_cnx_gemm(CNX_PW2, g2, Fmax, nb, s);
 }
 
 // upload the per-call tables (frames, pointers): a ring of pinned staging slots guarded by events, no stream sync
@@ -343,21 +374,21 @@ static int run_dvae(ctts_voc* h, int nb, int Fmax, bool to_mcl, hipStream_t s) {
     const long Fp = h->Fp;
     GemmF32Args g = {};
     g.A = h->in384; g.lda = ID; g.sA = Fp * ID; g.W = h->ci0_w; g.ldw = 3 * ID; g.C = h->b128 + BN; g.ldc = BN; g.sC = Fp * BN;
-    g.M = Fmax; g.Ms = h->d_F; g.N = BN; g.K = 3 * ID; g.bias = h->ci0_b;
+    g.M = Fmax; g.Ms = h->d_F; g.N = BN; g.K = 3 * ID; g.bias = h->ci0_b; g.Whi = h->s_ci0.hi; g.Wlo = h->s_ci0.lo;
     if (launch_gemm_f32(EP_BIAS_GELU, g, nb, s, 127)) return 1;                               // conv_in.0 + GELU (dvae.py:143-145)
     GemmF32Args g2 = {};
     g2.A = h->b128; g2.lda = BN; g2.sA = Fp * BN; g2.W = h->ci2_w; g2.ldw = 3 * BN; g2.C = h->y; g2.ldc = HD; g2.sC = Fp * HD;
-    g2.M = Fmax; g2.Ms = h->d_F; g2.N = HD; g2.K = 3 * BN; g2.bias = h->ci2_b;
+    g2.M = Fmax; g2.Ms = h->d_F; g2.N = HD; g2.K = 3 * BN; g2.bias = h->ci2_b; g2.Whi = h->s_ci2.hi; g2.Wlo = h->s_ci2.lo;
     if (launch_gemm_f32(EP_BIAS, g2, nb, s, 127)) return 1;                                    // conv_in.2 (dvae.py:146)
     for (int i = 0; i < c.dvae_layers; ++i)
         if (run_convnext(h, h->dblocks[i], nb, Fmax, HD, HD * 4, 2, s)) return 1;         // dvae.py:147-158,164-165
     GemmF32Args g3 = {};
     g3.A = h->y; g3.lda = HD; g3.sA = Fp * HD; g3.W = h->co_w; g3.ldw = HD; g3.C = h->co384 + ID; g3.ldc = ID; g3.sC = Fp * ID;
-    g3.M = Fmax; g3.Ms = h->d_F; g3.N = ID; g3.K = HD;
+    g3.M = Fmax; g3.Ms = h->d_F; g3.N = ID; g3.K = HD; g3.Whi = h->s_co.hi; g3.Wlo = h->s_co.lo;
     if (launch_gemm_f32(EP_NONE, g3, nb, s, 127)) return 1;                                    // conv_out 1x1, no bias (dvae.py:159,167)
     GemmF32Args g4 = {};
     g4.A = h->co384; g4.lda = ID; g4.sA = Fp * ID; g4.W = h->oc_w; g4.ldw = 3 * ID; g4.M = Fmax; g4.Ms = h->d_F; g4.N = c.n_mels; g4.K = 3 * ID;
-    g4.scale = h->coef;
+    g4.scale = h->coef; g4.Whi = h->s_oc.hi; g4.Wlo = h->s_oc.lo;
     if (to_mcl) {
         g4.C = h->mcl + 3 * h->mel_ld; g4.ldc = h->mel_ld; g4.sC = Fp * h->mel_ld;
         return launch_gemm_f32(EP_SCALE, g4, nb, s, 127);                                      // out_conv k3 * coef (dvae.py:285-291)
@@ -372,7 +403,7 @@ static int run_vocos(ctts_voc* h, int nb, int Fmax, hipStream_t s) {
     const long Fp = h->Fp;
     GemmF32Args g = {};
     g.A = h->mcl; g.lda = LD; g.sA = Fp * LD; g.W = h->em_w; g.ldw = 7 * LD; g.C = h->mid; g.ldc = VD; g.sC = Fp * h->mid_ld;
-    g.M = Fmax; g.Ms = h->d_F; g.N = VD; g.K = 7 * LD; g.bias = h->em_b;
+    g.M = Fmax; g.Ms = h->d_F; g.N = VD; g.K = 7 * LD; g.bias = h->em_b; g.Whi = h->s_em.hi; g.Wlo = h->s_em.lo;
     if (launch_gemm_f32(EP_BIAS, g, nb, s, 127)) return 1;                                     // embed conv k7 p3
     hipLaunchKernelGGL(dwconv_ln_kernel<8>, dim3((Fmax + 3) / 4, nb), dim3(256), 0, s, h->mid, h->y, nullptr, nullptr, h->n0_w, h->n0_b,
                        h->d_F, Fp * h->mid_ld, Fp * VD, VD, 1, 0);                        // post-embed LayerNorm -> residual stream
@@ -384,13 +415,13 @@ static int run_vocos(ctts_voc* h, int nb, int Fmax, hipStream_t s) {
     CTTS_HIP_CHECK(hipGetLastError());
     GemmF32Args g2 = {};
     g2.A = h->ln; g2.lda = VD; g2.sA = Fp * VD; g2.W = h->hd_w; g2.ldw = VD; g2.C = h->hbuf; g2.ldc = h->head_ld; g2.sC = Fp * h->head_ld;
-    g2.M = Fmax; g2.Ms = h->d_F; g2.N = 2 * NB; g2.K = VD; g2.bias = h->hd_b;
+    g2.M = Fmax; g2.Ms = h->d_F; g2.N = 2 * NB; g2.K = VD; g2.bias = h->hd_b; g2.Whi = h->s_hd.hi; g2.Wlo = h->s_hd.lo;
     if (launch_gemm_f32(EP_BIAS, g2, nb, s, 127)) return 1;                                    // ISTFTHead.out
     hipLaunchKernelGGL(head_spec_kernel, dim3(Fmax, nb), dim3(256), 0, s, h->hbuf, h->spec, h->d_F, Fp * h->head_ld, Fp * h->spec_ld, h->head_ld, h->spec_ld, NB);
     CTTS_HIP_CHECK(hipGetLastError());
     GemmF32Args g3 = {};
     g3.A = h->spec; g3.lda = h->spec_ld; g3.sA = Fp * h->spec_ld; g3.W = h->basis; g3.ldw = h->spec_ld; g3.C = h->frames; g3.ldc = c.n_fft;
-    g3.sC = Fp * c.n_fft; g3.M = Fmax; g3.Ms = h->d_F; g3.N = c.n_fft; g3.K = h->spec_ld;
+    g3.sC = Fp * c.n_fft; g3.M = Fmax; g3.Ms = h->d_F; g3.N = c.n_fft; g3.K = h->spec_ld; g3.Whi = h->s_basis.hi; g3.Wlo = h->s_basis.lo;
     if (launch_gemm_f32(EP_NONE, g3, nb, s, 127)) return 1;                                    // windowed irfft as GEMM
     const int lenmax = c.hop * (Fmax - 1);
     hipLaunchKernelGGL(overlap_add_kernel, dim3((lenmax + 255) / 256, nb), dim3(256), 0, s, h->frames, h->win, h->d_wav, h->d_F, Fp * c.n_fft, c.n_fft, c.hop);
