@@ -152,7 +152,7 @@ static int launch_cnx_gemm(int epi, const CnxGemm& p, int Fmax, int nb, hipStrea
 // head / tail fp16 fragment images [utterance][16-frame group][C / 32 k tiles][lane][8]: a lane's CPL consecutive channels are one (CPL = 8) or
 // half of one (CPL = 4) 16-byte fragment piece
 template <int CPL>
-__global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const float* x, half_t* ohi, half_t* olo, const float* w /*[C][7]*/, const float* b,
+__global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const float* x, half_t* ohi, half_t* olo, const float* w /*[taps][C]: transposed at load time*/, const float* b,
                                                               const float* lnw, const float* lnb, const int* Ts, long sx, long so, int C, int dil, int taps) {
     static_assert(CPL == 4 || CPL == 8, "4 or 8 channels per lane");
     const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -166,14 +166,14 @@ __global__ __launch_bounds__(256) void dwconv_ln_split_kernel(const float* x, ha
     for (int k = 0; k < taps; ++k) {
         const int tt = t + (k - taps / 2) * dil;
         if (tt < 0 || tt >= T) continue;
-        float xv[CPL];
+        // tap-major weights: a lane's CPL channels are contiguous (the [C][7] layout cost 7 * CPL strided loads per lane: 131 us per launch at
+        // 17408 frames, a quarter of the vocoder once the GEMMs were off the fp32 pipe)
 #pragma unroll
         for (int q4 = 0; q4 < CPL / 4; ++q4) {
-            const f32x4 pv = *(const f32x4*)(x + (size_t)tt * C + c0 + 4 * q4);
-            xv[4 * q4] = pv[0]; xv[4 * q4 + 1] = pv[1]; xv[4 * q4 + 2] = pv[2]; xv[4 * q4 + 3] = pv[3];
-        }
+            const f32x4 pv = *(const f32x4*)(x + (size_t)tt * C + c0 + 4 * q4), wv = *(const f32x4*)(w + (size_t)k * C + c0 + 4 * q4);
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) v[j] += w[(c0 + j) * taps + k] * xv[j];
+            for (int j = 0; j < 4; ++j) v[4 * q4 + j] += wv[j] * pv[j];
+        }
     }
     float s = 0.f;
 #pragma unroll

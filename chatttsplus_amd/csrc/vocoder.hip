@@ -196,7 +196,9 @@ static int load_convnext(ctts_voc* h, const std::string& p, int dim, int inter, 
                             *w2 = vneed(h, p + "pwconv2.weight", (size_t)dim * inter), *b2 = vneed(h, p + "pwconv2.bias", dim),
                             *g = vneed(h, p + "gamma", dim);
     if (!dw || !db || !lw || !lb || !w1 || !b1 || !w2 || !b2 || !g) return 1;
-    return upload(h, &cb->dw_w, *dw) || upload(h, &cb->dw_b, *db) || upload(h, &cb->ln_w, *lw) || upload(h, &cb->ln_b, *lb) ||
+    std::vector<float> dwT((size_t)7 * dim);                               // depthwise weights tap-major [7][C] (dwconv_ln_split_kernel)
+    for (int c = 0; c < dim; ++c) for (int k = 0; k < 7; ++k) dwT[(size_t)k * dim + c] = (*dw)[(size_t)c * 7 + k];
+    return upload(h, &cb->dw_w, dwT) || upload(h, &cb->dw_b, *db) || upload(h, &cb->ln_w, *lw) || upload(h, &cb->ln_b, *lb) ||
            upload_frag(h, &cb->s1, *w1, inter, dim) || upload(h, &cb->b1, *b1) || upload_frag(h, &cb->s2, *w2, dim, inter) || upload(h, &cb->b2, *b2) ||
            upload(h, &cb->gamma, *g);
 }
