@@ -246,6 +246,72 @@ def ragged_leg(g, dev, spk, rank, B=32, seed=2024):
             "useful_speedup": round(res["on"]["useful_tokens_per_s"] / res["off"]["useful_tokens_per_s"], 3)}
 
 
+def queue_leg(g, dev, spk, rank, NU=128, rows=32, seed=4048, admit_min=None, modes=("slices", "slices_compaction", "continuous")):
+    """A request of 128 utterances (a long text split into sentences) on 32 decode rows: prompt lengths U{16..96}, target lengths U{128..512}
+    enforced per row.  Host-inclusive wall clock of the GPT part, device noise, three ways of serving it: the reference's way -- slices, each
+    run to its slowest row (pipeline:391-397 with slice_size = 32 instead of 4); slices with finished-row compaction; continuous batching
+    (GPT.generate_many / ctts_gpt_admit: queued utterances take over rows as they free up).  Same tokens for every utterance in all three
+    (tests/test_gpu_properties.py); `useful` tokens/s = sum(n_b) / wall."""
+    from chatttsplus_amd import synth
+    cfg = synth.GPT_REAL
+    rng = np.random.Generator(np.random.Philox(key=seed + rank))
+    plen = rng.integers(16, 97, size=NU); plen[0] = 96
+    nb = [int(x) for x in rng.integers(128, 513, size=NU)]
+    P, N = 96, 512
+    pad = [int(P - p) for p in plen]
+    ids, mask = synth.prompt_ids(NU, P, cfg["num_text_tokens"], 99 + rank, pad_left=pad)
+    spk_id = 21143
+    for b in range(NU):
+        ids[b, pad[b] + 1, :] = spk_id
+    ids_t = torch.from_numpy(ids).to(dev)
+    srows = spk[torch.arange(NU, device=spk.device) % spk.shape[0]]
+    emb = g(ids_t, torch.ones(NU, P, dtype=torch.bool, device=dev), spk_emb=srows, spk_emb_ids=spk_id)
+    mask_t = torch.from_numpy(mask)
+    lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+    lp = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+    kw = dict(max_new_token=N, min_new_token=N, logits_warpers=lw, logits_processors=lp, return_hidden=False, seed=7)
+    uids = list(range(NU))
+
+    def sliced():
+        lens = []
+        for i in range(0, NU, rows):
+            sl = slice(i, i + rows)
+            out = list(g.generate(emb[sl].contiguous(), ids_t[sl], torch.tensor([0.3] * 4), 625, attention_mask=mask_t[sl], noise="device", utt_ids=uids[sl],
+                                  max_new_tokens_per_row=nb[sl], **kw))[-1]
+            lens += [int(i.shape[0]) for i in out.ids]
+        return lens
+
+    def continuous():
+        out = g.generate_many(emb, ids_t, torch.tensor([0.3] * 4), 625, attention_mask=mask_t, utt_ids=uids, max_new_tokens_per_row=nb, rows=rows, admit_min=admit_min, **kw)
+        return [int(i.shape[0]) for i in out.ids]
+
+    res = {}
+    keep = g.compact
+    try:
+        for name, fn, comp in (("slices", sliced, False), ("slices_compaction", sliced, True), ("continuous", continuous, True)):
+            if name not in modes:
+                continue
+            g.compact = comp
+            for rep in range(2):                                   # rep 0 captures the decode graphs of the batch sizes the run visits
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                lens = fn()
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+            if lens != nb:
+                raise SystemExit(f"queue leg ({name}) invalid: generated lengths {lens[:6]}.. != targets {nb[:6]}..")
+            res[name] = dict(wall_ms=round(dt * 1e3, 2), useful_tokens_per_s=round(float(sum(nb)) / dt, 1))
+        if "continuous" in res:
+            res["continuous"]["admissions"] = len(getattr(g, "admissions", []))
+    finally:
+        g.compact = keep
+    out = {"utterances": NU, "decode_rows": rows, "prompt_lengths": "U{16..96}", "target_lengths": "U{128..512}", "useful_tokens": int(sum(nb)), **res}
+    if "slices" in res:
+        base = res["slices"]["useful_tokens_per_s"]
+        out["speedup_vs_slices"] = {k: round(res[k]["useful_tokens_per_s"] / base, 3) for k in ("slices_compaction", "continuous") if k in res}
+    return out
+
+
 def summarize(r, world):
     step_ms = r["ev_ms"] / r["K"]
     ach = r["step_bytes"] / (step_ms * 1e-3) / 1e9
@@ -351,6 +417,8 @@ def main():
             extra["batch32_mixed_prompts"]["prompt_lengths"] = "U{16..96} left-padded to 96"
             # SURVEY 8d C3 with ragged TARGET lengths: useful vs padded tokens/s, finished-row compaction off / on
             extra["batch32_ragged_targets"] = ragged_leg(g, dev, spk, rank)
+            # the same lengths as a QUEUE: 128 utterances on 32 decode rows -- slices vs slices + compaction vs continuous batching
+            extra["queue128_on_32_rows"] = queue_leg(g, dev, spk, rank)
             # north_star: "decode tokens/s on synthetic 512-token prompts", batch 1
             e = leg.run(1, 512, EK, W, spk=spk, use_graph=use_graph)
             extra["prompt512_batch1"] = summarize(e, world)

@@ -37,14 +37,16 @@ struct DevState {
 // Per decode ROW state the sampler keeps in engine memory (one 32-byte record, fetched with the kernel's first batch of loads):
 // the engine-side mirror of {finish, end_idx} (gpt.py:339-342,486-487,530-531), and what keys the row's device noise stream --
 // the caller's global utterance id, the row's own regenerate attempt (ensure_non_empty, gpt.py:496-525) -- plus the row's own token
-// limit (<= max_new_token).  Rows are re-packed by ctts_gpt_compact; `seq` of RowMeta names the utterance (KV lane, output arrays).
+// limit (<= max_new_token).  Rows are re-packed by ctts_gpt_compact and re-used by ctts_gpt_admit; `seq` of RowMeta names the KV lane,
+// `out` the utterance's place in the caller's output arrays (equal until a lane is handed to another utterance).
 struct RowState {
     int fin;             // 0 = live; bit 0 = finished (no more tokens counted); bit 1 = ... by a sampled EOS (gpt.py:486-487) rather than by the row's limit
-    int end;             // end_idx
+    int end;             // end_idx = the row's OWN step: tokens it has sampled so far (rows admitted later run behind the batch's step counter)
     int attempt;         // first-step-EOS regenerations of THIS row so far
     int limit;           // the row stops after this many tokens
     unsigned uid_lo, uid_hi;   // global utterance id
-    int pad0, pad1;
+    int out;             // index of the utterance in ids / hiddens / finish / end_idx (and in the caller-supplied noise rows)
+    int pad1;
 };
 
 // fragment-major ("xfrag") activation layout used for every MFMA B operand:

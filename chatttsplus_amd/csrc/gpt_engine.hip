@@ -115,6 +115,10 @@ struct ctts_gpt {
     // finished-row compaction (ctts_gpt_compact): gather targets + the kept row indices
     float *cx = nullptr, *crope = nullptr; RowMeta* cmeta = nullptr; int* cring = nullptr; RowState* cfin = nullptr; int* keep_dev = nullptr;
     std::vector<int> keep_host;
+    // host mirrors of the decode rows: KV lane, context length (upper bound) and its cap (prompt + limit); see advance_rows / ctts_gpt_admit
+    std::vector<int> row_seq, row_ctx, row_cap;
+    std::vector<RowState> fresh_host;
+    int pre_T = 0;                               // tokens per sequence of the prompt rows being passed (begin: T; admit: T - 1)
     int B0 = 0;                                  // sequences the current generate() started with (h->B = rows still in the decode batch)
     // per generate()
     int B = 0, T = 0;
@@ -663,7 +667,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
-        if (st == nullptr) { at.T = h->T; at.row0 = (int)(meta - h->meta_pre); }       // prompt pass: position of this pass in the flattened [B][T] prompt
+        if (st == nullptr) { at.T = h->pre_T; at.row0 = (int)(meta - h->meta_pre); }       // prompt pass: position of this pass in the flattened [B][T] prompt
         at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
         if (pfs && S == 1) { if (launch_attention_split(at, h->sp_x_hi, h->sp_x_lo, s)) return 1; }      // writes o_proj's head / tail operand images directly
         else if (launch_attention(dt, at, s)) return 1;
@@ -725,6 +729,7 @@ static int run_heads(ctts_gpt* h, bool write_hidden, StreamForm form, hipStream_
     a.W = h->text_mode ? h->whead_text : h->whead; a.n_row_tiles = (nv + 15) / 16; a.K = h->H; a.x = h->x_dec; a.lnw = h->lnf;
     a.logits = h->logits; a.n_valid = nv;
     a.dyn = write_hidden ? h->dyn : nullptr;       // the kernel tests dyn->hidden_out itself
+    a.rows = h->finend;
     a.opart = h->dpart; a.np = form.parts ? 4 : 0;
     // the last down projection left the rows as packed fp16 + sums of squares (PRO_XH): no fp32 re-normalisation per block.  The text head is a
     // different launch shape (not measured): it keeps the fp32 prologue
@@ -756,7 +761,10 @@ static int reset_state(ctts_gpt* h, bool keep_draw, hipStream_t s) {
     CTTS_HIP_CHECK(hipMemsetAsync(h->io.end_idx, 0, h->B * 4, s));
     if (!keep_draw) {       // begin: {fin 0, end 0, attempt 0, limit, utterance id} per row (pageable source: staged before the call returns)
         CTTS_HIP_CHECK(hipMemcpyAsync(h->finend, h->rows_host.data(), h->B * sizeof(RowState), hipMemcpyHostToDevice, s));
-    } else if (launch_restart_rows(h->finend, h->B, s)) return 1;      // ensure_non_empty regenerate: rows that ended at step 0 move on to their next noise attempt
+    } else {
+        if (launch_restart_rows(h->finend, h->B, s)) return 1;
+        h->row_ctx.assign(h->B, h->T);
+    }      // ensure_non_empty regenerate: rows that ended at step 0 move on to their next noise attempt
     CTTS_HIP_CHECK(hipMemsetAsync(h->hist_ring, 0xFF, (size_t)h->B * CTTS_NUM_VQ * 16 * 4, s));      // -1: no id sampled yet
     return 0;
 }
@@ -784,7 +792,11 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
         int lim = io->row_limits ? io->row_limits[b] : sc->max_new_token;
         r.limit = lim < 1 ? 1 : (lim > sc->max_new_token ? sc->max_new_token : lim);
         r.uid_lo = (unsigned)uid; r.uid_hi = (unsigned)(uid >> 32);
+        r.out = b;
     }
+    h->row_seq.resize(B); h->row_ctx.assign(B, T); h->row_cap.resize(B);
+    for (int b = 0; b < B; ++b) { h->row_seq[b] = b; h->row_cap[b] = T + h->rows_host[b].limit; }
+    h->pre_T = T;
     h->io.utt_ids = nullptr; h->io.row_limits = nullptr;      // host arrays are consumed here, not kept
     memcpy(h->sc.temperature, sc->temperature, sizeof(sc->temperature));
     h->sc.top_p_threshold = sc->top_p_threshold; h->sc.top_k = sc->top_k; h->sc.min_keep = sc->min_tokens_to_keep;
@@ -833,6 +845,19 @@ extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
     return reset_state(h, true, s);
 }
 
+// host mirror of the decode rows' context lengths (an upper bound: a row stops growing when it finishes, at the latest at prompt + limit):
+// the longest one after `n_steps` more steps picks the attention's key-split count
+static int advance_rows(ctts_gpt* h, int n_steps) {
+    int longest = 1;
+    for (int r = 0; r < h->B; ++r) {
+        int c = h->row_ctx[r] + n_steps;
+        if (c > h->row_cap[r]) c = h->row_cap[r];
+        h->row_ctx[r] = c;
+        if (c > longest) longest = c;
+    }
+    return longest;
+}
+
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
     StreamForm form = {false, false};
     if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s, &form)) return 1;
@@ -867,7 +892,7 @@ extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* st
     if (!h || h->B == 0) { ctts_set_error("decode: call begin first"); return 1; }
     CTTS_RANGE("ctts_gpt_decode");              // reference: nvtx "forward" per decode step + "execute" (trt_models/predictor.py:164)
     hipStream_t s = (hipStream_t)stream;
-    h->cur_splits = decode_splits(h, h->B, h->T + h->launched + n_steps + 1);
+    h->cur_splits = decode_splits(h, h->B, advance_rows(h, n_steps) + 1);
     h->launched += n_steps;
     if (use_graph) {
         if (ensure_graph(h)) return 1;
@@ -921,7 +946,66 @@ extern "C" int ctts_gpt_compact(ctts_gpt* h, const int32_t* keep_rows, int n_kee
     h->keep_host.assign(keep_rows, keep_rows + n_keep);
     CTTS_HIP_CHECK(hipMemcpyAsync(h->keep_dev, h->keep_host.data(), (size_t)n_keep * 4, hipMemcpyHostToDevice, s));
     if (launch_compact_rows(h->keep_dev, n_keep, h->H, h->x_dec, h->rope_dec, h->meta_dec, h->hist_ring, h->finend, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->st, s)) return 1;
+    for (int i = 0; i < n_keep; ++i) { h->row_seq[i] = h->row_seq[keep_rows[i]]; h->row_ctx[i] = h->row_ctx[keep_rows[i]]; h->row_cap[i] = h->row_cap[keep_rows[i]]; }
     h->B = n_keep;
+    return 0;
+}
+
+
+// Continuous batching (no counterpart in the reference, whose slices run to their slowest row, pipeline:391-397 / gpt.py:527-546): `n` new
+// utterances take over decode rows whose utterance has finished.  Their prompts (all tokens but the last) go through an ordinary prompt pass
+// into the rows' KV lanes, starting at slot 0 of the lane; the last prompt token becomes the row's next decode input, so the next decode
+// step produces the utterance's first token together with everybody else's next one.  The row's step counter, noise stream (utterance id,
+// attempt), token limit and output index are its own (RowState), so an utterance's tokens do not depend on when or where it was admitted.
+extern "C" int ctts_gpt_admit(ctts_gpt* h, int n, const int32_t* rows, int T, const int32_t* mask, const float* emb, const uint64_t* utt_ids,
+                              const int32_t* row_limits, const int32_t* out_index, const int32_t* attempts, void* stream) {
+    if (!h || h->B == 0) { ctts_set_error("admit: call begin first"); return 1; }
+    if (!rows || !mask || !emb || !utt_ids || !out_index) { ctts_set_error("admit: null argument"); return 1; }
+    if (h->text_mode || h->lora_rows) { ctts_set_error("admit: code mode without per-utterance adapters only"); return 1; }
+    if (h->io.noise != nullptr) { ctts_set_error("admit: device noise only (caller-supplied noise is indexed by the batch's draw counter)"); return 1; }
+    if (n < 1 || n > h->B || T < 1 || T + h->sc.max_new > h->cfg.max_seq || (long long)n * (T - 1) > h->pass_rows) {
+        ctts_set_error("admit: n=%d of %d rows, T=%d (max_seq %d, %d prompt rows per pass)", n, h->B, T, h->cfg.max_seq, h->pass_rows);
+        return 1;
+    }
+    CTTS_RANGE("ctts_gpt_admit");
+    hipStream_t s = (hipStream_t)stream;
+    h->keep_host.assign(rows, rows + n);
+    std::vector<int> seqs(n);
+    h->fresh_host.assign(n, RowState{});
+    for (int i = 0; i < n; ++i) {
+        if (rows[i] < 0 || rows[i] >= h->B) { ctts_set_error("admit: row %d of %d", rows[i], h->B); return 1; }
+        for (int j = 0; j < i; ++j) if (rows[j] == rows[i]) { ctts_set_error("admit: row %d named twice", rows[i]); return 1; }
+        seqs[i] = h->row_seq[rows[i]];
+        RowState& r = h->fresh_host[i];
+        int lim = row_limits ? row_limits[i] : h->sc.max_new;
+        r.limit = lim < 1 ? 1 : (lim > h->sc.max_new ? h->sc.max_new : lim);
+        r.uid_lo = (unsigned)utt_ids[i]; r.uid_hi = (unsigned)(utt_ids[i] >> 32);
+        r.attempt = attempts ? attempts[i] : 0;
+        r.out = out_index[i];
+        if (r.out < 0) { ctts_set_error("admit: negative output index"); return 1; }
+    }
+    int* rows_dev = h->keep_dev;
+    int* seqs_dev = h->cring;                    // (compaction scratch: consumed in stream order)
+    RowState* fresh_dev = h->cfin;
+    CTTS_HIP_CHECK(hipMemcpyAsync(rows_dev, h->keep_host.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    CTTS_HIP_CHECK(hipMemcpyAsync(seqs_dev, seqs.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    CTTS_HIP_CHECK(hipMemcpyAsync(fresh_dev, h->fresh_host.data(), (size_t)n * sizeof(RowState), hipMemcpyHostToDevice, s));
+    AdmitArgs a = {};
+    a.mask = mask; a.emb = emb; a.rows = rows_dev; a.seqs = seqs_dev; a.fresh = fresh_dev; a.n = n; a.T = T; a.H = h->H;
+    a.pm = h->meta_pre; a.rope_pre = h->rope_pre; a.dm = h->meta_dec; a.rope_dec = h->rope_dec; a.x_dec = h->x_dec; a.ring = h->hist_ring; a.finend = h->finend;
+    a.rope = h->rope; a.st = h->st; a.finish = h->io.finish; a.end_idx = h->io.end_idx;
+    if (launch_admit_rows(a, s)) return 1;
+    const int R = n * (T - 1);
+    if (R > 0) {
+        // prompt rows [n][T-1] <- emb[i][0 .. T-2]
+        CTTS_HIP_CHECK(hipMemcpy2DAsync(h->x_pre, (size_t)(T - 1) * h->H * 4, emb, (size_t)T * h->H * 4, (size_t)(T - 1) * h->H * 4, n, hipMemcpyDeviceToDevice, s));
+        const int keepT = h->pre_T;
+        h->pre_T = T - 1;
+        const int rc = run_layers(h, h->x_pre, h->meta_pre, h->rope_pre, R, 1, nullptr, s);
+        h->pre_T = keepT;
+        if (rc) return 1;
+    }
+    for (int i = 0; i < n; ++i) { h->row_ctx[rows[i]] = T; h->row_cap[rows[i]] = T + h->fresh_host[i].limit; }
     return 0;
 }
 
@@ -977,12 +1061,14 @@ extern "C" int ctts_gpt_time_decode(ctts_gpt* h, int n_steps, float* ms_per_step
         if (pass == 1) CTTS_HIP_CHECK(hipEventRecord(h->ev0, s));
         for (int i = 0; i < n_steps; i += CH) {
             const int n = (n_steps - i < CH) ? n_steps - i : CH;
-            h->cur_splits = decode_splits(h, h->B, h->T + launched + n + 1);
+            int longest = 1;
+            for (int r = 0; r < h->B; ++r) { const int c = std::min(h->row_ctx[r] + (launched - h->launched) + n, h->row_cap[r]); if (c > longest) longest = c; }
+            h->cur_splits = decode_splits(h, h->B, longest + 1);
             launched += n;
             if (ensure_graph(h)) return 1;
             if (pass == 1) for (int j = 0; j < n; j += h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
         }
-        if (pass == 1) h->launched = launched;
+        if (pass == 1) { (void)advance_rows(h, launched - h->launched); h->launched = launched; }
     }
     CTTS_HIP_CHECK(hipEventRecord(h->ev1, s));
     CTTS_HIP_CHECK(hipEventSynchronize(h->ev1));

@@ -51,6 +51,7 @@ struct GemmArgs {
     // per-utterance LoRA (lora.hip): low-rank term of every row, added in the epilogue.  EPI_QKV: [rows][3][768]; EPI_RESID*: [rows][768]
     const float* lora_delta;
     int* sat;               // fp16 engines: counter of saturated / NaN fp16 stores (common.h sat_half); null = do not count
+    const RowState* rows;   // heads only: hidden row goes to hiddens[rows[r].out][rows[r].end] while the row is live
 };
 
 struct AttnArgs {
@@ -146,6 +147,19 @@ int launch_fill_meta(RowMeta* prefill_meta, RowMeta* decode_meta, DevState* st, 
 int launch_embed_prompt(const int* ids, const int* text_mask, const float* emb_text, const float* emb_code, const float* spk, int spk_id,
                         float* out, int rows, int T, int V, int H, hipStream_t s);
 int launch_restart_rows(RowState* rows, int B, hipStream_t s);
+// ctts_gpt_admit: n new utterances take over decode rows `rows[i]` (KV lanes `seqs[i]`); prompt rows (all but the last token) -> pm / rope_pre
+struct AdmitArgs {
+    const int* mask;        // [n][T] device
+    const float* emb;       // [n][T][H] device
+    const int* rows;        // [n] device: decode rows to overwrite
+    const int* seqs;        // [n] device: their KV lanes
+    const RowState* fresh;  // [n] device: the new rows' state
+    int n, T, H;
+    RowMeta* pm; float* rope_pre;                 // [n][T-1]
+    RowMeta* dm; float* rope_dec; float* x_dec; int* ring; RowState* finend;      // decode-row arrays
+    const float* rope; DevState* st; int* finish; int* end_idx;
+};
+int launch_admit_rows(const AdmitArgs& a, hipStream_t s);
 int launch_compact_rows(const int* keep, int n_keep, int H, float* x, float* rope_rows, RowMeta* meta, int* ring, RowState* fin,
                         float* cx, float* crope, RowMeta* cmeta, int* cring, RowState* cfin, DevState* st, hipStream_t s);
 int gemm_configure();

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void attn_prefill_split_kernel(const RowMeta* 
     typedef half_t (*ks_t)[64][FS_KPITCH];
     vt_t vth = (vt_t)fs_lds, vtl = (vt_t)(fs_lds + 2 * 64 * FS_PITCH * 2);
     ks_t ksh = (ks_t)(fs_lds + 4 * 64 * FS_PITCH * 2), ksl = (ks_t)(fs_lds + 4 * 64 * FS_PITCH * 2 + 2 * 64 * FS_KPITCH * 2);
-    __shared__ int range_s[4][2];
+    __shared__ int range_s[4][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qn = lane & 15, iq = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y, T = a.T;
@@ -255,15 +255,17 @@ __global__ __launch_bounds__(256) void attn_prefill_split_kernel(const RowMeta* 
     if (live) m = meta_p[r];
     const int lo = live ? m.kv_start : 0x7FFFFFFF, hi = live ? m.slot : -1;
     int wlo = lo, whi = hi;                                               // wave-uniform key range
+    int wsq = live ? m.seq : -1;                                          // KV lane of this block's sequence (b itself after begin; any lane after ctts_gpt_admit)
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) { wlo = min(wlo, __shfl_xor(wlo, off)); whi = max(whi, __shfl_xor(whi, off)); }
-    if (lane == 0) { range_s[wave][0] = wlo; range_s[wave][1] = whi; }
+    for (int off = 1; off < 16; off <<= 1) { wlo = min(wlo, __shfl_xor(wlo, off)); whi = max(whi, __shfl_xor(whi, off)); wsq = max(wsq, __shfl_xor(wsq, off)); }
+    if (lane == 0) { range_s[wave][0] = wlo; range_s[wave][1] = whi; range_s[wave][2] = wsq; }
     __syncthreads();
     const int blo = min(min(range_s[0][0], range_s[1][0]), min(range_s[2][0], range_s[3][0]));
     const int bhi = max(max(range_s[0][1], range_s[1][1]), max(range_s[2][1], range_s[3][1]));
     if (bhi < 0) return;                                                  // no live query in this block (uniform)
+    const int cseq = max(max(range_s[0][2], range_s[1][2]), max(range_s[2][2], range_s[3][2]));
     wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
-    const size_t head_off = ((size_t)b * NHp + h) * a.Lmax * CTTS_HEAD_DIM;
+    const size_t head_off = ((size_t)cseq * NHp + h) * a.Lmax * CTTS_HEAD_DIM;
     const float* kb = k_p + head_off;
     const float* vb = v_p + head_off;
     // Q fragments (B operand): lane (query qn, kq = iq): dims 8 iq .. + 7 of each 32-dim half, scaled by 1/sqrt(64), head / tail

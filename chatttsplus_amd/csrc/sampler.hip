@@ -271,13 +271,16 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
     // the finish / end_idx bookkeeping is mirrored in engine memory (the caller's arrays are write-only here).
     const int ring_v = ring_p[(size_t)(b * CTTS_NUM_VQ + vq) * 16 + (lane & 15)];
     const int4 fe = ((const int4*)(finend_p + b))[0];              // {fin, end, attempt, limit}
-    const int2 uid = ((const int2*)(finend_p + b))[2];              // {uid_lo, uid_hi}
+    const int4 uid = ((const int4*)(finend_p + b))[1];             // {uid_lo, uid_hi, out, -}
     if (tid < 17) tab[tid] = d->cfg.penalty_table[tid];
     const RowMeta meta_in = meta_p[b];
     if (__builtin_amdgcn_readfirstlane(hdr.z)) return;            // every sequence finished (gpt.py:545)
-    const int step = __builtin_amdgcn_readfirstlane(hdr.x), draw = __builtin_amdgcn_readfirstlane(hdr.y);
+    const int gstep = __builtin_amdgcn_readfirstlane(hdr.x), draw = __builtin_amdgcn_readfirstlane(hdr.y);
     const int fin_in = fe.x, end_in = fe.y;
-    const int seq = meta_in.seq;                                  // utterance of this row: output arrays, noise rows (rows are re-packed by ctts_gpt_compact)
+    // the row's OWN step (i of gpt.py:389 for this utterance) = tokens it has sampled so far: equal to the batch's step counter while the
+    // row is live and was part of the batch from its start; rows admitted later (ctts_gpt_admit) run behind it
+    const int step = end_in;
+    const int seq = uid.z;                                        // utterance of this row: output arrays, noise rows (rows are re-packed by ctts_gpt_compact)
     const float rope_next = (tid < 64) ? a.rope[(size_t)(meta_in.pos + 1) * 64 + tid] : 0.f;
     __syncthreads();
     const int row = seq * CTTS_NUM_VQ + vq;                       // row of the [B0 * 4, V] batch the call started with (gpt.py:444-447)
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
     const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg, cand_s[vq]);
     if (lane == 0) {
         idx_s[vq] = idx;
-        d->ids[((size_t)seq * d->cfg.max_new + step) * CTTS_NUM_VQ + vq] = idx;
+        if (fin_in == 0) d->ids[((size_t)seq * d->cfg.max_new + step) * CTTS_NUM_VQ + vq] = idx;      // (a finished row's tokens are never read: gpt.py:295-297)
         a.hist_ring[(size_t)(b * CTTS_NUM_VQ + vq) * 16 + (step & 15)] = idx;
     }
     __syncthreads();
@@ -313,12 +316,14 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
         bool fin = was || eos;
         const int end_out = fin ? end_in : end_in + 1;                               // gpt.py:530-531
         if (!fin) d->end_idx[seq] = end_out;
-        fin = fin || (end_out >= fe.w);                                              // the row's own token limit: done from the next step on
+        fin = fin || (end_out >= fe.w);                                              // the row's own token limit (<= max_new_token: the loop bound of gpt.py:389): done from the next step on
         d->finish[seq] = eos ? 1 : 0;                                                // the caller's `finish` keeps the reference's meaning: EOS seen
         ((int2*)(a.finend + b))[0] = make_int2(fin ? (eos ? 3 : 1) : 0, end_out);
-        RowMeta m = meta_in;                                                       // next decode row
-        m.pos += 1; m.slot += 1;
-        a.meta[b] = m;
+        if (!was) {                                                                // next decode row; a finished row stays on its last slot (it keeps
+            RowMeta m = meta_in;                                                   // computing like the reference's finished rows, gpt.py:527-546, but
+            m.pos += 1; m.slot += 1;                                               // never walks past the end of its cache lane)
+            a.meta[b] = m;
+        }
         // One agent-scope atomic carries both the arrival ticket (low 16 bits) and the number of finished
         // sequences (high 16 bits, persistent over the steps): no fences, no cross-block plain loads.
         const int add = 1 + ((fin && !was) ? 0x10000 : 0);
@@ -327,9 +332,9 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
         if ((tot & 0xFFFF) == a.B) {                           // last block of this step: advance the step state
             const int nfin = tot >> 16;
             st->ticket = nfin << 16;
-            st->step = step + 1;
+            st->step = gstep + 1;
             st->draw = draw + 1;
-            if (nfin == a.B || step + 1 >= d->cfg.max_new) st->all_done = 1;         // gpt.py:545 / loop bound :389
+            if (nfin == a.B) st->all_done = 1;                 // gpt.py:545 (every row ends by its limit <= max_new_token, the loop bound of :389)
         }
     }
     if (tid < 64) a.rope_rows[(size_t)b * 64 + tid] = rope_next;      // RoPE row of the next step's position (prefetched)
@@ -686,6 +691,57 @@ int launch_compact_rows(const int* keep, int n_keep, int H, float* x, float* rop
                        (const RowState*)fin, cx, crope, cmeta, cring, cfin);
     hipLaunchKernelGGL(compact_scatter_kernel, dim3(n_keep), dim3(256), 0, s, n_keep, H, x, rope_rows, meta, ring, fin, (const float*)cx, (const float*)crope,
                        (const RowMeta*)cmeta, (const int*)cring, (const RowState*)cfin, st);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+
+// ctts_gpt_admit: one wavefront per new utterance.  Prompt rows (all tokens but the last) get the metadata of an ordinary prompt pass into
+// KV lane seqs[i], from slot 0; the decode row rows[i] is re-initialised: input = the last prompt token's embedding at (slot T-1,
+// pos cumsum-1), empty penalty window, fresh RowState, finish / end_idx of the utterance cleared.  The rows being replaced are finished
+// ones: the batch's finished-row count goes down by n.
+__global__ __launch_bounds__(64) void admit_rows_kernel(const AdmitArgs a) {
+    const int i = blockIdx.x, lane = threadIdx.x, T = a.T;
+    const int row = a.rows[i], seq = a.seqs[i];
+    int cum = 0, pad = 0;
+    bool seen = false;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const int mk = (t < T) ? (a.mask[i * T + t] != 0) : 0;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(mk != 0);
+        if (!seen) {
+            if (bal != 0ull) { pad = t0 + (int)__builtin_ctzll(bal); seen = true; }
+            else pad = min(t0 + 64, T);
+        }
+        const int incl = cum + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) + mk;
+        RowMeta m;
+        m.seq = seq;
+        m.pos = mk ? incl - 1 : 1;             // gpt.py:238-245
+        m.slot = t;
+        m.kv_start = mk ? pad : t;
+        if (t < T - 1) a.pm[i * (T - 1) + t] = m;
+        for (int j = 0; j < 64 && t0 + j < T - 1; ++j) {          // the prompt rows' RoPE table rows, one coalesced 256-byte copy each
+            const int pj = __shfl(m.pos, j);
+            a.rope_pre[((size_t)i * (T - 1) + t0 + j) * 64 + lane] = a.rope[(size_t)pj * 64 + lane];
+        }
+        cum += __builtin_popcountll(bal);
+    }
+    const int pos_last = max(cum - 1, 0);
+    a.rope_dec[(size_t)row * 64 + lane] = a.rope[(size_t)pos_last * 64 + lane];
+    a.ring[(size_t)row * 64 + lane] = -1;
+    for (int k = lane; k < a.H; k += 64) a.x_dec[(size_t)row * a.H + k] = a.emb[((size_t)i * T + T - 1) * a.H + k];
+    if (lane == 0) {
+        RowMeta d;
+        d.seq = seq; d.pos = pos_last; d.slot = T - 1; d.kv_start = pad;
+        a.dm[row] = d;
+        const RowState r = a.fresh[i];
+        a.finend[row] = r;
+        a.finish[r.out] = 0; a.end_idx[r.out] = 0;
+        if (i == 0) { a.st->ticket -= a.n << 16; a.st->all_done = 0; }
+    }
+}
+int launch_admit_rows(const AdmitArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(admit_rows_kernel, dim3(a.n), dim3(64), 0, s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }

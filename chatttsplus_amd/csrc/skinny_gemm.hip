@@ -205,8 +205,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 store_x4<WT>(smem, n, k, KTILES, v[u][i][0] * rs, v[u][i][1] * rs, v[u][i][2] * rs, v[u][i][3] * rs);
             }
             float* const hid_out = (a.dyn != nullptr) ? ((SamplerDynPtr)a.dyn)->hidden_out : nullptr;
-            if (hid_out != nullptr && rt0 == 0) {                          // heads only: hidden = weight * (x * rs) (llama.py:87)
-                float* hrow = hid_out + (size_t)a.meta[r].seq * ((SamplerDynPtr)a.dyn)->hidden_stride + (size_t)a.st->step * K;
+            const int4 rstate = (hid_out != nullptr && rt0 == 0) ? *(const int4*)(a.rows + r) : make_int4(1, 0, 0, 0);      // {fin, end, ..}
+            if (hid_out != nullptr && rt0 == 0 && rstate.x == 0) {         // heads only: hidden = weight * (x * rs) (llama.py:87) -> hiddens[utterance][its own step]
+                float* hrow = hid_out + (size_t)a.rows[r].out * ((SamplerDynPtr)a.dyn)->hidden_stride + (size_t)rstate.y * K;
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     const int k = 4 * (lane + 64 * i);
@@ -455,7 +456,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 const int r = row0 + n;
                 const float rs = fac_s[NB + n];
                 const f32x4* xr = (const f32x4*)(a.x + (size_t)r * K);
-                float* hrow = hid_out + (size_t)a.meta[r].seq * ((SamplerDynPtr)a.dyn)->hidden_stride + (size_t)a.st->step * K;
+                const int4 rstate = *(const int4*)(a.rows + r);             // {fin, end, ..}: a live row's hidden goes to hiddens[utterance][its own step]
+                if (rstate.x != 0) continue;
+                float* hrow = hid_out + (size_t)a.rows[r].out * ((SamplerDynPtr)a.dyn)->hidden_stride + (size_t)rstate.y * K;
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     const int k = 4 * (lane + 64 * i);

@@ -538,6 +538,160 @@ class GPT:
             tick("outputs")
             yield out
 
+    # -- continuous batching: more utterances than decode rows (no counterpart in the reference) ------------------------------------
+    @torch.no_grad()
+    def generate_many(self, emb: torch.Tensor, inputs_ids: torch.Tensor, temperature: torch.Tensor, eos_token: Union[int, torch.Tensor],
+                      attention_mask: Optional[torch.Tensor] = None, max_new_token=2048, min_new_token=0, logits_warpers=[],
+                      logits_processors=[], return_hidden=False, ensure_non_empty=True, context=None, seed: Optional[int] = None,
+                      max_restarts: int = 64, utt_ids=None, max_new_tokens_per_row=None, rows: Optional[int] = None, admit_min: Optional[int] = None,
+                      on_done=None) -> GenerationOutputs:
+        """N utterances (left-padded prompts emb[N,T,H], like generate()) through `rows` <= max_batch decode rows: whenever utterances
+        finish, queued ones take over their rows (ctts_gpt_admit) instead of the whole slice waiting for its slowest row as the reference's
+        slices of 4 do (pipeline:391-397, gpt.py:527-546); once the queue is empty finished rows are compacted away (ctts_gpt_compact).
+        Device noise only: an utterance's noise stream is keyed by (seed, its utterance id, its own step, its regenerate attempt), its step
+        counter / token limit / outputs are its own, so it produces what generate() produces for it in any slice.  ensure_non_empty
+        (gpt.py:496-525) acts per utterance: one whose first token is EOS is admitted again with its next attempt, up to `max_restarts`.
+        `on_done(list_of_indices)` is called (on the host, while decoding continues) as utterances complete.
+        Returns one GenerationOutputs for all N utterances, in input order."""
+        if not self._finalized:
+            raise _lib.HipBackendError("weights not loaded")
+        if self._busy_token.owner is not None:
+            raise _lib.HipBackendError("GPT.generate is already running on this engine (or on an engine sharing its KV cache)")
+        self._busy_token.owner = self
+        try:
+            return self._generate_many(emb, inputs_ids, temperature, eos_token, attention_mask, int(max_new_token), min_new_token, logits_warpers,
+                                       logits_processors, return_hidden, ensure_non_empty, context or Context(), seed, max_restarts, utt_ids,
+                                       max_new_tokens_per_row, rows, admit_min, on_done)
+        finally:
+            self._busy_token.owner = None
+
+    def _generate_many(self, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token, logits_warpers, logits_processors,
+                       return_hidden, ensure_non_empty, context, seed, max_restarts, utt_ids, row_limits, rows, admit_min, on_done):
+        lib, h, dev = self._lib, self._h, self.device
+        N, T = int(inputs_ids.shape[0]), int(inputs_ids.shape[1])
+        H, NVQ = self.model_dim, self.num_vq
+        R = min(N, int(rows) if rows else self.max_batch, self.max_batch)
+        sc = sampler_cfg_from_objects(temperature, int(eos_token), max_new_token, min_new_token, logits_warpers, logits_processors, NVQ)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        mask = torch.ones(N, T, dtype=torch.int32, device=dev) if attention_mask is None else attention_mask.to(dev).to(torch.int32).contiguous()
+        emb = emb.to(dev, dtype=torch.float32).contiguous()
+        lens = mask.sum(1).cpu().tolist()
+        uids = [int(u) for u in utt_ids] if utt_ids is not None else list(range(N))
+        lims = [min(max(int(v), 1), max_new_token) for v in row_limits] if row_limits is not None else [max_new_token] * N
+        assert len(uids) == N and len(lims) == N
+        ids = torch.empty(N, max_new_token, NVQ, dtype=torch.int32, device=dev)
+        hid = torch.empty(N, max_new_token, H, dtype=torch.float32, device=dev) if return_hidden else None
+        finish = torch.zeros(N, dtype=torch.int32, device=dev)
+        end_idx = torch.zeros(N, dtype=torch.int32, device=dev)
+        admit_min = max(1, int(admit_min) if admit_min else R // 8)
+        chunk = max(4, min(self.chunk_steps, self.compact_chunk))
+        self.compactions, self.admissions = [], []
+
+        def prompts_of(idx):
+            """left-padded prompts of the utterances `idx`, trimmed to the longest of them"""
+            Ta = max(1, max(lens[u] for u in idx))
+            ii = torch.as_tensor(idx, dtype=torch.long, device=dev)
+            return Ta, emb.index_select(0, ii)[:, T - Ta:].contiguous(), mask.index_select(0, ii)[:, T - Ta:].contiguous()
+
+        with torch.cuda.device(dev):
+            st = self._stream()
+            first = list(range(R))
+            Ta, emb_a, mask_a = prompts_of(first)
+            uid_arr = np.ascontiguousarray([uids[u] for u in first], dtype=np.uint64)
+            lim_arr = np.ascontiguousarray([lims[u] for u in first], dtype=np.int32)
+            io = _lib.GenIO(ids=ids.data_ptr(), hiddens=hid.data_ptr() if hid is not None else None, finish=finish.data_ptr(),
+                            end_idx=end_idx.data_ptr(), noise=None, n_draws=max_new_token, seed=int(seed), utt_ids=uid_arr.ctypes.data,
+                            row_limits=lim_arr.ctypes.data)
+            _lib.check(lib.ctts_gpt_begin(h, R, Ta, mask_a.data_ptr(), C.byref(sc), C.byref(io), st), "begin")
+            _lib.check(lib.ctts_gpt_prefill(h, emb_a.data_ptr(), st), "prefill")
+            _lib.check(lib.ctts_gpt_sample(h, st), "sample")
+            queue = [(u, 0) for u in range(R, N)]                  # (utterance, regenerate attempt)
+            tickets = {}                                           # admission ticket -> [utterance, attempt, current row]
+            row_tk: List[Optional[int]] = []
+            next_tk = 0
+            for r in range(R):
+                tickets[next_tk] = [r, 0, r]
+                row_tk.append(next_tk)
+                next_tk += 1
+            n_done, since_free = 0, 0
+            pins = [torch.zeros(2 * R, dtype=torch.int32).pin_memory() for _ in range(2)]
+            evs = [torch.cuda.Event() for _ in range(2)]
+            layouts = [None, None]
+            pending, n_chunks, launched = [], 0, 1
+            while n_done < N and not context.get():
+                while len(pending) < 2:
+                    _lib.check(lib.ctts_gpt_decode(h, chunk, 1 if self.use_graph else 0, st), "decode")
+                    launched += chunk
+                    slot = n_chunks % 2
+                    n_chunks += 1
+                    _lib.check(lib.ctts_gpt_rows_enqueue(h, pins[slot].data_ptr(), st), "rows_enqueue")
+                    layouts[slot] = list(row_tk)
+                    evs[slot].record(torch.cuda.current_stream(dev))
+                    pending.append(slot)
+                slot = pending.pop(0)
+                evs[slot].synchronize()
+                lay = layouts[slot]
+                st_rows = pins[slot][:2 * len(lay)].view(-1, 2).tolist()
+                finished_now = []
+                for tk, (fin, end) in zip(lay, st_rows):
+                    if tk is None or tk not in tickets or not fin:
+                        continue
+                    u, att, r = tickets.pop(tk)
+                    row_tk[r] = None
+                    if (fin & 2) and end == 0 and ensure_non_empty and att + 1 < max_restarts:
+                        queue.insert(0, (u, att + 1))              # first token was EOS (gpt.py:496-525): next noise attempt
+                    else:
+                        n_done += 1
+                        finished_now.append(u)
+                if finished_now and on_done is not None:
+                    on_done(finished_now)
+                free = [r for r, tk in enumerate(row_tk) if tk is None]
+                since_free = since_free + 1 if free else 0
+                if queue and free and (len(free) >= min(admit_min, len(queue)) or since_free >= 4 or len(free) == len(row_tk)):
+                    k = min(len(free), len(queue))
+                    take, queue = queue[:k], queue[k:]
+                    idx = [u for u, _ in take]
+                    Ta, emb_a, mask_a = prompts_of(idx)
+                    rows_arr = np.ascontiguousarray(free[:k], dtype=np.int32)
+                    uid_arr = np.ascontiguousarray([uids[u] for u in idx], dtype=np.uint64)
+                    lim_arr = np.ascontiguousarray([lims[u] for u in idx], dtype=np.int32)
+                    out_arr = np.ascontiguousarray(idx, dtype=np.int32)
+                    att_arr = np.ascontiguousarray([a for _, a in take], dtype=np.int32)
+                    _lib.check(lib.ctts_gpt_admit(h, k, rows_arr.ctypes.data_as(C.c_void_p), Ta, mask_a.data_ptr(), emb_a.data_ptr(),
+                                                  uid_arr.ctypes.data_as(C.c_void_p), lim_arr.ctypes.data_as(C.c_void_p),
+                                                  out_arr.ctypes.data_as(C.c_void_p), att_arr.ctypes.data_as(C.c_void_p), st), "admit")
+                    for r, (u, a) in zip(free[:k], take):
+                        tickets[next_tk] = [u, a, r]
+                        row_tk[r] = next_tk
+                        next_tk += 1
+                    self.admissions.append((launched, k))
+                    since_free = 0
+                elif not queue and self.compact and len(row_tk) >= 2:
+                    live = [r for r, tk in enumerate(row_tk) if tk is not None]
+                    target = compact_size(len(live))
+                    if live and target < len(row_tk):
+                        fill = [r for r, tk in enumerate(row_tk) if tk is None][:target - len(live)]
+                        keep = sorted(live + fill)
+                        karr = np.ascontiguousarray(keep, dtype=np.int32)
+                        _lib.check(lib.ctts_gpt_compact(h, karr.ctypes.data_as(C.c_void_p), int(karr.size), st), "compact")
+                        row_tk = [row_tk[r] for r in keep]
+                        for nr, tk in enumerate(row_tk):
+                            if tk is not None:
+                                tickets[tk][2] = nr
+                        self.compactions.append((launched, len(row_tk)))
+            torch.cuda.current_stream(dev).synchronize()
+            self.saturations = 0
+            if self.dtype_code == _lib.DTYPE_F16:
+                nsat = C.c_int32(0)
+                _lib.check(lib.ctts_gpt_saturations(h, C.byref(nsat), st), "saturations")
+                self.saturations = int(nsat.value)
+                if self.saturations:
+                    import warnings
+                    warnings.warn(f"hip GPT (weight_dtype fp16): {self.saturations} fp16 stores saturated or were NaN during this generate_many(); "
+                                  f"use weight_dtype='fp32' for this checkpoint", RuntimeWarning)
+            return self._outputs(ids, hid, end_idx, False)
+
     def _staging(self, rows: int, V: int, cap: int):
         """Pinned [cap, rows, V] staging slots for the torch-generator noise, kept across calls (pinning is expensive)."""
         key = (rows, V, cap)

@@ -290,6 +290,12 @@ class ChatTTSPlusPipeline:
         num_code = int(gpt.emb_code[0].num_embeddings - 1)
         warpers, processors = gen_logits(num_code=num_code, top_P=params.top_P, top_K=params.top_K,
                                          repetition_penalty=params.repetition_penalty)
+        if gen_kwargs.pop("continuous", False):
+            # more utterances than decode rows: queued utterances take over rows as they free up (GPT.generate_many) -- one result, not a generator
+            gen_kwargs.pop("noise", None)
+            return gpt.generate_many(emb, input_ids, temperature=torch.tensor(temperature), eos_token=num_code, attention_mask=attention_mask,
+                                     max_new_token=params.max_new_token, min_new_token=params.min_new_token, logits_warpers=warpers,
+                                     logits_processors=processors, return_hidden=return_hidden, ensure_non_empty=params.ensure_non_empty, **gen_kwargs)
         return gpt.generate(emb, input_ids, temperature=torch.tensor(temperature), eos_token=num_code, attention_mask=attention_mask,
                             max_new_token=params.max_new_token, min_new_token=params.min_new_token, logits_warpers=warpers,
                             logits_processors=processors, infer_text=False, return_hidden=return_hidden, stream=stream,
@@ -421,6 +427,31 @@ class ChatTTSPlusPipeline:
         elif len(utt_ids) != len(text_in):
             raise _lib.HipBackendError(f"utt_ids: {len(utt_ids)} entries for {len(text_in)} utterances (after text splitting)")
         noise_seed = kwargs.get("noise_seed")      # None: drawn from torch's CPU generator when the first slice that uses device noise starts
+        # `continuous=True` (no counterpart in the reference): the request's utterances are NOT cut into slices that each wait for their slowest
+        # row (pipeline:391-397); slice_size decode rows are kept busy -- queued utterances take over the rows of finished ones
+        # (GPT.generate_many, ctts_gpt_admit).  Device noise keyed by utterance id: every utterance gets the waveform the sliced path gives it.
+        # One list with all waveforms is yielded.  Not for streaming, per-utterance adapters or caller-supplied noise.
+        if kwargs.get("continuous") and len(text_in) > slice_size:
+            if stream or lora_paths is not None or noise_mode not in ("auto", "device"):
+                raise _lib.HipBackendError("continuous=True works with stream=False, device noise and without per-utterance adapters")
+            texts_all = []
+            for ii in range(0, len(text_in), slice_size):
+                text = list(text_in[ii:ii + slice_size])
+                if not skip_refine_text:                                               # pipeline:399-411, still in slices (a short pass)
+                    refined = self._refine_text(text, params_refine_text)
+                    text = tok.decode([i[i.less(tok.break_0_ids)] for i in refined.ids])
+                    if refine_text_only:
+                        yield text
+                texts_all += text
+            if refine_text_only:
+                return
+            texts_all = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in texts_all]   # pipeline:414-416
+            if noise_seed is None:
+                noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            result = self._infer_code(texts_all, False, use_decoder, params_infer_code, gpt=gpt, continuous=True, seed=noise_seed, utt_ids=utt_ids,
+                                      rows=slice_size)
+            yield self._decode_to_wavs(result.hiddens if use_decoder else result.ids, use_decoder)
+            return
         for ii in range(0, len(text_in), slice_size):
             text = list(text_in[ii:ii + slice_size])
             if not skip_refine_text:                                                   # pipeline:399-411

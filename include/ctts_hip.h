@@ -189,6 +189,21 @@ int ctts_gpt_saturations(ctts_gpt* h, int32_t* count, void* stream);
 int ctts_gpt_rows_enqueue(ctts_gpt* h, int32_t* host_pinned_2B, void* stream);
 int ctts_gpt_compact(ctts_gpt* h, const int32_t* keep_rows, int n_keep, void* stream);
 
+/* Continuous batching (no counterpart in the reference: its slices of 4 run one after the other, each to its slowest row,
+ * pipeline:391-397): between two ctts_gpt_decode calls `n` NEW utterances take over decode rows whose utterance has finished (the
+ * caller has seen their finish flag through rows_enqueue).
+ *   rows        HOST [n] current row indices, distinct
+ *   T, mask, emb   the new utterances' left-padded prompts: DEVICE mask [n,T] int32, emb [n,T,H] fp32 (ctts_gpt_embed); T + max_new_token
+ *               must fit max_seq and n*(T-1) one prompt pass
+ *   utt_ids, row_limits (may be null), out_index, attempts (may be null)   HOST [n]: noise key, token limit, place in the ids / hiddens /
+ *               finish / end_idx arrays handed to ctts_gpt_begin (which must be large enough: they are indexed by out_index, not by
+ *               row), regenerate attempt (ensure_non_empty: an utterance whose first token was EOS is admitted again with attempt + 1)
+ * The prompt but its last token goes through a prompt pass into the rows' KV lanes; the last token becomes the rows' next decode input, so
+ * the next decode step samples the utterance's first token.  Step counter, noise stream, limit and outputs are per row, so an utterance's
+ * result does not depend on when or where it is admitted.  Code mode, device noise, no per-utterance adapters.  Asynchronous. */
+int ctts_gpt_admit(ctts_gpt* h, int n, const int32_t* rows, int T, const int32_t* mask, const float* emb, const uint64_t* utt_ids,
+                   const int32_t* row_limits, const int32_t* out_index, const int32_t* attempts, void* stream);
+
 /* Non-blocking variant: enqueues a copy of {steps_done, draws, all_finished, -} into 4 int32 of PINNED host memory; the
  * caller records an event after it and reads the words once the event has completed -- lets the host keep one chunk of
  * decode steps in flight while it inspects the previous one. */

@@ -182,6 +182,77 @@ def test_row_limits_and_compaction_keep_every_row_identical(gpt32):
         assert torch.equal(one.ids[0], kept.ids[b]), f"utterance {b}: batch row vs served alone"
 
 
+def _slices(g, emb, ids, mask, eos, N, min_new, limits, uids, size, ensure=True):
+    """the reference's way: slices of `size`, each run to its slowest row (finished rows stay in the batch)"""
+    out_ids, out_h = [], []
+    g.compact = False
+    try:
+        for i in range(0, ids.shape[0], size):
+            sl = slice(i, i + size)
+            res = list(g.generate(emb[sl].contiguous(), torch.from_numpy(ids[sl]), torch.tensor([0.3] * 4), eos, attention_mask=torch.from_numpy(mask[sl]),
+                                  max_new_token=N, min_new_token=min_new, logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="device",
+                                  seed=33, utt_ids=uids[sl], max_new_tokens_per_row=limits[sl], ensure_non_empty=ensure))
+            assert res, "slice produced nothing"
+            out_ids += res[-1].ids
+            out_h += res[-1].hiddens
+    finally:
+        g.compact = True
+    return out_ids, out_h
+
+
+@pytest.mark.parametrize("rows", [8, 20])
+def test_continuous_batching_gives_every_utterance_its_sliced_result(gpt32, rows):
+    """generate_many (ctts_gpt_admit): 44 utterances with ragged prompts and ragged token limits through 8 / 20 decode rows -- queued
+    utterances take over rows as soon as their utterance finishes, later the batch is compacted.  Every utterance's tokens are the ones the
+    reference's way of serving them produces (slices, each run to its slowest row): noise, step counter, limit and outputs are per row."""
+    g = gpt32
+    NU, T, N = 44, 40, 60
+    rng = np.random.Generator(np.random.Philox(key=15))
+    pads = [int(p) for p in rng.integers(0, 30, size=NU)]
+    limits = [int(x) for x in rng.integers(2, N + 1, size=NU)]
+    limits[5], limits[6] = 1, N
+    uids = [1000 + 7 * u for u in range(NU)]
+    ids, mask = synth.prompt_ids(NU, T, 21178, 83, pad_left=pads)
+    emb = g(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
+    ref_ids, ref_h = _slices(g, emb, ids, mask, 625, N, N, limits, uids, 8)
+    done_log = []
+    out = g.generate_many(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=N,
+                          logits_warpers=LW, logits_processors=LP, return_hidden=True, seed=33, utt_ids=uids, max_new_tokens_per_row=limits, rows=rows,
+                          on_done=done_log.extend)
+    assert g.admissions, "nothing was admitted"
+    assert sum(k for _, k in g.admissions) == NU - rows
+    assert sorted(done_log) == list(range(NU))
+    for u in range(NU):
+        assert out.ids[u].shape[0] == limits[u], (u, out.ids[u].shape, limits[u])
+        assert torch.equal(out.ids[u], ref_ids[u]), f"utterance {u}: continuous batching changed its tokens"
+        assert float((out.hiddens[u] - ref_h[u]).abs().max()) <= 5e-5, u
+
+
+def test_continuous_batching_with_eos_and_regenerate(gpt32):
+    """The same with utterances that end by a sampled EOS -- the `eos_token` is set to a token that utterance 3 samples as its very first
+    one, so that utterance takes the ensure_non_empty path (gpt.py:496-525: regenerate with fresh noise; here per utterance: it is admitted
+    again with its next attempt) and others end wherever they happen to sample it."""
+    g = gpt32
+    NU, T, N = 24, 24, 48
+    rng = np.random.Generator(np.random.Philox(key=16))
+    pads = [int(p) for p in rng.integers(0, 12, size=NU)]
+    uids = list(range(50, 50 + NU))
+    ids, mask = synth.prompt_ids(NU, T, 21178, 84, pad_left=pads)
+    emb = g(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
+    lim = [N] * NU
+    free_ids, _ = _slices(g, emb, ids, mask, 625, N, N, lim, uids, 8)
+    eos = int(free_ids[3][0, 1])                                     # codebook 1 of utterance 3's first token
+    ref_ids, ref_h = _slices(g, emb, ids, mask, eos, N, 0, lim, uids, 8)
+    assert any(r.shape[0] < N for r in ref_ids), "no utterance ended by EOS: the case does not test what it says"
+    assert not torch.equal(ref_ids[3][:1], free_ids[3][:1]) or ref_ids[3].shape[0] == 0
+    out = g.generate_many(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), eos, attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=0,
+                          logits_warpers=LW, logits_processors=LP, return_hidden=True, seed=33, utt_ids=uids, rows=6)
+    for u in range(NU):
+        assert torch.equal(out.ids[u], ref_ids[u]), f"utterance {u}: {out.ids[u].shape} vs {ref_ids[u].shape}"
+        if ref_ids[u].shape[0]:
+            assert float((out.hiddens[u] - ref_h[u]).abs().max()) <= 5e-5, u
+
+
 @pytest.mark.parametrize("wd", ["fp16", "fp32"])
 def test_runs_are_bitwise_reproducible(wd):
     """The same request three times on one engine: token ids, hiddens and the KV cache contents are bitwise identical (no atomics anywhere on
