@@ -448,9 +448,19 @@ class ChatTTSPlusPipeline:
             texts_all = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in texts_all]   # pipeline:414-416
             if noise_seed is None:
                 noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            result = self._infer_code(texts_all, False, use_decoder, params_infer_code, gpt=gpt, continuous=True, seed=noise_seed, utt_ids=utt_ids,
-                                      rows=slice_size)
-            yield self._decode_to_wavs(result.hiddens if use_decoder else result.ids, use_decoder)
+            # longest texts first (longest-processing-time order: the last rows to finish are then short utterances); an utterance's result
+            # does not depend on the order -- its noise is keyed by its id
+            order = sorted(range(len(texts_all)), key=lambda i: -len(texts_all[i]))
+            pic = params_infer_code
+            if torch.is_tensor(pic.spk_emb) and pic.spk_emb.dim() == 2 and pic.spk_emb.shape[0] == len(order):      # one speaker row per utterance
+                pic = dataclasses.replace(pic, spk_emb=pic.spk_emb[torch.as_tensor(order, device=pic.spk_emb.device)])
+            result = self._infer_code([texts_all[i] for i in order], False, use_decoder, pic, gpt=gpt, continuous=True, seed=noise_seed,
+                                      utt_ids=[utt_ids[i] for i in order], rows=slice_size)
+            items = result.hiddens if use_decoder else result.ids
+            back = [None] * len(order)
+            for k, i in enumerate(order):
+                back[i] = items[k]
+            yield self._decode_to_wavs(back, use_decoder)
             return
         for ii in range(0, len(text_in), slice_size):
             text = list(text_in[ii:ii + slice_size])
@@ -579,13 +589,17 @@ class ChatTTSPlusPipeline:
         kwargs.pop("noise", None); kwargs.pop("utt_ids", None)
         wavs_local: List[torch.Tensor] = []
 
+        continuous = bool(kwargs.pop("continuous", False))      # each rank keeps slice_size decode rows busy over ALL its utterances (infer(continuous=True))
+
         def run_local(indices, rows):
             lens = []
-            for ii in range(0, len(indices), slice_size):
-                sl = indices[ii:ii + slice_size]
+            step = len(indices) if continuous else slice_size
+            for ii in range(0, len(indices), max(step, 1)):
+                sl = indices[ii:ii + step]
                 p = dataclasses.replace(params, spk_emb=rows[ii:ii + len(sl)])
                 for wavs in self._infer([texts[i] for i in sl], False, None, skip_refine_text, False, True, True, False, True,
-                                        params_refine_text, p, slice_size=len(sl), utt_ids=list(sl), noise="device", noise_seed=noise_seed, **kwargs):
+                                        params_refine_text, p, slice_size=(slice_size if continuous else len(sl)), utt_ids=list(sl), noise="device",
+                                        noise_seed=noise_seed, continuous=continuous, **kwargs):
                     wavs_local.extend(wavs)
                     lens.extend([(int(w.shape[0]) // 256 + 1) // 2 if w.shape[0] else 0 for w in wavs])
             return lens

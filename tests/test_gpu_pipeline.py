@@ -132,13 +132,15 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
         runs[ss] = [w.cpu().numpy() for w in got]
     _, sw, lens = pipe.infer_sharded(list(many), params_infer_code=pv, noise_seed=77, slice_size=3)
     runs["sharded"] = [w.cpu().numpy() for w in sw]
+    _, sw, lens = pipe.infer_sharded(list(many), params_infer_code=pv, noise_seed=77, slice_size=3, continuous=True)
+    runs["sharded_continuous"] = [w.cpu().numpy() for w in sw]
     # continuous batching (infer(continuous=True): 7 utterances through 2 / 3 decode rows, rows re-used as utterances finish): same waveforms
     for rows in (2, 3):
         res = list(pipe.infer(list(many), skip_refine_text=True, do_text_optimization=False, params_infer_code=pv, noise="device", noise_seed=77,
                               slice_size=rows, continuous=True))
         assert len(res) == 1 and len(res[0]) == len(many)
         runs[f"continuous{rows}"] = [w.cpu().numpy() for w in res[0]]
-    for key in (4, 8, "sharded", "continuous2", "continuous3"):
+    for key in (4, 8, "sharded", "sharded_continuous", "continuous2", "continuous3"):
         for u in range(len(many)):
             a, b2 = runs[2][u], runs[key][u]
             assert a.shape == b2.shape, f"slice {key}, utterance {u}: {a.shape} vs {b2.shape} samples (token count differs)"
