@@ -26,11 +26,18 @@ timeout 250 python tools/pipe_wall.py --n 32 --tokens 256 2>&1 | tail -1 >> $O/p
 timeout 250 python tools/pipe_wall.py --dtype fp16 2>&1 | tail -1 >> $O/pipe_wall.log
 timeout 250 python tools/pipe_wall.py --dtype fp16 --n 32 --tokens 256 2>&1 | tail -1 >> $O/pipe_wall.log
 for cfg in "1 48" "32 48" "32 96" "32 512"; do for wd in fp32 fp16; do timeout 120 python tools/prefill_probe.py $cfg $wd 2>&1 | grep "prompt pass" | tail -1 | sed "s/$/  ($wd)/" >> $O/prefill.log; done; done
-cat $O/gen_wall.log $O/pipe_wall.log $O/prefill.log
+rm -f $O/queue.jsonl $O/vocoder.log
+for wd in fp32 fp16; do timeout 250 python tools/queue_probe.py $wd 2>&1 | tail -1 >> $O/queue.jsonl; done
+timeout 120 python tools/voc_batch_probe.py 2>&1 | tail -1 >> $O/vocoder.log
+cat $O/gen_wall.log $O/pipe_wall.log $O/prefill.log $O/queue.jsonl $O/vocoder.log
 R=$GRAFT_REPO_ROOT
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b1 -- python $R/bench.py --steps 128 --warmup 16 --cpu-steps 0 --no-extras > /tmp/prof_b1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b32 -- python $R/bench.py --batch 32 --steps 64 --warmup 16 --cpu-steps 0 --no-extras > /tmp/prof_b32.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_voc -- python $R/tools/voc_batch_probe.py > /tmp/prof_voc.log 2>&1
+f=$(find /tmp/prof_voc -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $R/$O/vocoder_32x272_kernel_stats.csv
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pre -- python $R/tools/prefill_probe.py 32 512 fp32 > /tmp/prof_pre.log 2>&1
+f=$(find /tmp/prof_pre -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $R/$O/prefill_32x512_fp32_kernel_stats.csv
 for t in b1 b32; do
   f=$(find /tmp/prof_$t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $R/$O/${t}_fp32_kernel_stats.csv
   grep '"metric"' /tmp/prof_$t.log | cut -c1-400 > $R/$O/${t}_prof_bench.json
