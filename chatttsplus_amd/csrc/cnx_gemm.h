@@ -15,7 +15,11 @@
 #include "conv_gemm.h"
 
 #define CNX_WSCALE 256.0f
-#define CNX_RING 3
+// LDS ring of k-tile stages.  2 stages = 64 KB = TWO blocks per CU (134 VGPRs): the second block's MFMAs fill the barrier / LDS-read bubbles of the
+// first -- 32 x 272 tokens 9.3 -> 7.7 ms against 3 stages (96 KB, one block per CU, one barrier per stage instead of two)
+#ifndef CNX_RING
+#define CNX_RING 2
+#endif
 #define CNX_STAGE (32 * 1024)
 enum { CNX_PW1 = 0, CNX_PW2 = 1 };
 
@@ -43,7 +47,7 @@ __device__ inline void cnx_split4(const f32x4 v, half4& hi, half4& lo) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256) void cnx_gemm_kernel(const CnxGemm p) {
+__global__ __launch_bounds__(256, CNX_RING == 2 ? 2 : 1) void cnx_gemm_kernel(const CnxGemm p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int z = blockIdx.z, M = p.Ms[z];
     if ((int)blockIdx.y * 128 >= M) return;
@@ -88,6 +92,10 @@ __global__ __launch_bounds__(256) void cnx_gemm_kernel(const CnxGemm p) {
         for (int g = 0; g < 4; ++g) {
             xh[g] = *(const half8*)(cur + (16 + wr * 4 + g) * 1024 + lane * 16);
             xl[g] = *(const half8*)(cur + (24 + wr * 4 + g) * 1024 + lane * 16);
+        }
+        if (CNX_RING == 2) {                               // two stages (64 KB: two blocks per CU): the stage just read is the one the next copy overwrites
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): this wave's fragments are in registers
+            __builtin_amdgcn_s_barrier();
         }
         if (kt + 2 < ktiles) {
             const int nb = (cb + 2 >= CNX_RING) ? cb + 2 - CNX_RING : cb + 2;

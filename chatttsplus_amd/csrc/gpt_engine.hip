@@ -118,6 +118,7 @@ struct ctts_gpt {
     // host mirrors of the decode rows: KV lane, context length (upper bound) and its cap (prompt + limit); see advance_rows / ctts_gpt_admit
     std::vector<int> row_seq, row_ctx, row_cap;
     std::vector<RowState> fresh_host;
+    std::vector<int> seq_host;
     int pre_T = 0;                               // tokens per sequence of the prompt rows being passed (begin: T; admit: T - 1)
     int B0 = 0;                                  // sequences the current generate() started with (h->B = rows still in the decode batch)
     // per generate()
@@ -970,7 +971,8 @@ extern "C" int ctts_gpt_admit(ctts_gpt* h, int n, const int32_t* rows, int T, co
     CTTS_RANGE("ctts_gpt_admit");
     hipStream_t s = (hipStream_t)stream;
     h->keep_host.assign(rows, rows + n);
-    std::vector<int> seqs(n);
+    std::vector<int>& seqs = h->seq_host;
+    seqs.assign(n, 0);
     h->fresh_host.assign(n, RowState{});
     for (int i = 0; i < n; ++i) {
         if (rows[i] < 0 || rows[i] >= h->B) { ctts_set_error("admit: row %d of %d", rows[i], h->B); return 1; }

@@ -13,12 +13,15 @@
 // residual (llama.py:666,731,739), SiLU(gate) * up (llama.py:214, precise expf + division like the decode kernels).
 //
 // Structure: block = 128 rows x 128 features, 4 waves (2 x 2) of 64 x 64 = 4 x 4 accumulators; a k-tile stage = 32 one-KiB fragments
-// (8 Whi, 8 Wlo, 8 Xhi, 8 Xlo) copied by LDS-DMA into a ring of 3 stages (96 KB: one block per CU, 48 MFMAs per wave and stage).
+// (8 Whi, 8 Wlo, 8 Xhi, 8 Xlo) copied by LDS-DMA into a ring of SP_RING stages (2 x 32 KB: two blocks per CU; 48 MFMAs per wave and stage).
 #include "kernels.h"
 
 #define SP_WSCALE 64.0f
 #define SP_ACT_SCALE 16.0f
-#define SP_RING 3
+// LDS ring of k-tile stages: 2 x 32 KB = two blocks per CU (see cnx_gemm.h): 32 x 512-token prompt pass 26.6 -> 22.8 ms against a ring of 3 (one block per CU)
+#ifndef SP_RING
+#define SP_RING 2
+#endif
 #define SP_STAGE (32 * 1024)
 
 __device__ inline void split_h4(const f32x4 v, half4& hi, half4& lo) {
@@ -78,7 +81,7 @@ struct SplitGemm {
 };
 
 template <int EPI>
-__global__ __launch_bounds__(256) void prefill_split_gemm_kernel(const SplitGemm p, const GemmArgs a) {
+__global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_kernel(const SplitGemm p, const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -130,6 +133,10 @@ __global__ __launch_bounds__(256) void prefill_split_gemm_kernel(const SplitGemm
         for (int g = 0; g < 4; ++g) {
             xh[g] = *(const half8*)(cur + (16 + wr * 4 + g) * 1024 + lane * 16);
             xl[g] = *(const half8*)(cur + (24 + wr * 4 + g) * 1024 + lane * 16);
+        }
+        if (SP_RING == 2) {                                // two stages (64 KB: two blocks per CU): the stage just read is the one the next copy overwrites
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): this wave's fragments are in registers
+            __builtin_amdgcn_s_barrier();
         }
         if (kt + 2 < ktiles) {
             const int nb = (cb + 2 >= SP_RING) ? cb + 2 - SP_RING : cb + 2;
