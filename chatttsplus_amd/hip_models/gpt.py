@@ -108,6 +108,60 @@ def compact_size(n_live: int) -> int:
     return (n + q - 1) // q * q
 
 
+class RowBook:
+    """Continuous batching bookkeeping (GPT.generate_many): which utterance sits in which decode row.  Every seating gets a ticket; the row
+    states the engine reports ({fin, end} per row, ctts_gpt_rows_enqueue) arrive one or two chunks late and are interpreted through the
+    ticket layout that was current when the report was ENQUEUED -- a report taken before an admission or a compaction can neither finish the
+    row's new occupant nor be confused by rows having moved."""
+
+    def __init__(self):
+        self.row_tk: List[Optional[int]] = []      # ticket per current decode row (None: the row's utterance is done, the row is free)
+        self.tickets = {}                          # live ticket -> [utterance, attempt, current row]
+        self._next = 0
+
+    def seat(self, row: int, utt: int, attempt: int = 0) -> int:
+        tk = self._next
+        self._next += 1
+        if row == len(self.row_tk):
+            self.row_tk.append(tk)
+        else:
+            assert self.row_tk[row] is None, "seat: the row is occupied"
+            self.row_tk[row] = tk
+        self.tickets[tk] = [utt, attempt, row]
+        return tk
+
+    def layout(self) -> list:
+        return list(self.row_tk)
+
+    def free_rows(self) -> List[int]:
+        return [r for r, tk in enumerate(self.row_tk) if tk is None]
+
+    def live_rows(self) -> List[int]:
+        return [r for r, tk in enumerate(self.row_tk) if tk is not None]
+
+    def report(self, layout, states, ensure_non_empty: bool, max_restarts: int):
+        """`states` = [(fin, end)] per row of `layout`.  Returns (utterances completed, [(utterance, next attempt)] to admit again: their
+        first token was EOS, gpt.py:496-525)."""
+        done, again = [], []
+        for tk, (fin, end) in zip(layout, states):
+            if tk is None or not fin or tk not in self.tickets:
+                continue
+            utt, att, row = self.tickets.pop(tk)
+            self.row_tk[row] = None
+            if (fin & 2) and end == 0 and ensure_non_empty and att + 1 < max_restarts:
+                again.append((utt, att + 1))
+            else:
+                done.append(utt)
+        return done, again
+
+    def compact(self, keep: List[int]) -> None:
+        """rows `keep` (ascending) become rows 0..len(keep)-1 (ctts_gpt_compact)"""
+        self.row_tk = [self.row_tk[r] for r in keep]
+        for nr, tk in enumerate(self.row_tk):
+            if tk is not None:
+                self.tickets[tk][2] = nr
+
+
 class _BusyToken:
     """One generate() at a time per KV cache: shared by every engine bound to the same KV tensor (LoRA-merged siblings, with_lora)."""
     def __init__(self):
@@ -607,13 +661,9 @@ class GPT:
             _lib.check(lib.ctts_gpt_prefill(h, emb_a.data_ptr(), st), "prefill")
             _lib.check(lib.ctts_gpt_sample(h, st), "sample")
             queue = [(u, 0) for u in range(R, N)]                  # (utterance, regenerate attempt)
-            tickets = {}                                           # admission ticket -> [utterance, attempt, current row]
-            row_tk: List[Optional[int]] = []
-            next_tk = 0
+            book = RowBook()
             for r in range(R):
-                tickets[next_tk] = [r, 0, r]
-                row_tk.append(next_tk)
-                next_tk += 1
+                book.seat(r, r)
             n_done, since_free = 0, 0
             pins = [torch.zeros(2 * R, dtype=torch.int32).pin_memory() for _ in range(2)]
             evs = [torch.cuda.Event() for _ in range(2)]
@@ -626,29 +676,20 @@ class GPT:
                     slot = n_chunks % 2
                     n_chunks += 1
                     _lib.check(lib.ctts_gpt_rows_enqueue(h, pins[slot].data_ptr(), st), "rows_enqueue")
-                    layouts[slot] = list(row_tk)
+                    layouts[slot] = book.layout()
                     evs[slot].record(torch.cuda.current_stream(dev))
                     pending.append(slot)
                 slot = pending.pop(0)
                 evs[slot].synchronize()
                 lay = layouts[slot]
-                st_rows = pins[slot][:2 * len(lay)].view(-1, 2).tolist()
-                finished_now = []
-                for tk, (fin, end) in zip(lay, st_rows):
-                    if tk is None or tk not in tickets or not fin:
-                        continue
-                    u, att, r = tickets.pop(tk)
-                    row_tk[r] = None
-                    if (fin & 2) and end == 0 and ensure_non_empty and att + 1 < max_restarts:
-                        queue.insert(0, (u, att + 1))              # first token was EOS (gpt.py:496-525): next noise attempt
-                    else:
-                        n_done += 1
-                        finished_now.append(u)
+                finished_now, again = book.report(lay, pins[slot][:2 * len(lay)].view(-1, 2).tolist(), ensure_non_empty, max_restarts)
+                queue = again + queue                              # first token was EOS (gpt.py:496-525): next noise attempt, ahead of the queue
+                n_done += len(finished_now)
                 if finished_now and on_done is not None:
                     on_done(finished_now)
-                free = [r for r, tk in enumerate(row_tk) if tk is None]
+                free = book.free_rows()
                 since_free = since_free + 1 if free else 0
-                if queue and free and (len(free) >= min(admit_min, len(queue)) or since_free >= 4 or len(free) == len(row_tk)):
+                if queue and free and (len(free) >= min(admit_min, len(queue)) or since_free >= 4 or len(free) == len(book.row_tk)):
                     k = min(len(free), len(queue))
                     take, queue = queue[:k], queue[k:]
                     idx = [u for u, _ in take]
@@ -662,24 +703,18 @@ class GPT:
                                                   uid_arr.ctypes.data_as(C.c_void_p), lim_arr.ctypes.data_as(C.c_void_p),
                                                   out_arr.ctypes.data_as(C.c_void_p), att_arr.ctypes.data_as(C.c_void_p), st), "admit")
                     for r, (u, a) in zip(free[:k], take):
-                        tickets[next_tk] = [u, a, r]
-                        row_tk[r] = next_tk
-                        next_tk += 1
+                        book.seat(r, u, a)
                     self.admissions.append((launched, k))
                     since_free = 0
-                elif not queue and self.compact and len(row_tk) >= 2:
-                    live = [r for r, tk in enumerate(row_tk) if tk is not None]
+                elif not queue and self.compact and len(book.row_tk) >= 2:
+                    live = book.live_rows()
                     target = compact_size(len(live))
-                    if live and target < len(row_tk):
-                        fill = [r for r, tk in enumerate(row_tk) if tk is None][:target - len(live)]
-                        keep = sorted(live + fill)
+                    if live and target < len(book.row_tk):
+                        keep = sorted(live + book.free_rows()[:target - len(live)])
                         karr = np.ascontiguousarray(keep, dtype=np.int32)
                         _lib.check(lib.ctts_gpt_compact(h, karr.ctypes.data_as(C.c_void_p), int(karr.size), st), "compact")
-                        row_tk = [row_tk[r] for r in keep]
-                        for nr, tk in enumerate(row_tk):
-                            if tk is not None:
-                                tickets[tk][2] = nr
-                        self.compactions.append((launched, len(row_tk)))
+                        book.compact(keep)
+                        self.compactions.append((launched, len(book.row_tk)))
             torch.cuda.current_stream(dev).synchronize()
             self.saturations = 0
             if self.dtype_code == _lib.DTYPE_F16:

@@ -233,3 +233,39 @@ def test_torch_seed_context_like_the_reference():
     assert torch.equal(torch.random.get_rng_state(), before)
     with TorchSeedContext(7):
         assert torch.equal(torch.rand(3), a)
+
+
+def test_row_book_late_reports_admission_and_compaction():
+    """GPT.generate_many's bookkeeping (hip_models.gpt.RowBook): row reports arrive late and are read through the ticket layout of the moment
+    they were enqueued -- a report older than an admission must not finish the row's new occupant, rows renumbered by a compaction are
+    still found, a first-token EOS is queued again with the next attempt (gpt.py:496-525) until max_restarts."""
+    from chatttsplus_amd.hip_models.gpt import RowBook
+    b = RowBook()
+    for r in range(4):
+        b.seat(r, utt=r)
+    lay0 = b.layout()                                   # report A enqueued
+    lay1 = b.layout()                                   # report B enqueued (one chunk later, same seating)
+    # report A: utterance 1 finished by its limit, utterance 2's FIRST token was EOS
+    done, again = b.report(lay0, [(0, 9), (1, 9), (3, 0), (0, 9)], ensure_non_empty=True, max_restarts=3)
+    assert done == [1] and again == [(2, 1)] and b.free_rows() == [1, 2]
+    b.seat(1, utt=7)                                    # admissions into the freed rows (enqueued AFTER report B)
+    b.seat(2, utt=2, attempt=1)
+    # report B still shows the old occupants of rows 1 and 2 as finished: nobody new may finish through it
+    done, again = b.report(lay1, [(0, 17), (1, 9), (3, 0), (1, 17)], True, 3)
+    assert done == [3] and again == [] and b.free_rows() == [3]
+    lay2 = b.layout()
+    # compaction: rows 0, 1, 2 kept -> a report enqueued before it is still attributed correctly afterwards
+    b.compact([0, 1, 2])
+    assert b.live_rows() == [0, 1, 2] and b.free_rows() == []
+    done, again = b.report(lay2, [(1, 20), (0, 4), (3, 0), (1, 17)], True, 3)       # utterance 0 done; utterance 2 EOS at step 0 AGAIN
+    assert done == [0] and again == [(2, 2)]
+    assert b.free_rows() == [0, 2]
+    b.seat(0, utt=2, attempt=2)
+    done, again = b.report(b.layout(), [(3, 0), (0, 9), (0, 0)], True, 3)           # third first-token EOS: max_restarts reached -> gives up (empty result)
+    assert done == [2] and again == []
+    # without ensure_non_empty a first-token EOS simply completes the utterance
+    c = RowBook()
+    c.seat(0, 5)
+    assert c.report(c.layout(), [(3, 0)], False, 64) == ([5], [])
+    with pytest.raises(AssertionError):
+        b.seat(1, utt=9)                                # row 1 is occupied (utterance 7)
