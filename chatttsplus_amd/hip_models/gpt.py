@@ -140,8 +140,8 @@ class RowBook:
         return [r for r, tk in enumerate(self.row_tk) if tk is not None]
 
     def report(self, layout, states, ensure_non_empty: bool, max_restarts: int):
-        """`states` = [(fin, end)] per row of `layout`.  Returns (utterances completed, [(utterance, next attempt)] to admit again: their
-        first token was EOS, gpt.py:496-525)."""
+        """`states` = [(fin, end)] per row of `layout`.  Returns ([(utterance, tokens generated)] completed, [(utterance, next attempt)] to admit
+        again: their first token was EOS, gpt.py:496-525)."""
         done, again = [], []
         for tk, (fin, end) in zip(layout, states):
             if tk is None or not fin or tk not in self.tickets:
@@ -151,7 +151,7 @@ class RowBook:
             if (fin & 2) and end == 0 and ensure_non_empty and att + 1 < max_restarts:
                 again.append((utt, att + 1))
             else:
-                done.append(utt)
+                done.append((utt, int(end)))
         return done, again
 
     def compact(self, keep: List[int]) -> None:
@@ -607,20 +607,39 @@ class GPT:
         (gpt.py:496-525) acts per utterance: one whose first token is EOS is admitted again with its next attempt, up to `max_restarts`.
         `on_done(list_of_indices)` is called (on the host, while decoding continues) as utterances complete.
         Returns one GenerationOutputs for all N utterances, in input order."""
+        gen = self.generate_many_iter(emb, inputs_ids, temperature, eos_token, attention_mask=attention_mask, max_new_token=max_new_token,
+                                      min_new_token=min_new_token, logits_warpers=logits_warpers, logits_processors=logits_processors,
+                                      return_hidden=return_hidden, ensure_non_empty=ensure_non_empty, context=context, seed=seed, max_restarts=max_restarts,
+                                      utt_ids=utt_ids, max_new_tokens_per_row=max_new_tokens_per_row, rows=rows, admit_min=admit_min)
+        try:
+            while True:
+                ev = next(gen)
+                if on_done is not None:
+                    on_done([u for u, _, _ in ev])
+        except StopIteration as stop:
+            return stop.value
+
+    @torch.no_grad()
+    def generate_many_iter(self, emb, inputs_ids, temperature, eos_token, attention_mask=None, max_new_token=2048, min_new_token=0, logits_warpers=[],
+                           logits_processors=[], return_hidden=False, ensure_non_empty=True, context=None, seed=None, max_restarts: int = 64,
+                           utt_ids=None, max_new_tokens_per_row=None, rows=None, admit_min=None):
+        """generate_many as a generator: yields [(utterance index, ids [n,4] long, hiddens [n,768] or None)] for the utterances that completed
+        since the last yield -- while the rest keeps decoding (what was yielded is final: its rows were written before the report that showed
+        the utterance finished) -- and returns (StopIteration.value) the GenerationOutputs of all N utterances."""
         if not self._finalized:
             raise _lib.HipBackendError("weights not loaded")
         if self._busy_token.owner is not None:
             raise _lib.HipBackendError("GPT.generate is already running on this engine (or on an engine sharing its KV cache)")
         self._busy_token.owner = self
         try:
-            return self._generate_many(emb, inputs_ids, temperature, eos_token, attention_mask, int(max_new_token), min_new_token, logits_warpers,
-                                       logits_processors, return_hidden, ensure_non_empty, context or Context(), seed, max_restarts, utt_ids,
-                                       max_new_tokens_per_row, rows, admit_min, on_done)
+            return (yield from self._generate_many(emb, inputs_ids, temperature, eos_token, attention_mask, int(max_new_token), min_new_token, logits_warpers,
+                                                   logits_processors, return_hidden, ensure_non_empty, context or Context(), seed, max_restarts, utt_ids,
+                                                   max_new_tokens_per_row, rows, admit_min))
         finally:
             self._busy_token.owner = None
 
     def _generate_many(self, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token, logits_warpers, logits_processors,
-                       return_hidden, ensure_non_empty, context, seed, max_restarts, utt_ids, row_limits, rows, admit_min, on_done):
+                       return_hidden, ensure_non_empty, context, seed, max_restarts, utt_ids, row_limits, rows, admit_min):
         lib, h, dev = self._lib, self._h, self.device
         N, T = int(inputs_ids.shape[0]), int(inputs_ids.shape[1])
         H, NVQ = self.model_dim, self.num_vq
@@ -685,8 +704,8 @@ class GPT:
                 finished_now, again = book.report(lay, pins[slot][:2 * len(lay)].view(-1, 2).tolist(), ensure_non_empty, max_restarts)
                 queue = again + queue                              # first token was EOS (gpt.py:496-525): next noise attempt, ahead of the queue
                 n_done += len(finished_now)
-                if finished_now and on_done is not None:
-                    on_done(finished_now)
+                if finished_now:
+                    yield [(u, ids[u, :n].to(torch.long), hid[u, :n] if hid is not None else None) for u, n in finished_now]
                 free = book.free_rows()
                 since_free = since_free + 1 if free else 0
                 if queue and free and (len(free) >= min(admit_min, len(queue)) or since_free >= 4 or len(free) == len(book.row_tk)):

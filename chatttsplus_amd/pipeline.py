@@ -291,9 +291,10 @@ class ChatTTSPlusPipeline:
         warpers, processors = gen_logits(num_code=num_code, top_P=params.top_P, top_K=params.top_K,
                                          repetition_penalty=params.repetition_penalty)
         if gen_kwargs.pop("continuous", False):
-            # more utterances than decode rows: queued utterances take over rows as they free up (GPT.generate_many) -- one result, not a generator
+            # more utterances than decode rows: queued utterances take over rows as they free up (GPT.generate_many_iter: a generator of
+            # completion events whose return value is the GenerationOutputs of all utterances)
             gen_kwargs.pop("noise", None)
-            return gpt.generate_many(emb, input_ids, temperature=torch.tensor(temperature), eos_token=num_code, attention_mask=attention_mask,
+            return gpt.generate_many_iter(emb, input_ids, temperature=torch.tensor(temperature), eos_token=num_code, attention_mask=attention_mask,
                                      max_new_token=params.max_new_token, min_new_token=params.min_new_token, logits_warpers=warpers,
                                      logits_processors=processors, return_hidden=return_hidden, ensure_non_empty=params.ensure_non_empty, **gen_kwargs)
         return gpt.generate(emb, input_ids, temperature=torch.tensor(temperature), eos_token=num_code, attention_mask=attention_mask,
@@ -427,10 +428,15 @@ class ChatTTSPlusPipeline:
         elif len(utt_ids) != len(text_in):
             raise _lib.HipBackendError(f"utt_ids: {len(utt_ids)} entries for {len(text_in)} utterances (after text splitting)")
         noise_seed = kwargs.get("noise_seed")      # None: drawn from torch's CPU generator when the first slice that uses device noise starts
+        # optional per-utterance token limits (<= params_infer_code.max_new_token): ctts_gen_io.row_limits
+        utt_limits = kwargs.get("max_new_tokens_per_utterance")
+        if utt_limits is not None and len(utt_limits) != len(text_in):
+            raise _lib.HipBackendError(f"max_new_tokens_per_utterance: {len(utt_limits)} entries for {len(text_in)} utterances (after text splitting)")
         # `continuous=True` (no counterpart in the reference): the request's utterances are NOT cut into slices that each wait for their slowest
         # row (pipeline:391-397); slice_size decode rows are kept busy -- queued utterances take over the rows of finished ones
-        # (GPT.generate_many, ctts_gpt_admit).  Device noise keyed by utterance id: every utterance gets the waveform the sliced path gives it.
-        # One list with all waveforms is yielded.  Not for streaming, per-utterance adapters or caller-supplied noise.
+        # (GPT.generate_many_iter, ctts_gpt_admit).  Device noise keyed by utterance id: every utterance gets the waveform the sliced path gives it.
+        # Lists of waveforms are yielded in input order as prefixes of the request complete.  Not for stream=True (sample windows),
+        # per-utterance adapters or caller-supplied noise.
         if kwargs.get("continuous") and len(text_in) > slice_size:
             if stream or lora_paths is not None or noise_mode not in ("auto", "device"):
                 raise _lib.HipBackendError("continuous=True works with stream=False, device noise and without per-utterance adapters")
@@ -448,19 +454,35 @@ class ChatTTSPlusPipeline:
             texts_all = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in texts_all]   # pipeline:414-416
             if noise_seed is None:
                 noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            # longest texts first (longest-processing-time order: the last rows to finish are then short utterances); an utterance's result
-            # does not depend on the order -- its noise is keyed by its id
-            order = sorted(range(len(texts_all)), key=lambda i: -len(texts_all[i]))
+            # continuous=True: utterances are admitted in input order and their waveforms are yielded IN ORDER as soon as a prefix of the request
+            # is complete (the first list as early as possible, later ones in groups of >= 8 so that the vocoder runs batched) while the rest keeps
+            # decoding.  continuous="throughput": longest texts first (longest-processing-time order: the last rows to finish are short
+            # utterances), one list at the end.  An utterance's result does not depend on the order -- its noise is keyed by its id.
+            ordered = kwargs.get("continuous") != "throughput"
+            n_all = len(texts_all)
+            order = list(range(n_all)) if ordered else sorted(range(n_all), key=lambda i: -len(texts_all[i]))
             pic = params_infer_code
-            if torch.is_tensor(pic.spk_emb) and pic.spk_emb.dim() == 2 and pic.spk_emb.shape[0] == len(order):      # one speaker row per utterance
+            if torch.is_tensor(pic.spk_emb) and pic.spk_emb.dim() == 2 and pic.spk_emb.shape[0] == n_all:      # one speaker row per utterance
                 pic = dataclasses.replace(pic, spk_emb=pic.spk_emb[torch.as_tensor(order, device=pic.spk_emb.device)])
-            result = self._infer_code([texts_all[i] for i in order], False, use_decoder, pic, gpt=gpt, continuous=True, seed=noise_seed,
-                                      utt_ids=[utt_ids[i] for i in order], rows=slice_size)
-            items = result.hiddens if use_decoder else result.ids
-            back = [None] * len(order)
-            for k, i in enumerate(order):
-                back[i] = items[k]
-            yield self._decode_to_wavs(back, use_decoder)
+            events = self._infer_code([texts_all[i] for i in order], False, use_decoder, pic, gpt=gpt, continuous=True, seed=noise_seed,
+                                      utt_ids=[utt_ids[i] for i in order], rows=slice_size,
+                                      max_new_tokens_per_row=[utt_limits[i] for i in order] if utt_limits is not None else None)
+            ready, next_i, first = {}, 0, True
+            for ev in events:
+                for k, ids_k, hid_k in ev:
+                    ready[order[k]] = hid_k if use_decoder else ids_k
+                if not ordered:
+                    continue
+                run = 0
+                while next_i + run in ready:
+                    run += 1
+                if run and (first or run >= 8 or next_i + run == n_all):
+                    yield self._decode_to_wavs([ready.pop(next_i + j) for j in range(run)], use_decoder)
+                    next_i += run
+                    first = False
+            rest = [i for i in range(next_i, n_all) if i in ready]      # (everything, in throughput mode; nothing unless the run was interrupted, otherwise)
+            if rest:
+                yield self._decode_to_wavs([ready[i] for i in rest], use_decoder)
             return
         for ii in range(0, len(text_in), slice_size):
             text = list(text_in[ii:ii + slice_size])
@@ -481,6 +503,8 @@ class ChatTTSPlusPipeline:
                 if noise_seed is None and (noise_mode in ("auto", "device")):
                     noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # ONE draw per request (torch.manual_seed reproduces it)
                 gen_kw = dict(noise=("device" if noise_mode == "auto" else noise_mode), seed=noise_seed, utt_ids=utt_ids[ii:ii + slice_size])
+            if utt_limits is not None:
+                gen_kw["max_new_tokens_per_row"] = list(utt_limits[ii:ii + slice_size])
             results = self._infer_code(text, stream, use_decoder, params_infer_code, gpt=gpt, **gen_kw)
             try:
                 for result in results:
@@ -599,7 +623,7 @@ class ChatTTSPlusPipeline:
                 p = dataclasses.replace(params, spk_emb=rows[ii:ii + len(sl)])
                 for wavs in self._infer([texts[i] for i in sl], False, None, skip_refine_text, False, True, True, False, True,
                                         params_refine_text, p, slice_size=(slice_size if continuous else len(sl)), utt_ids=list(sl), noise="device",
-                                        noise_seed=noise_seed, continuous=continuous, **kwargs):
+                                        noise_seed=noise_seed, continuous=("throughput" if continuous else False), **kwargs):
                     wavs_local.extend(wavs)
                     lens.extend([(int(w.shape[0]) // 256 + 1) // 2 if w.shape[0] else 0 for w in wavs])
             return lens

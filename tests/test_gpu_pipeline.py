@@ -138,9 +138,13 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
     for rows in (2, 3):
         res = list(pipe.infer(list(many), skip_refine_text=True, do_text_optimization=False, params_infer_code=pv, noise="device", noise_seed=77,
                               slice_size=rows, continuous=True))
-        assert len(res) == 1 and len(res[0]) == len(many)
-        runs[f"continuous{rows}"] = [w.cpu().numpy() for w in res[0]]
-    for key in (4, 8, "sharded", "sharded_continuous", "continuous2", "continuous3"):
+        assert len(res) >= 2 and sum(len(r) for r in res) == len(many)      # waveforms arrive in input order, the first list before the rest is done
+        runs[f"continuous{rows}"] = [w.cpu().numpy() for r in res for w in r]
+    res = list(pipe.infer(list(many), skip_refine_text=True, do_text_optimization=False, params_infer_code=pv, noise="device", noise_seed=77,
+                          slice_size=3, continuous="throughput"))
+    assert len(res) == 1 and len(res[0]) == len(many)                       # longest texts first, one list at the end
+    runs["continuous_lpt"] = [w.cpu().numpy() for w in res[0]]
+    for key in (4, 8, "sharded", "sharded_continuous", "continuous2", "continuous3", "continuous_lpt"):
         for u in range(len(many)):
             a, b2 = runs[2][u], runs[key][u]
             assert a.shape == b2.shape, f"slice {key}, utterance {u}: {a.shape} vs {b2.shape} samples (token count differs)"

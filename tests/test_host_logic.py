@@ -247,25 +247,25 @@ def test_row_book_late_reports_admission_and_compaction():
     lay1 = b.layout()                                   # report B enqueued (one chunk later, same seating)
     # report A: utterance 1 finished by its limit, utterance 2's FIRST token was EOS
     done, again = b.report(lay0, [(0, 9), (1, 9), (3, 0), (0, 9)], ensure_non_empty=True, max_restarts=3)
-    assert done == [1] and again == [(2, 1)] and b.free_rows() == [1, 2]
+    assert done == [(1, 9)] and again == [(2, 1)] and b.free_rows() == [1, 2]
     b.seat(1, utt=7)                                    # admissions into the freed rows (enqueued AFTER report B)
     b.seat(2, utt=2, attempt=1)
     # report B still shows the old occupants of rows 1 and 2 as finished: nobody new may finish through it
     done, again = b.report(lay1, [(0, 17), (1, 9), (3, 0), (1, 17)], True, 3)
-    assert done == [3] and again == [] and b.free_rows() == [3]
+    assert done == [(3, 17)] and again == [] and b.free_rows() == [3]
     lay2 = b.layout()
     # compaction: rows 0, 1, 2 kept -> a report enqueued before it is still attributed correctly afterwards
     b.compact([0, 1, 2])
     assert b.live_rows() == [0, 1, 2] and b.free_rows() == []
     done, again = b.report(lay2, [(1, 20), (0, 4), (3, 0), (1, 17)], True, 3)       # utterance 0 done; utterance 2 EOS at step 0 AGAIN
-    assert done == [0] and again == [(2, 2)]
+    assert done == [(0, 20)] and again == [(2, 2)]
     assert b.free_rows() == [0, 2]
     b.seat(0, utt=2, attempt=2)
     done, again = b.report(b.layout(), [(3, 0), (0, 9), (0, 0)], True, 3)           # third first-token EOS: max_restarts reached -> gives up (empty result)
-    assert done == [2] and again == []
+    assert done == [(2, 0)] and again == []
     # without ensure_non_empty a first-token EOS simply completes the utterance
     c = RowBook()
     c.seat(0, 5)
-    assert c.report(c.layout(), [(3, 0)], False, 64) == ([5], [])
+    assert c.report(c.layout(), [(3, 0)], False, 64) == ([(5, 0)], [])
     with pytest.raises(AssertionError):
         b.seat(1, utt=9)                                # row 1 is occupied (utterance 7)

@@ -25,6 +25,7 @@ timeout 250 python tools/pipe_wall.py 2>&1 | tail -1 >> $O/pipe_wall.log
 timeout 250 python tools/pipe_wall.py --n 32 --tokens 256 2>&1 | tail -1 >> $O/pipe_wall.log
 timeout 250 python tools/pipe_wall.py --dtype fp16 2>&1 | tail -1 >> $O/pipe_wall.log
 timeout 250 python tools/pipe_wall.py --dtype fp16 --n 32 --tokens 256 2>&1 | tail -1 >> $O/pipe_wall.log
+for c in "" "--continuous" "--continuous throughput"; do timeout 250 python tools/pipe_wall.py --n 128 --rows 32 --tokens 512 --ragged --reps 2 $c 2>&1 | tail -1 >> $O/pipe_wall.log; done
 for cfg in "1 48" "32 48" "32 96" "32 512"; do for wd in fp32 fp16; do timeout 120 python tools/prefill_probe.py $cfg $wd 2>&1 | grep "prompt pass" | tail -1 | sed "s/$/  ($wd)/" >> $O/prefill.log; done; done
 rm -f $O/queue.jsonl $O/vocoder.log
 for wd in fp32 fp16; do timeout 250 python tools/queue_probe.py $wd 2>&1 | tail -1 >> $O/queue.jsonl; done
