@@ -10,7 +10,7 @@ P = os.path.join(ROOT, "profiles")
 pairs = {"bench_b1_fp32.json": "r03_bench_b1_fp32.json", "bench_b1_fp32_driver_args.json": "r03_bench_b1_fp32_steps20.json",
          "b1_fp32_kernel_stats.csv": "r03_b1_fp32_kernel_stats.csv", "b32_fp32_kernel_stats.csv": "r03_b32_fp32_kernel_stats.csv",
          "step_time_vs_batch_fp32.jsonl": "r03_step_time_vs_batch_fp32.jsonl", "step_time_vs_batch_fp16.jsonl": "r03_step_time_vs_batch_fp16.jsonl",
-         "prefill.log": "r03_prefill_ms.log", "queue.jsonl": "r03_queue128_on_32_rows.jsonl", "vocoder.log": "r03_vocoder_32x272_ms.log",
+         "prefill.log": "r03_prefill_ms.log", "vocoder.log": "r03_vocoder_32x272_ms.log",
          "vocoder_32x272_kernel_stats.csv": "r03_vocoder_32x272_kernel_stats.csv", "prefill_32x512_fp32_kernel_stats.csv": "r03_prefill_32x512_fp32_kernel_stats.csv"}
 for B in (32, 64, 128):
     pairs[f"bench_b{B}_fp32.json"] = f"r03_bench_b{B}_fp32.json"
@@ -22,6 +22,12 @@ for src, dst in pairs.items():
         shutil.copy(sp, os.path.join(P, dst))
     else:
         print("missing", src)
+# the queue file keeps the two larger configurations measured separately (512 on 64 rows, 384 on 128 rows): only its first two lines are refreshed
+qsrc, qdst = os.path.join(F, "queue.jsonl"), os.path.join(P, "r03_queue128_on_32_rows.jsonl")
+if os.path.exists(qsrc):
+    new = open(qsrc).read().splitlines()
+    old = open(qdst).read().splitlines() if os.path.exists(qdst) else []
+    open(qdst, "w").write("\n".join(new + old[2:]) + "\n")
 with open(os.path.join(P, "r03_wall_clock.jsonl"), "w") as f:
     for n in ("gen_wall.log", "pipe_wall.log"):
         f.write(open(os.path.join(F, n)).read())
