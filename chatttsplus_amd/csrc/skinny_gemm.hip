@@ -285,9 +285,23 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         __syncthreads();
     }
 
-    if (PRO == PRO_PACKED) { CTTS_ISSUE_WEIGHT_LOADS(); CTTS_EXIT_IF_DONE(); }
+    // PRO_PACKED variants with one weight tile per block and <= 12 B fragments per wave: this wave's B fragments are requested in ONE batch ahead of the weights.  Left to
+    // the compiler they were loaded two at a time inside the MFMA loop, each pair behind an s_waitcnt: KPW / 2 dependent L2 round trips in a row
+    // (6 at the fp32 down projection, the longest GEMM launch of a batch-32 step).
+    constexpr bool PREB = (PRO == PRO_PACKED) && ((RT == 1 && NBG * KPW <= 12) || NBG * KPW <= 6);       // <= 48 VGPRs of B fragments (the 1024-thread variants have 128)
+    frag bpre[NBG][KPW];                                                 // PRO_XH / PREB: this wave's B fragments, requested ahead of the weights
+    if (PRO == PRO_PACKED) {
+        if (PREB) {
+            const frag* xq = (const frag*)in0 + (size_t)chunk * NBG * kt_all * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < NBG; ++g)
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) bpre[g][i] = xq[(size_t)(g * kt_all + kt_off + wave * KPW + i) * 64];
+        }
+        CTTS_ISSUE_WEIGHT_LOADS();
+        CTTS_EXIT_IF_DONE();
+    }
     float* fac_s = (float*)(smem + XS_BYTES + WAVES * NBG * 1024);      // PRO_XH: [NB] rs / scale of each row of the chunk
-    frag bpre[NBG][KPW];                                                 // PRO_XH: this wave's B fragments, requested ahead of the weights
     if (PRO == PRO_XH) {
         // the RMSNorm factor of every row from the producer's 48 per-tile sums of squares (fixed order: deterministic); one wave,
         // 64 / NB lanes per row; its loads are issued before the weight stream and consumed after this wave's MFMAs are queued.
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 #pragma unroll
         for (int g = 0; g < NBG; ++g) {
             frag b;
-            if (PRO == PRO_XH) b = bpre[g][i];
+            if (PRO == PRO_XH || PREB) b = bpre[g][i];
             else if (PRO == PRO_PACKED) b = xg[(size_t)(g * kt_all + kt_off + kt) * 64 + lane];
             else b = xs[(g * KTILES + kt) * 64 + lane];
 #pragma unroll
