@@ -226,14 +226,16 @@ def ragged_leg(g, dev, spk, rank, B=32, seed=2024):
     try:
         for mode in ("off", "on"):
             g.compact = (mode == "on")
-            for rep in range(2):                                   # rep 0 captures the decode graphs of the batch sizes the run visits
-                torch.cuda.synchronize(dev)
+            dt = 1e9
+            for rep in range(3):                                   # rep 0 captures the decode graphs of the (batch size, key split) pairs the run visits; where the host
+                torch.cuda.synchronize(dev)                        # learns of a finished row depends on timing, so a later rep can still meet a new pair: best of two
                 t0 = time.perf_counter()
                 out = list(g.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=N,
                                       logits_warpers=lw, logits_processors=lp, return_hidden=False, noise="device", seed=7,
                                       max_new_tokens_per_row=[int(x) for x in nb]))[-1]
                 torch.cuda.synchronize(dev)
-                dt = time.perf_counter() - t0
+                if rep:
+                    dt = min(dt, time.perf_counter() - t0)
             lens = [int(i.shape[0]) for i in out.ids]
             if lens != [int(x) for x in nb]:
                 raise SystemExit(f"ragged leg invalid: generated lengths {lens[:6]}.. != targets {nb[:6].tolist()}..")
@@ -292,12 +294,14 @@ def queue_leg(g, dev, spk, rank, NU=128, rows=32, seed=4048, admit_min=None, mod
             if name not in modes:
                 continue
             g.compact = comp
-            for rep in range(2):                                   # rep 0 captures the decode graphs of the batch sizes the run visits
+            dt = 1e9
+            for rep in range(3):                                   # rep 0 captures the decode graphs the run visits; best of the two timed reps (see ragged_leg)
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 lens = fn()
                 torch.cuda.synchronize(dev)
-                dt = time.perf_counter() - t0
+                if rep:
+                    dt = min(dt, time.perf_counter() - t0)
             if lens != nb:
                 raise SystemExit(f"queue leg ({name}) invalid: generated lengths {lens[:6]}.. != targets {nb[:6]}..")
             res[name] = dict(wall_ms=round(dt * 1e3, 2), useful_tokens_per_s=round(float(sum(nb)) / dt, 1))
