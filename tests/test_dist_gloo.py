@@ -101,6 +101,24 @@ class _FakeGPT:
                                  hiddens=[torch.full((k, 768), float(k)) for k in n]))
 
 
+    def generate_many_iter(self, emb, inputs_ids, temperature, eos_token, attention_mask=None, max_new_token=2048, return_hidden=False, **kw):
+        """continuous batching stand-in: utterances complete shortest first, two per event (so never in input order)"""
+        N = emb.shape[0]
+        assert len(kw["utt_ids"]) == N and kw.get("rows", 0) <= self.max_batch and "noise" not in kw
+        self.many_calls = getattr(self, "many_calls", []) + [(N, int(kw["rows"]))]
+        self.noise_keys = getattr(self, "noise_keys", []) + [(int(kw["seed"]), int(u)) for u in kw["utt_ids"]]
+        n = [int(emb[b, 0, 0].item()) + int(emb[b, 0, 1].item()) for b in range(N)]
+        lim = kw.get("max_new_tokens_per_row")
+        if lim is not None:
+            n = [min(a, int(b)) for a, b in zip(n, lim)]
+        ids = [torch.zeros(k, 4, dtype=torch.long) for k in n]
+        hid = [torch.full((k, 768), float(k)) for k in n]
+        order = sorted(range(N), key=lambda b: (n[b], b))
+        for i in range(0, N, 2):
+            yield [(b, ids[b], hid[b] if return_hidden else None) for b in order[i:i + 2]]
+        return type("O", (), dict(ids=ids, attentions=[], hiddens=hid if return_hidden else []))
+
+
 class _FakeSynth:
     def decode_batch(self, hiddens):
         return [torch.full((256 * (2 * h.shape[0] - 1),), float(h.shape[0])) if h.shape[0] else torch.zeros(0) for h in hiddens]
@@ -190,3 +208,43 @@ def test_pipeline_infer_sharded_single_process(tmp_path):
     with pytest.raises(Exception, match="speaker_table"):                                          # index without a table: a clear error, not an AttributeError
         pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=None)
     assert [int(w.shape[0]) for w in wavs] == [256 * (2 * n - 1) for n in all_lens]
+
+
+def test_pipeline_continuous_yields_in_input_order(tmp_path):
+    """infer(continuous=...) host logic with the fake engine: utterances complete shortest first, the waveform lists still come out in INPUT
+    order (first list as soon as utterance 0 is there, later ones in runs of >= 8 or at the end), every utterance keeps its own speaker row,
+    noise key and token limit; continuous="throughput" hands the engine the longest texts first and yields one list; requests that fit the
+    decode rows take the ordinary sliced path."""
+    from chatttsplus_amd.pipeline import InferCodeParams
+    from chatttsplus_amd import _lib
+    pipe = _fake_pipeline(str(tmp_path))
+    gpt = pipe.models_dict["gpt"]
+    table = (torch.arange(3, dtype=torch.float32)[:, None] * 3 + 1).expand(3, 8).contiguous()
+    rows = table[torch.tensor(SPK_IDX)]                                   # one speaker row per utterance
+    want = _expected_lengths(pipe)
+    p = InferCodeParams(show_tqdm=False, spk_emb=rows, prompt="[speed_5]")
+    for mode in (True, "throughput"):
+        gpt.noise_keys, gpt.many_calls = [], []
+        lists = list(pipe._infer(list(TEXTS), False, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3,
+                                 utt_ids=list(range(100, 110)), noise_seed=9, continuous=mode))
+        flat = [w for l in lists for w in l]
+        assert [(int(w.shape[0]) // 256 + 1) // 2 for w in flat] == want, mode                       # input order, own speaker row
+        assert gpt.many_calls == [(10, 3)]
+        assert sorted(gpt.noise_keys) == [(9, 100 + i) for i in range(10)]
+        if mode is True:
+            assert len(lists) >= 2 and len(lists[0]) >= 1 and all(len(l) >= 8 or l is lists[0] or l is lists[-1] for l in lists)
+        else:
+            assert len(lists) == 1
+            assert [u for _, u in gpt.noise_keys] == [100 + i for i in sorted(range(10), key=lambda i: -len(TEXTS[i] + " [uv_break]"))]   # longest first
+    # per-utterance limits travel with their utterance (both modes reorder nothing the caller sees)
+    lim = [2, 50, 1, 50, 3, 50, 50, 4, 50, 5]
+    lists = list(pipe._infer(list(TEXTS), False, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, noise_seed=9,
+                             continuous="throughput", max_new_tokens_per_utterance=lim))
+    assert [(int(w.shape[0]) // 256 + 1) // 2 for w in lists[0]] == [min(a, b) for a, b in zip(want, lim)]
+    # fits the decode rows -> ordinary path (generate), and the combinations that cannot work are refused
+    gpt.calls, gpt.many_calls = [], []
+    list(pipe._infer(list(TEXTS[:3]), False, None, True, False, True, True, False, True, params_infer_code=InferCodeParams(show_tqdm=False, spk_emb=rows[:3]),
+                     slice_size=3, noise="device", noise_seed=9, continuous=True))
+    assert gpt.calls == [3] and gpt.many_calls == []
+    with pytest.raises(_lib.HipBackendError):
+        list(pipe._infer(list(TEXTS), True, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, continuous=True))
