@@ -1,3 +1,5 @@
+"""Round-3 bisect of the irreproducible fp16 prompt pass (profiles/README.md, "finding"): runs one prompt pass three times on one engine
+and reports the first KV-cache / hidden element that differs between runs.  Developer script, not a test."""
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

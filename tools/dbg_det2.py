@@ -1,3 +1,4 @@
+"""dbg_det.py over several (batch, prompt length) shapes: which shapes reproduce the run-to-run difference.  Developer script."""
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

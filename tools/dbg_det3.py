@@ -1,3 +1,4 @@
+"""dbg_det.py against library variants (CTTS_HIP_LIB): bisects which saturating store made the prompt pass irreproducible.  Developer script."""
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,5 @@
+"""Round-3 check while porting the packed-residual hand-off to fp32: does a row's result depend on its position inside a 16-row group?
+Developer script, not a test."""
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
