@@ -89,6 +89,7 @@ SYMBOLS = [
     ("ctts_gpt_saturations", C.c_int, [_P, C.POINTER(C.c_int32), _P]),
     ("ctts_gpt_rows_enqueue", C.c_int, [_P, _P, _P]),
     ("ctts_gpt_compact", C.c_int, [_P, _P, C.c_int, _P]),
+    ("ctts_sampler_noise", C.c_int, [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     ("ctts_gpt_admit", C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     ("ctts_gpt_logits", C.c_int, [_P, _P, _P]),
     ("ctts_gpt_force_ids", C.c_int, [_P, _P, _P]),

@@ -48,14 +48,18 @@ __device__ inline SampleKnobs knobs_of(SamplerDynPtr d) {
     return k;
 }
 
-__device__ inline float exp_noise_of(const RowIn& in, int j) {
-    if (in.q != nullptr) return in.q[j];
-    // counter = (element | codebook << 24, utterance id, step | attempt << 20); nothing in it depends on the row's place in a batch, on
-    // the batch's size or on the batch's draw counter: an utterance draws the same noise in whatever slice / rank it is served
-    const uint4 rnd = philox4x32_10(make_uint4((unsigned)j | (in.vq << 24), in.uid_lo, in.uid_hi, (unsigned)in.step | (in.attempt << 20)),
-                                    make_uint2((unsigned)in.seed, (unsigned)(in.seed >> 32)));
+// Exp(1) noise of element j of one multinomial row, counter-based: Philox4x32-10 keyed by the request seed, counter = (element | stream << 24,
+// utterance id, step | attempt << 20), stream = codebook 0..3 or 4 for the refine-text row.  Nothing in it depends on the row's place in a
+// batch, on the batch's size or on the batch's draw counter: an utterance draws the same noise in whatever slice / rank / decode row it is
+// served.  u = (24 random bits + 0.5) / 2^24 in (0, 1); restated in oracle/device_noise.py and pinned through ctts_sampler_noise.
+__device__ inline float device_exp_noise(unsigned long long seed, unsigned uid_lo, unsigned uid_hi, unsigned stream, unsigned step, unsigned attempt, int j) {
+    const uint4 rnd = philox4x32_10(make_uint4((unsigned)j | (stream << 24), uid_lo, uid_hi, step | (attempt << 20)), make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
     const float u = ((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
     return -logf(u);
+}
+__device__ inline float exp_noise_of(const RowIn& in, int j) {
+    if (in.q != nullptr) return in.q[j];
+    return device_exp_noise(in.seed, in.uid_lo, in.uid_hi, in.vq, (unsigned)in.step, in.attempt, j);
 }
 
 // One row = one wavefront.  Selection of the survivors of top-p / top-k:
@@ -566,10 +570,8 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
             float qq;
             if (q != nullptr) qq = q[j];
             else {
-                // same keying as the code sampler (utterance id, own step, own attempt); codebook field = 4 marks the text stream
-                const uint4 rnd = philox4x32_10(make_uint4((unsigned)j | (4u << 24), rs_in.uid_lo, rs_in.uid_hi, (unsigned)step | ((unsigned)rs_in.attempt << 20)),
-                                                make_uint2((unsigned)d->seed, (unsigned)(d->seed >> 32)));
-                qq = -logf(((float)(rnd.x >> 8) + 0.5f) * (1.0f / 16777216.0f));
+                // same keying as the code sampler (utterance id, own step, own attempt); stream 4 marks the text row
+                qq = device_exp_noise(d->seed, rs_in.uid_lo, rs_in.uid_hi, 4u, (unsigned)step, (unsigned)rs_in.attempt, j);
             }
             const float e = expf(x[i] - m2);
             bkey = umax64(bkey, ((unsigned long long)f32_key(__fdiv_rn(e * inv2, qq)) << 32) | (unsigned)(0x7FFFFFFF - j));
@@ -629,6 +631,20 @@ __global__ __launch_bounds__(256) void sampler_rows_kernel(const SamplerArgs a) 
     for (int i = 0; i < VPL; ++i) { const int j = lane + 64 * i; lg[i] = (j < a.V) ? logits[j] : 0.f; }
     const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg, cand_s[w]);
     if (lane == 0) a.idx_out[row] = idx;
+}
+
+// test hook (ctts_sampler_noise): the device noise of one multinomial row, through the very function the samplers call
+__global__ void noise_probe_kernel(RowIn in, int n, float* out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = exp_noise_of(in, j);
+}
+extern "C" int ctts_sampler_noise(uint64_t seed, uint64_t utt_id, int stream_id, int step, int attempt, int n, float* out_dev, void* stream) {
+    if (!out_dev || n < 1 || stream_id < 0 || stream_id > 4 || step < 0 || attempt < 0) { ctts_set_error("sampler_noise: bad argument"); return 1; }
+    RowIn in = {};
+    in.q = nullptr; in.step = step; in.seed = seed; in.uid_lo = (unsigned)utt_id; in.uid_hi = (unsigned)(utt_id >> 32); in.vq = (unsigned)stream_id; in.attempt = (unsigned)attempt;
+    hipLaunchKernelGGL(noise_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, n, out_dev);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s) {

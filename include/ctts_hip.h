@@ -215,6 +215,10 @@ int ctts_gpt_logits(ctts_gpt* h, float* logits_dev, void* stream);
 /* force the next input token ids (teacher forcing): int32 [B][4] device; replaces the sampled ids and
  * re-embeds them (gpt.py:403-407). */
 int ctts_gpt_force_ids(ctts_gpt* h, const int32_t* ids_dev, void* stream);
+/* the Exp(1) noise the generate-mode sampler draws on the device (ctts_gen_io.noise == NULL) for one multinomial row:
+ * out[j] = -log(u_j), u_j from Philox4x32-10 keyed by `seed`, counter (j | stream << 24, utterance id, step | attempt << 20); stream = codebook
+ * 0..3, or 4 for the refine-text row.  fp32 [n] device.  Pinned by oracle/device_noise.py (tests/test_gpu_sampler.py). */
+int ctts_sampler_noise(uint64_t seed, uint64_t utt_id, int stream_id, int step, int attempt, int n, float* out_dev, void* stream);
 /* stand-alone sampler on caller-provided logits (fp32 [rows][vocab], rows = B*4; history int32
  * [rows][hist_len]; q fp32 [rows][vocab]) -> idx int32 [rows]; A15-A19 of SURVEY 8(a). */
 int ctts_sampler_run(const ctts_sampler_cfg* sc, const float* logits_dev, const int32_t* history_dev, int hist_len,

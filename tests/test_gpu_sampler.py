@@ -125,3 +125,49 @@ def test_sampler_short_history_windows():
                                   torch.full((rows, 1), 0.3, dtype=torch.float32)).numpy()
         idx = _run(_cfg(np.float32(0.3), 0.7, 20, 1.3, 0), logits, history, q, hist)
         assert np.array_equal(idx, ref.astype(np.int32)), f"hist {hist}: {(idx != ref).sum()} of {rows} rows differ"
+
+
+# ---- device noise (noise="device"): the stream the kernels draw == oracle/device_noise.py, keyed as documented -------------------------
+
+def _dev_noise(seed, uid, stream, step, attempt, n):
+    lib = _lib.load()
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    _lib.check(lib.ctts_sampler_noise(C.c_uint64(seed), C.c_uint64(uid), stream, step, attempt, n, out.data_ptr(),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "sampler_noise")
+    return out
+
+
+@pytest.mark.parametrize("key", [(0, 0, 0, 0, 0, 626), (2 ** 62 + 12345, 2 ** 40 + 7, 3, 2047, 5, 626), (77, 99, 4, 31, 2, 21178), (1, 2 ** 32, 1, 1, 0, 626)])
+def test_device_noise_is_the_oracle_stream(key):
+    """exp_noise_of / device_exp_noise (sampler.hip) through the ctts_sampler_noise hook == the Philox4x32-10 restatement pinned by the Random123
+    known answers (tests/test_device_noise.py): same 24 random bits per element, -log within the device logf's rounding."""
+    from oracle.device_noise import exp_noise
+    seed, uid, stream, step, attempt, n = key
+    got = _dev_noise(seed, uid, stream, step, attempt, n).cpu().numpy()
+    want = exp_noise(seed, uid, stream, step, attempt, n)
+    assert np.all(np.abs(got - want) <= 4e-7 * np.maximum(1.0, want)), float(np.abs(got - want).max())
+    # exp(-q) * 2^24 - 0.5 recovers the 24 random bits exactly unless the log lost them: they agree to within the rounding of exp/log at 2^-24
+    assert np.all(np.abs(np.exp(-got.astype(np.float64)) - np.exp(-want.astype(np.float64))) <= 2.0 ** -22)
+
+
+def test_generate_draws_the_documented_stream_per_utterance():
+    """noise="device" against the same run fed with a caller-supplied noise array built row by row from the hook with the documented key --
+    (seed, the row's utterance id, codebook, the row's own step, attempt 0): identical tokens.  Pins WHICH stream every (row, step) uses:
+    left-padded batch of 3 with arbitrary 64-bit utterance ids."""
+    from chatttsplus_amd import synth
+    from chatttsplus_amd.hip_models import GPT
+    LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+    LP = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+    g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=4, max_seq_len=128, weight_dtype="fp32")
+    g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+    B, T, N, seed = 3, 20, 12, 2 ** 40 + 99
+    uids = [5, 2 ** 33 + 1, 123456789]
+    ids, mask = synth.prompt_ids(B, T, 21178, 90, pad_left=[0, 7, 3])
+    emb = g(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
+    kw = dict(attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=N, logits_warpers=LW, logits_processors=LP, return_hidden=False)
+    dev = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, noise="device", seed=seed, utt_ids=uids, **kw))[-1]
+    q = torch.stack([torch.stack([_dev_noise(seed, uids[b], vq, step, 0, 626) for b in range(B) for vq in range(4)]) for step in range(N)])
+    arr = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, noise=q.cpu().numpy(), **kw))[-1]
+    for b in range(B):
+        assert dev.ids[b].shape[0] == N and torch.equal(dev.ids[b], arr.ids[b]), b
+    g.close()
