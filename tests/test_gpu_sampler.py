@@ -170,4 +170,13 @@ def test_generate_draws_the_documented_stream_per_utterance():
     arr = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, noise=q.cpu().numpy(), **kw))[-1]
     for b in range(B):
         assert dev.ids[b].shape[0] == N and torch.equal(dev.ids[b], arr.ids[b]), b
+    # refine-text pass (one 21178-way row per sequence): stream 4 of the same utterance
+    from chatttsplus_amd.pipeline import gen_logits
+    w, p = gen_logits(21178, 0.7, 20, 1.0)
+    kt = dict(attention_mask=torch.from_numpy(mask), max_new_token=6, min_new_token=6, logits_warpers=w, logits_processors=p, infer_text=True)
+    dev = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.7]), 21177, noise="device", seed=seed, utt_ids=uids, **kt))[-1]
+    q = torch.stack([torch.stack([_dev_noise(seed, uids[b], 4, step, 0, 21178) for b in range(B)]) for step in range(6)])
+    arr = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.7]), 21177, noise=q.cpu().numpy(), **kt))[-1]
+    for b in range(B):
+        assert dev.ids[b].shape[0] == 6 and torch.equal(dev.ids[b], arr.ids[b]), ("text", b)
     g.close()
