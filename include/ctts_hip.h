@@ -151,7 +151,9 @@ int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* attention_mask_dev,
 /* Prompt pass: emb fp32 [B][T][hidden] device (GPT.forward output after apply_spk_emb, gpt.py:125-149,
  * tokenizer.py:150-178).  Fills the KV cache and leaves the last position's residual row per sequence.
  * Asynchronous with respect to the host (enqueues on `stream`, never synchronises); prompts of more than 16384 rows (B * T) run in
- * several passes.  fp16 engines use the MFMA flash-attention kernel from 64 rows and the LDS-staged prompt GEMM from 1536 rows.
+ * several passes.  fp16 engines use the MFMA flash-attention kernel from 64 rows and the LDS-staged prompt GEMM from 1536 rows; fp32
+ * (parity) engines run the same tiling on head / tail fp16 operand images from 384 rows (three fp16 MFMAs per product, fp32-accurate, fp32 KV
+ * cache; prefill_split.hip); smaller prompts go through the decode kernels in 32-row chunks.
  * replaces the i == 0 iteration's LlamaModel.forward (gpt.py:410-418; llama.py:905-1019). */
 int ctts_gpt_prefill(ctts_gpt* h, const float* emb_dev, void* stream);
 
