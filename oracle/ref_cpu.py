@@ -10,8 +10,17 @@ Pinning status
   * GPT decoder + sampler + DVAE decoder: pinned against the imported reference
     (``oracle/make_golden.py`` -> ``tests/golden/*.npz``; ``tests/test_oracle_*``).
   * Vocos (third-party ``vocos`` 0.1.0, absent from /root/reference and from this
-    image): **parity unpinned** -- restated from the upstream algorithm
-    (VocosBackbone + ISTFTHead) and cross-checked only against ``torch.istft``.
+    image): restated from the upstream algorithm (VocosBackbone + ISTFTHead).  The
+    ISTFT head is pinned on the port of vocos' head inside ``transformers``
+    (``Xcodec2ISTFTHead``), ``torch.istft`` and a direct fp64 definition; the backbone's
+    ConvNeXt block is the reference's own (pinned through the DVAE goldens); the
+    backbone's wiring stays **parity unpinned**.
+  * GFSQ / mel extractor of the zero-shot branch (``vector_quantize_pytorch``,
+    ``torchaudio``: absent): the FSQ layer and the residual loop are pinned on
+    ``Xcodec2FiniteScalarQuantization`` (a port of that library's layer), the mel filterbank
+    on ``transformers.audio_utils.mel_filter_bank`` (tests/test_third_party_pins.py); the
+    grouped wrapper stays a restatement.
+  * Device noise stream: ``oracle/device_noise.py`` (Philox4x32-10, Random123 known answers).
 
 Every function cites the reference file:line it follows (paths relative to
 /root/reference/chattts_plus/).
