@@ -650,6 +650,9 @@ class GPT:
         mask = torch.ones(N, T, dtype=torch.int32, device=dev) if attention_mask is None else attention_mask.to(dev).to(torch.int32).contiguous()
         emb = emb.to(dev, dtype=torch.float32).contiguous()
         lens = mask.sum(1).cpu().tolist()
+        if max(lens) + max_new_token > self.max_seq:
+            # (every utterance is admitted with its own prompt, trimmed of padding: the longest one decides)
+            raise _lib.HipBackendError(f"generate_many: prompt of {max(lens)} tokens + max_new_token={max_new_token} exceed max_seq_len={self.max_seq}")
         uids = [int(u) for u in utt_ids] if utt_ids is not None else list(range(N))
         lims = [min(max(int(v), 1), max_new_token) for v in row_limits] if row_limits is not None else [max_new_token] * N
         assert len(uids) == N and len(lims) == N
