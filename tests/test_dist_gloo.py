@@ -157,7 +157,7 @@ def _expected_lengths(pipe):
     return out
 
 
-def _pipe_worker(rank, world, port, q, tmpdir):
+def _pipe_worker(rank, world, port, q, tmpdir, continuous=False):
     from chatttsplus_amd.pipeline import InferCodeParams
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -165,8 +165,9 @@ def _pipe_worker(rank, world, port, q, tmpdir):
         pipe = _fake_pipeline(tmpdir)
         table = (torch.arange(3, dtype=torch.float32)[:, None] * 3 + 1).expand(3, 8).contiguous() if rank == 0 else None
         mine, wavs, all_lens = pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=table,
-                                                  params_infer_code=InferCodeParams(show_tqdm=False), noise_seed=4242)
-        q.put((rank, mine, [int(w.shape[0]) for w in wavs], all_lens, pipe.models_dict["gpt"].calls, pipe.models_dict["gpt"].noise_keys))
+                                                  params_infer_code=InferCodeParams(show_tqdm=False), noise_seed=4242, continuous=continuous)
+        gpt = pipe.models_dict["gpt"]
+        q.put((rank, mine, [int(w.shape[0]) for w in wavs], all_lens, gpt.calls if not continuous else getattr(gpt, "many_calls", []), gpt.noise_keys))
     finally:
         dist.destroy_process_group()
 
@@ -192,6 +193,31 @@ def test_pipeline_infer_sharded_world2_gloo(tmp_path):
         assert all_lens == expect, (rank, all_lens, expect)                       # every rank sees every utterance's length
         assert wav_samples == [256 * (2 * expect[i] - 1) for i in mine]           # local waveforms, in the order of `mine`
         assert sum(calls) == len(mine) and max(calls) <= 3                        # sliced at max_batch
+        seen += mine
+    assert sorted(seen) == list(range(len(TEXTS)))
+
+
+def test_pipeline_infer_sharded_continuous_world2_gloo(tmp_path):
+    """infer_sharded(continuous=True): every rank keeps its decode rows busy over ALL its utterances (one generate_many call per rank when it holds
+    more utterances than rows); same lengths, same per-utterance noise keys, waveforms in the order of the rank's utterances."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, q, str(tmp_path), True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = _expected_lengths(_fake_pipeline(str(tmp_path)))
+    seen = []
+    for rank, mine, wav_samples, all_lens, many_calls, noise_keys in res:
+        assert sorted(noise_keys) == [(4242, i) for i in sorted(mine)], (rank, noise_keys, mine)
+        assert all_lens == expect
+        assert wav_samples == [256 * (2 * expect[i] - 1) for i in mine]
+        assert many_calls == [(len(mine), 3)]                                     # one continuous call over the rank's 5 utterances on 3 rows
         seen += mine
     assert sorted(seen) == list(range(len(TEXTS)))
 
