@@ -252,6 +252,60 @@ def golden_gpt_real_b32_ragged(ref, only_search=False):
         raise SystemExit("no ragged batch-32 case found")
 
 
+def golden_gpt_real_device_noise(ref):
+    """The device-noise mode (and with it continuous batching) pinned against the reference's OWN generate loop: 10 utterances served the
+    reference's way -- slices of 4, each run to its slowest row (pipeline:391-397) -- with `torch.multinomial` replaced at module level by
+    its definition argmax(p / q) (reproduces the native run exactly) where q is the counter-based Exp(1) stream the HIP sampler
+    draws on the device (oracle/device_noise.py: Philox4x32-10 keyed by the request seed, the utterance's id, codebook, the utterance's own
+    step, attempt 0).  EOS rows of the heads boosted: the utterances end at different steps; min_new_token = 2 keeps step 0 free of EOS (no
+    regenerate in this case)."""
+    from oracle.device_noise import exp_noise
+    cfg = synth.GPT_REAL
+    NU, T, N, seed, boost = 10, 20, 48, 2 ** 40 + 77, 1.5
+    pad = [0, 3, 7, 1, 0, 5, 2, 8, 0, 4]
+    uids = [1000 + 3 * u for u in range(NU)]
+    ids, mask = synth.prompt_ids(NU, T, cfg["num_text_tokens"], 335, pad_left=pad)
+    sd = synth.gpt_state_dict(cfg, 1234)
+    for i in range(4):
+        sd[f"head_code.{i}.parametrizations.weight.original0"][625] *= boost
+    g = build_ref_gpt(ref, cfg, sd)
+    all_ids, all_hid = [], []
+    native = torch.multinomial
+    try:
+        for s0 in range(0, NU, 4):
+            sl = slice(s0, min(s0 + 4, NU))
+            state = dict(step=0)
+            us = uids[sl]
+
+            def fake_multinomial(p, num_samples=1, replacement=False, *, generator=None, out=None):
+                rows, V = p.shape
+                assert rows == 4 * len(us) and num_samples == 1
+                q = np.stack([exp_noise(seed, us[r // 4], r % 4, state["step"], 0, V) for r in range(rows)])
+                state["step"] += 1
+                return torch.argmax(p / torch.from_numpy(q), dim=1, keepdim=True)
+
+            torch.multinomial = fake_multinomial
+            emb, out = run_ref_generate(ref, g, ids[sl], mask[sl], 0, N, 2)
+            all_ids += out.ids
+            all_hid += out.hiddens
+    finally:
+        torch.multinomial = native
+    lens = np.array([i.shape[0] for i in all_ids], dtype=np.int32)
+    n = int(lens.max())
+    allids = np.full((NU, n, 4), -1, dtype=np.int16)
+    for b in range(NU):
+        allids[b, :lens[b]] = all_ids[b].numpy()
+    rows = [int(np.argmin(lens)), int(np.argmax(lens))]
+    hid = np.zeros((2, n, 768), dtype=np.float32)
+    for j, r in enumerate(rows):
+        hid[j, :lens[r]] = all_hid[r].numpy()
+    meta = dict(weight_seed=1234, eos_boost=boost, prompt_seed=335, B=NU, T=T, pad_left=pad, max_new=N, min_new=2, noise_seed=seed, utt_ids=uids,
+                spk_seed=1234, spk_id=21143, spk_pos=-1, hidden_rows=rows, slice_size=4)
+    np.savez_compressed(os.path.join(OUT, "gpt_real_device_noise.npz"), lens=lens, ids=allids, hiddens=hid,
+                        **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
+    print("gpt_real_device_noise lens", lens.tolist())
+
+
 def golden_gpt_real_regen(ref):
     """Real config, first-step EOS -> ensure_non_empty regenerate (gpt.py:496-525): B=2 with left padding, EOS head rows
     boosted, min_new_token=0.  The torch seed is searched for a run whose first attempt(s) end at step 0 (finish.any()) and a
@@ -489,6 +543,7 @@ def main():
     golden_gpt_real_long(ref)
     golden_gpt_real_b32(ref)
     golden_gpt_real_b32_ragged(ref)
+    golden_gpt_real_device_noise(ref)
     golden_refine_text(ref)
 
 

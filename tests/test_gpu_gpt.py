@@ -249,3 +249,39 @@ def test_strict_state_dict_keys_and_busy_guard():
     it.close()
     out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, **kw))[-1]     # released: works again
     assert out.ids[0].shape[0] == 24
+
+
+def test_device_noise_and_continuous_batching_match_the_reference_minted_fixture():
+    """gpt_real_device_noise (minted by the reference's own generate loop in slices of 4, multinomial = argmax(p / q) on the device noise
+    stream): the HIP engine with noise="device" reproduces every utterance's ids -- served in the reference's slices of 4, as one batch of 10,
+    and through continuous batching on 3 decode rows (ctts_gpt_admit: rows re-used as utterances end) -- hiddens within the golden tolerance."""
+    from chatttsplus_amd.hip_models import GPT
+    z, meta = load_golden("gpt_real_device_noise")
+    sd, ids, mask, _ = gen_case_inputs(meta, synth.GPT_REAL)
+    seed, uids, N = int(meta["noise_seed"]), [int(u) for u in meta["utt_ids"]], int(meta["max_new"])
+    g = GPT(LLAMA, max_batch=16, max_seq_len=128, weight_dtype="fp32")
+    g.load_state_dict(sd)
+    emb = g(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))
+    kw = dict(attention_mask=None, max_new_token=N, min_new_token=int(meta["min_new"]), logits_warpers=LW, logits_processors=LP, return_hidden=True)
+
+    def check(out_ids, out_h, what):
+        assert [int(i.shape[0]) for i in out_ids] == z["lens"].tolist(), what
+        for b, n in enumerate(z["lens"]):
+            assert np.array_equal(out_ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64)), (what, b)
+        for k, r in enumerate(int(x) for x in meta["hidden_rows"]):
+            n = int(z["lens"][r])
+            assert float(np.abs(out_h[r].cpu().numpy() - z["hiddens"][k, :n]).max()) <= 1e-4, (what, r)
+
+    for size in (4, 10):
+        oi, oh = [], []
+        for s0 in range(0, len(uids), size):
+            sl = slice(s0, s0 + size)
+            out = list(g.generate(emb[sl].contiguous(), torch.from_numpy(ids[sl]), torch.tensor([0.3] * 4), 625, noise="device", seed=seed, utt_ids=uids[sl],
+                                  **dict(kw, attention_mask=torch.from_numpy(mask[sl]))))[-1]
+            oi += out.ids
+            oh += out.hiddens
+        check(oi, oh, f"slices of {size}")
+    out = g.generate_many(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, seed=seed, utt_ids=uids, rows=3, **dict(kw, attention_mask=torch.from_numpy(mask)))
+    assert g.admissions
+    check(out.ids, out.hiddens, "continuous batching on 3 rows")
+    g.close()

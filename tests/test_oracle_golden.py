@@ -275,3 +275,32 @@ def test_dvae_full_decode_codes_matches_reference_decoder_stack():
     assert torch.equal(lat[0][0], torch.tensor([-1.25, -1.25, -1.25, -1.25]))          # id 0: all levels 0 -> -1, + (-1) / 4
     assert torch.equal(lat[0][1], torch.tensor([0.75, 0.75, 0.75, 0.75]))              # 624 -> +1 on every dim, second id 0 -> -1 / 4
     assert torch.equal(lat[1][2], torch.tensor([-1.0, -1.0, -0.5, -1.0]) + torch.tensor([-1.0, -1.0, -1.0, -0.5]) / 4)
+
+
+def test_device_noise_mode_matches_reference():
+    """gpt_real_device_noise: the reference's own GPT.generate served the reference's way (slices of 4) with torch.multinomial replaced by its
+    definition argmax(p / q) on the DEVICE noise stream (oracle/device_noise.py keyed by request seed, utterance id, codebook, the utterance's
+    own step) -- the oracle fed the same stream reproduces every utterance, ragged EOS endings included.  The GPU tests hold noise="device"
+    (sliced, and continuous batching) to this fixture."""
+    from oracle.device_noise import exp_noise
+    z, meta = load_golden("gpt_real_device_noise")
+    sd, ids, mask, _ = gen_case_inputs(meta, synth.GPT_REAL)
+    seed, uids, N = int(meta["noise_seed"]), [int(u) for u in meta["utt_ids"]], int(meta["max_new"])
+    assert len(set(z["lens"].tolist())) >= 4 and z["lens"].min() < 16
+    o = ref_cpu.OracleGPT(sd, 12)
+    got_ids, got_h = [], []
+    for s0 in range(0, len(uids), int(meta["slice_size"])):
+        sl = slice(s0, s0 + int(meta["slice_size"]))
+        us = uids[sl]
+        q = np.stack([np.stack([exp_noise(seed, us[r // 4], r % 4, step, 0, 626) for r in range(4 * len(us))]) for step in range(N)])
+        emb = o.embed(torch.from_numpy(ids[sl]), torch.ones(ids[sl].shape[:2], dtype=torch.bool))
+        out = o.generate(emb, torch.from_numpy(ids[sl]), ref_cpu.SamplerParams(min_new_token=int(meta["min_new"])), attention_mask=torch.from_numpy(mask[sl]),
+                         max_new_token=N, noise=ref_cpu.ArrayNoise(q))
+        got_ids += out.ids
+        got_h += out.hiddens
+    assert [int(i.shape[0]) for i in got_ids] == z["lens"].tolist()
+    for b, n in enumerate(z["lens"]):
+        assert np.array_equal(got_ids[b].numpy(), z["ids"][b, :n].astype(np.int64)), b
+    for k, r in enumerate(int(x) for x in meta["hidden_rows"]):
+        n = int(z["lens"][r])
+        assert np.abs(got_h[r].numpy() - z["hiddens"][k, :n]).max() <= 2e-5, r
