@@ -383,6 +383,47 @@ def golden_refine_text(ref):
         print(name, "lens", lens.tolist())
 
 
+def golden_refine_text_device_noise(ref):
+    """The refine-text pass (infer_text=True, one 21178-way row per sequence) in the device-noise mode, minted like gpt_real_device_noise: the
+    reference's generate with torch.multinomial = argmax(p / q), q = stream 4 of (seed, utterance id, the utterance's own step)."""
+    from oracle.device_noise import exp_noise
+    cfg = synth.GPT_REAL
+    sd = synth.gpt_state_dict(cfg, 1234)
+    eos, boost, B, T, pad, N, min_new, seed = 21177, 9.0, 3, 10, [0, 3, 1], 30, 1, 2 ** 35 + 5
+    uids = [7, 2 ** 33 + 9, 12]
+    g0 = sd["head_text.parametrizations.weight.original0"].copy(); g0[eos] *= boost
+    sd["head_text.parametrizations.weight.original0"] = g0
+    g = build_ref_gpt(ref, cfg, sd)
+    ids, mask = synth.prompt_ids(B, T, cfg["num_text_tokens"], 47, pad_left=pad)
+    ids_t = torch.from_numpy(ids); mask_t = torch.from_numpy(mask)
+    with torch.no_grad():
+        emb = g(ids_t, torch.ones(B, T, dtype=torch.bool))
+    lw, lp = ref.processors.gen_logits(num_code=cfg["num_text_tokens"], top_P=0.7, top_K=20, repetition_penalty=1.0)
+    state = dict(step=0)
+    native = torch.multinomial
+
+    def fake_multinomial(p, num_samples=1, replacement=False, *, generator=None, out=None):
+        rows, V = p.shape
+        assert rows == B and num_samples == 1
+        q = np.stack([exp_noise(seed, uids[r], 4, state["step"], 0, V) for r in range(rows)])
+        state["step"] += 1
+        return torch.argmax(p / torch.from_numpy(q), dim=1, keepdim=True)
+
+    torch.multinomial = fake_multinomial
+    try:
+        out = next(g.generate(emb, ids_t, temperature=torch.tensor([0.7]), eos_token=eos, attention_mask=mask_t, max_new_token=N,
+                              min_new_token=min_new, logits_warpers=lw, logits_processors=lp, infer_text=True, stream=False, show_tqdm=False))
+    finally:
+        torch.multinomial = native
+    lens = np.array([i.shape[0] for i in out.ids], dtype=np.int32)
+    arr = np.full((B, int(lens.max())), -1, dtype=np.int32)
+    for b in range(B):
+        arr[b, :lens[b]] = out.ids[b].numpy()
+    meta = dict(weight_seed=1234, prompt_seed=47, B=B, T=T, pad_left=pad, max_new=N, min_new=min_new, eos=eos, eos_boost=boost, noise_seed=seed, utt_ids=uids)
+    np.savez_compressed(os.path.join(OUT, "gpt_real_text_device_noise.npz"), lens=lens, ids=arr, **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
+    print("gpt_real_text_device_noise lens", lens.tolist())
+
+
 def golden_sampler(ref):
     """The reference's actual objects (Custom rep-penalty + HF TopP/TopK + torch.multinomial) on random rows."""
     from transformers.generation import TopKLogitsWarper, TopPLogitsWarper  # noqa: F401
@@ -545,6 +586,7 @@ def main():
     golden_gpt_real_b32_ragged(ref)
     golden_gpt_real_device_noise(ref)
     golden_refine_text(ref)
+    golden_refine_text_device_noise(ref)
 
 
 if __name__ == "__main__":

@@ -197,6 +197,25 @@ def test_refine_text_generate_golden_bit_exact():
             w2, p2 = gen_logits(21178, 0.7, 20, 1.2)
             next(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.7]), eos, max_new_token=4, logits_warpers=w2, logits_processors=p2, infer_text=True))
         del g
+    # the same pass in the device-noise mode (the pipeline's default for it): fixture minted by the reference's generate with
+    # multinomial = argmax(p / q) on stream 4 of the device noise (oracle/make_golden.py golden_refine_text_device_noise)
+    z, meta = load_golden("gpt_real_text_device_noise")
+    sd = synth.gpt_state_dict(synth.GPT_REAL, int(meta["weight_seed"]))
+    eos = int(meta["eos"])
+    sd["head_text.parametrizations.weight.original0"][eos] *= float(meta["eos_boost"])
+    g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=4, max_seq_len=128, weight_dtype="fp32")
+    g.load_state_dict(sd)
+    B, T = int(meta["B"]), int(meta["T"])
+    ids, mask = synth.prompt_ids(B, T, 21178, int(meta["prompt_seed"]), pad_left=[int(x) for x in meta["pad_left"]])
+    emb = g(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))
+    w, p = gen_logits(21178, 0.7, 20, 1.0)
+    out = next(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.7]), eos, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]),
+                          min_new_token=int(meta["min_new"]), logits_warpers=w, logits_processors=p, infer_text=True, noise="device",
+                          seed=int(meta["noise_seed"]), utt_ids=[int(u) for u in meta["utt_ids"]]))
+    assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist()
+    for b, n in enumerate(z["lens"]):
+        assert np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64)), f"device noise, row {b}"
+    del g
 
 
 def test_lora_merge_matches_oracle():

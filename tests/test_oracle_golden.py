@@ -304,3 +304,24 @@ def test_device_noise_mode_matches_reference():
     for k, r in enumerate(int(x) for x in meta["hidden_rows"]):
         n = int(z["lens"][r])
         assert np.abs(got_h[r].numpy() - z["hiddens"][k, :n]).max() <= 2e-5, r
+
+
+def test_refine_text_device_noise_mode_matches_reference():
+    """gpt_real_text_device_noise: the refine-text pass of the reference with multinomial = argmax(p / q) on stream 4 of the device noise."""
+    from oracle.device_noise import exp_noise
+    z, meta = load_golden("gpt_real_text_device_noise")
+    cfg = synth.GPT_REAL
+    sd = synth.gpt_state_dict(cfg, int(meta["weight_seed"]))
+    eos = int(meta["eos"])
+    sd["head_text.parametrizations.weight.original0"][eos] *= float(meta["eos_boost"])
+    B, T, N = int(meta["B"]), int(meta["T"]), int(meta["max_new"])
+    seed, uids = int(meta["noise_seed"]), [int(u) for u in meta["utt_ids"]]
+    ids, mask = synth.prompt_ids(B, T, cfg["num_text_tokens"], int(meta["prompt_seed"]), pad_left=[int(x) for x in meta["pad_left"]])
+    o = ref_cpu.OracleGPT(sd, cfg["num_attention_heads"])
+    emb = o.embed(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))
+    q = np.stack([np.stack([exp_noise(seed, uids[b], 4, step, 0, 21178) for b in range(B)]) for step in range(N)])
+    out = o.generate_text(emb, torch.from_numpy(ids), 0.7, eos, attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=int(meta["min_new"]),
+                          noise=ref_cpu.ArrayNoise(q))
+    assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist() and len(set(z["lens"].tolist())) == 3
+    for b, n in enumerate(z["lens"]):
+        assert np.array_equal(out.ids[b].numpy(), z["ids"][b, :n].astype(np.int64))
