@@ -82,6 +82,124 @@ def self_spawn(args):
     os.execvpe(cmd[0], cmd, env)
 
 
+
+def _request_256(n_utt, rank_count_hint=None):
+    """The sharded request of BASELINE configs[3]: n_utt utterances, prompt lengths P ~ U{16..96} tokens (toy words + the 5 tags the pipeline wraps a
+    text in), target lengths U{128..512} enforced per utterance, speaker i % 4.  Identical on every rank (seeded)."""
+    from chatttsplus_amd import synth
+    texts = synth.toy_texts(n_utt, 11, 91, seed=256)
+    rng = np.random.Generator(np.random.Philox(key=2560))
+    limits = [int(x) for x in rng.integers(128, 513, size=n_utt)]
+    return texts, limits, [i % 4 for i in range(n_utt)]
+
+
+def _digest(values):
+    import hashlib
+    return hashlib.sha1(np.ascontiguousarray(np.asarray(values, dtype=np.int64)).tobytes()).hexdigest()[:16]
+
+
+def sharded_request_leg(pipe, dev, rank, world, n_utt=256, rows=32, reps=2, max_new=512):
+    """ONE batched-synthesis request over all ranks through ChatTTSPlusPipeline.infer_sharded(continuous=True) -- partition, speaker-table and seed
+    broadcast from rank 0, per-rank continuous batching on `rows` decode rows, DVAE decoder + Vocos, length all-reduce: what `--gpus N` means for
+    north_star's "batched synthesis" (the reference's counterpart is the sequential slice loop pipeline:391-397).  Host-inclusive wall clock,
+    MAX over ranks; rep 0 captures the decode graphs, the best of the later reps is reported.  `ids_digest` hashes a checksum of every
+    utterance's token ids (all-reduced over the ranks): identical for N = 1, 2, 4, 8 iff every utterance got the same tokens."""
+    import torch.distributed as dist
+    from chatttsplus_amd import synth
+    from chatttsplus_amd.pipeline import InferCodeParams
+    texts, limits, spk_index = _request_256(n_utt)
+    limits = [min(l, max_new) for l in limits]
+    table = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])) if rank == 0 else None
+    params = InferCodeParams(prompt="[speed_5]", max_new_token=max_new, min_new_token=max_new, show_tqdm=False)   # EOS masked: every row runs to its own limit
+    cpu = dev.type == "cpu"
+
+    def sync():
+        if not cpu:
+            torch.cuda.synchronize(dev)
+
+    best = None
+    for rep in range(reps + 1):
+        ids = []
+        sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        mine, wavs, lens = pipe.infer_sharded(list(texts), speaker_index=spk_index, speaker_table=table, params_infer_code=params, noise_seed=4242,
+                                              slice_size=rows, continuous=True, max_new_tokens_per_utterance=limits, ids_out=ids)
+        sync()
+        t_mine = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if lens != limits:
+            raise SystemExit(f"sharded request invalid: generated lengths {lens[:6]}.. != targets {limits[:6]}..")
+        if [int(w.shape[0]) for w in wavs] != [256 * (2 * limits[i] - 1) for i in mine]:
+            raise SystemExit("sharded request invalid: waveform lengths do not match the token counts")
+        tdev = torch.device("cpu") if cpu else dev
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        mine_tokens = float(sum(limits[i] for i in mine))
+        per = torch.zeros(world, 2, dtype=torch.float64, device=tdev)
+        per[rank, 0] = mine_tokens; per[rank, 1] = t_mine
+        chk = torch.zeros(n_utt, dtype=torch.int64, device=tdev)
+        for u, t in zip(mine, ids):
+            tt = t.to(torch.int64).cpu()
+            w = (torch.arange(tt.numel(), dtype=torch.int64) % 8191 + 1).view(tt.shape)
+            chk[u] = int((tt * w).sum())
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(per, op=dist.ReduceOp.SUM)
+            dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        if rep == 0:
+            continue
+        wall = float(tmax.item())
+        if best is None or wall < best["wall_s"]:
+            tok = per[:, 0].cpu().tolist()
+            best = dict(wall_s=wall, per_rank_useful_tokens=[int(x) for x in tok], per_rank_busy_s=[round(x, 4) for x in per[:, 1].cpu().tolist()],
+                        ids_digest=_digest(chk.cpu().numpy()))
+    total = float(sum(limits))
+    audio_s = sum(256 * (2 * n - 1) for n in limits) / 24000.0
+    tok = best["per_rank_useful_tokens"]
+    return {"utterances": n_utt, "decode_rows_per_gpu": rows, "prompt_lengths": "U{16..96} tokens", "target_lengths": "U{128..512} tokens", "speakers": 4,
+            "path": "ChatTTSPlusPipeline.infer_sharded(continuous=True): partition + speaker/seed broadcast + GPT (continuous batching) + DVAE decoder + Vocos + length all-reduce",
+            "wall_ms": round(best["wall_s"] * 1e3, 2), "useful_tokens": int(total), "useful_tokens_per_s": round(total / best["wall_s"], 1),
+            "audio_seconds": round(audio_s, 2), "rtf_audio_s_per_wall_s": round(audio_s / best["wall_s"], 2),
+            "per_rank_useful_tokens": tok, "per_rank_busy_s": best["per_rank_busy_s"],
+            "load_imbalance_max_over_mean": round(max(tok) / (sum(tok) / len(tok)), 4) if sum(tok) else None,
+            "lengths_digest": _digest(limits), "ids_digest": best["ids_digest"]}
+
+
+class _DryGPT:
+    """CPU stand-in for hip_models.GPT in `--dry-run`: same call surface as the pipeline uses; an utterance's ids are a pure function of its global
+    id and length, so `ids_digest` must not depend on the world size."""
+    num_vq, model_dim, max_batch = 4, 768, 32
+
+    def __init__(self):
+        self.emb_code = [type("E", (), dict(num_embeddings=626))() for _ in range(4)]
+
+    def __call__(self, input_ids, text_mask, spk_emb=None, spk_emb_ids=None):
+        return torch.zeros(input_ids.shape[0], input_ids.shape[1], 8)
+
+    def _ids(self, u, n):
+        return ((torch.arange(n * 4, dtype=torch.int64) * 31 + 7 * int(u)) % 626).view(n, 4).to(torch.int32)
+
+    def generate(self, emb, inputs_ids, temperature, eos_token, max_new_token=2048, return_hidden=False, **kw):
+        lim = kw.get("max_new_tokens_per_row") or [max_new_token] * emb.shape[0]
+        ids = [self._ids(u, int(n)) for u, n in zip(kw["utt_ids"], lim)]
+        yield type("O", (), dict(ids=ids, attentions=[], hiddens=[torch.zeros(i.shape[0], 768) for i in ids]))
+
+    def generate_many_iter(self, emb, inputs_ids, temperature, eos_token, max_new_token=2048, return_hidden=False, **kw):
+        lim = kw.get("max_new_tokens_per_row") or [max_new_token] * emb.shape[0]
+        ids = [self._ids(u, int(n)) for u, n in zip(kw["utt_ids"], lim)]
+        time.sleep(0.002 * len(ids))
+        for b in range(len(ids)):
+            yield [(b, ids[b], torch.zeros(ids[b].shape[0], 768) if return_hidden else None)]
+        return type("O", (), dict(ids=ids, attentions=[], hiddens=[]))
+
+
+class _DrySynth:
+    def decode_batch(self, hiddens):
+        return [torch.zeros(256 * (2 * h.shape[0] - 1)) if h.shape[0] else torch.zeros(0) for h in hiddens]
+
 def dry_run(args, world, rank):
     """Same collective sequence as the real run (speaker broadcast, barrier, timed region, barrier, MAX all-reduce, per-rank
     gather, rank-0 JSON) on the gloo backend with a sleep instead of the decode loop -- validates the N>1 control flow on CPU."""
@@ -109,8 +227,16 @@ def dry_run(args, world, rank):
         dist.all_gather(per, torch.tensor([mine], dtype=torch.float64))
     else:
         per = [torch.tensor([mine], dtype=torch.float64)]
+    # the sharded-request leg on the same control flow: real ChatTTSPlusPipeline.infer_sharded host code (partition, speaker + seed broadcast, per-rank
+    # slices / continuous batching, length all-reduce) around CPU stand-ins for the engines
+    import tempfile
+    from chatttsplus_amd.pipeline import ChatTTSPlusPipeline
+    with tempfile.TemporaryDirectory() as td:
+        pipe = ChatTTSPlusPipeline.from_components(_DryGPT(), _DrySynth(), synth.toy_tokenizer(td), "cpu")
+        sharded = sharded_request_leg(pipe, torch.device("cpu"), rank, world, n_utt=48, rows=8, reps=1, max_new=160)
     if rank == 0:
         print(json.dumps({"metric": "decode tokens/s", "value": round(args.batch * args.steps * world / float(dt), 2), "unit": "tokens/s",
+                          "extra": {"sharded_request": sharded},
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(dt) / args.steps * 1e3, 5),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                           "world_size": world, "per_rank_tokens_per_s": [round(args.batch * args.steps / float(p), 2) for p in per],
@@ -338,6 +464,7 @@ def main():
     ap.add_argument("--gen-tokens", type=int, default=GEN_TOKENS, help="length of the generation the timed window is centred in (0: the window starts right after the warm-up; used by the short profiler passes)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (batch 32, mixed prompts, 512-token prompt, LoRA)")
     ap.add_argument("--extra-steps", type=int, default=128, help="timed steps of each extra leg")
+    ap.add_argument("--request-utterances", type=int, default=256, help="utterances of the sharded-request leg (BASELINE configs[3]: 256)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank control flow (no HIP work, fake timing); used by tests/test_bench_dryrun.py")
     args = ap.parse_args()
 
@@ -367,7 +494,7 @@ def main():
     extras = not args.no_extras
     EB, EK = 32, args.extra_steps
     sd = synth.gpt_state_dict(synth.GPT_REAL, 1234)                    # every rank holds a full replica (0.45 GB fp16)
-    need_seq = max(P, 512 if (extras and world == 1) else 0) + W + max(GEN_TOKENS, args.gen_tokens, K) + 16
+    need_seq = max(P, 512 if (extras and world == 1) else (96 if extras else 0)) + W + max(GEN_TOKENS, args.gen_tokens, K) + 16     # (96: the sharded request's longest prompt)
     g = GPT(LLAMA, max_batch=max(B, EB if extras else 1), max_seq_len=need_seq, weight_dtype=args.dtype, device=str(dev))
     g.load_state_dict(sd)
     # speaker table (4 distinct speakers) lives on rank 0 and is broadcast over xGMI -- the path's only collective;
@@ -408,6 +535,18 @@ def main():
             e = leg.run(EB, P, EK, W, spk=spk, use_graph=use_graph)
             extra["batch32"] = summarize(e, world)
             extra["batch32"]["per_rank_tokens_per_s"] = [round(EB * EK / p, 1) for p in e["per_rank_s"]]
+            # configs[3]: ONE request of 256 ragged utterances sharded over the ranks through the pipeline's own entry point
+            #             (at N = 1 the same request on one GPU: the number the N-GPU lines are compared with)
+            import tempfile
+            from chatttsplus_amd.hip_models import Synth
+            from chatttsplus_amd.pipeline import ChatTTSPlusPipeline
+            with tempfile.TemporaryDirectory() as td:
+                syn_r = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2 * 512 + 64, device=str(dev), max_batch=32)
+                syn_r.load("dvae.", synth.dvae_state_dict(synth.DVAE_REAL, 1234))
+                syn_r.load("vocos.", synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
+                pipe = ChatTTSPlusPipeline.from_components(g, syn_r, synth.toy_tokenizer(td), dev)
+                extra["sharded_request"] = sharded_request_leg(pipe, dev, rank, world, n_utt=args.request_utterances, rows=EB)
+                del pipe, syn_r
             if world > 1:
                 # multi-rank runs stop here: the remaining legs characterise one GPU (measured at N = 1) and every leg is a rendezvous --
                 # a rank failing inside one of them would leave the others waiting at its barrier

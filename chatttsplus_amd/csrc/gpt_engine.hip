@@ -20,6 +20,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -40,6 +41,7 @@ extern "C" int ctts_version(void) { return 1; }
 #define PASS_ROWS_MAX 16384   // prompt rows per pass (32 x 512 tokens in one pass); an engine's workspaces are sized for min(this, max_batch * max_seq)
 #define PASS_PAD 256          // + PASS_PAD rows so that whole GEMM blocks stay in bounds
 #define SMAX 8        // == ATT_SMAX in skinny_gemm.hip
+#define CTTS_PERSIST_MAX_ROWS 4
 
 struct LayerW {
     void *qkv, *o, *gu, *d;      // RMSNorm weights are folded into qkv / gu columns
@@ -91,7 +93,11 @@ struct ctts_gpt {
                                                  // Measured: two 16-row chunks beat one 32-row block at batch 24 / 32 (598 vs 624,
                                                  // 640 vs 660 us/step) -- per-block prologue latency, not L2 traffic, is what these launches pay for;
                                                  // the prompt pass keeps 32-row blocks
-    int force_splits = 0;                        // diagnostic builds only: key splits of the decode attention (0 = decode_splits policy)
+    int force_splits = 0;                        // key splits of the decode attention (0 = decode_splits policy); ctts_gpt_set_option("decode_splits")
+    int opt_gen = 0;                             // bumped by ctts_gpt_set_option: part of the decode-graph key
+    int valu_rows = 4;                           // fp32 engines: decode batches of <= this many rows multiply on the VALU (skinny_gemm.hip, VR template argument):
+                                                 // an exact-f32 MFMA costs 32 cycles whatever the number of live columns, 48 of them per wave and launch
+    int persist_rows = 0;                        // fp32 engines: decode batches of <= this many rows run each layer as one persistent launch (persist_layer.hip)
     int no_prepack = 0, prefill_gemm_rows = 1536, xh_heads = 1;   // diagnostic builds only: see run_layers / run_decode_step
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
     DevState* st = nullptr;
@@ -121,6 +127,7 @@ struct ctts_gpt {
     std::vector<int> seq_host;
     int pre_T = 0;                               // tokens per sequence of the prompt rows being passed (begin: T; admit: T - 1)
     int B0 = 0;                                  // sequences the current generate() started with (h->B = rows still in the decode batch)
+    bool admitted = false;                       // ctts_gpt_admit handed a row of this generate() to another utterance: x_last / meta_dec0 no longer describe the rows
     // per generate()
     int B = 0, T = 0;
     SamplerCfgDev sc;
@@ -178,6 +185,33 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
         ctts_set_error("stream/event creation failed"); delete h; return 1;
     }
     *out = h;
+    return 0;
+}
+
+// Named engine options: explicit calls of the host side (hip_models.GPT(options=...)), never the environment.  Options that shape the launches bump
+// `opt_gen`, which is part of the decode-graph key, so graphs captured under other settings are not replayed.
+extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
+    if (!h || !name) { ctts_set_error("set_option: null argument"); return 1; }
+    const std::string n(name);
+    if (n == "prefill_split_rows") {             // prompt passes of >= this many rows use the head / tail fp16 split GEMMs (fp32 engines); 0 = never.  Before finalize.
+        if (h->finalized) { ctts_set_error("set_option(prefill_split_rows): set it before the weights are loaded"); return 1; }
+        h->split_rows_min = value < 0 ? 0 : value;
+    } else if (n == "valu_rows") {               // fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (0..4)
+        h->valu_rows = value < 0 ? 0 : (value > 4 ? 4 : value);
+    } else if (n == "persistent_rows") {         // fp32 engines: decode batches of <= this many rows run each layer as ONE persistent launch (0 = off)
+        h->persist_rows = value < 0 ? 0 : (value > CTTS_PERSIST_MAX_ROWS ? CTTS_PERSIST_MAX_ROWS : value);
+    } else if (n == "decode_splits") {           // key splits of the decode attention (0 = the decode_splits policy)
+        if (value < 0 || value > SMAX) { ctts_set_error("set_option(decode_splits): 0..%d", SMAX); return 1; }
+        h->force_splits = value;
+    } else if (n == "split_rows") {              // decode batches up to this size run the down projection as split-K launch slices
+        h->split_rows = value < 0 ? 0 : (value > 32 ? 32 : value);
+    } else if (n == "graph_steps") {
+        h->graph_steps = value < 1 ? 1 : (value > 64 ? 64 : value);
+    } else {
+        ctts_set_error("set_option: unknown option '%s'", name);
+        return 1;
+    }
+    h->opt_gen++;
     return 0;
 }
 
@@ -337,10 +371,13 @@ static void pack_tiles(WT* dst, int n_row_tiles, int K, RowFn rows, const float*
 }
 
 // head / tail fp16 images of 64 * W in the fp16 tile layout (prefill_split.hip): hi = fp16(v), lo = fp16(v - hi)
+// Returns false when a (norm-folded) weight times 64 leaves the fp16 range (|w| >= 1023.5): the images would hold inf; the caller then keeps the
+// engine on the exact fp32 prompt kernels.
 template <typename RowFn>
-static void pack_tiles_split(half_t* hi, half_t* lo, int n_row_tiles, int K, RowFn rows, const float* colscale = nullptr) {
+static bool pack_tiles_split(half_t* hi, half_t* lo, int n_row_tiles, int K, RowFn rows, const float* colscale = nullptr) {
     constexpr int KT = 32, EPL = 8;
     const int ktiles = K / KT;
+    bool in_range = true;
     for (int rt = 0; rt < n_row_tiles; ++rt)
         for (int i = 0; i < 16; ++i) {
             const float* src = rows(rt * 16 + i);
@@ -351,11 +388,13 @@ static void pack_tiles_split(half_t* hi, half_t* lo, int n_row_tiles, int K, Row
                     for (int j = 0; j < EPL; ++j) {
                         const float v = 64.0f * (colscale ? src[k0 + j] * colscale[k0 + j] : src[k0 + j]);       // == SP_WSCALE; the product rounds exactly like pack_tiles'
                         const half_t h = (half_t)v;
+                        if (!(fabsf(v) <= 65504.0f)) in_range = false;
                         hi[o + j] = h;
                         lo[o + j] = (half_t)(v - (float)h);
                     }
                 }
         }
+    return in_range;
 }
 
 static const std::vector<float>* need(ctts_gpt* h, const std::string& k, size_t numel) {
@@ -398,6 +437,7 @@ static int finalize_t(ctts_gpt* h) {
         CTTS_HIP_CHECK(hipMemcpy(h->ln1 + (size_t)l * H, t.l1->data(), (size_t)H * 4, hipMemcpyHostToDevice));
     }
     // host-side packing of the 20 layers on a few threads (pure CPU work on disjoint slices of the blobs)
+    std::atomic<bool> split_in_range(true);
     auto pack_layer = [&](int l) {
         const LayerSrc& t = ls[l];
         const int HT = H / 16;
@@ -422,10 +462,11 @@ static int finalize_t(ctts_gpt* h) {
         pack_tiles<WT>(base + n_qkv + n_o + n_gu, HT, I, d_row);
         if (want_split) {
             half_t *shi = sblob.data() + per_layer * 2 * l, *slo = shi + per_layer;
-            pack_tiles_split(shi, slo, 3 * HT, H, qkv_row, t.l1->data());
-            pack_tiles_split(shi + n_qkv, slo + n_qkv, HT, H, o_row);
-            pack_tiles_split(shi + n_qkv + n_o, slo + n_qkv + n_o, 2 * I / 16, H, gu_row, t.l2->data());
-            pack_tiles_split(shi + n_qkv + n_o + n_gu, slo + n_qkv + n_o + n_gu, HT, I, d_row);
+            bool ok = pack_tiles_split(shi, slo, 3 * HT, H, qkv_row, t.l1->data());
+            ok = pack_tiles_split(shi + n_qkv, slo + n_qkv, HT, H, o_row) && ok;
+            ok = pack_tiles_split(shi + n_qkv + n_o, slo + n_qkv + n_o, 2 * I / 16, H, gu_row, t.l2->data()) && ok;
+            ok = pack_tiles_split(shi + n_qkv + n_o + n_gu, slo + n_qkv + n_o + n_gu, HT, I, d_row) && ok;
+            if (!ok) split_in_range.store(false);
         }
     };
     {
@@ -451,6 +492,7 @@ static int finalize_t(ctts_gpt* h) {
         }
     }
     if (want_split) CTTS_HIP_CHECK(hipMemcpy(h->wsplit, sblob.data(), sblob.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    if (want_split && !split_in_range.load()) h->split_rows_min = 0;      // a weight beyond +-1023: the head / tail images would hold inf -- this engine keeps the exact fp32 prompt kernels
     // heads: fold weight norm, W = v * (g / ||v||_row)  (gpt.py:57-77; torch._weight_norm dim=0)
     std::vector<float> folded((size_t)h->NVQ * V * H);
     for (int i = 0; i < h->NVQ; ++i) {
@@ -642,6 +684,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
         a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq; a.sat = h->sat;
+        a.valu = (st != nullptr && dt == CTTS_DTYPE_F32 && R <= h->valu_rows && !lora) ? 1 : 0;
         // RMSNorm + QKV + RoPE + KV append
         GemmArgs g1 = a;
         g1.W = h->lw[l].qkv; g1.n_row_tiles = 3 * h->H / 16; g1.K = h->H; g1.x = x;
@@ -726,6 +769,7 @@ static int run_heads(ctts_gpt* h, bool write_hidden, StreamForm form, hipStream_
     const int chunks = (h->B + 16 * nbg - 1) / (16 * nbg);
     GemmArgs a = {};
     a.st = h->st; a.R = h->B; a.eps = 1e-6f; a.meta = h->meta_dec;
+    a.valu = (h->cfg.dtype == CTTS_DTYPE_F32 && h->B <= h->valu_rows) ? 1 : 0;
     const int nv = h->text_mode ? h->vocab_text_head : h->NVQ * h->V;
     a.W = h->text_mode ? h->whead_text : h->whead; a.n_row_tiles = (nv + 15) / 16; a.K = h->H; a.x = h->x_dec; a.lnw = h->lnf;
     a.logits = h->logits; a.n_valid = nv;
@@ -786,6 +830,7 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
     } else if (sc->past_window > 16 || sc->eos_token >= h->V) { ctts_set_error("begin: past_window>16 or eos out of range"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     h->B = B; h->B0 = B; h->T = T; h->io = *io;
+    h->admitted = false;
     h->rows_host.assign(B, RowState{});
     for (int b = 0; b < B; ++b) {
         RowState& r = h->rows_host[b];
@@ -841,6 +886,7 @@ extern "C" int ctts_gpt_sample(ctts_gpt* h, void* stream) {
 extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("restart: call begin first"); return 1; }
     if (h->B != h->B0) { ctts_set_error("restart: rows were compacted away (a regenerate restarts the whole batch at step 0, gpt.py:496-525)"); return 1; }
+    if (h->admitted) { ctts_set_error("restart: rows of this batch were handed to other utterances (ctts_gpt_admit); re-admit the utterance with attempt + 1 instead"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     CTTS_HIP_CHECK(hipMemcpyAsync(h->x_dec, h->x_last, (size_t)h->B * h->H * 4, hipMemcpyDeviceToDevice, s));
     return reset_state(h, true, s);
@@ -867,7 +913,7 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows);      // (diagnostic switches are fixed at create)
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen);      // (diagnostic switches are fixed at create)
     const std::string key(sig);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }
@@ -1008,6 +1054,7 @@ extern "C" int ctts_gpt_admit(ctts_gpt* h, int n, const int32_t* rows, int T, co
         if (rc) return 1;
     }
     for (int i = 0; i < n; ++i) { h->row_ctx[rows[i]] = T; h->row_cap[rows[i]] = T + h->fresh_host[i].limit; }
+    h->admitted = true;
     return 0;
 }
 

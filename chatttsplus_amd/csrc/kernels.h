@@ -52,6 +52,7 @@ struct GemmArgs {
     const float* lora_delta;
     int* sat;               // fp16 engines: counter of saturated / NaN fp16 stores (common.h sat_half); null = do not count
     const RowState* rows;   // heads only: hidden row goes to hiddens[rows[r].out][rows[r].end] while the row is live
+    int valu;               // fp32 decode, <= 4 rows: products on the VALU instead of exact-f32 MFMA (skinny_gemm.hip, VR; ctts_gpt_set_option "valu_rows")
 };
 
 struct AttnArgs {

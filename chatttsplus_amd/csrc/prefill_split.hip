@@ -24,10 +24,13 @@
 #endif
 #define SP_STAGE (32 * 1024)
 
-__device__ inline void split_h4(const f32x4 v, half4& hi, half4& lo) {
+// `sat` != null: a value beyond the fp16 range (or a NaN) is counted (ctts_gpt_saturations) -- passed where the operand is unbounded (SwiGLU outputs);
+// normalised rows, RoPE'd q / k, v and attention outputs are bounded by construction (|w_row| * sqrt(768))
+__device__ inline void split_h4(const f32x4 v, half4& hi, half4& lo, int* sat = nullptr) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float c = fminf(fmaxf(v[j], -65504.f), 65504.f);
+        if (sat != nullptr && !(c == v[j])) atomicAdd(sat, 1);
         hi[j] = (half_t)c;
         lo[j] = (half_t)(c - (float)hi[j]);
     }
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
                         y[j] = (gv / (1.0f + expf(-gv))) * uv * (1.0f / SP_ACT_SCALE);
                     }
                     half4 h, l;
-                    split_h4(y, h, l);
+                    split_h4(y, h, l, a.sat);              // silu(g) * u / 16 is unbounded: clamp + report, also in the fp32 engine's prompt pass
                     const size_t off = (size_t)G * ktiles_out * 64 * 8 + xfrag_index<half_t>(nn, (rt0 + t) * 8 + 4 * iq, ktiles_out);
                     *(half4*)(p.act_hi + off) = h;
                     *(half4*)(p.act_lo + off) = l;

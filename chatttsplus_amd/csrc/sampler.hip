@@ -296,7 +296,10 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
     const int age = ((step - 1 - lane) & 15) + 1;
     in.myid = (lane < 16 && age <= nh) ? ring_v : -1;
     in.T = d->cfg.temperature[vq];
-    in.penalize = d->cfg.use_penalty && (row < d->cfg.max_input_ids) && nh > 0;      // quirk SURVEY F8
+    // quirk SURVEY F8: the reference zeroes the penalty for rows >= max_input_ids of the flattened [B * 4] batch IT runs -- the row's place in the
+    // decode batch (b * 4 + vq <= 511), not the utterance's place in the caller's output arrays (`row`, which grows without bound under
+    // ctts_gpt_admit / generate_many and silently switched the penalty off from utterance 157 on)
+    in.penalize = d->cfg.use_penalty && (b * CTTS_NUM_VQ + vq < d->cfg.max_input_ids) && nh > 0;
     in.step = step;
     in.seed = d->seed; in.uid_lo = (unsigned)uid.x; in.uid_hi = (unsigned)uid.y; in.vq = (unsigned)vq; in.attempt = (unsigned)fe.z;
     const int idx = sample_row(knobs_of(d), tab, in, a.V, lane, lg, cand_s[vq]);
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(256) void sampler_generate_kernel(const int* st_wor
         const int end_out = fin ? end_in : end_in + 1;                               // gpt.py:530-531
         if (!fin) d->end_idx[seq] = end_out;
         fin = fin || (end_out >= fe.w);                                              // the row's own token limit (<= max_new_token: the loop bound of gpt.py:389): done from the next step on
-        d->finish[seq] = eos ? 1 : 0;                                                // the caller's `finish` keeps the reference's meaning: EOS seen
+        if (!was) d->finish[seq] = eos ? 1 : 0;                                      // the caller's `finish` keeps the reference's meaning: EOS seen (a row that was already finished
+                                                                                     // stores nothing: its `out` may have been handed to a re-admitted attempt of the same utterance)
         ((int2*)(a.finend + b))[0] = make_int2(fin ? (eos ? 3 : 1) : 0, end_out);
         if (!was) {                                                                // next decode row; a finished row stays on its last slot (it keeps
             RowMeta m = meta_in;                                                   // computing like the reference's finished rows, gpt.py:527-546, but

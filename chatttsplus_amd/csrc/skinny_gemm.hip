@@ -55,7 +55,12 @@ __device__ inline void store_x4<float>(void* base, int n, int k, int ktiles, flo
 
 // RT = weight row tiles per block: the activation prologue (replicated in every block) is paid once per RT tiles --
 // at 17-32 rows the 384 blocks of gate|up otherwise pull 37 MB of residual stream through L2 per launch.
-template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1>
+// VR > 0 (fp32 engines, decode batches of <= VR rows): the products run on the VALU.  An exact-f32 MFMA (v_mfma_f32_16x16x4_f32) issues in 32 cycles
+// whatever the number of live B columns -- 24 of them per wave and launch (48 per SIMD with two waves on it: 0.64 us of a ~3.5 us kernel at batch 1, twice
+// that for the 128 CUs that hold two gate|up blocks) -- while the same weight fragment times VR activation rows is 4 * VR v_fma per lane.  A lane keeps its
+// own weight row (lane & 15) and k-group (lane >> 4) of the MFMA-A image, so the packed weights are shared with the MFMA kernels; the four k-groups
+// are summed through the LDS crossbar and the waves' partials through `red`, in wave order (deterministic).
+template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1, int VR = 0>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done_p, const void* Wq, const void* in0, const void* in1,
                                                                   const float* resid_in, const int R, const int misc, const GemmArgs a) {
     // misc = np | S << 8 | ktiles_total << 16: the three struct fields that address the first loads of some variants (partial
@@ -66,6 +71,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     // overlaps the operand loads instead of preceding them.
     //   in0/in1: PRO_NORM[_P] x / opart   PRO_ATTN part_ml / part_o   PRO_PACKED xpacked / -
     static_assert(RT == 1 || EPI == EPI_QKV || EPI == EPI_SWIGLU, "multi-tile blocks: QKV / SwiGLU epilogues only");
+    static_assert(VR == 0 || (sizeof(WT) == 4 && NBG == 1 && RT == 1 && PRO != PRO_XH && VR <= 4), "VALU products: fp32, one 16-row chunk, <= 4 rows");
+    constexpr bool VALU = VR > 0;
     typedef typename FragOf<WT>::type frag;
     constexpr int KT = WTraits<WT>::KT;
     constexpr int KTILES = WAVES * KPW;
@@ -288,9 +295,17 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     // PRO_PACKED variants with one weight tile per block and <= 12 B fragments per wave: this wave's B fragments are requested in ONE batch ahead of the weights.  Left to
     // the compiler they were loaded two at a time inside the MFMA loop, each pair behind an s_waitcnt: KPW / 2 dependent L2 round trips in a row
     // (6 at the fp32 down projection, the longest GEMM launch of a batch-32 step).
-    constexpr bool PREB = (PRO == PRO_PACKED) && ((RT == 1 && NBG * KPW <= 12) || NBG * KPW <= 6);       // <= 48 VGPRs of B fragments (the 1024-thread variants have 128)
+    constexpr bool PREB = !VALU && (PRO == PRO_PACKED) && ((RT == 1 && NBG * KPW <= 12) || NBG * KPW <= 6);       // <= 48 VGPRs of B fragments (the 1024-thread variants have 128)
     frag bpre[NBG][KPW];                                                 // PRO_XH / PREB: this wave's B fragments, requested ahead of the weights
+    f32x4 bv[(VALU && PRO == PRO_PACKED) ? VR : 1][KPW];                 // VALU: activation row n, this lane's k-group (the 16 lanes of a group read the same 16 bytes)
     if (PRO == PRO_PACKED) {
+        if (VALU) {
+            const f32x4* xq = (const f32x4*)in0 + (size_t)chunk * NBG * kt_all * 64 + (lane & 48);
+#pragma unroll
+            for (int n = 0; n < VR; ++n)
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) bv[n][i] = xq[(size_t)(kt_off + wave * KPW + i) * 64 + n];
+        }
         if (PREB) {
             const frag* xq = (const frag*)in0 + (size_t)chunk * NBG * kt_all * 64 + lane;
 #pragma unroll
@@ -344,6 +359,29 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         }
     }
 
+    // 3a. VALU products over this wave's K slice (see the template comment)
+    float accv[VALU ? VR : 1];
+    if constexpr (VALU) {
+#pragma unroll
+        for (int n = 0; n < VR; ++n) accv[n] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int kt = wave * KPW + i;
+            const f32x4 w = __builtin_bit_cast(f32x4, wf[0][i]);
+#pragma unroll
+            for (int n = 0; n < VR; ++n) {
+                f32x4 b;
+                if (PRO == PRO_PACKED) b = bv[n][i];
+                else b = ((const f32x4*)smem)[kt * 64 + n + (lane & 48)];
+                accv[n] = fmaf(w[3], b[3], fmaf(w[2], b[2], fmaf(w[1], b[1], fmaf(w[0], b[0], accv[n]))));
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < VR; ++n) {          // the four k-groups of a weight row sit 16 lanes apart
+            accv[n] += __shfl_xor(accv[n], 16);
+            accv[n] += __shfl_xor(accv[n], 32);
+        }
+    }
     // 3. MFMA over this wave's K slice
     f32x4 acc[RT][NBG];
 #pragma unroll
@@ -352,6 +390,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         for (int g = 0; g < NBG; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const frag* xs = (const frag*)smem;
     const frag* xg = (const frag*)in0 + (size_t)chunk * NBG * kt_all * 64;
+    if constexpr (!VALU)
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         const int kt = wave * KPW + i;
@@ -373,11 +412,25 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     if (ti > 0) __syncthreads();                             // the previous tile's epilogue is done with red
     // 4. deterministic cross-wave reduction through LDS: every wave parks its partial C tile, the epilogue threads add the WAVES
     //    partials of their own element in wave order (one barrier; the former second LDS staging round is gone)
+    if constexpr (VALU) {
+        if (lane < 16) {
 #pragma unroll
-    for (int g = 0; g < NBG; ++g) *(f32x4*)(red + ((wave * NBG + g) * 64 + lane) * 4) = acc[ti][g];
+            for (int n = 0; n < VR; ++n) red[(wave * VR + n) * 16 + lane] = accv[n];
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < NBG; ++g) *(f32x4*)(red + ((wave * NBG + g) * 64 + lane) * 4) = acc[ti][g];
+    }
     __syncthreads();
     // C element (weight row i of the tile, activation row n): lane = (i / 4) * 16 + (n % 16), register i % 4, group n / 16
     auto c_elem = [&](int i, int n) -> float {
+        if constexpr (VALU) {
+            if (n >= VR) return 0.f;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) sum += red[(w * VR + n) * 16 + i];
+            return sum;
+        }
         const float* q = red + (((n >> 4) * 64) + ((i >> 2) << 4) + (n & 15)) * 4 + (i & 3);
         float sum = 0.f;
 #pragma unroll
@@ -485,12 +538,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1>
+template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1, int VR = 0>
 static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configure_only) {
     constexpr int KTILES = WAVES * KPW;
     constexpr int XS = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * 1024;
     constexpr int LDS = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4;
-    auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI, RT>;
+    auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI, RT, VR>;
     if (configure_only) {
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         return 0;
@@ -553,6 +606,14 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
             rc |= launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
             rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
         }
+        if constexpr (!F16 && NBG == 1) {
+#define CTTS_VALU_CFG(VRN) rc |= launch_one<float, 1, W768, P768, PRO_NORM_P, EPI_QKV, 1, VRN>(a, chunks, s, true); rc |= launch_one<float, 1, W768, P768, PRO_NORM, EPI_QKV, 1, VRN>(a, chunks, s, true); \
+            rc |= launch_one<float, 1, W768, P768, PRO_ATTN, EPI_RESID_P, 1, VRN>(a, chunks, s, true); rc |= launch_one<float, 1, W768, P768, PRO_NORM, EPI_SWIGLU, 1, VRN>(a, chunks, s, true); \
+            rc |= launch_one<float, 1, W768, P768, PRO_NORM_P, EPI_LOGITS, 1, VRN>(a, chunks, s, true); rc |= launch_one<float, 1, W768, P768, PRO_PACKED, EPI_PART, 1, VRN>(a, chunks, s, true); \
+            rc |= launch_one<float, 1, W768, P768, PRO_PACKED, EPI_RESID_P, 1, VRN>(a, chunks, s, true)
+            CTTS_VALU_CFG(1); CTTS_VALU_CFG(2); CTTS_VALU_CFG(4);
+#undef CTTS_VALU_CFG
+        }
         if constexpr (NBG == 1) {
             rc |= launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_SWIGLU>(a, chunks, s, true);
             rc |= launch_one<WT, 1, W3072, P3072, PRO_PACKED, EPI_RESID_P>(a, chunks, s, true);
@@ -563,6 +624,20 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
             rc |= launch_one<WT, 1, W768, P768, PRO_PACKED, EPI_PART>(a, chunks, s, true);
         }
         return rc;
+    }
+    if constexpr (!F16 && NBG == 1) {
+        // decode batches of <= 4 rows on an fp32 engine (GemmArgs.valu: the engine's valu_rows option): VALU products, VR = 1 / 2 / 4 compiled
+        if (a.valu && a.st != nullptr && a.R <= 4 && chunks == 1) {
+#define CTTS_VALU_CASE(P, E, VRN) if (pro == P && epi == E) return launch_one<float, 1, W768, P768, P, E, 1, VRN>(a, chunks, s, false)
+#define CTTS_VALU_ALL(VRN) do { CTTS_VALU_CASE(PRO_NORM_P, EPI_QKV, VRN); CTTS_VALU_CASE(PRO_NORM, EPI_QKV, VRN); CTTS_VALU_CASE(PRO_ATTN, EPI_RESID_P, VRN); \
+            CTTS_VALU_CASE(PRO_NORM, EPI_SWIGLU, VRN); CTTS_VALU_CASE(PRO_NORM_P, EPI_LOGITS, VRN); CTTS_VALU_CASE(PRO_PACKED, EPI_PART, VRN); \
+            if (a.K == 768) CTTS_VALU_CASE(PRO_PACKED, EPI_RESID_P, VRN); } while (0)
+            if (a.R == 1) CTTS_VALU_ALL(1);
+            else if (a.R == 2) CTTS_VALU_ALL(2);
+            else CTTS_VALU_ALL(4);
+#undef CTTS_VALU_ALL
+#undef CTTS_VALU_CASE
+        }
     }
     // 17-32 rows: RT_NORM weight row tiles per block for the two kernels whose prologue re-normalises every row in every block
     constexpr int RT_NORM = (NBG == 2) ? CTTS_RT_NORM : 1;

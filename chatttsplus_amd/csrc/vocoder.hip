@@ -162,9 +162,15 @@ static int upload(ctts_voc* h, float** p, const std::vector<float>& v) {
     CTTS_HIP_CHECK(hipMemcpy(*p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
     return 0;
 }
+// the head / tail images hold 256 * w as fp16: |w| >= 255.9 would become inf -- refuse such a checkpoint loudly instead of computing with inf
+static int check_split_range(const std::vector<float>& v) {
+    for (float x : v)
+        if (!(fabsf(x) * VOC_WSCALE <= 65504.0f)) { ctts_set_error("vocoder weight %g is outside the +-255 range of the split fp16 weight images", (double)x); return 1; }
+    return 0;
+}
 // a GEMM weight: the fp32 array (kept for reference / the fp32 kernel) + its head / tail fp16 images
 static int upload_w(ctts_voc* h, float** p, SplitW* sw, const std::vector<float>& v) {
-    if (upload(h, p, v)) return 1;
+    if (check_split_range(v) || upload(h, p, v)) return 1;
     std::vector<half_t> hi, lo;
     split_weights(v, hi, lo);
     CTTS_HIP_CHECK(hipMalloc((void**)&sw->hi, hi.size() * 2)); h->allocs.push_back(sw->hi);
@@ -175,6 +181,7 @@ static int upload_w(ctts_voc* h, float** p, SplitW* sw, const std::vector<float>
 }
 // a ConvNeXt pointwise weight [N][K]: head / tail fragment images for cnx_gemm_kernel
 static int upload_frag(ctts_voc* h, SplitW* sw, const std::vector<float>& w, int N, int K) {
+    if (check_split_range(w)) return 1;
     std::vector<half_t> hi, lo;
     cnx_pack_weights(w, N, K, hi, lo);
     CTTS_HIP_CHECK(hipMalloc((void**)&sw->hi, hi.size() * 2)); h->allocs.push_back(sw->hi);

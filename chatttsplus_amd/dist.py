@@ -39,6 +39,15 @@ def broadcast_speakers(table: Optional[torch.Tensor], n_spk: int, dim: int, devi
     return buf
 
 
+def broadcast_seed(seed: int, device, src: int = 0) -> int:
+    """The request's noise seed as drawn on rank `src` (8 bytes, same process group as the speaker table); world 1: the local draw."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(seed)
+    buf = torch.tensor([int(seed)], dtype=torch.int64, device=device)
+    dist.broadcast(buf, src=src)
+    return int(buf.item())
+
+
 def sharded_generate(lengths: Sequence[int], speaker_index: Sequence[int], speaker_table: Optional[torch.Tensor],
                      n_spk: int, dim: int, device,
                      run_local: Callable[[List[int], torch.Tensor], List[int]]) -> Tuple[List[int], List[int]]:

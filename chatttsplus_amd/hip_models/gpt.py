@@ -64,13 +64,23 @@ def sampler_cfg_from_objects(temperature, eos_token, max_new_token, min_new_toke
     sc.top_p_threshold = -1.0
     sc.top_k = 0
     sc.min_tokens_to_keep = 1
+    # the kernel applies top-p FIRST and top-k second -- the order processors.gen_logits builds (models/processors.py:43-48) and the
+    # reference's loop applies them in (gpt.py:474-475); the two do not commute, so any other list is rejected rather than re-ordered
+    seen = []
     for w in logits_warpers or []:
         if hasattr(w, "top_p"):
+            if seen:
+                raise _lib.HipBackendError("logits_warpers: the hip sampler applies [top-p, top-k] in that order (processors.gen_logits); "
+                                           f"got a top-p warper after {seen}")
             # torch compares the fp32 cumsum with the python double (1 - top_p) cast to fp32
             sc.top_p_threshold = float(np.float32(1 - float(w.top_p)))
             sc.min_tokens_to_keep = int(w.min_tokens_to_keep)
+            seen.append("top_p")
         elif hasattr(w, "top_k"):
+            if "top_k" in seen:
+                raise _lib.HipBackendError("logits_warpers: more than one top-k warper")
             sc.top_k = int(w.top_k)          # already max(top_k, min_tokens_to_keep)
+            seen.append("top_k")
         else:
             raise _lib.HipBackendError(f"unsupported logits warper for the hip backend: {type(w).__name__}")
     sc.use_penalty = 0
@@ -205,11 +215,21 @@ class GPT:
         self._kv = None
         self._busy_token = _BusyToken()
         self._lora = []
+        # engine options (ctts_gpt_set_option; include/ctts_hip.h lists them): {"prefill_split_rows": 0, ...}; applied before the weights are packed
+        self.options = dict(kwargs.get("options") or {})
+        for k, v in self.options.items():
+            self.set_option(k, v)
         self.compact = bool(kwargs.get("compact", True))      # finished-row compaction at chunk boundaries (batches of >= 8 sequences)
         self.compact_chunk = int(kwargs.get("compact_chunk", 8))   # ... whose chunks are this short: a finished row leaves the batch 1-2 chunks later
         self.model_path = kwargs.get("model_path", None)
         if self.model_path:
             self.from_pretrained(self.model_path)
+
+    def set_option(self, name: str, value: int) -> None:
+        """One named engine option (ctts_gpt_set_option): an explicit call, never the environment.  Unknown names are an error."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_gpt_set_option(self._h, str(name).encode(), int(value)), f"set_option({name})")
+        self.options[str(name)] = int(value)
 
     # -- nn.Module-like surface ------------------------------------------------------------------
     def eval(self):
@@ -294,7 +314,7 @@ class GPT:
         self._ctor = dict(gpt_config=self.gpt_config, num_audio_tokens=self.num_audio_tokens, num_text_tokens=self.num_text_tokens,
                           num_vq=self.num_vq, max_batch=self.max_batch, max_seq_len=self.max_seq,
                           weight_dtype="fp16" if self.dtype_code == _lib.DTYPE_F16 else "fp32", chunk_steps=self.chunk_steps,
-                          use_graph=self.use_graph, device=str(self.device))
+                          use_graph=self.use_graph, device=str(self.device), options=dict(self.options))
         self._sd_host = {k: v for k, v in sd.items() if k not in self.unexpected_keys}        # kept for LoRA-merged siblings (pipeline:420-432)
         return self
 
@@ -339,6 +359,13 @@ class GPT:
         ids = input_ids.to(self.device).to(torch.int32).contiguous()
         tm = text_mask.to(self.device).to(torch.int32).contiguous()
         B, T = int(ids.shape[0]), int(ids.shape[1])
+        # nn.Embedding raises on an id outside its table (gpt.py:125-149: emb_text on the text rows' first column, emb_code[i] on the code rows);
+        # the gather kernel does not check, so the same IndexError is raised here (one reduction + one flag read per prompt)
+        tmb = tm.bool()
+        bad = ((ids[..., 0] < 0) | (ids[..., 0] >= self.num_text_tokens)) & tmb
+        bad = bad | (((ids < 0) | (ids >= self.num_audio_tokens)).any(-1) & ~tmb)
+        if bool(bad.any()):
+            raise IndexError("index out of range in self")
         emb = torch.empty(B, T, self.model_dim, dtype=torch.float32, device=self.device)
         spk_t, sid = None, -1
         if spk_emb is not None:
@@ -360,6 +387,24 @@ class GPT:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @torch.no_grad()
+    def _report_saturations(self, h, st, what: str) -> int:
+        """fp16 stores of unbounded values saturate instead of overflowing to inf (fp16 engines: SwiGLU outputs, packed residual; fp32 engines:
+        only the SwiGLU head / tail images of a prompt pass over >= 384 rows, prefill_split.hip).  A non-zero count means the checkpoint drives
+        activations past the fp16 range: the result is finite but clipped -- say so."""
+        nsat = C.c_int32(0)
+        _lib.check(self._lib.ctts_gpt_saturations(h, C.byref(nsat), st), "saturations")
+        n = int(nsat.value)
+        if n:
+            import warnings
+            if self.dtype_code == _lib.DTYPE_F16:
+                msg = f"use weight_dtype='fp32' for this checkpoint"
+            else:
+                msg = ("the fp32 engine's long-prompt pass keeps silu(gate) * up / 16 as fp16 head / tail images; construct the GPT with "
+                       "prefill_split_rows=0 to keep the exact fp32 prompt kernels for this checkpoint")
+            warnings.warn(f"hip GPT (weight_dtype {'fp16' if self.dtype_code == _lib.DTYPE_F16 else 'fp32'}): {n} fp16 stores saturated or were NaN "
+                          f"during this {what}; {msg}", RuntimeWarning)
+        return n
+
     def generate(self, emb: torch.Tensor, inputs_ids: torch.Tensor, temperature: torch.Tensor,
                  eos_token: Union[int, torch.Tensor], attention_mask: Optional[torch.Tensor] = None, max_new_token=2048,
                  min_new_token=0, logits_warpers=[], logits_processors=[], infer_text=False, return_attn=False,
@@ -577,17 +622,7 @@ class GPT:
                 used_draws += steps.value - prev
                 tick("final_progress")
             self._restore_rng(rng_states, used_draws)
-            self.saturations = 0
-            if self.dtype_code == _lib.DTYPE_F16:
-                # fp16 stores (SwiGLU outputs, packed residual) saturate instead of overflowing to inf; a non-zero count means the
-                # checkpoint drives activations past the fp16 range -- the result is finite but clipped: say so (fp32 mode has no such limit)
-                nsat = C.c_int32(0)
-                _lib.check(lib.ctts_gpt_saturations(h, C.byref(nsat), st), "saturations")
-                self.saturations = int(nsat.value)
-                if self.saturations:
-                    import warnings
-                    warnings.warn(f"hip GPT (weight_dtype fp16): {self.saturations} fp16 stores saturated or were NaN during this generate(); "
-                                  f"use weight_dtype='fp32' for this checkpoint", RuntimeWarning)
+            self.saturations = self._report_saturations(h, st, "generate()")
             out = self._outputs(ids, hid, end_idx, infer_text)
             tick("outputs")
             yield out
@@ -738,15 +773,7 @@ class GPT:
                         book.compact(keep)
                         self.compactions.append((launched, len(book.row_tk)))
             torch.cuda.current_stream(dev).synchronize()
-            self.saturations = 0
-            if self.dtype_code == _lib.DTYPE_F16:
-                nsat = C.c_int32(0)
-                _lib.check(lib.ctts_gpt_saturations(h, C.byref(nsat), st), "saturations")
-                self.saturations = int(nsat.value)
-                if self.saturations:
-                    import warnings
-                    warnings.warn(f"hip GPT (weight_dtype fp16): {self.saturations} fp16 stores saturated or were NaN during this generate_many(); "
-                                  f"use weight_dtype='fp32' for this checkpoint", RuntimeWarning)
+            self.saturations = self._report_saturations(h, st, "generate_many()")
             return self._outputs(ids, hid, end_idx, False)
 
     def _staging(self, rows: int, V: int, cap: int):

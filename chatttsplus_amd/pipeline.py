@@ -168,6 +168,26 @@ class ChatTTSPlusPipeline:
         self._lora_cache = max(1, int(kwargs.get("lora_cache", 1)))
         self.load_models(**kwargs)
 
+    @classmethod
+    def from_components(cls, gpt, synth, tokenizer, device, normalizer=None, text_splitter=None):
+        """A pipeline around engines that are already loaded (bench.py's sharded-request leg, services that build their engines themselves):
+        the same infer() / infer_sharded() surface without the checkpoint-directory pass of load_models.  No zero-shot encoder, no use_decoder=False."""
+        self = object.__new__(cls)
+        self.logger = logging.getLogger(cls.__name__)
+        self.cfg = None
+        self.device = torch.device(device)
+        self.dtype = torch.float32
+        self.normalizer = normalizer if normalizer is not None else text_frontend.Normalizer(None)
+        self.text_splitter = text_splitter
+        self.load_lora = False
+        self._lora_models = OrderedDict()
+        self._lora_cache = 1
+        self.models_dict = dict(gpt=gpt, tokenizer=tokenizer)
+        self.synth = synth
+        self.std = self.mean = None
+        self.infer_type = "hip"
+        return self
+
     # -- loading (pipeline:53-155) -----------------------------------------------------------------
     def load_models(self, **kwargs):
         self.models_dict = {}
@@ -468,9 +488,12 @@ class ChatTTSPlusPipeline:
                                       utt_ids=[utt_ids[i] for i in order], rows=slice_size,
                                       max_new_tokens_per_row=[utt_limits[i] for i in order] if utt_limits is not None else None)
             ready, next_i, first = {}, 0, True
+            ids_sink = kwargs.get("_ids_sink")
             for ev in events:
                 for k, ids_k, hid_k in ev:
                     ready[order[k]] = hid_k if use_decoder else ids_k
+                    if ids_sink is not None:
+                        ids_sink.append((utt_ids[order[k]], ids_k))
                 if not ordered:
                     continue
                 run = 0
@@ -509,6 +532,8 @@ class ChatTTSPlusPipeline:
             try:
                 for result in results:
                     if not stream:
+                        if kwargs.get("_ids_sink") is not None:
+                            kwargs["_ids_sink"].extend(zip(utt_ids[ii:ii + slice_size], result.ids))
                         yield self._decode_to_wavs(result.hiddens if use_decoder else result.ids, use_decoder)      # pipeline:435-439
                         continue
                     # The reference's stream branch vocodes the whole prefix for every chunk and indexes a python list with
@@ -607,11 +632,20 @@ class ChatTTSPlusPipeline:
             else:
                 speaker_table = codec.speaker_to_vector(params.spk_emb).view(1, dim) if isinstance(params.spk_emb, str) else torch.as_tensor(params.spk_emb, dtype=torch.float32).view(1, dim)
         slice_size = int(kwargs.pop("slice_size", self.models_dict["gpt"].max_batch))
-        # the request's noise seed: the same on every rank (every rank is called with the same arguments, like `texts`); each utterance's
-        # device noise stream is keyed by (seed, its global index), so N ranks produce what one rank would
-        noise_seed = int(kwargs.pop("noise_seed", 0))
+        # the request's noise seed: the same on every rank; each utterance's device noise stream is keyed by (seed, its global index), so N ranks
+        # produce what one rank would.  Without `noise_seed` rank 0 draws it from torch's CPU generator -- like infer() does, so torch.manual_seed /
+        # TorchSeedContext reproduce a request and two requests differ -- and broadcasts it with the speaker table's process group.
+        noise_seed = kwargs.pop("noise_seed", None)
+        if noise_seed is None:
+            noise_seed = cdist.broadcast_seed(int(torch.randint(0, 2 ** 62, (1,)).item()), self.device)
+        noise_seed = int(noise_seed)
         kwargs.pop("noise", None); kwargs.pop("utt_ids", None)
         wavs_local: List[torch.Tensor] = []
+        limits_all = kwargs.pop("max_new_tokens_per_utterance", None)          # per GLOBAL utterance; each slice gets its own entries
+        if limits_all is not None and len(limits_all) != len(texts):
+            raise _lib.HipBackendError(f"max_new_tokens_per_utterance: {len(limits_all)} entries for {len(texts)} utterances")
+        ids_out = kwargs.pop("ids_out", None)                                  # optional list: receives this rank's generated ids, in `mine` order
+        sink = [] if ids_out is not None else None
 
         continuous = bool(kwargs.pop("continuous", False))      # each rank keeps slice_size decode rows busy over ALL its utterances (infer(continuous=True))
 
@@ -621,13 +655,21 @@ class ChatTTSPlusPipeline:
             for ii in range(0, len(indices), max(step, 1)):
                 sl = indices[ii:ii + step]
                 p = dataclasses.replace(params, spk_emb=rows[ii:ii + len(sl)])
+                kw_sl = dict(kwargs)
+                if limits_all is not None:
+                    kw_sl["max_new_tokens_per_utterance"] = [int(limits_all[i]) for i in sl]
+                if sink is not None:
+                    kw_sl["_ids_sink"] = sink
                 for wavs in self._infer([texts[i] for i in sl], False, None, skip_refine_text, False, True, True, False, True,
                                         params_refine_text, p, slice_size=(slice_size if continuous else len(sl)), utt_ids=list(sl), noise="device",
-                                        noise_seed=noise_seed, continuous=("throughput" if continuous else False), **kwargs):
+                                        noise_seed=noise_seed, continuous=("throughput" if continuous else False), **kw_sl):
                     wavs_local.extend(wavs)
                     lens.extend([(int(w.shape[0]) // 256 + 1) // 2 if w.shape[0] else 0 for w in wavs])
             return lens
 
         mine, all_lens = cdist.sharded_generate([len(t) for t in texts], speaker_index, speaker_table, n_spk, dim, self.device, run_local)
+        if ids_out is not None:
+            by_utt = dict(sink)
+            ids_out.extend(by_utt[i] for i in mine)
         return mine, wavs_local, all_lens
 

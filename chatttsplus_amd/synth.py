@@ -214,3 +214,45 @@ def exp_noise(seed: int, step: int, rows: int, vocab: int) -> np.ndarray:
 def speaker_vector(seed: int = 1234, dim: int = 768) -> np.ndarray:
     """Synthetic speaker embedding (real ones are 768 fp16 values, std ~4.8)."""
     return (_normal(seed, "speaker", (dim,), 4.8)).astype(np.float16).astype(np.float32)
+
+
+# ---- a complete synthetic "checkpoint directory" + toy tokenizer: what the end-to-end tests, the 2-process sharding test and bench.py's
+# ---- sharded-request leg build their ChatTTSPlusPipeline from (no ChatTTS checkpoint exists offline, SURVEY F3)
+TOY_VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "[Stts]", "[Ptts]", "[spk_emb]", "[empty_spk]", "[uv_break]", "[break_0]",
+             "[Ebreak]", "[speed_5]", "[Sbreak]", "[Pbreak]", "a", "b", "c", "d"]
+
+
+def toy_tokenizer(dir_path: str):
+    """chatttsplus_amd.tokenizer.Tokenizer around a BertTokenizerFast over TOY_VOCAB (one token per word / special tag)."""
+    import os
+    from transformers import BertTokenizerFast
+    from .tokenizer import Tokenizer
+    os.makedirs(dir_path, exist_ok=True)
+    vp = os.path.join(dir_path, "vocab.txt")
+    with open(vp, "w") as f:
+        f.write("\n".join(TOY_VOCAB))
+    bt = BertTokenizerFast(vocab_file=vp, do_lower_case=False)
+    bt.add_special_tokens({"additional_special_tokens": [v for v in TOY_VOCAB if v.startswith("[") and v not in ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]")]})
+    return Tokenizer(tokenizer=bt)
+
+
+def write_checkpoints(dir_path: str, seed: int = 1234, full: bool = True) -> str:
+    """<dir>/asset/{GPT,Decoder,Vocos[,DVAE_full]}.pt with the synthetic real-size weights (torch.save of the state dicts); returns dir_path."""
+    import os
+    import torch
+    os.makedirs(os.path.join(dir_path, "asset"), exist_ok=True)
+    items = [("GPT.pt", gpt_state_dict(GPT_REAL, seed)), ("Decoder.pt", dvae_state_dict(DVAE_REAL, seed)), ("Vocos.pt", vocos_state_dict(VOCOS_REAL, seed))]
+    if full:
+        esd = dvae_encoder_state_dict(DVAE_ENC_REAL, seed)
+        esd.update(dvae_full_decoder_state_dict(DVAE_FULL_DEC, seed))
+        items.append(("DVAE_full.pt", esd))
+    for name, sd in items:
+        torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, os.path.join(dir_path, "asset", name))
+    return dir_path
+
+
+def toy_texts(n: int, lo: int, hi: int, seed: int = 1234):
+    """n texts of U{lo..hi} toy words ("a".."d"): one token per word."""
+    r = _rng(seed, "toy_texts")
+    lens = r.integers(lo, hi + 1, size=n)
+    return [" ".join("abcd"[int(c)] for c in r.integers(0, 4, size=int(k))) for k in lens]

@@ -60,6 +60,16 @@ typedef struct {
 int ctts_gpt_create(const ctts_gpt_cfg* cfg, ctts_gpt** out);
 void ctts_gpt_destroy(ctts_gpt* h);
 
+/* Named engine options (the YAML's `kwargs.options` of the hip GPT; no counterpart in the reference -- the TensorRT path fixes such choices when
+ * the engine is built, trt_models/llama_trt_model.py:25-81).  Explicit calls only: the product library reads no behaviour from the environment.
+ *   "prefill_split_rows"  fp32 engines: prompt passes of >= this many rows use the 3-term fp16 split GEMMs (default 384; 0 = never; before finalize)
+ *   "valu_rows"           fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (default 4; 0..4)
+ *   "persistent_rows"     fp32 engines: decode batches of <= this many rows run each decoder layer as ONE persistent launch (default 0 = off)
+ *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection up to this batch size
+ *   "graph_steps"         decode steps captured per hipGraph (default 4)
+ * Unknown names are an error. */
+int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value);
+
 /* replaces GPT.from_pretrained -> load_state_dict (gpt.py:84-85).  `name` is the reference
  * state-dict key; `data` is HOST fp32, row-major, `numel` elements.
  * Accepted keys: gpt.layers.N.{self_attn.{q,k,v,o}_proj,mlp.{gate,up,down}_proj,input_layernorm,
@@ -179,7 +189,9 @@ int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_finished, v
 
 /* fp16 engines store SwiGLU outputs and the packed residual copy as fp16: values beyond the fp16 range are SATURATED at +-65504 and
  * counted (the reference's .half() path would produce inf -> NaN silently on such a checkpoint, pipeline:37-41); `count` = saturated or NaN
- * stores since ctts_gpt_begin.  Synchronises the stream.  Always 0 for fp32 engines. */
+ * stores since ctts_gpt_begin.  Synchronises the stream.  fp32 engines store fp32 everywhere EXCEPT in the prompt pass over >= 384 rows, whose
+ * split GEMMs keep silu(g) * u / 16 as fp16 head / tail images (prefill_split.hip): a value beyond +-65504 * 16 there is clamped and counted too
+ * (the decode steps of an fp32 engine never count). */
 int ctts_gpt_saturations(ctts_gpt* h, int32_t* count, void* stream);
 
 /* Finished-row compaction (no counterpart in the reference, whose finished rows keep computing until the slowest sequence ends,

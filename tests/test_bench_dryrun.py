@@ -23,6 +23,15 @@ def test_bench_dry_run_world2():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["ms_per_step"] * 8 / 1e3 >= 0.09            # the slower rank (0.1 s) defines the time
+    # the sharded-request leg (BASELINE configs[3]) rehearsed through the real ChatTTSPlusPipeline.infer_sharded host code: both ranks serve a
+    # share, every utterance keeps its tokens (digest == the world-1 digest), the lengths are the targets
+    sr = d["extra"]["sharded_request"]
+    assert sr["utterances"] == 48 and len(sr["per_rank_useful_tokens"]) == 2 and all(t > 0 for t in sr["per_rank_useful_tokens"])
+    assert sum(sr["per_rank_useful_tokens"]) == sr["useful_tokens"] and sr["load_imbalance_max_over_mean"] < 1.2
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "4"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    sr1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])["extra"]["sharded_request"]
+    assert sr1["ids_digest"] == sr["ids_digest"] and sr1["lengths_digest"] == sr["lengths_digest"]
 
 
 def test_bench_dry_run_single():

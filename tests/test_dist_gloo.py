@@ -157,15 +157,17 @@ def _expected_lengths(pipe):
     return out
 
 
-def _pipe_worker(rank, world, port, q, tmpdir, continuous=False):
+def _pipe_worker(rank, world, port, q, tmpdir, continuous=False, seed=4242):
     from chatttsplus_amd.pipeline import InferCodeParams
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         pipe = _fake_pipeline(tmpdir)
         table = (torch.arange(3, dtype=torch.float32)[:, None] * 3 + 1).expand(3, 8).contiguous() if rank == 0 else None
+        kw = {} if seed is None else dict(noise_seed=seed)
+        torch.manual_seed(100 + rank)                     # (seed=None: the ranks' own generators disagree; rank 0's draw must win)
         mine, wavs, all_lens = pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=table,
-                                                  params_infer_code=InferCodeParams(show_tqdm=False), noise_seed=4242, continuous=continuous)
+                                                  params_infer_code=InferCodeParams(show_tqdm=False), continuous=continuous, **kw)
         gpt = pipe.models_dict["gpt"]
         q.put((rank, mine, [int(w.shape[0]) for w in wavs], all_lens, gpt.calls if not continuous else getattr(gpt, "many_calls", []), gpt.noise_keys))
     finally:
@@ -195,6 +197,26 @@ def test_pipeline_infer_sharded_world2_gloo(tmp_path):
         assert sum(calls) == len(mine) and max(calls) <= 3                        # sliced at max_batch
         seen += mine
     assert sorted(seen) == list(range(len(TEXTS)))
+
+
+def test_pipeline_infer_sharded_seed_is_rank0s_draw_world2_gloo(tmp_path):
+    """Without noise_seed the request's seed is drawn from torch's CPU generator on rank 0 and broadcast (a constant default made every
+    sharded request sample the same noise and ignored torch.manual_seed): both ranks key their utterances with rank 0's draw."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, q, str(tmp_path), False, None)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(100)
+    want = int(torch.randint(0, 2 ** 62, (1,)).item())
+    for rank, mine, wav_samples, all_lens, calls, noise_keys in res:
+        assert noise_keys == [(want, i) for i in mine], (rank, noise_keys[:2], want)
 
 
 def test_pipeline_infer_sharded_continuous_world2_gloo(tmp_path):

@@ -1,0 +1,46 @@
+"""A/B of engine options (ctts_gpt_set_option) on ONE engine, interleaved rounds (cdna_hip_programming.md 5.4 rule 24): decode step time in the
+bench window for each setting, median and min over the rounds.
+usage: python tools/ab_options.py fp32 "valu_rows=0,4" --batches 1 2 4 [--rounds 3] [--steps 64]"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from chatttsplus_amd import synth  # noqa: E402
+from chatttsplus_amd.hip_models.gpt import GPT  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("dtype")
+ap.add_argument("sweep", help="option=v0,v1,...")
+ap.add_argument("--batches", type=int, nargs="+", default=[1])
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--steps", type=int, default=64)
+ap.add_argument("--fixed", default="", help="other options held fixed: a=1,b=2")
+a = ap.parse_args()
+name, vals = a.sweep.split("=")
+vals = [int(v) for v in vals.split(",")]
+dev = torch.device("cuda", 0)
+g = GPT(bench.LLAMA, max_batch=max(a.batches), max_seq_len=48 + 16 + 512 + 16, weight_dtype=a.dtype, device=str(dev))
+g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+for kv in [x for x in a.fixed.split(",") if x]:
+    k, v = kv.split("=")
+    g.set_option(k, int(v))
+spk = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
+leg = bench.Leg(g, dev, 0, 1)
+for B in a.batches:
+    times = {v: [] for v in vals}
+    for rnd in range(a.rounds + 1):
+        for v in vals:
+            g.set_option(name, v)
+            r = leg.run(B, 48, a.steps, 8, spk=spk)
+            if rnd:                      # round 0 captures the graphs
+                times[v].append(r["ev_ms"] / r["K"])
+    print(json.dumps({"dtype": a.dtype, "B": B, "option": name, "fixed": a.fixed,
+                      "ms_per_step": {str(v): {"median": round(statistics.median(t), 5), "min": round(min(t), 5)} for v, t in times.items()}}), flush=True)
