@@ -26,6 +26,7 @@
 
 #include "../../include/ctts_hip.h"
 #include "kernels.h"
+#include "persist.h"
 #include "roctx_range.h"
 
 static thread_local char g_err[512] = "";
@@ -41,7 +42,7 @@ extern "C" int ctts_version(void) { return 1; }
 #define PASS_ROWS_MAX 16384   // prompt rows per pass (32 x 512 tokens in one pass); an engine's workspaces are sized for min(this, max_batch * max_seq)
 #define PASS_PAD 256          // + PASS_PAD rows so that whole GEMM blocks stay in bounds
 #define SMAX 8        // == ATT_SMAX in skinny_gemm.hip
-#define CTTS_PERSIST_MAX_ROWS 4
+#define CTTS_PERSIST_MAX_ROWS PL_MAXR
 
 struct LayerW {
     void *qkv, *o, *gu, *d;      // RMSNorm weights are folded into qkv / gu columns
@@ -95,9 +96,18 @@ struct ctts_gpt {
                                                  // the prompt pass keeps 32-row blocks
     int force_splits = 0;                        // key splits of the decode attention (0 = decode_splits policy); ctts_gpt_set_option("decode_splits")
     int opt_gen = 0;                             // bumped by ctts_gpt_set_option: part of the decode-graph key
-    int valu_rows = 4;                           // fp32 engines: decode batches of <= this many rows multiply on the VALU (skinny_gemm.hip, VR template argument):
-                                                 // an exact-f32 MFMA costs 32 cycles whatever the number of live columns, 48 of them per wave and launch
+    int valu_rows = 2;                           // fp32 engines: decode batches of <= this many rows multiply on the VALU (skinny_gemm.hip, VR template argument):
+                                                 // an exact-f32 MFMA costs 32 cycles whatever the number of live columns, 48 of them per SIMD and launch.
+                                                 // Measured (us/step, MFMA -> VALU, profiles/r04_ab_valu_rows.jsonl): batch 1 481.9 -> 450.8, 2 491.7 -> 477.5,
+                                                 // 3 532.6 -> 555.9, 4 536.7 -> 560.3 (the 4-row variant re-reads four LDS operand rows per weight fragment)
     int persist_rows = 0;                        // fp32 engines: decode batches of <= this many rows run each layer as one persistent launch (persist_layer.hip)
+    char* pimg = nullptr;                        //   per-workgroup register images of the layer weights [L][192][192 KB], built on the device from the packed tiles
+    unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
+    unsigned* pl_epoch = nullptr;                //   launch counter = granule tag
+    int* pl_error = nullptr;                     //   first give-up code (0 = none); reported by ctts_gpt_progress
+    unsigned long long* pl_ts = nullptr;         //   diagnostics: per-workgroup phase marks of the last launch ("persistent_timestamps")
+    int cur_persist = 0;                         //   the steps being launched use the persistent layer
+    int pl_ts_on = 0;
     int no_prepack = 0, prefill_gemm_rows = 1536, xh_heads = 1;   // diagnostic builds only: see run_layers / run_decode_step
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
     DevState* st = nullptr;
@@ -188,6 +198,27 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     return 0;
 }
 
+// The persistent decode layer's device state: weight images (repacked on the device from the MFMA tile images: no host copy of the weights is
+// needed after finalize), granule buffers, epoch, error word.  Needs every one of the 256 workgroups resident at once.
+static int ensure_persist(ctts_gpt* h) {
+    if (h->pimg != nullptr) return 0;
+    if (h->cfg.dtype != CTTS_DTYPE_F32) { ctts_set_error("persistent layers: fp32 engines only"); return 1; }
+    if (!h->finalized) return 0;                 // built by finalize
+    int dev = 0, cus = 0;
+    CTTS_HIP_CHECK(hipGetDevice(&dev));
+    CTTS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus < PL_BLOCKS) { ctts_set_error("persistent layers need %d compute units resident at once, the device has %d", PL_BLOCKS, cus); return 1; }
+    if (persist_configure()) return 1;
+    if (dev_alloc((void**)&h->pimg, PL_LAYER_BYTES * h->L) || dev_alloc((void**)&h->pl_g, (size_t)(PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT) * 8) ||
+        dev_alloc((void**)&h->pl_epoch, 4) || dev_alloc((void**)&h->pl_error, 4)) return 1;
+    const unsigned one = 1;
+    CTTS_HIP_CHECK(hipMemcpy(h->pl_epoch, &one, 4, hipMemcpyHostToDevice));
+    for (int l = 0; l < h->L; ++l)
+        if (launch_persist_repack(h->lw[l].qkv, h->lw[l].o, h->lw[l].gu, h->lw[l].d, h->pimg + PL_LAYER_BYTES * l, nullptr)) return 1;
+    CTTS_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
 // Named engine options: explicit calls of the host side (hip_models.GPT(options=...)), never the environment.  Options that shape the launches bump
 // `opt_gen`, which is part of the decode-graph key, so graphs captured under other settings are not replayed.
 extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
@@ -200,6 +231,10 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->valu_rows = value < 0 ? 0 : (value > 4 ? 4 : value);
     } else if (n == "persistent_rows") {         // fp32 engines: decode batches of <= this many rows run each layer as ONE persistent launch (0 = off)
         h->persist_rows = value < 0 ? 0 : (value > CTTS_PERSIST_MAX_ROWS ? CTTS_PERSIST_MAX_ROWS : value);
+        if (h->persist_rows > 0 && ensure_persist(h)) { h->persist_rows = 0; return 1; }
+    } else if (n == "persistent_timestamps") {   // diagnostics: every workgroup of a persistent launch records wall_clock64 marks (ctts_gpt_debug_read "pl_ts")
+        if (value && !h->pl_ts && dev_alloc((void**)&h->pl_ts, (size_t)PL_BLOCKS * 9 * 8)) return 1;
+        h->pl_ts_on = value ? 1 : 0;
     } else if (n == "decode_splits") {           // key splits of the decode attention (0 = the decode_splits policy)
         if (value < 0 || value > SMAX) { ctts_set_error("set_option(decode_splits): 0..%d", SMAX); return 1; }
         h->force_splits = value;
@@ -221,7 +256,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
-                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do};
+                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -600,6 +635,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
     }
     h->host.clear();
     h->finalized = true;
+    if (h->persist_rows > 0 && ensure_persist(h)) return 1;
     return 0;
 }
 
@@ -680,6 +716,19 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // fp32: the RMSNorm factor then multiplies the C tile instead of the operand -- (sum w x) rs instead of sum w (x rs), one rounding
     // apart; token ids stay bit-exact on every golden (tests/test_gpu_gpt.py)
     const bool xhm = (st != nullptr) && h->xh_mode && !splitd;
+    if (st != nullptr && h->cur_persist && h->pimg != nullptr && dt == CTTS_DTYPE_F32 && R <= PL_MAXR && !lora) {
+        // one persistent launch per layer (persist_layer.hip): the residual stream stays in x, nothing is left in partial or packed form
+        if (form) { form->parts = false; form->xh = false; }
+        for (int l = 0; l < h->L; ++l) {
+            PersistArgs pa = {};
+            pa.w = h->pimg + PL_LAYER_BYTES * l; pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
+            pa.k_cache = kv_layer(h, l, 0); pa.v_cache = kv_layer(h, l, 1); pa.Lmax = h->cfg.max_seq;
+            pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1;
+            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f;
+            if (launch_persist_layer(R, pa, s)) return 1;
+        }
+        return 0;
+    }
     if (form) { form->parts = splitd; form->xh = xhm; }
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
@@ -856,6 +905,7 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
     CTTS_HIP_CHECK(hipMemcpyAsync(h->dyn, &d, sizeof(d), hipMemcpyHostToDevice, s));       // pageable source: staged before the call returns
     if (launch_fill_meta(h->meta_pre, h->meta_dec0, h->st, mask, B, T, h->rope, h->rope_pre, s)) return 1;
     CTTS_HIP_CHECK(hipMemsetAsync(h->sat, 0, 4, s));
+    if (h->pl_error) CTTS_HIP_CHECK(hipMemsetAsync(h->pl_error, 0, 4, s));
     return reset_state(h, false, s);
 }
 
@@ -905,6 +955,12 @@ static int advance_rows(ctts_gpt* h, int n_steps) {
     return longest;
 }
 
+// The steps about to be launched run their layers as persistent launches: small fp32 batches without per-utterance adapters whose longest context stays
+// within what one workgroup per (row, head) serves.
+static inline int decode_persist(const ctts_gpt* h, int B, int L) {
+    return (h->persist_rows > 0 && h->pimg != nullptr && h->cfg.dtype == CTTS_DTYPE_F32 && B <= h->persist_rows && !h->lora_rows && L <= PL_MAX_CONTEXT) ? 1 : 0;
+}
+
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
     StreamForm form = {false, false};
     if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s, &form)) return 1;
@@ -913,7 +969,7 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen);      // (diagnostic switches are fixed at create)
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen, h->cur_persist);      // (diagnostic switches are fixed at create)
     const std::string key(sig);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }
@@ -939,7 +995,11 @@ extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* st
     if (!h || h->B == 0) { ctts_set_error("decode: call begin first"); return 1; }
     CTTS_RANGE("ctts_gpt_decode");              // reference: nvtx "forward" per decode step + "execute" (trt_models/predictor.py:164)
     hipStream_t s = (hipStream_t)stream;
-    h->cur_splits = decode_splits(h, h->B, advance_rows(h, n_steps) + 1);
+    {
+        const int longest = advance_rows(h, n_steps) + 1;
+        h->cur_splits = decode_splits(h, h->B, longest);
+        h->cur_persist = decode_persist(h, h->B, longest);
+    }
     h->launched += n_steps;
     if (use_graph) {
         if (ensure_graph(h)) return 1;
@@ -956,9 +1016,16 @@ extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_
     if (!h) { ctts_set_error("null handle"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     CTTS_HIP_CHECK(hipMemcpyAsync(h->host_pin, h->st, 16, hipMemcpyDeviceToHost, s));
+    h->host_pin[12] = 0;
+    if (h->pl_error) CTTS_HIP_CHECK(hipMemcpyAsync(h->host_pin + 12, h->pl_error, 4, hipMemcpyDeviceToHost, s));
     CTTS_HIP_CHECK(hipStreamSynchronize(s));
     if (steps_done) *steps_done = h->host_pin[0];
     if (all_finished) *all_finished = h->host_pin[2];
+    if (h->host_pin[12] != 0) {
+        ctts_set_error("persistent decode layer: a workgroup gave up waiting on edge %d (2 = q|k|v -> attention, 3 = attention -> o_proj, 4 = o_proj -> gate|up, "
+                       "5 = gate|up -> down); is the GPU shared with another process?  Use options={'persistent_rows': 0}", h->host_pin[12]);
+        return 1;
+    }
     return 0;
 }
 
@@ -1058,6 +1125,34 @@ extern "C" int ctts_gpt_admit(ctts_gpt* h, int n, const int32_t* rows, int T, co
     return 0;
 }
 
+// Diagnostics: copies a named internal buffer to HOST memory (tools/persist_probe.py compares the persistent layer's intermediates with the
+// launch path's).  Synchronises the stream.  Returns the number of bytes copied through *bytes.
+extern "C" int ctts_gpt_debug_read(ctts_gpt* h, const char* name, void* out, size_t max_bytes, size_t* bytes, void* stream) {
+    if (!h || !name || !out) { ctts_set_error("debug_read: null argument"); return 1; }
+    const std::string n(name);
+    const void* src = nullptr; size_t nb = 0;
+    if (n == "x_dec") { src = h->x_dec; nb = (size_t)CTTS_MAX_B * h->H * 4; }
+    else if (n == "q_buf") { src = h->q_buf; nb = (size_t)32 * h->H * 4; }
+    else if (n == "logits") { src = h->logits; nb = (size_t)CTTS_MAX_B * h->NVQ * h->V * 4; }
+    else if (n == "pl_g" && h->pl_g) { src = h->pl_g; nb = (size_t)(PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT) * 8; }
+    else if (n == "pl_ts" && h->pl_ts) { src = h->pl_ts; nb = (size_t)PL_BLOCKS * 9 * 8; }
+    else if (n == "pl_state" && h->pl_epoch) {
+        unsigned* o = (unsigned*)out;
+        if (max_bytes < 8) { ctts_set_error("debug_read: buffer too small"); return 1; }
+        CTTS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        CTTS_HIP_CHECK(hipMemcpy(o, h->pl_epoch, 4, hipMemcpyDeviceToHost));
+        CTTS_HIP_CHECK(hipMemcpy(o + 1, h->pl_error, 4, hipMemcpyDeviceToHost));
+        if (bytes) *bytes = 8;
+        return 0;
+    }
+    if (!src) { ctts_set_error("debug_read: unknown or unallocated buffer '%s'", name); return 1; }
+    if (nb > max_bytes) nb = max_bytes;
+    CTTS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    CTTS_HIP_CHECK(hipMemcpy(out, src, nb, hipMemcpyDeviceToHost));
+    if (bytes) *bytes = nb;
+    return 0;
+}
+
 extern "C" int ctts_gpt_logits(ctts_gpt* h, float* out, void* stream) {
     if (!h || !out || h->B == 0) { ctts_set_error("logits: call begin first"); return 1; }
     CTTS_HIP_CHECK(hipMemcpyAsync(out, h->logits, (size_t)h->B * (h->text_mode ? h->vocab_text_head : h->NVQ * h->V) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1113,6 +1208,7 @@ extern "C" int ctts_gpt_time_decode(ctts_gpt* h, int n_steps, float* ms_per_step
             int longest = 1;
             for (int r = 0; r < h->B; ++r) { const int c = std::min(h->row_ctx[r] + (launched - h->launched) + n, h->row_cap[r]); if (c > longest) longest = c; }
             h->cur_splits = decode_splits(h, h->B, longest + 1);
+            h->cur_persist = decode_persist(h, h->B, longest + 1);
             launched += n;
             if (ensure_graph(h)) return 1;
             if (pass == 1) for (int j = 0; j < n; j += h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));

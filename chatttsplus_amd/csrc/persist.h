@@ -1,0 +1,48 @@
+// Persistent decode layer (persist_layer.hip): geometry and the argument block shared with gpt_engine.hip.
+#pragma once
+#include "common.h"
+
+#define PL_GEMV_BLOCKS 192                 // workgroups that own weight slices
+#define PL_ATT_BLOCKS 64                   // workgroups that own one (row, head) of the attention
+#define PL_BLOCKS (PL_GEMV_BLOCKS + PL_ATT_BLOCKS)
+#define PL_THREADS 640                     // 8 compute waves + 2 edge waves
+#define PL_H 768
+#define PL_I 3072
+#define PL_NH 12
+#define PL_MAXR 4
+#define PL_MAX_CONTEXT 1024                // longest context served (one workgroup per (row, head): 256 keys prefetched, the rest streamed)
+// per-workgroup weight image of one layer: 12 q|k|v rows, 4 o_proj rows, 16 gate|up pairs, 4 down rows (fp32)
+#define PL_QKV_BYTES (12 * 768 * 4)
+#define PL_O_BYTES (4 * 768 * 4)
+#define PL_GU_BYTES (32 * 768 * 4)
+#define PL_D_BYTES (4 * 3072 * 4)
+#define PL_BLOCK_BYTES (PL_QKV_BYTES + PL_O_BYTES + PL_GU_BYTES + PL_D_BYTES)      // 196608
+#define PL_LAYER_BYTES ((size_t)PL_GEMV_BLOCKS * PL_BLOCK_BYTES)                   // 37.75 MB = the layer's weights, once
+// granule buffers (8 bytes = {tag, value}), sized for PL_MAXR rows
+#define PL_G_QKV (PL_MAXR * PL_NH * 192)
+#define PL_G_ATT (PL_MAXR * PL_H)
+#define PL_G_X1 (PL_MAXR * PL_H)
+#define PL_G_ACT (PL_MAXR * PL_I)
+
+struct PersistArgs {
+    const char* w;                  // this layer's image [192][PL_BLOCK_BYTES]
+    float* x;                       // residual stream [R][768], read at entry, rewritten at the end
+    const RowMeta* meta;            // decode rows
+    const float* rope_rows;         // [R][64] cos | sin of each row's position
+    void* k_cache;                  // this layer's K [maxB][12][Lmax][64] fp32
+    void* v_cache;
+    int Lmax;
+    unsigned long long* g_qkv;      // [R][12][q 64 | k 64 | v 64]
+    unsigned long long* g_att;      // [R][768]
+    unsigned long long* g_x1;       // [R][768]
+    unsigned long long* g_act;      // [R][3072]
+    unsigned* epoch;                // launch counter = this launch's granule tag (never 0)
+    int* error;                     // 0, or the phase code of the first wave that gave up
+    const int* done;                // DevState.all_done
+    unsigned long long* ts;         // diagnostics: [256][9] wall_clock64 marks per workgroup, or null
+    float eps;
+};
+
+int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s);
+int launch_persist_repack(const void* qkv, const void* o, const void* gu, const void* d, void* dst, hipStream_t s);
+int persist_configure();

@@ -1,0 +1,505 @@
+// One decoder layer of a small decode batch (<= 4 rows, fp32 engine) as ONE persistent launch (gfx950).
+//
+// Reference arithmetic: LlamaDecoderLayer.forward, chattts_plus/models/llama.py:719-749 (RMSNorm :82-87, q/k/v + RoPE + cache append :619-633,
+// SDPA :653-661, o_proj + residual :666,731, SwiGLU MLP + residual :214,737-739) -- the loop it serves is gpt.py:389-546.
+//
+// Why: a batch-1 decode step of the launch path is 102 dependent launches of ~4.8 us each although the layer's 37.7 MB of fp32 weights stream
+// in ~6 us: every launch pays boundary + ramp + one load round trip + drain.  Here a layer is ONE launch of 256 resident workgroups:
+//   * 192 GEMV workgroups own a fixed slice of every projection (12 q/k/v rows, 4 o_proj rows, 16 gate|up pairs, 4 down rows = 192 KB of
+//     weights); their 8 compute waves request the whole slice with non-temporal loads at kernel entry, so the weight stream runs AHEAD of
+//     the layer's dependency edges (MI355X_MICROARCH.md price list, row prefetch-credit) and every product is VALU work on registers;
+//   * 64 attention workgroups own one (row, head) each and pull its cached K / V rows into registers before the query exists;
+//   * the activations travel between workgroups as 8-byte {tag, value} granules (one sc1 store each, cdna_hip_programming.md Guideline 16 R2):
+//     the data is the flag, a consumer wave re-reads its granules until every tag equals this launch's epoch -- no fences, no counters,
+//     placement-independent.  Two "edge" waves per workgroup do all gathering, epilogues and publishing, so the compute waves never poll
+//     (a poll's result would queue behind their in-flight weight loads: vmcnt retires in order);
+//   * the residual stream enters and leaves through plain global memory (the launch boundary orders it), so consecutive layers are
+//     consecutive launches and a layer has four in-launch edges: q|k|v -> attention, attention -> o_proj, o_proj -> gate|up, gate|up -> down.
+// Every spin is bounded; a give-up sets a device error word that makes this and every later launch return at once (ctts_gpt_progress
+// reports it).  The epoch is a device counter the launch itself advances (graph replay freezes kernel arguments).
+#include "kernels.h"
+#include "persist.h"
+
+typedef unsigned long long u64;
+
+#define PL_SPIN_LIMIT (1u << 18)      // ~0.3 s of polling before a wave gives up
+
+__device__ inline void store_granule(u64* g, unsigned tag, float v) {
+    __hip_atomic_store(g, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave re-reads its N granules (lane's granule k at g[OFF(k)]) every pass until every tag equals `tag`; values -> v.  `take` = this lane has
+// granules at all.  Returns false after PL_SPIN_LIMIT passes or once the workgroup / the engine has given up.
+template <int N, typename OffFn>
+__device__ inline bool sweep(const u64* g, OffFn off, unsigned tag, bool take, float (&v)[N], int* err, int code, volatile int* abort_s) {
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        if (take) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const u64 x = __hip_atomic_load(g + off(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[k] = __builtin_bit_cast(float, (unsigned)x);
+                ok = ok && ((unsigned)(x >> 32) == tag);
+            }
+        }
+        if (__all(ok)) return true;
+        bool giveup = spins >= PL_SPIN_LIMIT || *abort_s != 0;
+        if (!giveup && (spins & 1023u) == 1023u) giveup = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (giveup) {
+            if ((threadIdx.x & 63) == 0) { atomicCAS(err, 0, code); *abort_s = 1; }
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+__device__ inline float dot4(const f32x4 w, const f32x4 x, float acc) {
+    return fmaf(w[3], x[3], fmaf(w[2], x[2], fmaf(w[1], x[1], fmaf(w[0], x[0], acc))));
+}
+__device__ inline float pl_exp_diff(float m, float mn) { return (m == -INFINITY) ? 0.f : expf(m - mn); }
+
+template <int R>
+__global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const xs = (float*)smem;                       // activations of the current phase [R][768] ([R][3072] for the down projection)
+    float* const red = xs + R * PL_I;                     // compute waves' results [8 waves][4 slots][R]
+    float* const ssq = red + 8 * 4 * R;                   // sums of squares of the gathered rows [2 edge waves][R]
+    float* const xres = ssq + 2 * R;                      // this workgroup's 4 columns of the residual stream [R][4] (x, later x + attention)
+    int* const abort_s = (int*)(xres + 4 * R);            // [4]
+    float* const att_s = (float*)(abort_s + 4);           // attention workgroups: q[64] | k_new[64] | v_new[64] | merge[8][8][10]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    if (*a.done != 0) return;                                                                   // every sequence finished (gpt.py:545): the same for every workgroup
+    if (__hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;    // an earlier launch gave up
+    const unsigned tag = *a.epoch;                        // advanced by workgroup 0 at the very end (every workgroup has read it by then: see below)
+    unsigned long long t_mark[9];
+#define PL_MARK(i) do { if (a.ts != nullptr) t_mark[i] = wall_clock64(); } while (0)
+    PL_MARK(0);
+    if (tid == 0) abort_s[0] = 0;
+
+    if (b < PL_GEMV_BLOCKS) {
+        const char* const wb = a.w + (size_t)b * PL_BLOCK_BYTES;
+        if (wave < 8) {
+            // ------------------------------------------------ compute wave: weights in registers, products on the VALU
+            const f32x4* const wq = (const f32x4*)wb + (size_t)wave * (2 * 3 * 64) + lane;                                 // [row 2][j 3][lane]
+            const f32x4* const wo = (const f32x4*)(wb + PL_QKV_BYTES) + (size_t)wave * (3 * 64) + lane;                      // [j 3][lane]
+            const f32x4* const wg = (const f32x4*)(wb + PL_QKV_BYTES + PL_O_BYTES) + (size_t)wave * (4 * 3 * 64) + lane;     // [pair 2][gate|up][j 3][lane]
+            const f32x4* const wd = (const f32x4*)(wb + PL_QKV_BYTES + PL_O_BYTES + PL_GU_BYTES) + (size_t)wave * (6 * 64) + lane;   // [j 6][lane]
+            f32x4 q_w[2][3], o_w[3], g_w[4][3], d_w[6];
+            if (wave < 6) {
+#pragma unroll
+                for (int row = 0; row < 2; ++row)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) q_w[row][j] = __builtin_nontemporal_load(wq + (row * 3 + j) * 64);
+            }
+            if (wave < 4) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) o_w[j] = __builtin_nontemporal_load(wo + j * 64);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) g_w[s][j] = __builtin_nontemporal_load(wg + (s * 3 + j) * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                  // S0
+            // ---- phase A: q | k | v rows
+            __syncthreads();                                  // B1(A): xs = x
+            f32x4 xr[R][3];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+            if (wave < 6) {
+#pragma unroll
+                for (int row = 0; row < 2; ++row)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc = dot4(q_w[row][j], xr[r][j], acc);
+                        acc = wave_sum(acc);
+                        if (lane == 0) red[(wave * 4 + row) * R + r] = acc;
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d_w[j] = __builtin_nontemporal_load(wd + j * 64);     // (the q | k | v registers are free now)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                  // B2(A)
+            // ---- phase C: o_proj rows
+            __syncthreads();                                  // B1(C): xs = attention output
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+            if (wave < 4) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc = dot4(o_w[j], xr[r][j], acc);
+                    acc = wave_sum(acc);
+                    if (lane == 0) red[(wave * 4) * R + r] = acc;
+                }
+            }
+            __syncthreads();                                  // B2(C)
+            // ---- phase D: gate | up pairs
+            __syncthreads();                                  // B1(D): xs = x + attention
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc = dot4(g_w[s][j], xr[r][j], acc);
+                    acc = wave_sum(acc);
+                    if (lane == 0) red[(wave * 4 + s) * R + r] = acc;
+                }
+            __syncthreads();                                  // B2(D)
+            // ---- phase E: down rows, two K halves per row
+            __syncthreads();                                  // B1(E): xs = silu(gate) * up, [R][3072]
+            const int half = wave & 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc = dot4(d_w[j], ((const f32x4*)(xs + r * PL_I))[384 * half + 64 * j + lane], acc);
+                acc = wave_sum(acc);
+                if (lane == 0) red[(wave * 4) * R + r] = acc;
+            }
+            __syncthreads();                                  // B2(E)
+        } else {
+            // ------------------------------------------------ edge wave: gathers, epilogues, publishing
+            const int ew = wave - 8, e = ew * 64 + lane;      // 0..127
+            const int hh = b >> 4, jj = b & 15;               // q | k | v rows of this workgroup: head hh, dims (2jj, 2jj+1, +32) / v dims 4jj..4jj+3
+            // epilogue operands of phase A, requested now
+            const int tA = e, pwA = tA % 6, rA = (tA / 6 < R) ? tA / 6 : 0;
+            const bool doA = tA < 6 * R;
+            RowMeta mA = {0, 0, 0, 0};
+            float cA = 1.f, sA = 0.f;
+            if (doA) {
+                mA = a.meta[rA];
+                if (pwA < 4) {
+                    const int d = 2 * jj + (pwA & 1);
+                    cA = a.rope_rows[(size_t)rA * 64 + d];
+                    sA = a.rope_rows[(size_t)rA * 64 + 32 + d];
+                }
+            }
+            // the residual stream: [R][768] from global memory (written by the previous launch) -> xs, sums of squares, own 4 columns
+            constexpr int XIT = (R * 192 + 127) / 128;
+            f32x4 xv[XIT];
+#pragma unroll
+            for (int i = 0; i < XIT; ++i) {
+                const int idx = e + 128 * i;
+                xv[i] = (idx < R * 192) ? ((const f32x4*)a.x)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (e < R) *(f32x4*)(xres + 4 * e) = *(const f32x4*)(a.x + (size_t)e * PL_H + 4 * b);
+            float ssp[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) ssp[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < XIT; ++i) {
+                const int idx = e + 128 * i;
+                if (idx < R * 192) ((f32x4*)xs)[idx] = xv[i];
+                const float d = xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) ssp[r] += (idx / 192 == r) ? d : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float s = wave_sum(ssp[r]);
+                if (lane == 0) ssq[ew * R + r] = s;
+            }
+            __syncthreads();                                  // S0
+            PL_MARK(1);
+            __syncthreads();                                  // B1(A)
+            __syncthreads();                                  // B2(A)
+            if (doA) {
+                const float rs = 1.0f / sqrtf((ssq[rA] + ssq[R + rA]) / (float)PL_H + a.eps);          // llama.py:82-87 (the weight is folded into W's columns)
+                const float va = red[(pwA * 4 + 0) * R + rA] * rs, vb = red[(pwA * 4 + 1) * R + rA] * rs;
+                float ya = va, yb = vb;
+                int which, dA, dB;
+                if (pwA < 4) {                                   // q / k: RoPE pair (d, d + 32), products rounded separately like the reference (llama.py:180-181)
+                    which = pwA >> 1; dA = 2 * jj + (pwA & 1); dB = dA + 32;
+                    ya = __fadd_rn(__fmul_rn(va, cA), __fmul_rn(-vb, sA));
+                    yb = __fadd_rn(__fmul_rn(vb, cA), __fmul_rn(va, sA));
+                } else {
+                    which = 2; dA = 4 * jj + 2 * (pwA - 4); dB = dA + 1;
+                }
+                u64* const gq = a.g_qkv + ((size_t)(rA * PL_NH + hh) * 192 + which * 64);
+                store_granule(gq + dA, tag, ya);
+                store_granule(gq + dB, tag, yb);
+                if (which >= 1) {                                // KV append (llama.py:633): later steps read it from the cache
+                    float* c = (float*)(which == 1 ? a.k_cache : a.v_cache) + (((size_t)mA.seq * PL_NH + hh) * a.Lmax + mA.slot) * CTTS_HEAD_DIM;
+                    c[dA] = ya; c[dB] = yb;
+                }
+            }
+            PL_MARK(2);
+            // ---- phase C: attention output -> o_proj + residual
+            {
+                float v[6 * R];
+                const bool got = sweep<6 * R>(a.g_att + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, true, v, a.error, 3, abort_s);
+                (void)got;
+#pragma unroll
+                for (int k = 0; k < 6 * R; ++k) xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
+            }
+            PL_MARK(3);
+            __syncthreads();                                  // B1(C)
+            __syncthreads();                                  // B2(C)
+            if (e < 4 * R) {
+                const int i = e & 3, r = e >> 2;
+                const float x1 = xres[4 * r + i] + red[(i * 4) * R + r];                               // llama.py:731
+                xres[4 * r + i] = x1;
+                store_granule(a.g_x1 + (size_t)r * PL_H + 4 * b + i, tag, x1);
+            }
+            PL_MARK(4);
+            // ---- phase D: x + attention -> RMSNorm, gate | up, SiLU * up
+            {
+                float v[6 * R];
+                const bool got = sweep<6 * R>(a.g_x1 + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, true, v, a.error, 4, abort_s);
+                (void)got;
+#pragma unroll
+                for (int r = 0; r < R; ++r) ssp[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6 * R; ++k) {
+                    xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
+                    ssp[k / 6] += v[k] * v[k];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float s = wave_sum(ssp[r]);
+                    if (lane == 0) ssq[ew * R + r] = s;
+                }
+            }
+            PL_MARK(5);
+            __syncthreads();                                  // B1(D)
+            __syncthreads();                                  // B2(D)
+            if (e < 16 * R) {
+                const int pi = e & 15, r = e >> 4, w = pi >> 1, p = pi & 1;
+                const float rs = 1.0f / sqrtf((ssq[r] + ssq[R + r]) / (float)PL_H + a.eps);
+                const float gv = red[(w * 4 + 2 * p) * R + r] * rs, uv = red[(w * 4 + 2 * p + 1) * R + r] * rs;
+                store_granule(a.g_act + (size_t)r * PL_I + 16 * b + pi, tag, (gv / (1.0f + expf(-gv))) * uv);       // llama.py:214
+            }
+            PL_MARK(6);
+            // ---- phase E: silu(gate) * up [R][3072] -> down + residual
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float v[24];
+                const bool got = sweep<24>(a.g_act + (size_t)r * PL_I + e, [](int k) { return 128 * k; }, tag, true, v, a.error, 5, abort_s);
+                (void)got;
+#pragma unroll
+                for (int k = 0; k < 24; ++k) xs[r * PL_I + 128 * k + e] = v[k];
+            }
+            PL_MARK(7);
+            __syncthreads();                                  // B1(E)
+            __syncthreads();                                  // B2(E)
+            if (e < 4 * R) {
+                const int i = e & 3, r = e >> 2;
+                a.x[(size_t)r * PL_H + 4 * b + i] = xres[4 * r + i] + (red[((2 * i) * 4) * R + r] + red[((2 * i + 1) * 4) * R + r]);      // llama.py:739
+            }
+            PL_MARK(8);
+            if (a.ts != nullptr && e == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) a.ts[(size_t)b * 9 + i] = t_mark[i];
+            }
+            // Advance the epoch for the next launch.  Safe although other workgroups may still be running: workgroup 0 reaches this point only after its
+            // phase C gather, i.e. after every attention item was published, i.e. after all 192 GEMV workgroups published their q | k | v rows --
+            // each of them read `tag` before that; attention workgroups read it before their gather.
+            if (b == 0 && e == 0) __hip_atomic_fetch_add(a.epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- attention workgroup: one (row, head)
+    const int item = b - PL_GEMV_BLOCKS;
+    if (item >= PL_NH * R) return;
+    const int r = item / PL_NH, hh = item % PL_NH;
+    float* const qs = att_s;
+    float* const ks = att_s + 64;
+    float* const vs = att_s + 128;
+    float* const merge = att_s + 192;                         // [8 waves][8 subs][10]
+    if (wave < 8) {
+        const RowMeta m = a.meta[r];
+        const int kv0 = m.kv_start, kv1 = m.slot;             // cached keys [kv0, kv1); this step's key / value arrive with the query
+        const int grp = lane >> 3, sub = lane & 7;
+        const size_t head_off = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
+        const float* const kb = (const float*)a.k_cache + head_off;
+        const float* const vb = (const float*)a.v_cache + head_off;
+        constexpr int PRE = 4;                                // iterations requested before the query exists: 8 waves x 8 keys x 4 = 256 keys
+        f32x4 kf[PRE][2], vf[PRE][2];
+        bool ok[PRE];
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int p = kv0 + 8 * (wave + 8 * u) + grp;
+            ok[u] = p < kv1;
+            const int pc = ok[u] ? p : kv0;
+            kf[u][0] = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM); kf[u][1] = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM + 4);
+            vf[u][0] = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM); vf[u][1] = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                      // S0
+        __syncthreads();                                      // B1: q (x 1/8), k_new, v_new in LDS
+        const f32x4 q0 = *(const f32x4*)(qs + 8 * sub), q1 = *(const f32x4*)(qs + 8 * sub + 4);
+        float mrun = -INFINITY, lrun = 0.f, o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        auto key_step = [&](const f32x4 k0, const f32x4 k1, const f32x4 v0, const f32x4 v1, bool live) {
+            float dot = q0[0] * k0[0] + q0[1] * k0[1] + q0[2] * k0[2] + q0[3] * k0[3] + q1[0] * k1[0] + q1[1] * k1[1] + q1[2] * k1[2] + q1[3] * k1[3];
+            dot += dpp_f<DPP_XOR1>(dot);
+            dot += dpp_f<DPP_XOR2>(dot);
+            dot += dpp_f<DPP_HALF_MIRROR>(dot);
+            if (live) {
+                const float mn = fmaxf(mrun, dot);
+                const float sc = pl_exp_diff(mrun, mn);
+                const float pe = expf(dot - mn);
+                lrun = lrun * sc + pe;
+                o[0] = o[0] * sc + pe * v0[0]; o[1] = o[1] * sc + pe * v0[1]; o[2] = o[2] * sc + pe * v0[2]; o[3] = o[3] * sc + pe * v0[3];
+                o[4] = o[4] * sc + pe * v1[0]; o[5] = o[5] * sc + pe * v1[1]; o[6] = o[6] * sc + pe * v1[2]; o[7] = o[7] * sc + pe * v1[3];
+                mrun = mn;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) key_step(kf[u][0], kf[u][1], vf[u][0], vf[u][1], ok[u]);
+        for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64) {       // contexts beyond 256 keys: the rest streams behind the query (wave-uniform bound)
+            const int p = wb0 + grp;
+            const bool live = p < kv1;
+            const int pc = live ? p : kv0;
+            const f32x4 k0 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM), k1 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM + 4);
+            const f32x4 v0 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM), v1 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM + 4);
+            key_step(k0, k1, v0, v1, live);
+        }
+        // merge the 8 key groups of this wave (lanes with equal `sub`)
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(mrun, off), l2 = __shfl_xor(lrun, off);
+            const float mn = fmaxf(mrun, m2);
+            const float s1 = pl_exp_diff(mrun, mn), s2 = pl_exp_diff(m2, mn);
+            lrun = lrun * s1 + l2 * s2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float o2 = __shfl_xor(o[j], off);
+                o[j] = o[j] * s1 + o2 * s2;
+            }
+            mrun = mn;
+        }
+        if (grp == 0) {
+            float* mg = merge + (wave * 8 + sub) * 10;
+            mg[0] = mrun; mg[1] = lrun;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mg[2 + j] = o[j];
+        }
+        __syncthreads();                                      // B2
+    } else if (wave == 8) {
+        __syncthreads();                                      // S0
+        float v[3];
+        const bool got = sweep<3>(a.g_qkv + (size_t)(r * PL_NH + hh) * 192 + lane, [](int k) { return 64 * k; }, tag, true, v, a.error, 2, abort_s);
+        (void)got;
+        qs[lane] = v[0] * 0.125f;                             // 1 / sqrt(64) (llama.py:653-661)
+        ks[lane] = v[1];
+        vs[lane] = v[2];
+        PL_MARK(1);
+        __syncthreads();                                      // B1
+        __syncthreads();                                      // B2
+        if (lane < 8) {
+            float M = merge[lane * 10], L = merge[lane * 10 + 1], O[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) O[j] = merge[lane * 10 + 2 + j];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                const float* mg = merge + (w * 8 + lane) * 10;
+                const float mn = fmaxf(M, mg[0]);
+                const float s1 = pl_exp_diff(M, mn), s2 = pl_exp_diff(mg[0], mn);
+                L = L * s1 + mg[1] * s2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) O[j] = O[j] * s1 + mg[2 + j] * s2;
+                M = mn;
+            }
+            // this step's own key (slot `m.slot`, causal end of the row: llama.py:1073-1087)
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += qs[8 * lane + j] * ks[8 * lane + j];
+            dot += dpp_f<DPP_XOR1>(dot);
+            dot += dpp_f<DPP_XOR2>(dot);
+            dot += dpp_f<DPP_HALF_MIRROR>(dot);
+            const float mn = fmaxf(M, dot);
+            const float s1 = pl_exp_diff(M, mn), pe = expf(dot - mn);
+            L = L * s1 + pe;
+            const float inv = 1.0f / L;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                store_granule(a.g_att + (size_t)r * PL_H + hh * CTTS_HEAD_DIM + 8 * lane + j, tag, (O[j] * s1 + pe * vs[8 * lane + j]) * inv);
+        }
+        PL_MARK(2);
+        if (a.ts != nullptr && lane == 0) {
+            a.ts[(size_t)b * 9 + 0] = t_mark[0]; a.ts[(size_t)b * 9 + 1] = t_mark[1]; a.ts[(size_t)b * 9 + 2] = t_mark[2];
+        }
+    } else {
+        __syncthreads();                                      // S0
+        __syncthreads();                                      // B1
+        __syncthreads();                                      // B2
+    }
+}
+
+// ---- packed MFMA-A tile images (gpt_engine.hip pack_tiles: [row tile][k tile][lane][4 floats]) -> the per-workgroup register images above
+__global__ __launch_bounds__(256) void persist_repack_kernel(const f32x4* qkv, const f32x4* o, const f32x4* gu, const f32x4* d, f32x4* dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;               // destination float4 of this layer: [192 workgroups][12288]
+    if (idx >= PL_GEMV_BLOCKS * (PL_BLOCK_BYTES / 16)) return;
+    const int g = idx / (PL_BLOCK_BYTES / 16), oo = idx % (PL_BLOCK_BYTES / 16);
+    const f32x4* src;
+    int row_tile, i, k4, ktiles;
+    if (oo < PL_QKV_BYTES / 16) {
+        const int pw = oo / 384, rem = oo % 384, row = rem / 192, j = (rem % 192) / 64, ln = rem % 64;
+        const int hh = g >> 4, jj = g & 15;
+        int which, dd;
+        if (pw < 4) { which = pw >> 1; dd = 2 * jj + (pw & 1) + 32 * row; }
+        else { which = 2; dd = 4 * jj + 2 * (pw - 4) + row; }
+        row_tile = which * 48 + hh * 4 + (dd & 31) / 8;            // tile rows = dims [8t..8t+7 | 8t+32..8t+39] of one head (finalize_t qkv_row)
+        i = (dd & 7) + (dd >= 32 ? 8 : 0);
+        k4 = 64 * j + ln; ktiles = 48; src = qkv;
+    } else if (oo < (PL_QKV_BYTES + PL_O_BYTES) / 16) {
+        const int o2 = oo - PL_QKV_BYTES / 16, w = o2 / 192, rem = o2 % 192, j = rem / 64, ln = rem % 64;
+        const int row = 4 * g + w;
+        row_tile = row >> 4; i = row & 15; k4 = 64 * j + ln; ktiles = 48; src = o;
+    } else if (oo < (PL_QKV_BYTES + PL_O_BYTES + PL_GU_BYTES) / 16) {
+        const int o2 = oo - (PL_QKV_BYTES + PL_O_BYTES) / 16, w = o2 / 768, rem = o2 % 768, s = rem / 192, j = (rem % 192) / 64, ln = rem % 64;
+        const int dim = 16 * g + 2 * w + (s >> 1), isup = s & 1;
+        row_tile = dim >> 3; i = (dim & 7) + 8 * isup;             // tile rows = [8 gate rows | the matching 8 up rows]
+        k4 = 64 * j + ln; ktiles = 48; src = gu;
+    } else {
+        const int o2 = oo - (PL_QKV_BYTES + PL_O_BYTES + PL_GU_BYTES) / 16, w = o2 / 384, rem = o2 % 384, j = rem / 64, ln = rem % 64;
+        const int row = 4 * g + (w >> 1);
+        row_tile = row >> 4; i = row & 15; k4 = 384 * (w & 1) + 64 * j + ln; ktiles = 192; src = d;
+    }
+    dst[idx] = src[((size_t)row_tile * ktiles + (k4 >> 2)) * 64 + i + 16 * (k4 & 3)];
+}
+
+int launch_persist_repack(const void* qkv, const void* o, const void* gu, const void* d, void* dst, hipStream_t s) {
+    const int n = PL_GEMV_BLOCKS * (PL_BLOCK_BYTES / 16);
+    hipLaunchKernelGGL(persist_repack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const f32x4*)qkv, (const f32x4*)o, (const f32x4*)gu, (const f32x4*)d, (f32x4*)dst);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + 8 * 4 * R + 2 * R + 4 * R) * 4 + 16 + (192 + 8 * 8 * 10) * 4; }
+
+int persist_configure() {
+    CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)persist_layer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(1)));
+    CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)persist_layer_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(2)));
+    CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)persist_layer_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(3)));
+    CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)persist_layer_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(4)));
+    return 0;
+}
+
+int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s) {
+    if (R == 1) hipLaunchKernelGGL(persist_layer_kernel<1>, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(1), s, a);
+    else if (R == 2) hipLaunchKernelGGL(persist_layer_kernel<2>, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(2), s, a);
+    else if (R == 3) hipLaunchKernelGGL(persist_layer_kernel<3>, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(3), s, a);      // (exact row counts: a spare row
+    else if (R == 4) hipLaunchKernelGGL(persist_layer_kernel<4>, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(4), s, a);      //  would append stale K / V rows)
+    else { ctts_set_error("persistent layer: %d rows (max %d)", R, PL_MAXR); return 1; }
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
