@@ -503,6 +503,7 @@ def main():
     if world > 1:
         dist.broadcast(spk, src=0)
     use_graph = 0 if args.no_graph else 1
+    persist_rows = g.get_option("persistent_rows")             # effective value: 1 on fp32 engines that hold the device's persistent-launch lock
     leg = Leg(g, dev, rank, world)
     r = leg.run(B, P, K, W, spk=spk, use_graph=use_graph, keep_hidden=True, gen_tokens=args.gen_tokens)
     dt, expect, hid = r["dt"], r["expect"], r["hid"]
@@ -562,6 +563,12 @@ def main():
             extra["batch32_ragged_targets"] = ragged_leg(g, dev, spk, rank)
             # the same lengths as a QUEUE: 128 utterances on 32 decode rows -- slices vs slices + compaction vs continuous batching
             extra["queue128_on_32_rows"] = queue_leg(g, dev, spk, rank)
+            if persist_rows >= 1:
+                # the headline workload on the launch chain (102 dependent launches per step) -- what the persistent launch replaces
+                g.set_option("persistent_rows", 0)
+                e = leg.run(1, P, min(K, 256), W, spk=spk, use_graph=use_graph, gen_tokens=args.gen_tokens)
+                g.set_option("persistent_rows", persist_rows)
+                extra["batch1_launch_chain"] = summarize(e, world)
             # north_star: "decode tokens/s on synthetic 512-token prompts", batch 1
             e = leg.run(1, 512, EK, W, spk=spk, use_graph=use_graph)
             extra["prompt512_batch1"] = summarize(e, world)
@@ -635,11 +642,13 @@ def main():
                                    f"(mean context {r['mean_ctx']:.0f}), top-p 0.7 top-k 20 T 0.3 rep 1.05 (BASELINE configs[{1 if B == 1 else 2}]), "
                                    f"random-init weights of the real 20x768 architecture",
                        "batch_per_gpu": B, "prompt_len": P, "untimed_steps_before_window": r["s0"], "weights": args.dtype, "kv_cache": args.dtype,
-                       "accumulate": "f32", "hipgraph": bool(use_graph), "parallelism": f"replicas x{world} (utterance sharding)"},
+                       "accumulate": "f32", "hipgraph": bool(use_graph), "parallelism": f"replicas x{world} (utterance sharding)",
+                       "decode_path": ("persistent launch (20 layers = 1 launch, persist_layer.hip)" if (persist_rows >= B and r["mean_ctx"] + K / 2 <= 1024)
+                                       else "launch chain (5 launches per layer)"), "persistent_rows": persist_rows},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": "PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE bytes per step from profiles/r0N_pmc_*.json (separate rocprofv3 --pmc passes on a short generation: mean context ~98, i.e. ~14 MB less KV traffic per sequence and step than the timed window's)",
-                         "per": "decode step (one hipGraph replay = 4 steps)",
+                         "per": "decode step (one hipGraph replay = 4 steps); the persistent path is one layer-stack launch + heads + sampler per step",
                          "algorithmic_bytes_per_step": int(step_bytes), "step_ms_hip_events": round(step_ms, 5)},
             "rtf_decode_only": round(B * K * world * (512 / 24000.0) / dt, 2),
             "rtf_end_to_end": (round(B * 256 * (2 * expect - 1) / 24000.0 / ((r["prefill_ms"] + (dt / K) * 1e3 * (expect - 1) + voc_ms) / 1e3), 2)

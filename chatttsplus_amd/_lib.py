@@ -70,6 +70,7 @@ SYMBOLS = [
     ("ctts_gpt_create", C.c_int, [C.POINTER(GptCfg), C.POINTER(_P)]),
     ("ctts_gpt_destroy", None, [_P]),
     ("ctts_gpt_set_option", C.c_int, [_P, C.c_char_p, C.c_int]),
+    ("ctts_gpt_get_option", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int)]),
     ("ctts_gpt_debug_read", C.c_int, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_size_t), _P]),
     ("ctts_gpt_set_weight", C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),
     ("ctts_gpt_merge_lora", C.c_int, [_P, C.c_int, C.c_char_p, _P, _P, C.c_int, C.c_float]),

@@ -12,10 +12,13 @@
 //   dpart            [rows <= 32][4][768] ordered split-K partial sums of the down projection (decode batches <= split_rows)
 //   st / dyn         DevState (per-step counters) and SamplerDyn (per-call buffers and sampling parameters): everything a captured
 //                    decode graph would otherwise bake in is read from these two device blocks
+#include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 #include <map>
 #include <mutex>
@@ -100,7 +103,9 @@ struct ctts_gpt {
                                                  // an exact-f32 MFMA costs 32 cycles whatever the number of live columns, 48 of them per SIMD and launch.
                                                  // Measured (us/step, MFMA -> VALU, profiles/r04_ab_valu_rows.jsonl): batch 1 481.9 -> 450.8, 2 491.7 -> 477.5,
                                                  // 3 532.6 -> 555.9, 4 536.7 -> 560.3 (the 4-row variant re-reads four LDS operand rows per weight fragment)
-    int persist_rows = 0;                        // fp32 engines: decode batches of <= this many rows run each layer as one persistent launch (persist_layer.hip)
+    int persist_rows = 0;                        // fp32 engines (default 1, set at create): decode batches of <= this many rows run the decoder stack as ONE persistent
+                                                 // launch (persist_layer.hip).  us/step, launches -> persistent (profiles/r04_persist_probe_*.jsonl): batch 1 449.6 -> 384.6;
+                                                 // batch 2 478.8 -> 574.2 and batch 4 538.9 -> 1208 (gathers grow with the rows, the 2- to 4-row kernels spill) -> 1
     char* pimg = nullptr;                        //   per-workgroup register images of the layer weights [L][192][192 KB], built on the device from the packed tiles
     unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
     unsigned* pl_epoch = nullptr;                //   launch counter = granule tag
@@ -108,6 +113,8 @@ struct ctts_gpt {
     unsigned long long* pl_ts = nullptr;         //   diagnostics: per-workgroup phase marks of the last launch ("persistent_timestamps")
     int cur_persist = 0;                         //   the steps being launched use the persistent layer
     int pl_ts_on = 0;
+    int persist_lpl = 0;                         //   decoder layers per persistent launch (0 = all of them in one launch)
+    int persist_sched = 1;                       //   weight request schedule (PersistArgs.sched)
     int no_prepack = 0, prefill_gemm_rows = 1536, xh_heads = 1;   // diagnostic builds only: see run_layers / run_decode_step
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
     DevState* st = nullptr;
@@ -178,6 +185,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = (c->dtype == CTTS_DTYPE_F16) ? 8 : 16;
+    h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 1 : 0;
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
     // product library takes no behaviour from the environment on its launch paths (diag_env() is a constant null there).
     if (const char* sr = diag_env("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 32) h->split_rows = 32; }
@@ -198,24 +206,65 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     return 0;
 }
 
+// Persistent launches need all 256 workgroups resident at once: two processes that both run them on ONE device can starve each other until the
+// spin limit (the engine then reports an error).  One advisory file lock per device and process keeps the mode to the first process that asks for
+// it on that device; later processes (the 2-rank-on-one-GPU test, a second service on a shared box) quietly stay on the launch path.
+static bool persist_device_lock(int dev) {
+    static std::mutex mu;
+    static std::map<int, int> fds;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = fds.find(dev);
+    if (it != fds.end()) return it->second >= 0;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), dev) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", dev);
+    for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+    char path[160];
+    snprintf(path, sizeof(path), "/tmp/ctts_persist_%s.lock", bus);
+    int fd = open(path, O_CREAT | O_RDWR, 0666);
+    if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); fd = -1; }
+    fds[dev] = fd;                                 // (kept for the life of the process)
+    return fd >= 0;
+}
+
 // The persistent decode layer's device state: weight images (repacked on the device from the MFMA tile images: no host copy of the weights is
-// needed after finalize), granule buffers, epoch, error word.  Needs every one of the 256 workgroups resident at once.
-static int ensure_persist(ctts_gpt* h) {
-    if (h->pimg != nullptr) return 0;
-    if (h->cfg.dtype != CTTS_DTYPE_F32) { ctts_set_error("persistent layers: fp32 engines only"); return 1; }
-    if (!h->finalized) return 0;                 // built by finalize
+// needed after finalize), granule buffers, launch counter, error word.  `required`: the caller asked for the mode explicitly (an unmet precondition is
+// an error); otherwise the mode is simply left off.
+static int ensure_persist(ctts_gpt* h, bool required) {
+    if (h->pimg != nullptr || !h->finalized) return 0;          // (before finalize: built by finalize)
     int dev = 0, cus = 0;
     CTTS_HIP_CHECK(hipGetDevice(&dev));
     CTTS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus < PL_BLOCKS) { ctts_set_error("persistent layers need %d compute units resident at once, the device has %d", PL_BLOCKS, cus); return 1; }
+    const char* why = nullptr;
+    if (h->cfg.dtype != CTTS_DTYPE_F32) why = "fp32 engines only";
+    else if (h->L > 31) why = "at most 31 decoder layers";
+    else if (cus < PL_BLOCKS) why = "the device has fewer than 256 compute units";
+    else if (!persist_device_lock(dev)) why = "another process already runs persistent launches on this device";
+    if (why) {
+        h->persist_rows = 0;
+        if (required) { ctts_set_error("persistent layers unavailable: %s", why); return 1; }
+        return 0;
+    }
     if (persist_configure()) return 1;
-    if (dev_alloc((void**)&h->pimg, PL_LAYER_BYTES * h->L) || dev_alloc((void**)&h->pl_g, (size_t)(PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT) * 8) ||
+    if (dev_alloc((void**)&h->pimg, PL_LAYER_BYTES * h->L) || dev_alloc((void**)&h->pl_g, (size_t)PL_G_TOTAL * 8) ||
         dev_alloc((void**)&h->pl_epoch, 4) || dev_alloc((void**)&h->pl_error, 4)) return 1;
     const unsigned one = 1;
     CTTS_HIP_CHECK(hipMemcpy(h->pl_epoch, &one, 4, hipMemcpyHostToDevice));
     for (int l = 0; l < h->L; ++l)
         if (launch_persist_repack(h->lw[l].qkv, h->lw[l].o, h->lw[l].gu, h->lw[l].d, h->pimg + PL_LAYER_BYTES * l, nullptr)) return 1;
     CTTS_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
+    if (!h || !name || !value) { ctts_set_error("get_option: null argument"); return 1; }
+    const std::string n(name);
+    if (n == "persistent_rows") *value = (h->pimg != nullptr || !h->finalized) ? h->persist_rows : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
+    else if (n == "valu_rows") *value = h->valu_rows;
+    else if (n == "prefill_split_rows") *value = h->split_rows_min;
+    else if (n == "split_rows") *value = h->split_rows;
+    else if (n == "graph_steps") *value = h->graph_steps;
+    else if (n == "decode_splits") *value = h->force_splits;
+    else { ctts_set_error("get_option: unknown option '%s'", name); return 1; }
     return 0;
 }
 
@@ -231,9 +280,13 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->valu_rows = value < 0 ? 0 : (value > 4 ? 4 : value);
     } else if (n == "persistent_rows") {         // fp32 engines: decode batches of <= this many rows run each layer as ONE persistent launch (0 = off)
         h->persist_rows = value < 0 ? 0 : (value > CTTS_PERSIST_MAX_ROWS ? CTTS_PERSIST_MAX_ROWS : value);
-        if (h->persist_rows > 0 && ensure_persist(h)) { h->persist_rows = 0; return 1; }
+        if (h->persist_rows > 0 && ensure_persist(h, true)) { h->persist_rows = 0; return 1; }
+    } else if (n == "persistent_layers_per_launch") {      // 0 = the whole stack in one launch (default); 1 = one launch per layer
+        h->persist_lpl = value < 0 ? 0 : value;
+    } else if (n == "persistent_schedule") {               // 0 / 1: see persist_layer.hip
+        h->persist_sched = value ? 1 : 0;
     } else if (n == "persistent_timestamps") {   // diagnostics: every workgroup of a persistent launch records wall_clock64 marks (ctts_gpt_debug_read "pl_ts")
-        if (value && !h->pl_ts && dev_alloc((void**)&h->pl_ts, (size_t)PL_BLOCKS * 9 * 8)) return 1;
+        if (value && !h->pl_ts && dev_alloc((void**)&h->pl_ts, (size_t)PL_BLOCKS * 10 * 8)) return 1;
         h->pl_ts_on = value ? 1 : 0;
     } else if (n == "decode_splits") {           // key splits of the decode attention (0 = the decode_splits policy)
         if (value < 0 || value > SMAX) { ctts_set_error("set_option(decode_splits): 0..%d", SMAX); return 1; }
@@ -635,7 +688,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
     }
     h->host.clear();
     h->finalized = true;
-    if (h->persist_rows > 0 && ensure_persist(h)) return 1;
+    if (h->persist_rows > 0 && ensure_persist(h, false)) return 1;
     return 0;
 }
 
@@ -719,12 +772,15 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     if (st != nullptr && h->cur_persist && h->pimg != nullptr && dt == CTTS_DTYPE_F32 && R <= PL_MAXR && !lora) {
         // one persistent launch per layer (persist_layer.hip): the residual stream stays in x, nothing is left in partial or packed form
         if (form) { form->parts = false; form->xh = false; }
-        for (int l = 0; l < h->L; ++l) {
+        // (persistent_layers_per_launch, default all: the whole stack is ONE launch; 1 = a launch per layer, the first version of the structure)
+        const int per = (h->persist_lpl > 0 && h->persist_lpl < h->L) ? h->persist_lpl : h->L;
+        for (int l = 0; l < h->L; l += per) {
             PersistArgs pa = {};
-            pa.w = h->pimg + PL_LAYER_BYTES * l; pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
-            pa.k_cache = kv_layer(h, l, 0); pa.v_cache = kv_layer(h, l, 1); pa.Lmax = h->cfg.max_seq;
-            pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1;
-            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f;
+            pa.w = h->pimg + PL_LAYER_BYTES * l; pa.n_layers = (h->L - l < per) ? h->L - l : per;
+            pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
+            pa.kv = kv_layer(h, l, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
+            pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1; pa.g_x = pa.g_act + PL_G_ACT;
+            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched;
             if (launch_persist_layer(R, pa, s)) return 1;
         }
         return 0;
@@ -1134,8 +1190,8 @@ extern "C" int ctts_gpt_debug_read(ctts_gpt* h, const char* name, void* out, siz
     if (n == "x_dec") { src = h->x_dec; nb = (size_t)CTTS_MAX_B * h->H * 4; }
     else if (n == "q_buf") { src = h->q_buf; nb = (size_t)32 * h->H * 4; }
     else if (n == "logits") { src = h->logits; nb = (size_t)CTTS_MAX_B * h->NVQ * h->V * 4; }
-    else if (n == "pl_g" && h->pl_g) { src = h->pl_g; nb = (size_t)(PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT) * 8; }
-    else if (n == "pl_ts" && h->pl_ts) { src = h->pl_ts; nb = (size_t)PL_BLOCKS * 9 * 8; }
+    else if (n == "pl_g" && h->pl_g) { src = h->pl_g; nb = (size_t)PL_G_TOTAL * 8; }
+    else if (n == "pl_ts" && h->pl_ts) { src = h->pl_ts; nb = (size_t)PL_BLOCKS * 10 * 8; }
     else if (n == "pl_state" && h->pl_epoch) {
         unsigned* o = (unsigned*)out;
         if (max_bytes < 8) { ctts_set_error("debug_read: buffer too small"); return 1; }

@@ -23,24 +23,29 @@
 #define PL_G_ATT (PL_MAXR * PL_H)
 #define PL_G_X1 (PL_MAXR * PL_H)
 #define PL_G_ACT (PL_MAXR * PL_I)
+#define PL_G_X (PL_MAXR * PL_H)
+#define PL_G_TOTAL (PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT + PL_G_X)
 
 struct PersistArgs {
-    const char* w;                  // this layer's image [192][PL_BLOCK_BYTES]
+    const char* w;                  // layer 0's image [192][PL_BLOCK_BYTES]; layer l at + l * PL_LAYER_BYTES
+    int n_layers;                   // decoder layers run by this launch (<= 31: a granule tag is launch counter * 32 + layer)
     float* x;                       // residual stream [R][768], read at entry, rewritten at the end
     const RowMeta* meta;            // decode rows
     const float* rope_rows;         // [R][64] cos | sin of each row's position
-    void* k_cache;                  // this layer's K [maxB][12][Lmax][64] fp32
-    void* v_cache;
+    void* kv;                       // KV cache [layer][K | V][maxB][12][Lmax][64] fp32
+    size_t kv_per;                  //   floats per [maxB][12][Lmax][64] block
     int Lmax;
     unsigned long long* g_qkv;      // [R][12][q 64 | k 64 | v 64]
     unsigned long long* g_att;      // [R][768]
     unsigned long long* g_x1;       // [R][768]
     unsigned long long* g_act;      // [R][3072]
-    unsigned* epoch;                // launch counter = this launch's granule tag (never 0)
-    int* error;                     // 0, or the phase code of the first wave that gave up
+    unsigned long long* g_x;        // [R][768] a layer's output on its way to the next layer
+    unsigned* epoch;                // launch counter (never 0)
+    int* error;                     // 0, or the edge code of the first wave that gave up
     const int* done;                // DevState.all_done
-    unsigned long long* ts;         // diagnostics: [256][9] wall_clock64 marks per workgroup, or null
+    unsigned long long* ts;         // diagnostics: [256][10] wall_clock64 marks per workgroup (last layer), or null
     float eps;
+    int sched;                      // weight request schedule of the compute waves (persist_layer.hip)
 };
 
 int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s);

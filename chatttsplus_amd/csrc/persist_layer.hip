@@ -64,119 +64,135 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
     float* const xs = (float*)smem;                       // activations of the current phase [R][768] ([R][3072] for the down projection)
     float* const red = xs + R * PL_I;                     // compute waves' results [8 waves][4 slots][R]
     float* const ssq = red + 8 * 4 * R;                   // sums of squares of the gathered rows [2 edge waves][R]
-    float* const xres = ssq + 2 * R;                      // this workgroup's 4 columns of the residual stream [R][4] (x, later x + attention)
+    float* const xres = ssq + 2 * R;                      // this workgroup's 4 columns of the residual stream [R][4] (x, later x + attention, then the layer output)
     int* const abort_s = (int*)(xres + 4 * R);            // [4]
     float* const att_s = (float*)(abort_s + 4);           // attention workgroups: q[64] | k_new[64] | v_new[64] | merge[8][8][10]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
-    if (*a.done != 0) return;                                                                   // every sequence finished (gpt.py:545): the same for every workgroup
-    if (__hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;    // an earlier launch gave up
-    const unsigned tag = *a.epoch;                        // advanced by workgroup 0 at the very end (every workgroup has read it by then: see below)
-    unsigned long long t_mark[9];
+    // the three words every workgroup needs first travel together (vector loads with an opaque offset: a scalar load + branch each would be three
+    // serial cache-miss round trips in front of everything else -- measured 4.4 us before the first useful load in the first version)
+    const int done_v = vload_flag(a.done), err_v = vload_flag(a.error), ep_v = vload_flag((const int*)a.epoch);
+    const int NL = a.n_layers;
+    unsigned long long t_mark[10];
 #define PL_MARK(i) do { if (a.ts != nullptr) t_mark[i] = wall_clock64(); } while (0)
     PL_MARK(0);
     if (tid == 0) abort_s[0] = 0;
 
     if (b < PL_GEMV_BLOCKS) {
-        const char* const wb = a.w + (size_t)b * PL_BLOCK_BYTES;
+        const char* wb = a.w + (size_t)b * PL_BLOCK_BYTES;
         if (wave < 8) {
-            // ------------------------------------------------ compute wave: weights in registers, products on the VALU
-            const f32x4* const wq = (const f32x4*)wb + (size_t)wave * (2 * 3 * 64) + lane;                                 // [row 2][j 3][lane]
-            const f32x4* const wo = (const f32x4*)(wb + PL_QKV_BYTES) + (size_t)wave * (3 * 64) + lane;                      // [j 3][lane]
-            const f32x4* const wg = (const f32x4*)(wb + PL_QKV_BYTES + PL_O_BYTES) + (size_t)wave * (4 * 3 * 64) + lane;     // [pair 2][gate|up][j 3][lane]
-            const f32x4* const wd = (const f32x4*)(wb + PL_QKV_BYTES + PL_O_BYTES + PL_GU_BYTES) + (size_t)wave * (6 * 64) + lane;   // [j 6][lane]
+            // ------------------------------------------------ compute wave: weights in registers, products on the VALU.
+            // The four weight arrays form a ring over the layers: each is re-requested for layer l + 1 right after its last use in layer l, so the
+            // weight stream runs a whole layer ahead of the dependency edges without a single extra register.
+            const size_t oq = (size_t)wave * (2 * 3 * 64) + lane;                                                  // [row 2][j 3][lane]
+            const size_t oo = (size_t)PL_QKV_BYTES / 16 + (size_t)wave * (3 * 64) + lane;                          // [j 3][lane]
+            const size_t og = (size_t)(PL_QKV_BYTES + PL_O_BYTES) / 16 + (size_t)wave * (4 * 3 * 64) + lane;       // [pair 2][gate|up][j 3][lane]
+            const size_t od = (size_t)(PL_QKV_BYTES + PL_O_BYTES + PL_GU_BYTES) / 16 + (size_t)wave * (6 * 64) + lane;   // [j 6][lane]
             f32x4 q_w[2][3], o_w[3], g_w[4][3], d_w[6];
-            if (wave < 6) {
-#pragma unroll
-                for (int row = 0; row < 2; ++row)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) q_w[row][j] = __builtin_nontemporal_load(wq + (row * 3 + j) * 64);
-            }
-            if (wave < 4) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) o_w[j] = __builtin_nontemporal_load(wo + j * 64);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) g_w[s][j] = __builtin_nontemporal_load(wg + (s * 3 + j) * 64);
+#define PL_LOAD_Q(base_) do { if (wave < 6) { _Pragma("unroll") for (int row = 0; row < 2; ++row) _Pragma("unroll") for (int j = 0; j < 3; ++j) \
+                q_w[row][j] = __builtin_nontemporal_load((const f32x4*)(base_) + oq + (row * 3 + j) * 64); } } while (0)
+#define PL_LOAD_O(base_) do { if (wave < 4) { _Pragma("unroll") for (int j = 0; j < 3; ++j) o_w[j] = __builtin_nontemporal_load((const f32x4*)(base_) + oo + j * 64); } } while (0)
+#define PL_LOAD_G(base_) do { _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int j = 0; j < 3; ++j) \
+                g_w[s][j] = __builtin_nontemporal_load((const f32x4*)(base_) + og + (s * 3 + j) * 64); } while (0)
+#define PL_LOAD_D(base_) do { _Pragma("unroll") for (int j = 0; j < 6; ++j) d_w[j] = __builtin_nontemporal_load((const f32x4*)(base_) + od + j * 64); } while (0)
+            // a.sched = 0: every array is re-requested right after its last use (a whole layer ahead; the gate|up burst then sits in front of the
+            //              act gather's polls and the down burst in front of the next layer's x gather: +6.7 us per layer measured);
+            // a.sched = 1: gate|up of layer l are requested when layer l's attention wait begins and down when its x + attention wait begins -- the polls of
+            //              those two waits cannot succeed for microseconds anyway -- and nothing is queued in front of the act and x gathers.
+            const int sched = a.sched;
+            PL_LOAD_Q(wb); PL_LOAD_O(wb);
+            if (sched == 0) PL_LOAD_G(wb);
             __builtin_amdgcn_sched_barrier(0);
+            if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;      // every sequence finished (gpt.py:545) / an earlier launch gave up: the same for every workgroup
             __syncthreads();                                  // S0
-            // ---- phase A: q | k | v rows
-            __syncthreads();                                  // B1(A): xs = x
-            f32x4 xr[R][3];
+            for (int l = 0; l < NL; ++l) {
+                const char* const wn = wb + PL_LAYER_BYTES;   // next layer's image
+                const bool more = l + 1 < NL;
+                // ---- phase A: q | k | v rows
+                __syncthreads();                              // B1(A): xs = x
+                f32x4 xr[R][3];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+                for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
-            if (wave < 6) {
+                    for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+                if (wave < 6) {
 #pragma unroll
-                for (int row = 0; row < 2; ++row)
+                    for (int row = 0; row < 2; ++row)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc = dot4(q_w[row][j], xr[r][j], acc);
+                            acc = wave_sum(acc);
+                            if (lane == 0) red[(wave * 4 + row) * R + r] = acc;
+                        }
+                }
+                if (sched == 0) { if (l == 0) PL_LOAD_D(wb); }   // (layer 0's down rows: requested behind everything phase A needed)
+                else PL_LOAD_G(wb);
+                if (more) PL_LOAD_Q(wn);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                              // B2(A)
+                // ---- phase C: o_proj rows
+                __syncthreads();                              // B1(C): xs = attention output
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+                if (wave < 4) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         float acc = 0.f;
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) acc = dot4(q_w[row][j], xr[r][j], acc);
+                        for (int j = 0; j < 3; ++j) acc = dot4(o_w[j], xr[r][j], acc);
                         acc = wave_sum(acc);
-                        if (lane == 0) red[(wave * 4 + row) * R + r] = acc;
+                        if (lane == 0) red[(wave * 4) * R + r] = acc;
                     }
-            }
+                }
+                if (sched != 0) PL_LOAD_D(wb);
+                if (more) PL_LOAD_O(wn);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                              // B2(C)
+                // ---- phase D: gate | up pairs
+                __syncthreads();                              // B1(D): xs = x + attention
 #pragma unroll
-            for (int j = 0; j < 6; ++j) d_w[j] = __builtin_nontemporal_load(wd + j * 64);     // (the q | k | v registers are free now)
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                                  // B2(A)
-            // ---- phase C: o_proj rows
-            __syncthreads();                                  // B1(C): xs = attention output
+                for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+                    for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
-            if (wave < 4) {
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc = dot4(g_w[s][j], xr[r][j], acc);
+                        acc = wave_sum(acc);
+                        if (lane == 0) red[(wave * 4 + s) * R + r] = acc;
+                    }
+                if (sched == 0 && more) PL_LOAD_G(wn);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                              // B2(D)
+                // ---- phase E: down rows, two K halves per row
+                __syncthreads();                              // B1(E): xs = silu(gate) * up, [R][3072]
+                const int half = wave & 1;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float acc = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) acc = dot4(o_w[j], xr[r][j], acc);
+                    for (int j = 0; j < 6; ++j) acc = dot4(d_w[j], ((const f32x4*)(xs + r * PL_I))[384 * half + 64 * j + lane], acc);
                     acc = wave_sum(acc);
                     if (lane == 0) red[(wave * 4) * R + r] = acc;
                 }
+                if (sched == 0 && more) PL_LOAD_D(wn);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                              // B2(E)
+                wb = wn;
             }
-            __syncthreads();                                  // B2(C)
-            // ---- phase D: gate | up pairs
-            __syncthreads();                                  // B1(D): xs = x + attention
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc = dot4(g_w[s][j], xr[r][j], acc);
-                    acc = wave_sum(acc);
-                    if (lane == 0) red[(wave * 4 + s) * R + r] = acc;
-                }
-            __syncthreads();                                  // B2(D)
-            // ---- phase E: down rows, two K halves per row
-            __syncthreads();                                  // B1(E): xs = silu(gate) * up, [R][3072]
-            const int half = wave & 1;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc = dot4(d_w[j], ((const f32x4*)(xs + r * PL_I))[384 * half + 64 * j + lane], acc);
-                acc = wave_sum(acc);
-                if (lane == 0) red[(wave * 4) * R + r] = acc;
-            }
-            __syncthreads();                                  // B2(E)
         } else {
             // ------------------------------------------------ edge wave: gathers, epilogues, publishing
             const int ew = wave - 8, e = ew * 64 + lane;      // 0..127
             const int hh = b >> 4, jj = b & 15;               // q | k | v rows of this workgroup: head hh, dims (2jj, 2jj+1, +32) / v dims 4jj..4jj+3
-            // epilogue operands of phase A, requested now
+            // epilogue operands of phase A (the same in every layer), requested now
             const int tA = e, pwA = tA % 6, rA = (tA / 6 < R) ? tA / 6 : 0;
             const bool doA = tA < 6 * R;
             RowMeta mA = {0, 0, 0, 0};
@@ -197,7 +213,11 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 const int idx = e + 128 * i;
                 xv[i] = (idx < R * 192) ? ((const f32x4*)a.x)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            if (e < R) *(f32x4*)(xres + 4 * e) = *(const f32x4*)(a.x + (size_t)e * PL_H + 4 * b);
+            f32x4 xown = {0.f, 0.f, 0.f, 0.f};
+            if (e < R) xown = *(const f32x4*)(a.x + (size_t)e * PL_H + 4 * b);
+            if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
+            const unsigned tag0 = (unsigned)ep_v * 32u;       // + layer: one tag per (launch, layer); the launch counter advances at the very end
+            if (e < R) *(f32x4*)(xres + 4 * e) = xown;
             float ssp[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) ssp[r] = 0.f;
@@ -216,105 +236,133 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
             }
             __syncthreads();                                  // S0
             PL_MARK(1);
-            __syncthreads();                                  // B1(A)
-            __syncthreads();                                  // B2(A)
-            if (doA) {
-                const float rs = 1.0f / sqrtf((ssq[rA] + ssq[R + rA]) / (float)PL_H + a.eps);          // llama.py:82-87 (the weight is folded into W's columns)
-                const float va = red[(pwA * 4 + 0) * R + rA] * rs, vb = red[(pwA * 4 + 1) * R + rA] * rs;
-                float ya = va, yb = vb;
-                int which, dA, dB;
-                if (pwA < 4) {                                   // q / k: RoPE pair (d, d + 32), products rounded separately like the reference (llama.py:180-181)
-                    which = pwA >> 1; dA = 2 * jj + (pwA & 1); dB = dA + 32;
-                    ya = __fadd_rn(__fmul_rn(va, cA), __fmul_rn(-vb, sA));
-                    yb = __fadd_rn(__fmul_rn(vb, cA), __fmul_rn(va, sA));
-                } else {
-                    which = 2; dA = 4 * jj + 2 * (pwA - 4); dB = dA + 1;
-                }
-                u64* const gq = a.g_qkv + ((size_t)(rA * PL_NH + hh) * 192 + which * 64);
-                store_granule(gq + dA, tag, ya);
-                store_granule(gq + dB, tag, yb);
-                if (which >= 1) {                                // KV append (llama.py:633): later steps read it from the cache
-                    float* c = (float*)(which == 1 ? a.k_cache : a.v_cache) + (((size_t)mA.seq * PL_NH + hh) * a.Lmax + mA.slot) * CTTS_HEAD_DIM;
-                    c[dA] = ya; c[dB] = yb;
-                }
-            }
-            PL_MARK(2);
-            // ---- phase C: attention output -> o_proj + residual
-            {
-                float v[6 * R];
-                const bool got = sweep<6 * R>(a.g_att + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, true, v, a.error, 3, abort_s);
-                (void)got;
+            const size_t kv_per = a.kv_per;                   // floats between K and V of a layer (and half the distance between layers)
+            for (int l = 0; l < NL; ++l) {
+                const unsigned tag = tag0 + (unsigned)l;
+                const bool last = l + 1 == NL;
+                if (l > 0) {
+                    // ---- edge 1: the previous layer's output, published by the 192 GEMV workgroups -> xs, sums of squares
+                    float v[6 * R];
+                    const bool got = sweep<6 * R>(a.g_x + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag - 1u, true, v, a.error, 1, abort_s);
+                    (void)got;
 #pragma unroll
-                for (int k = 0; k < 6 * R; ++k) xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
-            }
-            PL_MARK(3);
-            __syncthreads();                                  // B1(C)
-            __syncthreads();                                  // B2(C)
-            if (e < 4 * R) {
-                const int i = e & 3, r = e >> 2;
-                const float x1 = xres[4 * r + i] + red[(i * 4) * R + r];                               // llama.py:731
-                xres[4 * r + i] = x1;
-                store_granule(a.g_x1 + (size_t)r * PL_H + 4 * b + i, tag, x1);
-            }
-            PL_MARK(4);
-            // ---- phase D: x + attention -> RMSNorm, gate | up, SiLU * up
-            {
-                float v[6 * R];
-                const bool got = sweep<6 * R>(a.g_x1 + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, true, v, a.error, 4, abort_s);
-                (void)got;
+                    for (int r = 0; r < R; ++r) ssp[r] = 0.f;
 #pragma unroll
-                for (int r = 0; r < R; ++r) ssp[r] = 0.f;
+                    for (int k = 0; k < 6 * R; ++k) {
+                        xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
+                        ssp[k / 6] += v[k] * v[k];
+                    }
 #pragma unroll
-                for (int k = 0; k < 6 * R; ++k) {
-                    xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
-                    ssp[k / 6] += v[k] * v[k];
+                    for (int r = 0; r < R; ++r) {
+                        const float s = wave_sum(ssp[r]);
+                        if (lane == 0) ssq[ew * R + r] = s;
+                    }
                 }
+                if (last) PL_MARK(2);
+                __syncthreads();                              // B1(A)
+                __syncthreads();                              // B2(A)
+                if (doA) {
+                    const float rs = 1.0f / sqrtf((ssq[rA] + ssq[R + rA]) / (float)PL_H + a.eps);          // llama.py:82-87 (the weight is folded into W's columns)
+                    const float va = red[(pwA * 4 + 0) * R + rA] * rs, vb = red[(pwA * 4 + 1) * R + rA] * rs;
+                    float ya = va, yb = vb;
+                    int which, dA, dB;
+                    if (pwA < 4) {                               // q / k: RoPE pair (d, d + 32), products rounded separately like the reference (llama.py:180-181)
+                        which = pwA >> 1; dA = 2 * jj + (pwA & 1); dB = dA + 32;
+                        ya = __fadd_rn(__fmul_rn(va, cA), __fmul_rn(-vb, sA));
+                        yb = __fadd_rn(__fmul_rn(vb, cA), __fmul_rn(va, sA));
+                    } else {
+                        which = 2; dA = 4 * jj + 2 * (pwA - 4); dB = dA + 1;
+                    }
+                    u64* const gq = a.g_qkv + ((size_t)(rA * PL_NH + hh) * 192 + which * 64);
+                    store_granule(gq + dA, tag, ya);
+                    store_granule(gq + dB, tag, yb);
+                    if (which >= 1) {                            // KV append (llama.py:633): later steps read it from the cache
+                        float* c = (float*)a.kv + (size_t)l * 2 * kv_per + (which == 2 ? kv_per : 0) + (((size_t)mA.seq * PL_NH + hh) * a.Lmax + mA.slot) * CTTS_HEAD_DIM;
+                        c[dA] = ya; c[dB] = yb;
+                    }
+                }
+                if (last) PL_MARK(3);
+                // ---- phase C: attention output -> o_proj + residual
+                {
+                    float v[6 * R];
+                    const bool got = sweep<6 * R>(a.g_att + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, true, v, a.error, 3, abort_s);
+                    (void)got;
+#pragma unroll
+                    for (int k = 0; k < 6 * R; ++k) xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
+                }
+                if (last) PL_MARK(4);
+                __syncthreads();                              // B1(C)
+                __syncthreads();                              // B2(C)
+                if (e < 4 * R) {
+                    const int i = e & 3, r = e >> 2;
+                    const float x1 = xres[4 * r + i] + red[(i * 4) * R + r];                               // llama.py:731
+                    xres[4 * r + i] = x1;
+                    store_granule(a.g_x1 + (size_t)r * PL_H + 4 * b + i, tag, x1);
+                }
+                if (last) PL_MARK(5);
+                // ---- phase D: x + attention -> RMSNorm, gate | up, SiLU * up
+                {
+                    float v[6 * R];
+                    const bool got = sweep<6 * R>(a.g_x1 + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, true, v, a.error, 4, abort_s);
+                    (void)got;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ssp[r] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 6 * R; ++k) {
+                        xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
+                        ssp[k / 6] += v[k] * v[k];
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float s = wave_sum(ssp[r]);
+                        if (lane == 0) ssq[ew * R + r] = s;
+                    }
+                }
+                if (last) PL_MARK(6);
+                __syncthreads();                              // B1(D)
+                __syncthreads();                              // B2(D)
+                if (e < 16 * R) {
+                    const int pi = e & 15, r = e >> 4, w = pi >> 1, p = pi & 1;
+                    const float rs = 1.0f / sqrtf((ssq[r] + ssq[R + r]) / (float)PL_H + a.eps);
+                    const float gv = red[(w * 4 + 2 * p) * R + r] * rs, uv = red[(w * 4 + 2 * p + 1) * R + r] * rs;
+                    store_granule(a.g_act + (size_t)r * PL_I + 16 * b + pi, tag, (gv / (1.0f + expf(-gv))) * uv);       // llama.py:214
+                }
+                if (last) PL_MARK(7);
+                // ---- phase E: silu(gate) * up [R][3072] -> down + residual
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float s = wave_sum(ssp[r]);
-                    if (lane == 0) ssq[ew * R + r] = s;
+                    float v[24];
+                    const bool got = sweep<24>(a.g_act + (size_t)r * PL_I + e, [](int k) { return 128 * k; }, tag, true, v, a.error, 5, abort_s);
+                    (void)got;
+#pragma unroll
+                    for (int k = 0; k < 24; ++k) xs[r * PL_I + 128 * k + e] = v[k];
+                }
+                if (last) PL_MARK(8);
+                __syncthreads();                              // B1(E)
+                __syncthreads();                              // B2(E)
+                if (e < 4 * R) {
+                    const int i = e & 3, r = e >> 2;
+                    const float x2 = xres[4 * r + i] + (red[((2 * i) * 4) * R + r] + red[((2 * i + 1) * 4) * R + r]);      // llama.py:739
+                    if (last) a.x[(size_t)r * PL_H + 4 * b + i] = x2;          // the heads read it after the launch boundary
+                    else {
+                        xres[4 * r + i] = x2;
+                        store_granule(a.g_x + (size_t)r * PL_H + 4 * b + i, tag, x2);
+                    }
                 }
             }
-            PL_MARK(5);
-            __syncthreads();                                  // B1(D)
-            __syncthreads();                                  // B2(D)
-            if (e < 16 * R) {
-                const int pi = e & 15, r = e >> 4, w = pi >> 1, p = pi & 1;
-                const float rs = 1.0f / sqrtf((ssq[r] + ssq[R + r]) / (float)PL_H + a.eps);
-                const float gv = red[(w * 4 + 2 * p) * R + r] * rs, uv = red[(w * 4 + 2 * p + 1) * R + r] * rs;
-                store_granule(a.g_act + (size_t)r * PL_I + 16 * b + pi, tag, (gv / (1.0f + expf(-gv))) * uv);       // llama.py:214
-            }
-            PL_MARK(6);
-            // ---- phase E: silu(gate) * up [R][3072] -> down + residual
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float v[24];
-                const bool got = sweep<24>(a.g_act + (size_t)r * PL_I + e, [](int k) { return 128 * k; }, tag, true, v, a.error, 5, abort_s);
-                (void)got;
-#pragma unroll
-                for (int k = 0; k < 24; ++k) xs[r * PL_I + 128 * k + e] = v[k];
-            }
-            PL_MARK(7);
-            __syncthreads();                                  // B1(E)
-            __syncthreads();                                  // B2(E)
-            if (e < 4 * R) {
-                const int i = e & 3, r = e >> 2;
-                a.x[(size_t)r * PL_H + 4 * b + i] = xres[4 * r + i] + (red[((2 * i) * 4) * R + r] + red[((2 * i + 1) * 4) * R + r]);      // llama.py:739
-            }
-            PL_MARK(8);
+            PL_MARK(9);
             if (a.ts != nullptr && e == 0) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) a.ts[(size_t)b * 9 + i] = t_mark[i];
+                for (int i = 0; i < 10; ++i) a.ts[(size_t)b * 10 + i] = t_mark[i];
             }
-            // Advance the epoch for the next launch.  Safe although other workgroups may still be running: workgroup 0 reaches this point only after its
-            // phase C gather, i.e. after every attention item was published, i.e. after all 192 GEMV workgroups published their q | k | v rows --
-            // each of them read `tag` before that; attention workgroups read it before their gather.
+            // Advance the launch counter.  Safe although other workgroups may still be running: workgroup 0 gets here only after its last gather, i.e.
+            // after every attention item of the last layer was published, i.e. after every workgroup has long read its copy at entry.
             if (b == 0 && e == 0) __hip_atomic_fetch_add(a.epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
 
-    // ---------------------------------------------------- attention workgroup: one (row, head)
+    // ---------------------------------------------------- attention workgroup: one (row, head) in every layer
     const int item = b - PL_GEMV_BLOCKS;
     if (item >= PL_NH * R) return;
     const int r = item / PL_NH, hh = item % PL_NH;
@@ -322,125 +370,142 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
     float* const ks = att_s + 64;
     float* const vs = att_s + 128;
     float* const merge = att_s + 192;                         // [8 waves][8 subs][10]
+    const size_t kv_per = a.kv_per;
     if (wave < 8) {
         const RowMeta m = a.meta[r];
         const int kv0 = m.kv_start, kv1 = m.slot;             // cached keys [kv0, kv1); this step's key / value arrive with the query
         const int grp = lane >> 3, sub = lane & 7;
         const size_t head_off = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
-        const float* const kb = (const float*)a.k_cache + head_off;
-        const float* const vb = (const float*)a.v_cache + head_off;
         constexpr int PRE = 4;                                // iterations requested before the query exists: 8 waves x 8 keys x 4 = 256 keys
         f32x4 kf[PRE][2], vf[PRE][2];
         bool ok[PRE];
+        bool any_ok[PRE];
 #pragma unroll
         for (int u = 0; u < PRE; ++u) {
             const int p = kv0 + 8 * (wave + 8 * u) + grp;
             ok[u] = p < kv1;
-            const int pc = ok[u] ? p : kv0;
-            kf[u][0] = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM); kf[u][1] = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM + 4);
-            vf[u][0] = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM); vf[u][1] = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM + 4);
+            any_ok[u] = kv0 + 8 * (wave + 8 * u) < kv1;       // wave-uniform: some lane group of this wave has a key in iteration u
         }
+#define PL_LOAD_KV(l_) do { const float* const kb_ = (const float*)a.kv + (size_t)(l_) * 2 * kv_per + head_off; const float* const vb_ = kb_ + kv_per; \
+        _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p_ = kv0 + 8 * (wave + 8 * u) + grp; const int pc_ = ok[u] ? p_ : kv0; \
+            kf[u][0] = *(const f32x4*)(kb_ + (size_t)pc_ * CTTS_HEAD_DIM); kf[u][1] = *(const f32x4*)(kb_ + (size_t)pc_ * CTTS_HEAD_DIM + 4); \
+            vf[u][0] = *(const f32x4*)(vb_ + (size_t)pc_ * CTTS_HEAD_DIM); vf[u][1] = *(const f32x4*)(vb_ + (size_t)pc_ * CTTS_HEAD_DIM + 4); } } while (0)
+        PL_LOAD_KV(0);
         __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
         __syncthreads();                                      // S0
-        __syncthreads();                                      // B1: q (x 1/8), k_new, v_new in LDS
-        const f32x4 q0 = *(const f32x4*)(qs + 8 * sub), q1 = *(const f32x4*)(qs + 8 * sub + 4);
-        float mrun = -INFINITY, lrun = 0.f, o[8];
+        for (int l = 0; l < NL; ++l) {
+            const float* const kb = (const float*)a.kv + (size_t)l * 2 * kv_per + head_off;
+            const float* const vb = kb + kv_per;
+            __syncthreads();                                  // B1: q (x 1/8), k_new, v_new in LDS
+            const f32x4 q0 = *(const f32x4*)(qs + 8 * sub), q1 = *(const f32x4*)(qs + 8 * sub + 4);
+            // two passes over the keys held in registers: scores -> the wave's maximum -> ONE exponential per key (no running rescale)
+            float sc[PRE];
+            float mw = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = 0.f;
-        auto key_step = [&](const f32x4 k0, const f32x4 k1, const f32x4 v0, const f32x4 v1, bool live) {
-            float dot = q0[0] * k0[0] + q0[1] * k0[1] + q0[2] * k0[2] + q0[3] * k0[3] + q1[0] * k1[0] + q1[1] * k1[1] + q1[2] * k1[2] + q1[3] * k1[3];
-            dot += dpp_f<DPP_XOR1>(dot);
-            dot += dpp_f<DPP_XOR2>(dot);
-            dot += dpp_f<DPP_HALF_MIRROR>(dot);
-            if (live) {
-                const float mn = fmaxf(mrun, dot);
-                const float sc = pl_exp_diff(mrun, mn);
-                const float pe = expf(dot - mn);
-                lrun = lrun * sc + pe;
-                o[0] = o[0] * sc + pe * v0[0]; o[1] = o[1] * sc + pe * v0[1]; o[2] = o[2] * sc + pe * v0[2]; o[3] = o[3] * sc + pe * v0[3];
-                o[4] = o[4] * sc + pe * v1[0]; o[5] = o[5] * sc + pe * v1[1]; o[6] = o[6] * sc + pe * v1[2]; o[7] = o[7] * sc + pe * v1[3];
+            for (int u = 0; u < PRE; ++u) {
+                sc[u] = -INFINITY;
+                if (any_ok[u]) {
+                    float dot = q0[0] * kf[u][0][0] + q0[1] * kf[u][0][1] + q0[2] * kf[u][0][2] + q0[3] * kf[u][0][3] +
+                                q1[0] * kf[u][1][0] + q1[1] * kf[u][1][1] + q1[2] * kf[u][1][2] + q1[3] * kf[u][1][3];
+                    dot += dpp_f<DPP_XOR1>(dot);
+                    dot += dpp_f<DPP_XOR2>(dot);
+                    dot += dpp_f<DPP_HALF_MIRROR>(dot);
+                    sc[u] = ok[u] ? dot : -INFINITY;
+                    mw = fmaxf(mw, sc[u]);
+                }
+            }
+            float mrun = wave_max(mw);                        // the same in every lane (-inf: this wave holds no key)
+            float lrun = 0.f, o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) {
+                if (any_ok[u]) {
+                    const float pe = (sc[u] == -INFINITY) ? 0.f : expf(sc[u] - mrun);
+                    lrun += pe;
+                    o[0] += pe * vf[u][0][0]; o[1] += pe * vf[u][0][1]; o[2] += pe * vf[u][0][2]; o[3] += pe * vf[u][0][3];
+                    o[4] += pe * vf[u][1][0]; o[5] += pe * vf[u][1][1]; o[6] += pe * vf[u][1][2]; o[7] += pe * vf[u][1][3];
+                }
+            }
+            for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64) {       // contexts beyond 256 keys: the rest streams behind the query (wave-uniform bound)
+                const int p = wb0 + grp;
+                const bool live = p < kv1;
+                const int pc = live ? p : kv0;
+                const f32x4 k0 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM), k1 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM + 4);
+                const f32x4 v0 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM), v1 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM + 4);
+                float dot = q0[0] * k0[0] + q0[1] * k0[1] + q0[2] * k0[2] + q0[3] * k0[3] + q1[0] * k1[0] + q1[1] * k1[1] + q1[2] * k1[2] + q1[3] * k1[3];
+                dot += dpp_f<DPP_XOR1>(dot);
+                dot += dpp_f<DPP_XOR2>(dot);
+                dot += dpp_f<DPP_HALF_MIRROR>(dot);
+                const float mn = wave_max(fmaxf(mrun, live ? dot : -INFINITY));       // the wave keeps ONE running maximum
+                const float scl = pl_exp_diff(mrun, mn);
+                const float pe = live ? expf(dot - mn) : 0.f;
+                lrun = lrun * scl + pe;
+                o[0] = o[0] * scl + pe * v0[0]; o[1] = o[1] * scl + pe * v0[1]; o[2] = o[2] * scl + pe * v0[2]; o[3] = o[3] * scl + pe * v0[3];
+                o[4] = o[4] * scl + pe * v1[0]; o[5] = o[5] * scl + pe * v1[1]; o[6] = o[6] * scl + pe * v1[2]; o[7] = o[7] * scl + pe * v1[3];
                 mrun = mn;
             }
-        };
+            // the 8 key groups of the wave share mrun: plain sums over the lanes with equal `sub`
 #pragma unroll
-        for (int u = 0; u < PRE; ++u) key_step(kf[u][0], kf[u][1], vf[u][0], vf[u][1], ok[u]);
-        for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64) {       // contexts beyond 256 keys: the rest streams behind the query (wave-uniform bound)
-            const int p = wb0 + grp;
-            const bool live = p < kv1;
-            const int pc = live ? p : kv0;
-            const f32x4 k0 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM), k1 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM + 4);
-            const f32x4 v0 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM), v1 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM + 4);
-            key_step(k0, k1, v0, v1, live);
-        }
-        // merge the 8 key groups of this wave (lanes with equal `sub`)
+            for (int off = 8; off < 64; off <<= 1) {
+                lrun += __shfl_xor(lrun, off);
 #pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            const float m2 = __shfl_xor(mrun, off), l2 = __shfl_xor(lrun, off);
-            const float mn = fmaxf(mrun, m2);
-            const float s1 = pl_exp_diff(mrun, mn), s2 = pl_exp_diff(m2, mn);
-            lrun = lrun * s1 + l2 * s2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float o2 = __shfl_xor(o[j], off);
-                o[j] = o[j] * s1 + o2 * s2;
+                for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
             }
-            mrun = mn;
-        }
-        if (grp == 0) {
-            float* mg = merge + (wave * 8 + sub) * 10;
-            mg[0] = mrun; mg[1] = lrun;
+            if (grp == 0) {
+                float* mg = merge + (wave * 8 + sub) * 10;
+                mg[0] = mrun; mg[1] = lrun;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) mg[2 + j] = o[j];
+                for (int j = 0; j < 8; ++j) mg[2 + j] = o[j];
+            }
+            if (l + 1 < NL) PL_LOAD_KV(l + 1);                // the next layer's cached rows: a whole layer ahead of its query
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                  // B2
         }
-        __syncthreads();                                      // B2
     } else if (wave == 8) {
+        if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
+        const unsigned tag0 = (unsigned)ep_v * 32u;
         __syncthreads();                                      // S0
-        float v[3];
-        const bool got = sweep<3>(a.g_qkv + (size_t)(r * PL_NH + hh) * 192 + lane, [](int k) { return 64 * k; }, tag, true, v, a.error, 2, abort_s);
-        (void)got;
-        qs[lane] = v[0] * 0.125f;                             // 1 / sqrt(64) (llama.py:653-661)
-        ks[lane] = v[1];
-        vs[lane] = v[2];
-        PL_MARK(1);
-        __syncthreads();                                      // B1
-        __syncthreads();                                      // B2
-        if (lane < 8) {
-            float M = merge[lane * 10], L = merge[lane * 10 + 1], O[8];
+        for (int l = 0; l < NL; ++l) {
+            const unsigned tag = tag0 + (unsigned)l;
+            float v[3];
+            const bool got = sweep<3>(a.g_qkv + (size_t)(r * PL_NH + hh) * 192 + lane, [](int k) { return 64 * k; }, tag, true, v, a.error, 2, abort_s);
+            (void)got;
+            qs[lane] = v[0] * 0.125f;                         // 1 / sqrt(64) (llama.py:653-661)
+            ks[lane] = v[1];
+            vs[lane] = v[2];
+            if (l + 1 == NL) PL_MARK(1);
+            __syncthreads();                                  // B1
+            // this step's own key (slot `m.slot`, the causal end of the row: llama.py:1073-1087): its score, on all 64 lanes
+            const float dnew = wave_sum(qs[lane] * ks[lane]);
+            __syncthreads();                                  // B2
+            // lane = output dim: combine the 8 waves' partials and the new key
+            const int sub = lane >> 3, j = lane & 7;
+            float mwv[8], M = dnew;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) O[j] = merge[lane * 10 + 2 + j];
+            for (int w = 0; w < 8; ++w) { mwv[w] = merge[(w * 8 + sub) * 10]; M = fmaxf(M, mwv[w]); }
+            const float pe = expf(dnew - M);
+            float L = pe, O = pe * vs[lane];
 #pragma unroll
-            for (int w = 1; w < 8; ++w) {
-                const float* mg = merge + (w * 8 + lane) * 10;
-                const float mn = fmaxf(M, mg[0]);
-                const float s1 = pl_exp_diff(M, mn), s2 = pl_exp_diff(mg[0], mn);
-                L = L * s1 + mg[1] * s2;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) O[j] = O[j] * s1 + mg[2 + j] * s2;
-                M = mn;
+            for (int w = 0; w < 8; ++w) {
+                const float sw = pl_exp_diff(mwv[w], M);
+                L += merge[(w * 8 + sub) * 10 + 1] * sw;
+                O += merge[(w * 8 + sub) * 10 + 2 + j] * sw;
             }
-            // this step's own key (slot `m.slot`, causal end of the row: llama.py:1073-1087)
-            float dot = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dot += qs[8 * lane + j] * ks[8 * lane + j];
-            dot += dpp_f<DPP_XOR1>(dot);
-            dot += dpp_f<DPP_XOR2>(dot);
-            dot += dpp_f<DPP_HALF_MIRROR>(dot);
-            const float mn = fmaxf(M, dot);
-            const float s1 = pl_exp_diff(M, mn), pe = expf(dot - mn);
-            L = L * s1 + pe;
-            const float inv = 1.0f / L;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                store_granule(a.g_att + (size_t)r * PL_H + hh * CTTS_HEAD_DIM + 8 * lane + j, tag, (O[j] * s1 + pe * vs[8 * lane + j]) * inv);
+            store_granule(a.g_att + (size_t)r * PL_H + hh * CTTS_HEAD_DIM + lane, tag, O / L);
+            if (l + 1 == NL) PL_MARK(2);
         }
-        PL_MARK(2);
         if (a.ts != nullptr && lane == 0) {
-            a.ts[(size_t)b * 9 + 0] = t_mark[0]; a.ts[(size_t)b * 9 + 1] = t_mark[1]; a.ts[(size_t)b * 9 + 2] = t_mark[2];
+            a.ts[(size_t)b * 10 + 0] = t_mark[0]; a.ts[(size_t)b * 10 + 1] = t_mark[1]; a.ts[(size_t)b * 10 + 2] = t_mark[2];
         }
     } else {
+        if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
         __syncthreads();                                      // S0
-        __syncthreads();                                      // B1
-        __syncthreads();                                      // B2
+        for (int l = 0; l < NL; ++l) {
+            __syncthreads();                                  // B1
+            __syncthreads();                                  // B2
+        }
     }
 }
 

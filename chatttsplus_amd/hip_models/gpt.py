@@ -231,6 +231,12 @@ class GPT:
             _lib.check(self._lib.ctts_gpt_set_option(self._h, str(name).encode(), int(value)), f"set_option({name})")
         self.options[str(name)] = int(value)
 
+    def get_option(self, name: str) -> int:
+        """The effective value of an engine option (ctts_gpt_get_option)."""
+        v = C.c_int(0)
+        _lib.check(self._lib.ctts_gpt_get_option(self._h, str(name).encode(), C.byref(v)), f"get_option({name})")
+        return int(v.value)
+
     # -- nn.Module-like surface ------------------------------------------------------------------
     def eval(self):
         return self

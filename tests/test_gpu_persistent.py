@@ -1,0 +1,98 @@
+"""The persistent decode launch (persist_layer.hip: the 20-layer stack of a batch-1 decode step as ONE launch of 256 resident workgroups, activations
+handed between workgroups as tagged 8-byte granules) against the launch path it replaces -- same loop of the reference, gpt.py:389-546 over
+llama.py:719-749 -- plus the advisor's round-3 finding on the repetition-penalty gate under continuous batching.
+
+The bit-exact-vs-reference statement for the mode rides on the existing goldens: every batch-1 golden of tests/test_gpu_gpt.py and the 512-token
+property test now run through the persistent launch (the fp32 engine's default for one decode row)."""
+import numpy as np
+import pytest
+import torch
+
+from chatttsplus_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+LP = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20)
+
+
+@pytest.fixture(scope="module")
+def gpt():
+    from chatttsplus_amd.hip_models import GPT
+    g = GPT(LLAMA, max_batch=8, max_seq_len=1400, weight_dtype="fp32")
+    g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+    yield g
+    g.close()
+
+
+def _gen(g, B, P, N, pad=None, lp=LP, seed=7):
+    ids, mask = synth.prompt_ids(B, P, 21178, 4321, pad_left=pad)
+    emb = g(torch.from_numpy(ids), torch.ones(B, P, dtype=torch.bool))
+    res = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=N,
+                          logits_warpers=LW, logits_processors=lp, return_hidden=True, noise="device", seed=seed))[-1]
+    return res.ids, res.hiddens
+
+
+def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
+    g = gpt
+    assert g.get_option("persistent_rows") == 1, "fp32 engines serve one decode row through the persistent launch by default"
+    cases = [(1, 48, 96, None), (1, 600, 24, None), (1, 1000, 40, None),        # ... a context that crosses 1024 keys hands over to the launch path mid-generation
+             (2, 40, 32, [0, 9]), (3, 33, 24, [0, 5, 17]), (4, 48, 24, [3, 0, 11, 20])]
+    for (B, P, N, pad) in cases:
+        g.set_option("persistent_rows", 0)
+        ref_ids, ref_h = _gen(g, B, P, N, pad)
+        variants = [dict(persistent_rows=4), dict(persistent_rows=4, persistent_layers_per_launch=1), dict(persistent_rows=4, persistent_schedule=0)]
+        for v in variants:
+            for k, val in v.items():
+                g.set_option(k, val)
+            ids, hid = _gen(g, B, P, N, pad)
+            for b in range(B):
+                assert torch.equal(ids[b], ref_ids[b]), f"B={B} P={P} {v}: row {b} tokens differ from the launch path"
+                assert float((hid[b] - ref_h[b]).abs().max()) <= 5e-5, (B, P, v, b)
+            g.set_option("persistent_layers_per_launch", 0)
+            g.set_option("persistent_schedule", 1)
+    g.set_option("persistent_rows", 1)
+
+
+def test_persistent_launch_replay_is_bitwise_reproducible_and_graph_equals_eager(gpt):
+    g = gpt
+    g.set_option("persistent_rows", 1)
+    a_ids, a_h = _gen(g, 1, 48, 128)
+    b_ids, b_h = _gen(g, 1, 48, 128)
+    g.use_graph = False
+    try:
+        c_ids, c_h = _gen(g, 1, 48, 128)
+    finally:
+        g.use_graph = True
+    assert torch.equal(a_ids[0], b_ids[0]) and torch.equal(a_h[0], b_h[0]), "two replays differ (fixed reduction orders, no atomics on the data path)"
+    assert torch.equal(a_ids[0], c_ids[0]) and torch.equal(a_h[0], c_h[0]), "hipGraph replay != eager launches"
+
+
+def test_repetition_penalty_reaches_every_utterance_of_a_long_queue(gpt):
+    """the F8 gate (processors.py:23-27: the penalty skips rows >= 625 of the flattened [B * 4] batch the REFERENCE runs) was applied to the
+    utterance's index in the caller's output arrays; under continuous batching that index grows without bound, so from utterance 157 on the penalty
+    was silently off.  170 utterances through 8 rows with a strong penalty: every utterance must equal what a slice gives it."""
+    g = gpt
+    NU, T, N = 170, 6, 14
+    strong = [type("R", (), dict(penalty=2.0, past_window=16, max_input_ids=625))()]
+    ids, mask = synth.prompt_ids(NU, T, 21178, 91)
+    emb = g(torch.from_numpy(ids), torch.ones(NU, T, dtype=torch.bool))
+    uids = list(range(NU))
+    kw = dict(max_new_token=N, min_new_token=N, logits_warpers=LW, return_hidden=False, seed=5)
+
+    def sliced(lp, lo, hi):
+        out = []
+        for i in range(lo, hi, 8):
+            sl = slice(i, min(i + 8, hi))
+            out += list(g.generate(emb[sl].contiguous(), torch.from_numpy(ids[sl]), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask[sl]),
+                                   noise="device", utt_ids=uids[sl], logits_processors=lp, **kw))[-1].ids
+        return out
+
+    many = g.generate_many(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), utt_ids=uids, rows=8,
+                           logits_processors=strong, **kw)
+    want = sliced(strong, 144, NU)
+    plain = sliced([], 144, NU)
+    assert any(not torch.equal(a, b) for a, b in zip(want[13:], plain[13:])), "the penalty changes nothing on these utterances: the case has no teeth"
+    for u in range(144, NU):
+        assert torch.equal(many.ids[u], want[u - 144]), f"utterance {u}: continuous batching sampled without the repetition penalty"

@@ -119,7 +119,7 @@ if not args.skip_layer:
         ids, hid, emb = gen(g1, B, P, 3, persist=4)           # step 0 = prompt pass; steps 1, 2 = decode (persistent); granules hold the LAST launch (step 2)
         st = debug_read(g1, "pl_state", 8).view(np.uint32)
         gs = granules(g1)
-        epoch = int(st[0]) - 1                                 # tag of the last launch
+        epoch = (int(st[0]) - 1) * 32                          # tag of the last launch's layer 0 (launch counter * 32 + layer)
         worst = {}
         for r in range(B):
             # decode step 2 of row r: input = embedding of the tokens sampled at step 1, cache = prompt + token 0's row + token 1's row: rebuild the rows
@@ -151,38 +151,39 @@ if not args.skip_times:
     spk = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
     leg = bench.Leg(g, dev, 0, 1)
     for B in (1, 2, 4):
-        times = {0: [], 4: []}
+        arms = {"launches": (0, 0), "persistent_one_launch": (4, 0), "persistent_launch_per_layer": (4, 1)}
+        times = {k: [] for k in arms}
         for rnd in range(4):
-            for v in (0, 4):
-                g.set_option("persistent_rows", v)
+            for k, (pr, lpl) in arms.items():
+                g.set_option("persistent_rows", pr)
+                g.set_option("persistent_layers_per_launch", lpl)
                 r = leg.run(B, 48, 64, 8, spk=spk)
                 if rnd:
-                    times[v].append(r["ev_ms"] / r["K"])
-        out(check="step_time_ms", B=B, launches={"median": round(statistics.median(times[0]), 5), "min": round(min(times[0]), 5)},
-            persistent={"median": round(statistics.median(times[4]), 5), "min": round(min(times[4]), 5)},
-            ratio=round(statistics.median(times[4]) / statistics.median(times[0]), 4))
+                    times[k].append(r["ev_ms"] / r["K"])
+        g.set_option("persistent_layers_per_launch", 0)
+        out(check="step_time_ms", B=B, **{k: {"median": round(statistics.median(t), 5), "min": round(min(t), 5)} for k, t in times.items()},
+            ratio_one_launch=round(statistics.median(times["persistent_one_launch"]) / statistics.median(times["launches"]), 4))
 
-    # ---- 4. per-edge prices from the phase marks of one launch (eager launches, batch 1, context ~ 300) ----------------------------------------
+    # ---- 4. per-edge prices from the phase marks of the LAST layer of one launch (eager launches) -------------------------------------------
     g.set_option("persistent_rows", 4)
     g.set_option("persistent_timestamps", 1)
-    for B in (1, 4):
-        rows = []
-        for rep in range(6):
+    for B in (1, 2):
+        for rep in range(4):
             leg.run(B, 48, 4, 4, spk=spk, use_graph=0, gen_tokens=0)
-            ts = debug_read(g, "pl_ts", 256 * 9 * 8).view(np.uint64).reshape(256, 9).astype(np.float64) * 0.01        # us
-            rows.append(ts)
-        ts = rows[-1]
+            ts = debug_read(g, "pl_ts", 256 * 10 * 8).view(np.uint64).reshape(256, 10).astype(np.float64) * 0.01        # us
         gem, att = ts[:192], ts[192:192 + 12 * B, :3]
         t0 = min(gem[:, 0].min(), att[:, 0].min())
-        names = ["start", "x_loaded", "qkv_published", "attention_gathered", "x1_published", "x1_gathered", "act_published", "act_gathered", "x_stored"]
+        names = ["start", "x_loaded", "x_gathered", "qkv_published", "attention_gathered", "x1_published", "x1_gathered", "act_published", "act_gathered", "end"]
         med = {n: round(float(np.median(gem[:, i] - t0)), 2) for i, n in enumerate(names)}
         mx = {n: round(float((gem[:, i] - t0).max()), 2) for i, n in enumerate(names)}
         amed = {n: round(float(np.median(att[:, i] - t0)), 2) for i, n in enumerate(["start", "qkv_gathered", "attention_published"])}
-        out(check="phase_marks_us", B=B, gemv_median=med, gemv_max=mx, attention_median=amed,
-            edges_us={"launch_to_qkv_published": med["qkv_published"], "qkv_to_attention_published": round(amed["attention_published"] - med["qkv_published"], 2),
-                      "attention_published_to_gathered": round(med["attention_gathered"] - amed["attention_published"], 2),
+        out(check="phase_marks_us_last_layer", B=B, layers_in_launch=20, gemv_median=med, gemv_max=mx, attention_median=amed,
+            edges_us={"entry_to_first_barrier": med["x_loaded"], "mean_layer": round((med["end"] - med["x_loaded"]) / 20.0, 3),
+                      "qkv_phase": round(med["qkv_published"] - med["x_gathered"], 2), "qkv_edge": round(amed["qkv_gathered"] - med["qkv_published"], 2),
+                      "attention_phase": round(amed["attention_published"] - amed["qkv_gathered"], 2),
+                      "attention_edge": round(med["attention_gathered"] - amed["attention_published"], 2),
                       "o_proj_phase": round(med["x1_published"] - med["attention_gathered"], 2), "x1_edge": round(med["x1_gathered"] - med["x1_published"], 2),
                       "gate_up_phase": round(med["act_published"] - med["x1_gathered"], 2), "act_edge": round(med["act_gathered"] - med["act_published"], 2),
-                      "down_phase": round(med["x_stored"] - med["act_gathered"], 2), "layer_total_last_workgroup": mx["x_stored"]})
+                      "down_phase_to_end": round(med["end"] - med["act_gathered"], 2), "launch_total_last_workgroup": mx["end"]})
     g.set_option("persistent_timestamps", 0)
 g.close()
