@@ -98,14 +98,17 @@ struct ctts_gpt {
                                                  // 640 vs 660 us/step) -- per-block prologue latency, not L2 traffic, is what these launches pay for;
                                                  // the prompt pass keeps 32-row blocks
     int force_splits = 0;                        // key splits of the decode attention (0 = decode_splits policy); ctts_gpt_set_option("decode_splits")
+    int down_sk_rows = 17;                       // xh-mode decode batches of >= this many rows (one 16-row chunk per block) slice the down projection's K four ways inside the
+                                                 // launch (EPI_RESID_XH_SK); 0 = never.  "down_splitk_rows"
+    float* sk_slab = nullptr; int* sk_cnt = nullptr;
     int opt_gen = 0;                             // bumped by ctts_gpt_set_option: part of the decode-graph key
     int valu_rows = 2;                           // fp32 engines: decode batches of <= this many rows multiply on the VALU (skinny_gemm.hip, VR template argument):
                                                  // an exact-f32 MFMA costs 32 cycles whatever the number of live columns, 48 of them per SIMD and launch.
                                                  // Measured (us/step, MFMA -> VALU, profiles/r04_ab_valu_rows.jsonl): batch 1 481.9 -> 450.8, 2 491.7 -> 477.5,
                                                  // 3 532.6 -> 555.9, 4 536.7 -> 560.3 (the 4-row variant re-reads four LDS operand rows per weight fragment)
-    int persist_rows = 0;                        // fp32 engines (default 1, set at create): decode batches of <= this many rows run the decoder stack as ONE persistent
-                                                 // launch (persist_layer.hip).  us/step, launches -> persistent (profiles/r04_persist_probe_*.jsonl): batch 1 449.6 -> 384.6;
-                                                 // batch 2 478.8 -> 574.2 and batch 4 538.9 -> 1208 (gathers grow with the rows, the 2- to 4-row kernels spill) -> 1
+    int persist_rows = 0;                        // fp32 engines (default 3, set at create): decode batches of <= this many rows run the decoder stack as ONE persistent
+                                                 // launch (persist_layer.hip).  us/step, launch chain -> persistent (profiles/r04_persist_probe_v3_no_spills.jsonl,
+                                                 // r04_ab_persist_options.jsonl): batch 1 451 -> 379, batch 2 480 -> 431, batch 4 540 -> 538 (break-even: stays on launches)
     char* pimg = nullptr;                        //   per-workgroup register images of the layer weights [L][192][192 KB], built on the device from the packed tiles
     unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
     unsigned* pl_epoch = nullptr;                //   launch counter = granule tag
@@ -114,7 +117,9 @@ struct ctts_gpt {
     int cur_persist = 0;                         //   the steps being launched use the persistent layer
     int pl_ts_on = 0;
     int persist_lpl = 0;                         //   decoder layers per persistent launch (0 = all of them in one launch)
-    int persist_sched = 1;                       //   weight request schedule (PersistArgs.sched)
+    int persist_sched = 1;                       //   weight request schedule (PersistArgs.sched): 1 and 2 measure the same (389.3 / 389.5 us at batch 1, 436.0 / 436.4 at 2)
+    int persist_poll = -1;                       //   PersistArgs.poll; -1 = by row count: the sentinel pass costs one serial poll at 1-2 rows (batch 1 379.2 -> 387.1 us,
+                                                 //   batch 2 430.7 -> 437.8) and pays from 3 rows on, where a full sweep re-reads up to 96 granules per lane (batch 4 547.5 -> 537.6)
     int no_prepack = 0, prefill_gemm_rows = 1536, xh_heads = 1;   // diagnostic builds only: see run_layers / run_decode_step
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
     DevState* st = nullptr;
@@ -185,7 +190,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = (c->dtype == CTTS_DTYPE_F16) ? 8 : 16;
-    h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 1 : 0;
+    h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 3 : 0;
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
     // product library takes no behaviour from the environment on its launch paths (diag_env() is a constant null there).
     if (const char* sr = diag_env("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 32) h->split_rows = 32; }
@@ -283,8 +288,10 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         if (h->persist_rows > 0 && ensure_persist(h, true)) { h->persist_rows = 0; return 1; }
     } else if (n == "persistent_layers_per_launch") {      // 0 = the whole stack in one launch (default); 1 = one launch per layer
         h->persist_lpl = value < 0 ? 0 : value;
-    } else if (n == "persistent_schedule") {               // 0 / 1: see persist_layer.hip
-        h->persist_sched = value ? 1 : 0;
+    } else if (n == "persistent_schedule") {               // 1 / 2: see persist_layer.hip
+        h->persist_sched = (value == 1) ? 1 : 2;
+    } else if (n == "persistent_poll") {                   // bit 0: sentinel granules before the full sweeps
+        h->persist_poll = value < 0 ? -1 : (value & 1);
     } else if (n == "persistent_timestamps") {   // diagnostics: every workgroup of a persistent launch records wall_clock64 marks (ctts_gpt_debug_read "pl_ts")
         if (value && !h->pl_ts && dev_alloc((void**)&h->pl_ts, (size_t)PL_BLOCKS * 10 * 8)) return 1;
         h->pl_ts_on = value ? 1 : 0;
@@ -293,6 +300,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->force_splits = value;
     } else if (n == "split_rows") {              // decode batches up to this size run the down projection as split-K launch slices
         h->split_rows = value < 0 ? 0 : (value > 32 ? 32 : value);
+    } else if (n == "down_splitk_rows") {        // see down_sk_rows
+        h->down_sk_rows = value < 0 ? 0 : value;
     } else if (n == "graph_steps") {
         h->graph_steps = value < 1 ? 1 : (value > 64 ? 64 : value);
     } else {
@@ -309,7 +318,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
-                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts};
+                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -662,6 +671,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->st, sizeof(DevState)) || dev_alloc((void**)&h->last_rows, CTTS_MAX_B * 4) ||
         dev_alloc((void**)&h->dyn, sizeof(SamplerDyn)) || dev_alloc((void**)&h->hist_ring, (size_t)CTTS_MAX_B * CTTS_NUM_VQ * 16 * 4) ||
         dev_alloc((void**)&h->finend, (size_t)CTTS_MAX_B * sizeof(RowState)) || dev_alloc((void**)&h->sat, 4) ||
+        dev_alloc((void**)&h->sk_slab, (size_t)(H / 16) * (CTTS_MAX_B / 16) * 4 * 256 * 4) || dev_alloc((void**)&h->sk_cnt, (size_t)(H / 16) * (CTTS_MAX_B / 16) * 4) ||
         dev_alloc((void**)&h->cx, (size_t)CTTS_MAX_B * H * 4) || dev_alloc((void**)&h->crope, (size_t)CTTS_MAX_B * 64 * 4) ||
         dev_alloc((void**)&h->cmeta, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->cring, (size_t)CTTS_MAX_B * CTTS_NUM_VQ * 16 * 4) ||
         dev_alloc((void**)&h->cfin, (size_t)CTTS_MAX_B * sizeof(RowState)) || dev_alloc((void**)&h->keep_dev, CTTS_MAX_B * 4) ||
@@ -780,7 +790,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
             pa.kv = kv_layer(h, l, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
             pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1; pa.g_x = pa.g_act + PL_G_ACT;
-            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched;
+            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched; pa.poll = (h->persist_poll < 0) ? (R >= 3 ? 1 : 0) : h->persist_poll;
             if (launch_persist_layer(R, pa, s)) return 1;
         }
         return 0;
@@ -862,7 +872,11 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             if (launch_gemm(dt, nbg, PRO_PACKED, EPI_PART, g4, chunks, s)) return 1;
         } else if (xhm) {                          // (the last layer's copy is for the heads: run_heads)
             g4.xh = h->xh; g4.ssq = h->ssq; g4.scale_in = h->scale_d;
-            if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH, g4, chunks, s)) return 1;
+            if (nbg == 1 && R >= h->down_sk_rows && h->down_sk_rows > 0 && !lora) {
+                // K sliced 4 ways inside the launch, last arriver combines (EPI_RESID_XH_SK, kernels.h)
+                g4.ktiles_total = h->I / (h->esz == 2 ? 32 : 16); g4.sk_slab = h->sk_slab; g4.sk_cnt = h->sk_cnt;
+                if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH_SK, g4, chunks, s)) return 1;
+            } else if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH, g4, chunks, s)) return 1;
         } else if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID, g4, chunks, s)) return 1;
     }
     return 0;

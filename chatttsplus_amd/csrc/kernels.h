@@ -7,7 +7,10 @@ enum { PRO_NORM = 0, PRO_ATTN = 1, PRO_PACKED = 2, PRO_NORM_P = 3, PRO_XH = 4 };
 // it -- engine dtype, fragment-major, scaled by a per-row power of two -- and the RMSNorm factor is applied to the C tile after the MFMAs from the
 // producer's per-tile sums of squares: no block re-reads and re-normalises fp32 rows (16 rows x 3 KB per block, replicated in up to
 // 768 blocks per launch, was the prologue of every QKV / gate|up launch).
-enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_P = 4, EPI_PART = 5, EPI_RESID_XH = 6 };   // PART: write a split-K partial, no residual; RESID_XH: see PRO_XH
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_P = 4, EPI_PART = 5, EPI_RESID_XH = 6, EPI_RESID_XH_SK = 7 };   // PART: write a split-K partial, no residual; RESID_XH: see PRO_XH
+// EPI_RESID_XH_SK: EPI_RESID_XH for a launch whose grid.z slices K (the 17-32-row down projection: 96 blocks that each pull 393 KB through one CU become
+// 384 blocks of 98 KB): every slice block parks its 16 x 16 partial tile in a 1 KB slab with write-through stores and takes a ticket on the tile's
+// counter; the LAST arriver adds the slices IN SLICE ORDER (deterministic whatever the arrival order) and runs the residual / packed-copy epilogue.
 #define CTTS_NPART 4       // split-K partial sums of the down projection per row (decode batches <= 4)
 
 // out[R rows][N] = prologue(x)[R][K] . W[N][K]^T  followed by a fused epilogue.
@@ -52,6 +55,8 @@ struct GemmArgs {
     const float* lora_delta;
     int* sat;               // fp16 engines: counter of saturated / NaN fp16 stores (common.h sat_half); null = do not count
     const RowState* rows;   // heads only: hidden row goes to hiddens[rows[r].out][rows[r].end] while the row is live
+    float* sk_slab;         // EPI_RESID_XH_SK: partial tiles [row tile][chunk][slice][256] fp32
+    int* sk_cnt;            //                  arrival tickets [row tile][chunk], zero between launches (the last arriver resets its counter)
     int valu;               // fp32 decode, <= 4 rows: products on the VALU instead of exact-f32 MFMA (skinny_gemm.hip, VR; ctts_gpt_set_option "valu_rows")
 };
 

@@ -45,7 +45,8 @@ struct PersistArgs {
     const int* done;                // DevState.all_done
     unsigned long long* ts;         // diagnostics: [256][10] wall_clock64 marks per workgroup (last layer), or null
     float eps;
-    int sched;                      // weight request schedule of the compute waves (persist_layer.hip)
+    int sched;                      // weight request schedule of the compute waves (persist_layer.hip: 1 or 2)
+    int poll;                       // bit 0: watch one sentinel granule per producer before the full sweep of an edge
 };
 
 int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s);

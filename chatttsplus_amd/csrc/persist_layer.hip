@@ -28,19 +28,22 @@ __device__ inline void store_granule(u64* g, unsigned tag, float v) {
     __hip_atomic_store(g, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One wave re-reads its N granules (lane's granule k at g[OFF(k)]) every pass until every tag equals `tag`; values -> v.  `take` = this lane has
-// granules at all.  Returns false after PL_SPIN_LIMIT passes or once the workgroup / the engine has given up.
+// One wave re-reads its N granules (lane's granule k = base[lane_elem + OFF(k)], OFF(k) a compile-time constant) every pass until every tag equals `tag`;
+// values -> v.  The lane's pointer is formed ONCE per sweep and made opaque: the granule addresses are then that register pair + immediates (the first
+// version let hipcc hoist a separate 64-bit address pair per granule of every edge out of the layer loop: ~100 VGPRs alive through the loop, spills).
+// Returns false after PL_SPIN_LIMIT passes or once the workgroup / the engine has given up.
 template <int N, typename OffFn>
-__device__ inline bool sweep(const u64* g, OffFn off, unsigned tag, bool take, float (&v)[N], int* err, int code, volatile int* abort_s) {
+__device__ inline bool sweep(const u64* base, unsigned lane_elem, OffFn off, unsigned tag, float (&v)[N], int* err, int code, volatile int* abort_s) {
+    const u64* p = base + lane_elem;
+    asm volatile("" : "+v"(p));
+#pragma unroll 1
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
-        if (take) {
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const u64 x = __hip_atomic_load(g + off(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[k] = __builtin_bit_cast(float, (unsigned)x);
-                ok = ok && ((unsigned)(x >> 32) == tag);
-            }
+        for (int k = 0; k < N; ++k) {
+            const u64 x = __hip_atomic_load(p + off(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[k] = __builtin_bit_cast(float, (unsigned)x);
+            ok = ok && ((unsigned)(x >> 32) == tag);
         }
         if (__all(ok)) return true;
         bool giveup = spins >= PL_SPIN_LIMIT || *abort_s != 0;
@@ -53,12 +56,36 @@ __device__ inline bool sweep(const u64* g, OffFn off, unsigned tag, bool take, f
     }
 }
 
+// Before a wave sweeps ALL its granules of an edge it watches one "sentinel" granule per producer workgroup that feeds it (the last one that producer
+// stores): 96 eight-byte loads per pass instead of up to 3072.  A hint only -- stores of different lanes land in any order -- the sweep that follows checks
+// every tag; bounded, silent (the sweep reports).
+template <typename OffFn>
+__device__ inline void watch_sentinels(const u64* base, OffFn off, int n, unsigned tag, int lane, volatile int* abort_s) {
+    const u64* p0 = base + ((lane < n) ? off(lane) : 0);
+    const u64* p1 = base + ((lane + 64 < n) ? off(lane + 64) : 0);
+    asm volatile("" : "+v"(p0), "+v"(p1));
+#pragma unroll 1
+    for (unsigned spins = 0; spins < 8192u; ++spins) {
+        bool ok = true;
+        if (lane < n) ok = (unsigned)(__hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag;
+        if (lane + 64 < n) ok = ok && ((unsigned)(__hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag);
+        if (__all(ok) || *abort_s != 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 __device__ inline float dot4(const f32x4 w, const f32x4 x, float acc) {
     return fmaf(w[3], x[3], fmaf(w[2], x[2], fmaf(w[1], x[1], fmaf(w[0], x[0], acc))));
 }
 __device__ inline float pl_exp_diff(float m, float mn) { return (m == -INFINITY) ? 0.f : expf(m - mn); }
 
-template <int R>
+// SCHED = when a compute wave requests its weight arrays (each array is needed one phase per layer: q|k|v rows in A, o_proj rows in C, gate|up in D, down in E):
+//   1: gate|up(l) + q|k|v(l+1) when layer l's attention wait begins, down(l) + o_proj(l+1) when its (x + attention) wait begins;
+//   2: o_proj(l) + gate|up(l) at the attention wait, down(l) at the (x + attention) wait, q|k|v(l+1) at the end of the layer -- nothing is requested
+//      more than one wait ahead, so at most gate|up + down (18 of the 27 fragments) are live at once: 36 fewer VGPRs (the 2- to 4-row kernels spill under 1).
+// (Re-requesting every array right after its use, a whole layer ahead, put the gate|up burst in front of the act gather's polls and the down burst in
+//  front of the next layer's x gather: +6.7 us per layer, profiles/r04_persist_probe_v2_one_launch.jsonl.)
+template <int R, int SCHED>
 __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const xs = (float*)smem;                       // activations of the current phase [R][768] ([R][3072] for the down projection)
@@ -96,19 +123,27 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
 #define PL_LOAD_G(base_) do { _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int j = 0; j < 3; ++j) \
                 g_w[s][j] = __builtin_nontemporal_load((const f32x4*)(base_) + og + (s * 3 + j) * 64); } while (0)
 #define PL_LOAD_D(base_) do { _Pragma("unroll") for (int j = 0; j < 6; ++j) d_w[j] = __builtin_nontemporal_load((const f32x4*)(base_) + od + j * 64); } while (0)
-            // a.sched = 0: every array is re-requested right after its last use (a whole layer ahead; the gate|up burst then sits in front of the
-            //              act gather's polls and the down burst in front of the next layer's x gather: +6.7 us per layer measured);
-            // a.sched = 1: gate|up of layer l are requested when layer l's attention wait begins and down when its x + attention wait begins -- the polls of
-            //              those two waits cannot succeed for microseconds anyway -- and nothing is queued in front of the act and x gathers.
-            const int sched = a.sched;
-            PL_LOAD_Q(wb); PL_LOAD_O(wb);
-            if (sched == 0) PL_LOAD_G(wb);
+            PL_LOAD_Q(wb);
+            if (SCHED == 1) PL_LOAD_O(wb);
             __builtin_amdgcn_sched_barrier(0);
             if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;      // every sequence finished (gpt.py:545) / an earlier launch gave up: the same for every workgroup
             __syncthreads();                                  // S0
             for (int l = 0; l < NL; ++l) {
                 const char* const wn = wb + PL_LAYER_BYTES;   // next layer's image
                 const bool more = l + 1 < NL;
+                if (SCHED == 2) {
+                    // these three are requested and used inside one layer: say so (the conditional requests otherwise make them loop-carried and all 27
+                    // fragments stay allocated through the whole loop)
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) o_w[j] = z;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) g_w[s][j] = z;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) d_w[j] = z;
+                }
                 // ---- phase A: q | k | v rows
                 __syncthreads();                              // B1(A): xs = x
                 f32x4 xr[R][3];
@@ -128,9 +163,9 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                             if (lane == 0) red[(wave * 4 + row) * R + r] = acc;
                         }
                 }
-                if (sched == 0) { if (l == 0) PL_LOAD_D(wb); }   // (layer 0's down rows: requested behind everything phase A needed)
-                else PL_LOAD_G(wb);
-                if (more) PL_LOAD_Q(wn);
+                if (SCHED == 2) PL_LOAD_O(wb);
+                PL_LOAD_G(wb);
+                if (SCHED == 1 && more) PL_LOAD_Q(wn);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                              // B2(A)
                 // ---- phase C: o_proj rows
@@ -149,8 +184,8 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                         if (lane == 0) red[(wave * 4) * R + r] = acc;
                     }
                 }
-                if (sched != 0) PL_LOAD_D(wb);
-                if (more) PL_LOAD_O(wn);
+                PL_LOAD_D(wb);
+                if (SCHED == 1 && more) PL_LOAD_O(wn);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                              // B2(C)
                 // ---- phase D: gate | up pairs
@@ -169,7 +204,6 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                         acc = wave_sum(acc);
                         if (lane == 0) red[(wave * 4 + s) * R + r] = acc;
                     }
-                if (sched == 0 && more) PL_LOAD_G(wn);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                              // B2(D)
                 // ---- phase E: down rows, two K halves per row
@@ -183,7 +217,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     acc = wave_sum(acc);
                     if (lane == 0) red[(wave * 4) * R + r] = acc;
                 }
-                if (sched == 0 && more) PL_LOAD_D(wn);
+                if (SCHED == 2 && more) PL_LOAD_Q(wn);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                              // B2(E)
                 wb = wn;
@@ -242,8 +276,10 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 const bool last = l + 1 == NL;
                 if (l > 0) {
                     // ---- edge 1: the previous layer's output, published by the 192 GEMV workgroups -> xs, sums of squares
+                    // (producers of this wave's columns e + 128 k: workgroups 16 (2 m + ew) + t; each stores its 4 columns of every row in one instruction)
+                    if (a.poll & 1) watch_sentinels(a.g_x, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag - 1u, lane, abort_s);
                     float v[6 * R];
-                    const bool got = sweep<6 * R>(a.g_x + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag - 1u, true, v, a.error, 1, abort_s);
+                    const bool got = sweep<6 * R>(a.g_x, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag - 1u, v, a.error, 1, abort_s);
                     (void)got;
 #pragma unroll
                     for (int r = 0; r < R; ++r) ssp[r] = 0.f;
@@ -284,8 +320,10 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 if (last) PL_MARK(3);
                 // ---- phase C: attention output -> o_proj + residual
                 {
+                    // (this wave's columns belong to the heads 2 m + ew: one sentinel per (row, head))
+                    if (a.poll & 1) watch_sentinels(a.g_att, [ew](int i) { return (i / 6) * PL_H + 64 * (2 * (i % 6) + ew) + 63; }, 6 * R, tag, lane, abort_s);
                     float v[6 * R];
-                    const bool got = sweep<6 * R>(a.g_att + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, true, v, a.error, 3, abort_s);
+                    const bool got = sweep<6 * R>(a.g_att, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, v, a.error, 3, abort_s);
                     (void)got;
 #pragma unroll
                     for (int k = 0; k < 6 * R; ++k) xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
@@ -302,8 +340,9 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 if (last) PL_MARK(5);
                 // ---- phase D: x + attention -> RMSNorm, gate | up, SiLU * up
                 {
+                    if (a.poll & 1) watch_sentinels(a.g_x1, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag, lane, abort_s);
                     float v[6 * R];
-                    const bool got = sweep<6 * R>(a.g_x1 + e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, true, v, a.error, 4, abort_s);
+                    const bool got = sweep<6 * R>(a.g_x1, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, v, a.error, 4, abort_s);
                     (void)got;
 #pragma unroll
                     for (int r = 0; r < R; ++r) ssp[r] = 0.f;
@@ -329,10 +368,12 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 }
                 if (last) PL_MARK(7);
                 // ---- phase E: silu(gate) * up [R][3072] -> down + residual
+                // (producers of this wave's columns e + 128 k: workgroups 8 k + 4 ew + t, t < 4; each stores its 16 columns of every row in one instruction)
+                if (a.poll & 1) watch_sentinels(a.g_act, [ew](int i) { return (R - 1) * PL_I + 16 * (8 * (i >> 2) + 4 * ew + (i & 3)) + 15; }, 96, tag, lane, abort_s);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float v[24];
-                    const bool got = sweep<24>(a.g_act + (size_t)r * PL_I + e, [](int k) { return 128 * k; }, tag, true, v, a.error, 5, abort_s);
+                    const bool got = sweep<24>(a.g_act, (unsigned)(r * PL_I + e), [](int k) { return 128 * k; }, tag, v, a.error, 5, abort_s);
                     (void)got;
 #pragma unroll
                     for (int k = 0; k < 24; ++k) xs[r * PL_I + 128 * k + e] = v[k];
@@ -470,7 +511,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
         for (int l = 0; l < NL; ++l) {
             const unsigned tag = tag0 + (unsigned)l;
             float v[3];
-            const bool got = sweep<3>(a.g_qkv + (size_t)(r * PL_NH + hh) * 192 + lane, [](int k) { return 64 * k; }, tag, true, v, a.error, 2, abort_s);
+            const bool got = sweep<3>(a.g_qkv, (unsigned)((r * PL_NH + hh) * 192 + lane), [](int k) { return 64 * k; }, tag, v, a.error, 2, abort_s);
             (void)got;
             qs[lane] = v[0] * 0.125f;                         // 1 / sqrt(64) (llama.py:653-661)
             ks[lane] = v[1];
@@ -551,20 +592,33 @@ int launch_persist_repack(const void* qkv, const void* o, const void* gu, const 
 
 static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + 8 * 4 * R + 2 * R + 4 * R) * 4 + 16 + (192 + 8 * 8 * 10) * 4; }
 
-int persist_configure() {
-    CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)persist_layer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(1)));
-    CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)persist_layer_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(2)));
-    CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)persist_layer_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(3)));
-    CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)persist_layer_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(4)));
+template <int R, int SCHED>
+static int persist_launch_t(const PersistArgs& a, hipStream_t s, bool configure_only) {
+    auto kern = persist_layer_kernel<R, SCHED>;
+    if (configure_only) { CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(R))); return 0; }
+    hipLaunchKernelGGL(kern, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(R), s, a);
+    CTTS_HIP_CHECK(hipGetLastError());
     return 0;
+}
+template <int SCHED>
+static int persist_launch_r(int R, const PersistArgs& a, hipStream_t s, bool cfg) {
+    // exact row counts: a spare row would append stale K / V rows to a live cache lane
+    if (cfg) return persist_launch_t<1, SCHED>(a, s, true) | persist_launch_t<2, SCHED>(a, s, true) | persist_launch_t<3, SCHED>(a, s, true) | persist_launch_t<4, SCHED>(a, s, true);
+    switch (R) {
+        case 1: return persist_launch_t<1, SCHED>(a, s, false);
+        case 2: return persist_launch_t<2, SCHED>(a, s, false);
+        case 3: return persist_launch_t<3, SCHED>(a, s, false);
+        case 4: return persist_launch_t<4, SCHED>(a, s, false);
+    }
+    ctts_set_error("persistent layer: %d rows (max %d)", R, PL_MAXR);
+    return 1;
+}
+
+int persist_configure() {
+    PersistArgs a = {};
+    return persist_launch_r<1>(1, a, nullptr, true) | persist_launch_r<2>(1, a, nullptr, true);
 }
 
 int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s) {
-    if (R == 1) hipLaunchKernelGGL(persist_layer_kernel<1>, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(1), s, a);
-    else if (R == 2) hipLaunchKernelGGL(persist_layer_kernel<2>, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(2), s, a);
-    else if (R == 3) hipLaunchKernelGGL(persist_layer_kernel<3>, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(3), s, a);      // (exact row counts: a spare row
-    else if (R == 4) hipLaunchKernelGGL(persist_layer_kernel<4>, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(4), s, a);      //  would append stale K / V rows)
-    else { ctts_set_error("persistent layer: %d rows (max %d)", R, PL_MAXR); return 1; }
-    CTTS_HIP_CHECK(hipGetLastError());
-    return 0;
+    return (a.sched == 1) ? persist_launch_r<1>(R, a, s, false) : persist_launch_r<2>(R, a, s, false);
 }

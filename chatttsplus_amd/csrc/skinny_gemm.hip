@@ -96,8 +96,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     // fragments last; nothing issued after them is consumed before the MFMAs.
     // split-K launches (EPI_PART): this block owns k-tiles [blockIdx.z*KTILES, +KTILES) of a matrix with ktiles_total k-tiles
     const int np_ = misc & 0xFF, S_ = (misc >> 8) & 0xFF;
-    const int kt_all = (EPI == EPI_PART) ? (misc >> 16) : KTILES;
-    const int kt_off = (EPI == EPI_PART) ? (int)blockIdx.z * KTILES : 0;
+    constexpr bool SLICED = (EPI == EPI_PART || EPI == EPI_RESID_XH_SK);
+    const int kt_all = SLICED ? (misc >> 16) : KTILES;
+    const int kt_off = SLICED ? (int)blockIdx.z * KTILES : 0;
     const frag* Wp = (const frag*)Wq + ((size_t)rt0 * kt_all + kt_off + (size_t)wave * KPW) * 64 + lane;
     frag wf[RT][KPW];
     // (sched_barrier: hipcc otherwise hoists the weight loads above the prologue loads again)
@@ -112,13 +113,13 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     constexpr int RITEMS = (16 * NB + WAVES * 64 - 1) / (WAVES * 64);
     float resid_pf[RITEMS];
     float xh_scale_pf[RITEMS];
-    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_RESID_XH) {
+    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_RESID_XH || EPI == EPI_RESID_XH_SK) {
 #pragma unroll
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
             const int r = row0 + (t >> 4);
             // scale_in rides on the leading scalar in1 (free for PRO_PACKED); the rare PRO_ATTN variant reads it from the struct
-            xh_scale_pf[u] = (EPI == EPI_RESID_XH && t < 16 * NB && r < R) ? ((PRO == PRO_ATTN) ? a.scale_in[r] : ((const float*)in1)[r])
+            xh_scale_pf[u] = ((EPI == EPI_RESID_XH || EPI == EPI_RESID_XH_SK) && t < 16 * NB && r < R) ? ((PRO == PRO_ATTN) ? a.scale_in[r] : ((const float*)in1)[r])
                            : 1.f;
             const int N = a.n_row_tiles * 16, col = rt0 * 16 + (t & 15);
             float v = 0.f;
@@ -439,8 +440,47 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         return sum;
     };
 
+    // 4b. EPI_RESID_XH_SK: in-launch combine of the K slices (kernels.h).  Write-through (sc1) slab stores + a drained ticket -- no fences; the slabs
+    //     are read back with sc1 loads (cdna_hip_programming.md Guideline 16 R1).  The sum runs in slice order, so the result does not depend on who is last.
+    float sk_v[RITEMS];
+    if constexpr (EPI == EPI_RESID_XH_SK) {
+        static_assert(RT == 1 && NBG == 1, "split-K combine: one 16 x 16 tile per block");
+        const int nz = gridDim.z, slice = blockIdx.z;
+        float* const slab0 = a.sk_slab + ((size_t)(rt * gridDim.y + chunk) * nz) * 256;
+        int* const lastp = (int*)(red + WAVES * NBG * 256);          // one LDS word behind the partials (the 16 x 16 x NBG epilogue scratch)
+#pragma unroll
+        for (int u = 0; u < RITEMS; ++u) {
+            const int t = tid + u * WAVES * 64;
+            sk_v[u] = 0.f;
+            if (t < 256) {
+                sk_v[u] = c_elem(t & 15, t >> 4);
+                __hip_atomic_store(slab0 + (size_t)slice * 256 + t, sk_v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int* const cnt = a.sk_cnt + rt * gridDim.y + chunk;
+            const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == nz - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            *lastp = (ticket == nz - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*lastp == 0) return;
+#pragma unroll
+        for (int u = 0; u < RITEMS; ++u) {
+            const int t = tid + u * WAVES * 64;
+            if (t < 256) {
+                float pq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    pq[q] = (q >= nz) ? 0.f : (q == slice) ? sk_v[u] : __hip_atomic_load(slab0 + (size_t)q * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sk_v[u] = ((pq[0] + pq[1]) + pq[2]) + pq[3];
+            }
+        }
+    }
     // 5. fused epilogue
-    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_LOGITS || EPI == EPI_PART || EPI == EPI_RESID_XH) {
+    if (EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_LOGITS || EPI == EPI_PART || EPI == EPI_RESID_XH || EPI == EPI_RESID_XH_SK) {
 #pragma unroll
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
@@ -449,15 +489,15 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             const int r = row0 + n;
             if (r >= R) continue;
             const int col = rt * 16 + i;
-            float v = c_elem(i, n);
-            if ((EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_RESID_XH) && a.lora_delta != nullptr)
+            float v = (EPI == EPI_RESID_XH_SK) ? sk_v[u] : c_elem(i, n);
+            if ((EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_RESID_XH || EPI == EPI_RESID_XH_SK) && a.lora_delta != nullptr)
                 v += a.lora_delta[(size_t)r * (a.n_row_tiles * 16) + col];          // per-utterance LoRA term of o_proj (lora.hip)
             if (EPI == EPI_PART) {
                 a.part_out[((size_t)r * gridDim.z + blockIdx.z) * (a.n_row_tiles * 16) + col] = v;
             } else if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
                 const float xn = resid_pf[u] + v;                                    // residual + proj (llama.py:731,739)
                 a.x_out[(size_t)r * (a.n_row_tiles * 16) + col] = xn;
-            } else if (EPI == EPI_RESID_XH) {
+            } else if (EPI == EPI_RESID_XH || EPI == EPI_RESID_XH_SK) {
                 // the 16 lanes of a DPP row hold the 16 columns of (row r, tile rt): fp32 residual as before, plus what the next
                 // PRO_XH kernel reads -- the row's sum of squares over this tile and the fp16 (power-of-two scaled) packed copy
                 const float xn = resid_pf[u] + v;
@@ -542,14 +582,14 @@ template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1
 static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configure_only) {
     constexpr int KTILES = WAVES * KPW;
     constexpr int XS = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * 1024;
-    constexpr int LDS = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4;
+    constexpr int LDS = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4 + 16;
     auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI, RT, VR>;
     if (configure_only) {
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         return 0;
     }
     int nz = 1;
-    if (EPI == EPI_PART) {
+    if (EPI == EPI_PART || EPI == EPI_RESID_XH_SK) {
         if (a.ktiles_total % KTILES || a.K != a.ktiles_total * WTraits<WT>::KT) { ctts_set_error("skinny_gemm: split-K tiling mismatch"); return 1; }
         nz = a.ktiles_total / KTILES;
     } else if (a.K != KTILES * WTraits<WT>::KT) {
@@ -560,7 +600,8 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
     const int* done_p = a.st ? &a.st->all_done : nullptr;
     const void* in0 = (PRO == PRO_ATTN) ? (const void*)a.part_ml : (PRO == PRO_PACKED) ? (const void*)a.xpacked : (PRO == PRO_XH) ? (const void*)a.xh : (const void*)a.x;
     const void* in1 = (PRO == PRO_ATTN) ? (const void*)a.part_o : (PRO == PRO_NORM_P) ? (const void*)a.opart : (PRO == PRO_XH) ? (const void*)a.ssq :
-                      (EPI == EPI_RESID_XH) ? (const void*)a.scale_in : nullptr;
+                      (EPI == EPI_RESID_XH || EPI == EPI_RESID_XH_SK) ? (const void*)a.scale_in : nullptr;
+    if (EPI == EPI_RESID_XH_SK && (nz > 4 || a.sk_slab == nullptr || a.sk_cnt == nullptr)) { ctts_set_error("skinny_gemm: split-K combine needs <= 4 slices and its slabs"); return 1; }
     const float* resid_arg = (PRO == PRO_XH) ? a.scale_in : (const float*)a.x_out;
     const int misc = (a.np & 0xFF) | ((a.S & 0xFF) << 8) | (a.ktiles_total << 16);
     hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc, a);
@@ -605,6 +646,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
             rc |= launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID_XH>(a, chunks, s, true);
             rc |= launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
             rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
+            if constexpr (NBG == 1) rc |= launch_one<WT, 1, W768, P768, PRO_PACKED, EPI_RESID_XH_SK>(a, chunks, s, true);
         }
         if constexpr (!F16 && NBG == 1) {
 #define CTTS_VALU_CFG(VRN) rc |= launch_one<float, 1, W768, P768, PRO_NORM_P, EPI_QKV, 1, VRN>(a, chunks, s, true); rc |= launch_one<float, 1, W768, P768, PRO_NORM, EPI_QKV, 1, VRN>(a, chunks, s, true); \
@@ -658,6 +700,7 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
         if (pro == PRO_ATTN && epi == EPI_RESID_XH) return launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID_XH>(a, chunks, s, false);
         if (pro == PRO_PACKED && epi == EPI_RESID_XH && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, false);
         if (pro == PRO_PACKED && epi == EPI_RESID_XH) return launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, false);
+        if constexpr (NBG == 1) { if (pro == PRO_PACKED && epi == EPI_RESID_XH_SK) return launch_one<WT, 1, W768, P768, PRO_PACKED, EPI_RESID_XH_SK>(a, chunks, s, false); }
     }
     if constexpr (NBG == 1) {
         if (pro == PRO_NORM_P && epi == EPI_SWIGLU) return launch_one<WT, 1, W768, P768, PRO_NORM_P, EPI_SWIGLU>(a, chunks, s, false);
