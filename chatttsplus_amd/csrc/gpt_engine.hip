@@ -99,7 +99,8 @@ struct ctts_gpt {
                                                  // the prompt pass keeps 32-row blocks
     int force_splits = 0;                        // key splits of the decode attention (0 = decode_splits policy); ctts_gpt_set_option("decode_splits")
     int down_sk_rows = 17;                       // xh-mode decode batches of >= this many rows (one 16-row chunk per block) slice the down projection's K four ways inside the
-                                                 // launch (EPI_RESID_XH_SK); 0 = never.  "down_splitk_rows"
+                                                 // launch (EPI_RESID_XH_SK); 0 = never.  "down_splitk_rows".  us/step without -> with (profiles/r04_ab_down_splitk.jsonl):
+                                                 // fp32 batch 17 795 -> 767, 24 862 -> 833, 32 894 -> 868; fp16 batch 9 475 -> 465, 16 507 -> 496, 24 / 32 unchanged
     float* sk_slab = nullptr; int* sk_cnt = nullptr;
     int opt_gen = 0;                             // bumped by ctts_gpt_set_option: part of the decode-graph key
     int valu_rows = 2;                           // fp32 engines: decode batches of <= this many rows multiply on the VALU (skinny_gemm.hip, VR template argument):
@@ -191,6 +192,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = (c->dtype == CTTS_DTYPE_F16) ? 8 : 16;
     h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 3 : 0;
+    h->down_sk_rows = (c->dtype == CTTS_DTYPE_F16) ? 9 : 17;     // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
     // product library takes no behaviour from the environment on its launch paths (diag_env() is a constant null there).
     if (const char* sr = diag_env("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 32) h->split_rows = 32; }
@@ -1121,7 +1123,6 @@ extern "C" int ctts_gpt_rows_enqueue(ctts_gpt* h, int32_t* host_pinned_2B, void*
 
 extern "C" int ctts_gpt_compact(ctts_gpt* h, const int32_t* keep_rows, int n_keep, void* stream) {
     if (!h || !keep_rows || h->B == 0) { ctts_set_error("compact: call begin first"); return 1; }
-    if (h->text_mode) { ctts_set_error("compact: code mode only"); return 1; }
     if (n_keep < 1 || n_keep > h->B) { ctts_set_error("compact: n_keep=%d of %d rows", n_keep, h->B); return 1; }
     for (int i = 0; i < n_keep; ++i)
         if (keep_rows[i] < 0 || keep_rows[i] >= h->B || (i > 0 && keep_rows[i] <= keep_rows[i - 1])) { ctts_set_error("compact: keep_rows must be ascending row indices < %d", h->B); return 1; }
@@ -1145,7 +1146,7 @@ extern "C" int ctts_gpt_admit(ctts_gpt* h, int n, const int32_t* rows, int T, co
                               const int32_t* row_limits, const int32_t* out_index, const int32_t* attempts, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("admit: call begin first"); return 1; }
     if (!rows || !mask || !emb || !utt_ids || !out_index) { ctts_set_error("admit: null argument"); return 1; }
-    if (h->text_mode || h->lora_rows) { ctts_set_error("admit: code mode without per-utterance adapters only"); return 1; }
+    if (h->lora_rows) { ctts_set_error("admit: not with per-utterance adapters"); return 1; }
     if (h->io.noise != nullptr) { ctts_set_error("admit: device noise only (caller-supplied noise is indexed by the batch's draw counter)"); return 1; }
     if (n < 1 || n > h->B || T < 1 || T + h->sc.max_new > h->cfg.max_seq || (long long)n * (T - 1) > h->pass_rows) {
         ctts_set_error("admit: n=%d of %d rows, T=%d (max_seq %d, %d prompt rows per pass)", n, h->B, T, h->cfg.max_seq, h->pass_rows);

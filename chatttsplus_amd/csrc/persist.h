@@ -10,7 +10,7 @@
 #define PL_I 3072
 #define PL_NH 12
 #define PL_MAXR 4
-#define PL_MAX_CONTEXT 1024                // longest context served (one workgroup per (row, head): 256 keys prefetched, the rest streamed)
+#define PL_MAX_CONTEXT 1024                // longest context served (one workgroup per (row, head): 384 keys prefetched, the rest streamed)
 // per-workgroup weight image of one layer: 12 q|k|v rows, 4 o_proj rows, 16 gate|up pairs, 4 down rows (fp32)
 #define PL_QKV_BYTES (12 * 768 * 4)
 #define PL_O_BYTES (4 * 768 * 4)

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
         const int kv0 = m.kv_start, kv1 = m.slot;             // cached keys [kv0, kv1); this step's key / value arrive with the query
         const int grp = lane >> 3, sub = lane & 7;
         const size_t head_off = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
-        constexpr int PRE = 4;                                // iterations requested before the query exists: 8 waves x 8 keys x 4 = 256 keys
+        constexpr int PRE = 6;                                // iterations requested before the query exists: 8 waves x 8 keys x 6 = 384 keys
         f32x4 kf[PRE][2], vf[PRE][2];
         bool ok[PRE];
         bool any_ok[PRE];

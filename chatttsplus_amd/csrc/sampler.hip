@@ -423,10 +423,13 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
     if (st->all_done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, V = a.V;
-    const int step = st->step, draw = st->draw;
+    const int gstep = st->step, draw = st->draw;
     const RowState rs_in = a.finend[b];
+    // per-row bookkeeping like the code sampler's (RowState, common.h): the row's OWN step, its utterance's place in the output arrays, its own limit --
+    // so text rows can be compacted away and re-used by queued utterances (ctts_gpt_admit) exactly like code rows
+    const int step = rs_in.end, seq = rs_in.out;
     const float* lg = a.logits + (size_t)b * V;
-    const float* q = (d->noise != nullptr) ? d->noise + ((size_t)min(draw, d->n_draws - 1) * a.B + b) * V : nullptr;
+    const float* q = (d->noise != nullptr) ? d->noise + ((size_t)min(draw, d->n_draws - 1) * d->rows0 + seq) * V : nullptr;
     const float T = d->cfg.temperature[0];
     float x[TVPT];
     unsigned valid = 0;
@@ -585,25 +588,27 @@ __global__ __launch_bounds__(1024) void sampler_text_kernel(const SamplerArgs a)
     const int idx = 0x7FFFFFFF - (int)(unsigned)bkey;
     // next input = emb_text[idx]  (gpt.py:400-401); ids buffer keeps the reference's [.., num_vq] layout (gpt.py:492-494)
     for (int k = tid; k < a.H; k += 1024) a.x_next[(size_t)b * a.H + k] = a.emb_code[(size_t)idx * a.H + k];
-    if (tid < CTTS_NUM_VQ) d->ids[((size_t)b * d->cfg.max_new + step) * CTTS_NUM_VQ + tid] = idx;
+    if (tid < CTTS_NUM_VQ && rs_in.fin == 0) d->ids[((size_t)seq * d->cfg.max_new + step) * CTTS_NUM_VQ + tid] = idx;      // (a finished row's tokens are never read: gpt.py:295-297)
     if (tid == 0) {
-        const bool was = d->finish[b] != 0;
-        const bool fin = was || (idx == d->cfg.eos);                                  // gpt.py:490-491
-        d->finish[b] = fin ? 1 : 0;
-        if (!fin) d->end_idx[b] += 1;
-        ((int2*)(a.finend + b))[0] = make_int2(fin ? 3 : 0, rs_in.end + (fin ? 0 : 1));   // mirror (read by ctts_gpt_restart's attempt bookkeeping)
+        const bool was = rs_in.fin != 0;
+        const bool eos = (rs_in.fin & 2) != 0 || (idx == d->cfg.eos);                // gpt.py:490-491
+        bool fin = was || eos;
+        const int end_out = fin ? rs_in.end : rs_in.end + 1;                          // gpt.py:530-531
+        if (!fin) d->end_idx[seq] = end_out;
+        fin = fin || (end_out >= rs_in.limit);                                        // the row's own token limit (<= max_new_token, the loop bound of gpt.py:389)
+        if (!was) d->finish[seq] = eos ? 1 : 0;
+        ((int2*)(a.finend + b))[0] = make_int2(fin ? (eos ? 3 : 1) : 0, end_out);
         RowMeta m = a.meta[b];
-        m.pos += 1; m.slot += 1;
-        a.meta[b] = m;
+        if (!was) { m.pos += 1; m.slot += 1; a.meta[b] = m; }                         // a finished row stays on its last slot (like the code sampler's rows)
         pos_s = m.pos;
         const int add = 1 + ((fin && !was) ? 0x10000 : 0);
         const int tot_t = __hip_atomic_fetch_add(&st->ticket, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
         if ((tot_t & 0xFFFF) == a.B) {
             const int nfin = tot_t >> 16;
             st->ticket = nfin << 16;
-            st->step = step + 1;
+            st->step = gstep + 1;
             st->draw = draw + 1;
-            if (nfin == a.B || step + 1 >= d->cfg.max_new) st->all_done = 1;
+            if (nfin == a.B) st->all_done = 1;                                        // (every row ends by its limit <= max_new_token)
         }
     }
     __syncthreads();

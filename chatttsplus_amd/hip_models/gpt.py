@@ -639,7 +639,7 @@ class GPT:
                       attention_mask: Optional[torch.Tensor] = None, max_new_token=2048, min_new_token=0, logits_warpers=[],
                       logits_processors=[], return_hidden=False, ensure_non_empty=True, context=None, seed: Optional[int] = None,
                       max_restarts: int = 64, utt_ids=None, max_new_tokens_per_row=None, rows: Optional[int] = None, admit_min: Optional[int] = None,
-                      on_done=None) -> GenerationOutputs:
+                      on_done=None, infer_text: bool = False) -> GenerationOutputs:
         """N utterances (left-padded prompts emb[N,T,H], like generate()) through `rows` <= max_batch decode rows: whenever utterances
         finish, queued ones take over their rows (ctts_gpt_admit) instead of the whole slice waiting for its slowest row as the reference's
         slices of 4 do (pipeline:391-397, gpt.py:527-546); once the queue is empty finished rows are compacted away (ctts_gpt_compact).
@@ -651,7 +651,7 @@ class GPT:
         gen = self.generate_many_iter(emb, inputs_ids, temperature, eos_token, attention_mask=attention_mask, max_new_token=max_new_token,
                                       min_new_token=min_new_token, logits_warpers=logits_warpers, logits_processors=logits_processors,
                                       return_hidden=return_hidden, ensure_non_empty=ensure_non_empty, context=context, seed=seed, max_restarts=max_restarts,
-                                      utt_ids=utt_ids, max_new_tokens_per_row=max_new_tokens_per_row, rows=rows, admit_min=admit_min)
+                                      utt_ids=utt_ids, max_new_tokens_per_row=max_new_tokens_per_row, rows=rows, admit_min=admit_min, infer_text=infer_text)
         try:
             while True:
                 ev = next(gen)
@@ -663,10 +663,11 @@ class GPT:
     @torch.no_grad()
     def generate_many_iter(self, emb, inputs_ids, temperature, eos_token, attention_mask=None, max_new_token=2048, min_new_token=0, logits_warpers=[],
                            logits_processors=[], return_hidden=False, ensure_non_empty=True, context=None, seed=None, max_restarts: int = 64,
-                           utt_ids=None, max_new_tokens_per_row=None, rows=None, admit_min=None):
+                           utt_ids=None, max_new_tokens_per_row=None, rows=None, admit_min=None, infer_text: bool = False):
         """generate_many as a generator: yields [(utterance index, ids [n,4] long, hiddens [n,768] or None)] for the utterances that completed
         since the last yield -- while the rest keeps decoding (what was yielded is final: its rows were written before the report that showed
-        the utterance finished) -- and returns (StopIteration.value) the GenerationOutputs of all N utterances."""
+        the utterance finished) -- and returns (StopIteration.value) the GenerationOutputs of all N utterances.
+        `infer_text=True`: the refine-text pass (gpt.py infer_text: the 21178-way text head, one id per step) through the same row re-use; ids are [n]."""
         if not self._finalized:
             raise _lib.HipBackendError("weights not loaded")
         if self._busy_token.owner is not None:
@@ -675,17 +676,17 @@ class GPT:
         try:
             return (yield from self._generate_many(emb, inputs_ids, temperature, eos_token, attention_mask, int(max_new_token), min_new_token, logits_warpers,
                                                    logits_processors, return_hidden, ensure_non_empty, context or Context(), seed, max_restarts, utt_ids,
-                                                   max_new_tokens_per_row, rows, admit_min))
+                                                   max_new_tokens_per_row, rows, admit_min, bool(infer_text)))
         finally:
             self._busy_token.owner = None
 
     def _generate_many(self, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token, logits_warpers, logits_processors,
-                       return_hidden, ensure_non_empty, context, seed, max_restarts, utt_ids, row_limits, rows, admit_min):
+                       return_hidden, ensure_non_empty, context, seed, max_restarts, utt_ids, row_limits, rows, admit_min, infer_text=False):
         lib, h, dev = self._lib, self._h, self.device
         N, T = int(inputs_ids.shape[0]), int(inputs_ids.shape[1])
         H, NVQ = self.model_dim, self.num_vq
         R = min(N, int(rows) if rows else self.max_batch, self.max_batch)
-        sc = sampler_cfg_from_objects(temperature, int(eos_token), max_new_token, min_new_token, logits_warpers, logits_processors, NVQ)
+        sc = sampler_cfg_from_objects(temperature, int(eos_token), max_new_token, min_new_token, logits_warpers, logits_processors, NVQ, infer_text=infer_text)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         mask = torch.ones(N, T, dtype=torch.int32, device=dev) if attention_mask is None else attention_mask.to(dev).to(torch.int32).contiguous()
@@ -749,7 +750,7 @@ class GPT:
                 queue = again + queue                              # first token was EOS (gpt.py:496-525): next noise attempt, ahead of the queue
                 n_done += len(finished_now)
                 if finished_now:
-                    yield [(u, ids[u, :n].to(torch.long), hid[u, :n] if hid is not None else None) for u, n in finished_now]
+                    yield [(u, ids[u, :n, 0].to(torch.long) if infer_text else ids[u, :n].to(torch.long), hid[u, :n] if hid is not None else None) for u, n in finished_now]
                 free = book.free_rows()
                 since_free = since_free + 1 if free else 0
                 if queue and free and (len(free) >= min(admit_min, len(queue)) or since_free >= 4 or len(free) == len(book.row_tk)):
@@ -780,7 +781,7 @@ class GPT:
                         self.compactions.append((launched, len(book.row_tk)))
             torch.cuda.current_stream(dev).synchronize()
             self.saturations = self._report_saturations(h, st, "generate_many()")
-            return self._outputs(ids, hid, end_idx, False)
+            return self._outputs(ids, hid, end_idx, infer_text)
 
     def _staging(self, rows: int, V: int, cap: int):
         """Pinned [cap, rows, V] staging slots for the torch-generator noise, kept across calls (pinning is expensive)."""

@@ -323,13 +323,19 @@ class ChatTTSPlusPipeline:
                             show_tqdm=params.show_tqdm, ensure_non_empty=params.ensure_non_empty, stream_batch=params.stream_batch, **gen_kwargs)
 
     @torch.no_grad()
-    def _refine_text(self, text, params: RefineTextParams):
-        """pipeline:237-277: "[Sbreak]{text}[Pbreak]{prompt}" -> GPT.generate(infer_text=True) on the 21178-way text head."""
+    def _refine_text(self, text, params: RefineTextParams, continuous_rows: int = 0, seed=None, utt_ids=None):
+        """pipeline:237-277: "[Sbreak]{text}[Pbreak]{prompt}" -> GPT.generate(infer_text=True) on the 21178-way text head.
+        `continuous_rows` > 0 (no counterpart in the reference, which refines slice by slice): all sentences of the request through that many decode
+        rows with row re-use (GPT.generate_many, device noise keyed by utterance id: a sentence's refined text does not depend on its neighbours)."""
         gpt, tok = self.models_dict["gpt"], self.models_dict["tokenizer"]
         text = [f"[Sbreak]{i}[Pbreak]{params.prompt}" for i in text]
         input_ids, attention_mask, text_mask = tok.encode(text, gpt.num_vq, device=self.device)
         warpers, processors = gen_logits(num_code=tok.len, top_P=params.top_P, top_K=params.top_K, repetition_penalty=params.repetition_penalty)
         emb = gpt(input_ids, text_mask)
+        if continuous_rows > 0:
+            return gpt.generate_many(emb, input_ids, temperature=torch.tensor([params.temperature]), eos_token=tok.eos_token, attention_mask=attention_mask,
+                                     max_new_token=params.max_new_token, min_new_token=params.min_new_token, logits_warpers=warpers, logits_processors=processors,
+                                     ensure_non_empty=params.ensure_non_empty, seed=seed, utt_ids=utt_ids, rows=continuous_rows, infer_text=True)
         return next(gpt.generate(emb, input_ids, temperature=torch.tensor([params.temperature]), eos_token=tok.eos_token,
                                  attention_mask=attention_mask, max_new_token=params.max_new_token, min_new_token=params.min_new_token,
                                  logits_warpers=warpers, logits_processors=processors, infer_text=True, stream=False,
@@ -460,20 +466,18 @@ class ChatTTSPlusPipeline:
         if kwargs.get("continuous") and len(text_in) > slice_size:
             if stream or lora_paths is not None or noise_mode not in ("auto", "device"):
                 raise _lib.HipBackendError("continuous=True works with stream=False, device noise and without per-utterance adapters")
-            texts_all = []
-            for ii in range(0, len(text_in), slice_size):
-                text = list(text_in[ii:ii + slice_size])
-                if not skip_refine_text:                                               # pipeline:399-411, still in slices (a short pass)
-                    refined = self._refine_text(text, params_refine_text)
-                    text = tok.decode([i[i.less(tok.break_0_ids)] for i in refined.ids])
-                    if refine_text_only:
-                        yield text
-                texts_all += text
-            if refine_text_only:
-                return
-            texts_all = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in texts_all]   # pipeline:414-416
             if noise_seed is None:
                 noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            texts_all = list(text_in)
+            if not skip_refine_text:
+                # pipeline:399-411 for the whole request at once: the refine-text pass keeps `slice_size` rows busy too (its noise is keyed by utterance id on
+                # stream 4, so a sentence is refined to the same text whatever shares the batch with it)
+                refined = self._refine_text(texts_all, params_refine_text, continuous_rows=slice_size, seed=noise_seed, utt_ids=utt_ids)
+                texts_all = tok.decode([i[i.less(tok.break_0_ids)] for i in refined.ids])
+                if refine_text_only:
+                    yield texts_all
+                    return
+            texts_all = [t if t.strip().endswith("[uv_break]") else t + " [uv_break]" for t in texts_all]   # pipeline:414-416
             # continuous=True: utterances are admitted in input order and their waveforms are yielded IN ORDER as soon as a prefix of the request
             # is complete (the first list as early as possible, later ones in groups of >= 8 so that the vocoder runs batched) while the rest keeps
             # decoding.  continuous="throughput": longest texts first (longest-processing-time order: the last rows to finish are short

@@ -99,3 +99,23 @@ def test_repetition_penalty_reaches_every_utterance_of_a_long_queue(gpt):
     assert any(not torch.equal(a, b) for a, b in zip(want[13:], plain[13:])), "the penalty changes nothing on these utterances: the case has no teeth"
     for u in range(144, NU):
         assert torch.equal(many.ids[u], want[u - 144]), f"utterance {u}: continuous batching sampled without the repetition penalty"
+
+
+def test_out_of_range_ids_raise_like_nn_embedding(gpt):
+    """gpt.py:125-149: nn.Embedding raises IndexError on an id outside its table; the gather kernel does not check, so GPT.__call__ does."""
+    g = gpt
+    ids, _ = synth.prompt_ids(2, 6, 21178, 3)
+    tm = torch.ones(2, 6, dtype=torch.bool)
+    g(torch.from_numpy(ids), tm)                                         # fine
+    bad = ids.copy(); bad[1, 2, :] = 21178                               # one past the text table
+    with pytest.raises(IndexError):
+        g(torch.from_numpy(bad), tm)
+    bad = ids.copy(); bad[0, 0, :] = -1
+    with pytest.raises(IndexError):
+        g(torch.from_numpy(bad), tm)
+    code = ids.copy(); code[:, 4:, :] = 625                              # code rows (text_mask 0): ids < 626 per codebook
+    tm2 = tm.clone(); tm2[:, 4:] = False
+    g(torch.from_numpy(code), tm2)
+    code[0, 5, 3] = 626
+    with pytest.raises(IndexError):
+        g(torch.from_numpy(code), tm2)

@@ -159,6 +159,15 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
     full = list(pipe.infer(list(texts), skip_refine_text=False, do_text_optimization=False, params_refine_text=rp,
                            params_infer_code=InferCodeParams(spk_emb=spk, max_new_token=8, min_new_token=8, show_tqdm=False)))
     assert len(full) == 1 and [w.shape[0] for w in full[0]] == [256 * 15, 256 * 15]
+    # continuous=True also serves the refine-text pass through row re-use (round 4): 7 sentences on 2 and on 3 decode rows refine to the same texts
+    # (noise keyed by utterance id on stream 4), and the synthesis that follows keeps its waveform count
+    rp2 = RefineTextParams(max_new_token=9, show_tqdm=False)
+    ref2 = list(pipe.infer(list(many), refine_text_only=True, do_text_optimization=False, params_refine_text=rp2, continuous=True, slice_size=2, noise_seed=5))
+    ref3 = list(pipe.infer(list(many), refine_text_only=True, do_text_optimization=False, params_refine_text=rp2, continuous=True, slice_size=3, noise_seed=5))
+    assert len(ref2) == 1 and len(ref2[0]) == len(many) and ref2 == ref3, (ref2, ref3)
+    both = list(pipe.infer(list(many), do_text_optimization=False, params_refine_text=rp2, params_infer_code=InferCodeParams(spk_emb=spk, max_new_token=6, min_new_token=6, show_tqdm=False),
+                           continuous=True, slice_size=3, noise_seed=5))
+    assert sum(len(l) for l in both) == len(many) and all(w.shape[0] == 256 * 11 for l in both for w in l)
 
     # default text optimisation (text_frontend.split_text + short-sentence merge + Normalizer, pipeline:349-388): two short lines become ONE
     # utterance joined by [uv_break] -- identical to handing that utterance over with the optimisation switched off
@@ -215,6 +224,16 @@ def test_refine_text_generate_golden_bit_exact():
     assert [int(i.shape[0]) for i in out.ids] == z["lens"].tolist()
     for b, n in enumerate(z["lens"]):
         assert np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64)), f"device noise, row {b}"
+    # ... and through continuous batching (round 4: text rows carry the same per-row state as code rows, ctts_gpt_admit serves infer_text): the three
+    # sentences on TWO decode rows -- the third takes over the row of whichever finishes first -- and on one row; every sentence keeps the reference's ids
+    for rows in (2, 1):
+        many = g.generate_many(emb, torch.from_numpy(ids), torch.tensor([0.7]), eos, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]),
+                               min_new_token=int(meta["min_new"]), logits_warpers=w, logits_processors=p, seed=int(meta["noise_seed"]),
+                               utt_ids=[int(u) for u in meta["utt_ids"]], rows=rows, infer_text=True)
+        assert g.admissions, "nothing was admitted"
+        assert [int(i.shape[0]) for i in many.ids] == z["lens"].tolist(), rows
+        for b, n in enumerate(z["lens"]):
+            assert many.ids[b].dim() == 1 and np.array_equal(many.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64)), f"generate_many on {rows} row(s), sentence {b}"
     del g
 
 

@@ -269,3 +269,22 @@ def test_row_book_late_reports_admission_and_compaction():
     assert c.report(c.layout(), [(3, 0)], False, 64) == ([(5, 0)], [])
     with pytest.raises(AssertionError):
         b.seat(1, utt=9)                                # row 1 is occupied (utterance 7)
+
+
+def test_warper_list_must_be_top_p_then_top_k():
+    """The kernel applies top-p first and top-k second -- the order processors.gen_logits builds (models/processors.py:43-48) and gpt.py:474-475 applies;
+    the two do not commute, so any other list is rejected instead of silently re-ordered."""
+    from chatttsplus_amd import _lib
+    from chatttsplus_amd.hip_models.gpt import sampler_cfg_from_objects
+    P = type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))
+    K = type("K", (), dict(top_k=20))
+    sc = sampler_cfg_from_objects([0.3] * 4, 625, 8, 0, [P(), K()], [], 4)
+    assert sc.top_k == 20 and abs(sc.top_p_threshold - 0.3) < 1e-6
+    assert sampler_cfg_from_objects([0.3] * 4, 625, 8, 0, [K()], [], 4).top_p_threshold < 0          # top-k alone / top-p alone stay legal
+    assert sampler_cfg_from_objects([0.3] * 4, 625, 8, 0, [P()], [], 4).top_k == 0
+    with pytest.raises(_lib.HipBackendError, match="top-p, top-k"):
+        sampler_cfg_from_objects([0.3] * 4, 625, 8, 0, [K(), P()], [], 4)
+    with pytest.raises(_lib.HipBackendError, match="more than one top-k"):
+        sampler_cfg_from_objects([0.3] * 4, 625, 8, 0, [P(), K(), K()], [], 4)
+    with pytest.raises(_lib.HipBackendError):
+        sampler_cfg_from_objects([0.3] * 4, 625, 8, 0, [P(), P()], [], 4)
