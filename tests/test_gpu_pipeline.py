@@ -162,11 +162,11 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
     # continuous=True also serves the refine-text pass through row re-use (round 4): 7 sentences on 2 and on 3 decode rows refine to the same texts
     # (noise keyed by utterance id on stream 4), and the synthesis that follows keeps its waveform count
     rp2 = RefineTextParams(max_new_token=9, show_tqdm=False)
-    ref2 = list(pipe.infer(list(many), refine_text_only=True, do_text_optimization=False, params_refine_text=rp2, continuous=True, slice_size=2, noise_seed=5))
-    ref3 = list(pipe.infer(list(many), refine_text_only=True, do_text_optimization=False, params_refine_text=rp2, continuous=True, slice_size=3, noise_seed=5))
+    pc = InferCodeParams(spk_emb=spk, max_new_token=6, min_new_token=6, show_tqdm=False)
+    ref2 = list(pipe.infer(list(many), refine_text_only=True, do_text_optimization=False, params_refine_text=rp2, params_infer_code=pc, continuous=True, slice_size=2, noise_seed=5))
+    ref3 = list(pipe.infer(list(many), refine_text_only=True, do_text_optimization=False, params_refine_text=rp2, params_infer_code=pc, continuous=True, slice_size=3, noise_seed=5))
     assert len(ref2) == 1 and len(ref2[0]) == len(many) and ref2 == ref3, (ref2, ref3)
-    both = list(pipe.infer(list(many), do_text_optimization=False, params_refine_text=rp2, params_infer_code=InferCodeParams(spk_emb=spk, max_new_token=6, min_new_token=6, show_tqdm=False),
-                           continuous=True, slice_size=3, noise_seed=5))
+    both = list(pipe.infer(list(many), do_text_optimization=False, params_refine_text=rp2, params_infer_code=pc, continuous=True, slice_size=3, noise_seed=5))
     assert sum(len(l) for l in both) == len(many) and all(w.shape[0] == 256 * 11 for l in both for w in l)
 
     # default text optimisation (text_frontend.split_text + short-sentence merge + Normalizer, pipeline:349-388): two short lines become ONE
