@@ -107,9 +107,9 @@ struct ctts_gpt {
                                                  // an exact-f32 MFMA costs 32 cycles whatever the number of live columns, 48 of them per SIMD and launch.
                                                  // Measured (us/step, MFMA -> VALU, profiles/r04_ab_valu_rows.jsonl): batch 1 481.9 -> 450.8, 2 491.7 -> 477.5,
                                                  // 3 532.6 -> 555.9, 4 536.7 -> 560.3 (the 4-row variant re-reads four LDS operand rows per weight fragment)
-    int persist_rows = 0;                        // fp32 engines (default 3, set at create): decode batches of <= this many rows run the decoder stack as ONE persistent
-                                                 // launch (persist_layer.hip).  us/step, launch chain -> persistent (profiles/r04_persist_probe_v3_no_spills.jsonl,
-                                                 // r04_ab_persist_options.jsonl): batch 1 451 -> 379, batch 2 480 -> 431, batch 4 540 -> 538 (break-even: stays on launches)
+    int persist_rows = 0;                        // fp32 engines (default 4, set at create): decode batches of <= this many rows run the decoder stack as ONE persistent
+                                                 // launch (persist_layer.hip).  us/step, launch chain -> persistent (profiles/r04_ab_persist_options.jsonl):
+                                                 // batch 1 452 -> 285, batch 2 480 -> 347, batch 4 540 -> 467
     char* pimg = nullptr;                        //   per-workgroup register images of the layer weights [L][192][192 KB], built on the device from the packed tiles
     unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
     unsigned* pl_epoch = nullptr;                //   launch counter = granule tag
@@ -118,7 +118,14 @@ struct ctts_gpt {
     int cur_persist = 0;                         //   the steps being launched use the persistent layer
     int pl_ts_on = 0;
     int persist_lpl = 0;                         //   decoder layers per persistent launch (0 = all of them in one launch)
-    int persist_sched = 1;                       //   weight request schedule (PersistArgs.sched): 1 and 2 measure the same (389.3 / 389.5 us at batch 1, 436.0 / 436.4 at 2)
+    int persist_sched = 3;                       //   weight request schedule (PersistArgs.sched): 1 and 2 measure the same (389.3 / 389.5 us at batch 1, 436.0 / 436.4 at 2);
+                                                 //   3 = paced requests: batch 1 373.0 -> 337.4, 2 425.7 -> 404.0, 3 490.1 -> 467.6 (profiles/r04_ab_persist_options.jsonl)
+    int persist_pace = 3;                        //   PersistArgs.pace (us/step at batch 1 before the poll delays: 0 -> 356, 2 -> 342, 3 -> 337.5, 4 -> 339, 6 -> 341, 8 -> 354.6; with them 2 / 3 / 4 / 6: 285.0 / 286.6 / 293.0 / 297.7)
+    // ~128-cycle units an edge wave sleeps before its first poll of the (x + attention) / act / layer-output edge: a pass that starts before the producers'
+    // stores are visible fails and costs a whole extra pass, and its loads sit in the queues of the very stores it waits for.  us/step at batch 1 with all three at
+    // 0 / 6 / 10 / 14 / 18 / 24 / 32: 334.9 / 307.6 / 288.8 / 281.6 / 286.5 / 295.9 / 316.3; batch 2 at 0 / 12: 402.3 / 346.9; batch 4: 521.2 / 467.4.
+    // One at a time around 14 each curve is flat from 11 to 17 (profiles/r04_ab_persist_options.jsonl).  The attention edge needs none (its wait is long).
+    int persist_delay_att = 0, persist_delay = 12, persist_delay_act = 16, persist_delay_x = 15, persist_nap = 1, persist_nap_qkv = 1;
     int persist_poll = -1;                       //   PersistArgs.poll; -1 = by row count: the sentinel pass costs one serial poll at 1-2 rows (batch 1 379.2 -> 387.1 us,
                                                  //   batch 2 430.7 -> 437.8) and pays from 3 rows on, where a full sweep re-reads up to 96 granules per lane (batch 4 547.5 -> 537.6)
     int no_prepack = 0, prefill_gemm_rows = 1536, xh_heads = 1;   // diagnostic builds only: see run_layers / run_decode_step
@@ -191,7 +198,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = (c->dtype == CTTS_DTYPE_F16) ? 8 : 16;
-    h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 3 : 0;
+    h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 4 : 0;
     h->down_sk_rows = (c->dtype == CTTS_DTYPE_F16) ? 9 : 17;     // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
     // product library takes no behaviour from the environment on its launch paths (diag_env() is a constant null there).
@@ -291,7 +298,21 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
     } else if (n == "persistent_layers_per_launch") {      // 0 = the whole stack in one launch (default); 1 = one launch per layer
         h->persist_lpl = value < 0 ? 0 : value;
     } else if (n == "persistent_schedule") {               // 1 / 2: see persist_layer.hip
-        h->persist_sched = (value == 1) ? 1 : 2;
+        h->persist_sched = (value >= 1 && value <= 3) ? value : 1;
+    } else if (n == "persistent_pace") {                   // SCHED 3: ~128-cycle units between two paced weight requests of a wave
+        h->persist_pace = value < 0 ? 0 : (value > 64 ? 64 : value);
+    } else if (n == "persistent_delay_att") {
+        h->persist_delay_att = value < 0 ? 0 : (value > 256 ? 256 : value);
+    } else if (n == "persistent_delay") {
+        h->persist_delay = value < 0 ? 0 : (value > 256 ? 256 : value);
+    } else if (n == "persistent_delay_act") {
+        h->persist_delay_act = value < 0 ? 0 : (value > 256 ? 256 : value);
+    } else if (n == "persistent_delay_x") {
+        h->persist_delay_x = value < 0 ? 0 : (value > 256 ? 256 : value);
+    } else if (n == "persistent_nap_qkv") {
+        h->persist_nap_qkv = value < 0 ? 0 : (value > 256 ? 256 : value);
+    } else if (n == "persistent_nap") {
+        h->persist_nap = value < 0 ? 0 : (value > 256 ? 256 : value);
     } else if (n == "persistent_poll") {                   // bit 0: sentinel granules before the full sweeps
         h->persist_poll = value < 0 ? -1 : (value & 1);
     } else if (n == "persistent_timestamps") {   // diagnostics: every workgroup of a persistent launch records wall_clock64 marks (ctts_gpt_debug_read "pl_ts")
@@ -792,7 +813,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
             pa.kv = kv_layer(h, l, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
             pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1; pa.g_x = pa.g_act + PL_G_ACT;
-            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched; pa.poll = (h->persist_poll < 0) ? (R >= 3 ? 1 : 0) : h->persist_poll;
+            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched; pa.pace = h->persist_pace; pa.delay_att = h->persist_delay_att; pa.delay = h->persist_delay; pa.delay_act = h->persist_delay_act; pa.delay_x = h->persist_delay_x; pa.nap = h->persist_nap; pa.nap_qkv = h->persist_nap_qkv; pa.poll = (h->persist_poll < 0) ? 0 : h->persist_poll;
             if (launch_persist_layer(R, pa, s)) return 1;
         }
         return 0;

@@ -46,6 +46,10 @@ struct PersistArgs {
     unsigned long long* ts;         // diagnostics: [256][10] wall_clock64 marks per workgroup (last layer), or null
     float eps;
     int sched;                      // weight request schedule of the compute waves (persist_layer.hip: 1 or 2)
+    int pace;                       // SCHED 3: s_sleep(2) units (~128 cycles each) between two paced weight requests of a compute wave
+    int delay_act, delay_x, nap_qkv;   // (x1 edge: delay; act edge: delay_act; layer-output edge: delay_x; poll interval of the attention workgroups' q|k|v sweep)
+    int delay_att, delay;           // ~128-cycle units an edge wave sleeps before it starts polling the attention edge / the other edges (the data cannot be there yet)
+    int nap;                        // ~128-cycle units between two poll passes of a GEMV edge wave
     int poll;                       // bit 0: watch one sentinel granule per producer before the full sweep of an edge
 };
 

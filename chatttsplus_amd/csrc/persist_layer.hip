@@ -33,7 +33,7 @@ __device__ inline void store_granule(u64* g, unsigned tag, float v) {
 // version let hipcc hoist a separate 64-bit address pair per granule of every edge out of the layer loop: ~100 VGPRs alive through the loop, spills).
 // Returns false after PL_SPIN_LIMIT passes or once the workgroup / the engine has given up.
 template <int N, typename OffFn>
-__device__ inline bool sweep(const u64* base, unsigned lane_elem, OffFn off, unsigned tag, float (&v)[N], int* err, int code, volatile int* abort_s) {
+__device__ inline bool sweep(const u64* base, unsigned lane_elem, OffFn off, unsigned tag, float (&v)[N], int* err, int code, volatile int* abort_s, int nap = 1) {
     const u64* p = base + lane_elem;
     asm volatile("" : "+v"(p));
 #pragma unroll 1
@@ -52,7 +52,7 @@ __device__ inline bool sweep(const u64* base, unsigned lane_elem, OffFn off, uns
             if ((threadIdx.x & 63) == 0) { atomicCAS(err, 0, code); *abort_s = 1; }
             return false;
         }
-        __builtin_amdgcn_s_sleep(2);
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
     }
 }
 
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
     float* const red = xs + R * PL_I;                     // compute waves' results [8 waves][4 slots][R]
     float* const ssq = red + 8 * 4 * R;                   // sums of squares of the gathered rows [2 edge waves][R]
     float* const xres = ssq + 2 * R;                      // this workgroup's 4 columns of the residual stream [R][4] (x, later x + attention, then the layer output)
-    int* const abort_s = (int*)(xres + 4 * R);            // [4]
+    int* const abort_s = (int*)(xres + 4 * R);            // [4]: [0] give-up flag, [1] SCHED 3: gathers completed by the edge waves (2 per phase)
     float* const att_s = (float*)(abort_s + 4);           // attention workgroups: q[64] | k_new[64] | v_new[64] | merge[8][8][10]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
     unsigned long long t_mark[10];
 #define PL_MARK(i) do { if (a.ts != nullptr) t_mark[i] = wall_clock64(); } while (0)
     PL_MARK(0);
-    if (tid == 0) abort_s[0] = 0;
+    if (tid == 0) { abort_s[0] = 0; abort_s[1] = 0; }
 
     if (b < PL_GEMV_BLOCKS) {
         const char* wb = a.w + (size_t)b * PL_BLOCK_BYTES;
@@ -128,6 +128,120 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
             __builtin_amdgcn_sched_barrier(0);
             if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;      // every sequence finished (gpt.py:545) / an earlier launch gave up: the same for every workgroup
             __syncthreads();                                  // S0
+            if constexpr (SCHED == 3) {
+                // Paced requests: instead of sleeping in a barrier while the edge waves gather, a compute wave requests ONE weight fragment (1 KB) every
+                // ~0.27 us until the gather is complete (then the rest at once).  8 waves x 1 KB per interval = the rate one CU drains anyway, so the
+                // queue in front of the edge waves' polls stays a few KB deep instead of a 50-100 KB burst.  Each array is requested during the wait
+                // that precedes the phase BEFORE its use: o_proj(l) while x is gathered, gate|up(l) during the attention wait, down(l) during the
+                // (x + attention) wait, q|k|v(l+1) during the act wait -- at most 18 of the 27 fragments are live at once.
+                typedef __attribute__((address_space(3))) int lds_int;
+                lds_int* const arrive = (lds_int*)(abort_s + 1);
+                int phase = 0;
+                const int pace = a.pace;                      // x 128 cycles between two requests of a wave
+#define PL_PACE_BEGIN() const int tgt_ = 2 * (++phase); bool ready_ = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= tgt_
+#define PL_PIECE(stmt_) do { stmt_; if (!ready_) { for (int z_ = 0; z_ < pace; ++z_) __builtin_amdgcn_s_sleep(2); ready_ = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= tgt_; } } while (0)
+#define PL_PACE_END() do { while (!ready_) { __builtin_amdgcn_s_sleep(1); ready_ = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= tgt_; } asm volatile("" ::: "memory"); } while (0)
+                for (int l = 0; l < NL; ++l) {
+                    const char* const wn = wb + PL_LAYER_BYTES;
+                    const bool more = l + 1 < NL;
+                    f32x4 xr[R][3];
+                    // ---- wait for x, requesting o_proj(l); phase A
+                    {
+                        PL_PACE_BEGIN();
+                        if (wave < 4) {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) PL_PIECE(o_w[j] = __builtin_nontemporal_load((const f32x4*)wb + oo + j * 64));
+                        }
+                        PL_PACE_END();
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+                    if (wave < 6) {
+#pragma unroll
+                        for (int row = 0; row < 2; ++row)
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                float acc = 0.f;
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) acc = dot4(q_w[row][j], xr[r][j], acc);
+                                acc = wave_sum(acc);
+                                if (lane == 0) red[(wave * 4 + row) * R + r] = acc;
+                            }
+                    }
+                    __syncthreads();                          // B2(A)
+                    // ---- wait for the attention output, requesting gate|up(l); phase C
+                    {
+                        PL_PACE_BEGIN();
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) PL_PIECE(g_w[s][j] = __builtin_nontemporal_load((const f32x4*)wb + og + (s * 3 + j) * 64));
+                        PL_PACE_END();
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+                    if (wave < 4) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc = dot4(o_w[j], xr[r][j], acc);
+                            acc = wave_sum(acc);
+                            if (lane == 0) red[(wave * 4) * R + r] = acc;
+                        }
+                    }
+                    __syncthreads();                          // B2(C)
+                    // ---- wait for x + attention, requesting down(l); phase D
+                    {
+                        PL_PACE_BEGIN();
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) PL_PIECE(d_w[j] = __builtin_nontemporal_load((const f32x4*)wb + od + j * 64));
+                        PL_PACE_END();
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc = dot4(g_w[s][j], xr[r][j], acc);
+                            acc = wave_sum(acc);
+                            if (lane == 0) red[(wave * 4 + s) * R + r] = acc;
+                        }
+                    __syncthreads();                          // B2(D)
+                    // ---- wait for silu(gate) * up, requesting q|k|v(l+1); phase E
+                    {
+                        PL_PACE_BEGIN();
+                        if (more && wave < 6) {
+#pragma unroll
+                            for (int row = 0; row < 2; ++row)
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) PL_PIECE(q_w[row][j] = __builtin_nontemporal_load((const f32x4*)wn + oq + (row * 3 + j) * 64));
+                        }
+                        PL_PACE_END();
+                    }
+                    const int half = wave & 1;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc = dot4(d_w[j], ((const f32x4*)(xs + r * PL_I))[384 * half + 64 * j + lane], acc);
+                        acc = wave_sum(acc);
+                        if (lane == 0) red[(wave * 4) * R + r] = acc;
+                    }
+                    __syncthreads();                          // B2(E)
+                    wb = wn;
+                }
+                return;
+            }
             for (int l = 0; l < NL; ++l) {
                 const char* const wn = wb + PL_LAYER_BYTES;   // next layer's image
                 const bool more = l + 1 < NL;
@@ -224,6 +338,10 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
             }
         } else {
             // ------------------------------------------------ edge wave: gathers, epilogues, publishing
+#define PL_B1() do { if (SCHED == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(abort_s + 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } \
+        else __syncthreads(); } while (0)
+
             const int ew = wave - 8, e = ew * 64 + lane;      // 0..127
             const int hh = b >> 4, jj = b & 15;               // q | k | v rows of this workgroup: head hh, dims (2jj, 2jj+1, +32) / v dims 4jj..4jj+3
             // epilogue operands of phase A (the same in every layer), requested now
@@ -276,10 +394,11 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 const bool last = l + 1 == NL;
                 if (l > 0) {
                     // ---- edge 1: the previous layer's output, published by the 192 GEMV workgroups -> xs, sums of squares
+                    for (int z = 0; z < a.delay_x; ++z) __builtin_amdgcn_s_sleep(2);
                     // (producers of this wave's columns e + 128 k: workgroups 16 (2 m + ew) + t; each stores its 4 columns of every row in one instruction)
                     if (a.poll & 1) watch_sentinels(a.g_x, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag - 1u, lane, abort_s);
                     float v[6 * R];
-                    const bool got = sweep<6 * R>(a.g_x, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag - 1u, v, a.error, 1, abort_s);
+                    const bool got = sweep<6 * R>(a.g_x, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag - 1u, v, a.error, 1, abort_s, a.nap);
                     (void)got;
 #pragma unroll
                     for (int r = 0; r < R; ++r) ssp[r] = 0.f;
@@ -295,7 +414,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     }
                 }
                 if (last) PL_MARK(2);
-                __syncthreads();                              // B1(A)
+                PL_B1();                                      // B1(A): the gather is in LDS
                 __syncthreads();                              // B2(A)
                 if (doA) {
                     const float rs = 1.0f / sqrtf((ssq[rA] + ssq[R + rA]) / (float)PL_H + a.eps);          // llama.py:82-87 (the weight is folded into W's columns)
@@ -319,17 +438,18 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 }
                 if (last) PL_MARK(3);
                 // ---- phase C: attention output -> o_proj + residual
+                for (int z = 0; z < a.delay_att; ++z) __builtin_amdgcn_s_sleep(2);      // the attention cannot have published yet: do not poll into the weight stream
                 {
                     // (this wave's columns belong to the heads 2 m + ew: one sentinel per (row, head))
                     if (a.poll & 1) watch_sentinels(a.g_att, [ew](int i) { return (i / 6) * PL_H + 64 * (2 * (i % 6) + ew) + 63; }, 6 * R, tag, lane, abort_s);
                     float v[6 * R];
-                    const bool got = sweep<6 * R>(a.g_att, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, v, a.error, 3, abort_s);
+                    const bool got = sweep<6 * R>(a.g_att, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, v, a.error, 3, abort_s, a.nap);
                     (void)got;
 #pragma unroll
                     for (int k = 0; k < 6 * R; ++k) xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
                 }
                 if (last) PL_MARK(4);
-                __syncthreads();                              // B1(C)
+                PL_B1();                                      // B1(C): the gather is in LDS
                 __syncthreads();                              // B2(C)
                 if (e < 4 * R) {
                     const int i = e & 3, r = e >> 2;
@@ -339,10 +459,11 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 }
                 if (last) PL_MARK(5);
                 // ---- phase D: x + attention -> RMSNorm, gate | up, SiLU * up
+                for (int z = 0; z < a.delay; ++z) __builtin_amdgcn_s_sleep(2);
                 {
                     if (a.poll & 1) watch_sentinels(a.g_x1, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag, lane, abort_s);
                     float v[6 * R];
-                    const bool got = sweep<6 * R>(a.g_x1, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, v, a.error, 4, abort_s);
+                    const bool got = sweep<6 * R>(a.g_x1, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, v, a.error, 4, abort_s, a.nap);
                     (void)got;
 #pragma unroll
                     for (int r = 0; r < R; ++r) ssp[r] = 0.f;
@@ -358,7 +479,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     }
                 }
                 if (last) PL_MARK(6);
-                __syncthreads();                              // B1(D)
+                PL_B1();                                      // B1(D): the gather is in LDS
                 __syncthreads();                              // B2(D)
                 if (e < 16 * R) {
                     const int pi = e & 15, r = e >> 4, w = pi >> 1, p = pi & 1;
@@ -368,18 +489,19 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 }
                 if (last) PL_MARK(7);
                 // ---- phase E: silu(gate) * up [R][3072] -> down + residual
+                for (int z = 0; z < a.delay_act; ++z) __builtin_amdgcn_s_sleep(2);
                 // (producers of this wave's columns e + 128 k: workgroups 8 k + 4 ew + t, t < 4; each stores its 16 columns of every row in one instruction)
                 if (a.poll & 1) watch_sentinels(a.g_act, [ew](int i) { return (R - 1) * PL_I + 16 * (8 * (i >> 2) + 4 * ew + (i & 3)) + 15; }, 96, tag, lane, abort_s);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float v[24];
-                    const bool got = sweep<24>(a.g_act, (unsigned)(r * PL_I + e), [](int k) { return 128 * k; }, tag, v, a.error, 5, abort_s);
+                    const bool got = sweep<24>(a.g_act, (unsigned)(r * PL_I + e), [](int k) { return 128 * k; }, tag, v, a.error, 5, abort_s, a.nap);
                     (void)got;
 #pragma unroll
                     for (int k = 0; k < 24; ++k) xs[r * PL_I + 128 * k + e] = v[k];
                 }
                 if (last) PL_MARK(8);
-                __syncthreads();                              // B1(E)
+                PL_B1();                                      // B1(E): the gather is in LDS
                 __syncthreads();                              // B2(E)
                 if (e < 4 * R) {
                     const int i = e & 3, r = e >> 2;
@@ -511,7 +633,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
         for (int l = 0; l < NL; ++l) {
             const unsigned tag = tag0 + (unsigned)l;
             float v[3];
-            const bool got = sweep<3>(a.g_qkv, (unsigned)((r * PL_NH + hh) * 192 + lane), [](int k) { return 64 * k; }, tag, v, a.error, 2, abort_s);
+            const bool got = sweep<3>(a.g_qkv, (unsigned)((r * PL_NH + hh) * 192 + lane), [](int k) { return 64 * k; }, tag, v, a.error, 2, abort_s, a.nap_qkv);
             (void)got;
             qs[lane] = v[0] * 0.125f;                         // 1 / sqrt(64) (llama.py:653-661)
             ks[lane] = v[1];
@@ -616,9 +738,9 @@ static int persist_launch_r(int R, const PersistArgs& a, hipStream_t s, bool cfg
 
 int persist_configure() {
     PersistArgs a = {};
-    return persist_launch_r<1>(1, a, nullptr, true) | persist_launch_r<2>(1, a, nullptr, true);
+    return persist_launch_r<1>(1, a, nullptr, true) | persist_launch_r<2>(1, a, nullptr, true) | persist_launch_r<3>(1, a, nullptr, true);
 }
 
 int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s) {
-    return (a.sched == 1) ? persist_launch_r<1>(R, a, s, false) : persist_launch_r<2>(R, a, s, false);
+    return (a.sched == 1) ? persist_launch_r<1>(R, a, s, false) : (a.sched == 2) ? persist_launch_r<2>(R, a, s, false) : persist_launch_r<3>(R, a, s, false);
 }

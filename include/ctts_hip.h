@@ -64,11 +64,13 @@ void ctts_gpt_destroy(ctts_gpt* h);
  * the engine is built, trt_models/llama_trt_model.py:25-81).  Explicit calls only: the product library reads no behaviour from the environment.
  *   "prefill_split_rows"  fp32 engines: prompt passes of >= this many rows use the 3-term fp16 split GEMMs (default 384; 0 = never; before finalize)
  *   "valu_rows"           fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (default 2; 0..4)
- *   "persistent_rows"     fp32 engines: decode batches of <= this many rows (<= 4; default 3) run the whole decoder stack of a step as ONE persistent
+ *   "persistent_rows"     fp32 engines: decode batches of <= this many rows (<= 4; default 4) run the whole decoder stack of a step as ONE persistent
  *                         launch of 256 resident workgroups (persist_layer.hip; contexts up to 1024 keys, no per-utterance adapters).  0 = off.  The first
  *                         process that loads an fp32 engine on a device holds the mode (advisory lock /tmp/ctts_persist_<pci>.lock); others stay on launches
  *   "persistent_layers_per_launch"  0 = the whole stack in one launch (default), n = n layers per launch
- *   "persistent_schedule" weight request schedule of the persistent launch (1 / 2, default 1)       "persistent_poll"  -1 (by row count) / 0 / 1: sentinel granules
+ *   "persistent_schedule" weight request schedule of the persistent launch (1 / 2 / 3, default 3 = paced requests)    "persistent_pace"  its pacing interval
+ *   "persistent_delay", "persistent_delay_act", "persistent_delay_x", "persistent_delay_att", "persistent_nap", "persistent_nap_qkv"  when and how often the edge waves poll
+ *   "persistent_poll"     0 / 1: sentinel granules before the full sweeps (default 0)
  *   "persistent_timestamps" diagnostics: the persistent launches record per-workgroup phase marks
  *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection up to this batch size
  *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 17; 0 = never)

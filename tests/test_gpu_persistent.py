@@ -36,14 +36,14 @@ def _gen(g, B, P, N, pad=None, lp=LP, seed=7):
 
 def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
     g = gpt
-    assert g.get_option("persistent_rows") == 3, "fp32 engines serve up to three decode rows through the persistent launch by default"
+    assert g.get_option("persistent_rows") == 4, "fp32 engines serve up to four decode rows through the persistent launch by default"
     cases = [(1, 48, 96, None), (1, 600, 24, None), (1, 1000, 40, None),        # ... a context that crosses 1024 keys hands over to the launch path mid-generation
              (2, 40, 32, [0, 9]), (3, 33, 24, [0, 5, 17]), (4, 48, 24, [3, 0, 11, 20])]
     for (B, P, N, pad) in cases:
         g.set_option("persistent_rows", 0)
         ref_ids, ref_h = _gen(g, B, P, N, pad)
         variants = [dict(persistent_rows=4), dict(persistent_rows=4, persistent_layers_per_launch=1), dict(persistent_rows=4, persistent_schedule=2, persistent_poll=1),
-                    dict(persistent_rows=4, persistent_poll=0)]
+                    dict(persistent_rows=4, persistent_schedule=1, persistent_poll=0), dict(persistent_rows=4, persistent_schedule=3, persistent_delay=0, persistent_delay_act=0, persistent_delay_x=0)]
         for v in variants:
             for k, val in v.items():
                 g.set_option(k, val)
@@ -52,9 +52,10 @@ def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
                 assert torch.equal(ids[b], ref_ids[b]), f"B={B} P={P} {v}: row {b} tokens differ from the launch path"
                 assert float((hid[b] - ref_h[b]).abs().max()) <= 5e-5, (B, P, v, b)
             g.set_option("persistent_layers_per_launch", 0)
-            g.set_option("persistent_schedule", 1)
-            g.set_option("persistent_poll", -1)
-    g.set_option("persistent_rows", 3)
+            g.set_option("persistent_schedule", 3)
+            g.set_option("persistent_poll", 0)
+            g.set_option("persistent_delay", 12); g.set_option("persistent_delay_act", 16); g.set_option("persistent_delay_x", 15)
+    g.set_option("persistent_rows", 4)
 
 
 def test_persistent_launch_replay_is_bitwise_reproducible_and_graph_equals_eager(gpt):
@@ -69,7 +70,7 @@ def test_persistent_launch_replay_is_bitwise_reproducible_and_graph_equals_eager
         g.use_graph = True
     assert torch.equal(a_ids[0], b_ids[0]) and torch.equal(a_h[0], b_h[0]), "two replays differ (fixed reduction orders, no atomics on the data path)"
     assert torch.equal(a_ids[0], c_ids[0]) and torch.equal(a_h[0], c_h[0]), "hipGraph replay != eager launches"
-    g.set_option("persistent_rows", 3)
+    g.set_option("persistent_rows", 4)
 
 
 def test_repetition_penalty_reaches_every_utterance_of_a_long_queue(gpt):
