@@ -464,6 +464,7 @@ def main():
     ap.add_argument("--gen-tokens", type=int, default=GEN_TOKENS, help="length of the generation the timed window is centred in (0: the window starts right after the warm-up; used by the short profiler passes)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (batch 32, mixed prompts, 512-token prompt, LoRA)")
     ap.add_argument("--extra-steps", type=int, default=128, help="timed steps of each extra leg")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="engine option (ctts_gpt_set_option) for A/B runs, e.g. --option persistent_rows=0")
     ap.add_argument("--request-utterances", type=int, default=256, help="utterances of the sharded-request leg (BASELINE configs[3]: 256)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank control flow (no HIP work, fake timing); used by tests/test_bench_dryrun.py")
     args = ap.parse_args()
@@ -497,6 +498,9 @@ def main():
     need_seq = max(P, 512 if (extras and world == 1) else (96 if extras else 0)) + W + max(GEN_TOKENS, args.gen_tokens, K) + 16     # (96: the sharded request's longest prompt)
     g = GPT(LLAMA, max_batch=max(B, EB if extras else 1), max_seq_len=need_seq, weight_dtype=args.dtype, device=str(dev))
     g.load_state_dict(sd)
+    for kv in args.option:
+        k, v = kv.split("=")
+        g.set_option(k, int(v))
     # speaker table (4 distinct speakers) lives on rank 0 and is broadcast over xGMI -- the path's only collective;
     # sequence b of every batch speaks with speaker b % 4
     spk = (torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev) if rank == 0 else torch.zeros(4, 768, device=dev))
@@ -619,14 +623,15 @@ def main():
             extra["error"] = f"{type(ex).__name__}: {ex}"
 
     if rank == 0:
-        traffic = None
-        try:      # HBM bytes/step from the committed rocprofv3 PMC passes (profiles/), same kernels and batch; not live
-            for rr in ("r03", "r02", "r01"):
-                fp = os.path.join(ROOT, "profiles", f"{rr}_pmc_traffic.json")
-                if os.path.exists(fp):
-                    traffic = json.load(open(fp)).get(f"b{B}_{args.dtype}", {}).get("hbm_bytes_per_step")
-                    if traffic:
-                        break
+        traffic, traffic_note = None, None
+        try:      # HBM bytes/step from the committed rocprofv3 PMC passes (profiles/): same kernels, same batch, same context as the timed window; not live
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            ent = tj.get(f"b{B}_{args.dtype}" + ("" if persist_rows >= B else "_launch_chain"))
+            if ent:
+                traffic = ent.get("hbm_bytes_per_step")
+                traffic_note = (f"PMC FETCH_SIZE (x2, the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per decode step, separate rocprofv3 --pmc passes of "
+                                f"`{ent.get('command')}` (profiles/r04_pmc_*.json): mean context {ent.get('mean_context')} = the timed window's; "
+                                f"{ent.get('traffic_over_algorithmic')} x the algorithmic bytes")
         except Exception:
             pass
         step_bytes = r["step_bytes"]
@@ -643,11 +648,11 @@ def main():
                                    f"random-init weights of the real 20x768 architecture",
                        "batch_per_gpu": B, "prompt_len": P, "untimed_steps_before_window": r["s0"], "weights": args.dtype, "kv_cache": args.dtype,
                        "accumulate": "f32", "hipgraph": bool(use_graph), "parallelism": f"replicas x{world} (utterance sharding)",
-                       "decode_path": ("persistent launch (20 layers = 1 launch, persist_layer.hip)" if (persist_rows >= B and r["mean_ctx"] + K / 2 <= 1024)
-                                       else "launch chain (5 launches per layer)"), "persistent_rows": persist_rows},
+                       "decode_path": ("persistent launch (20 layers = 1 launch, persist_layer.hip)" if persist_rows >= B else "launch chain (5 launches per layer)"),
+                       "persistent_rows": persist_rows},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_note": "PMC FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE bytes per step from profiles/r0N_pmc_*.json (separate rocprofv3 --pmc passes on a short generation: mean context ~98, i.e. ~14 MB less KV traffic per sequence and step than the timed window's)",
+                         "traffic_note": traffic_note,
                          "per": "decode step (one hipGraph replay = 4 steps); the persistent path is one layer-stack launch + heads + sampler per step",
                          "algorithmic_bytes_per_step": int(step_bytes), "step_ms_hip_events": round(step_ms, 5)},
             "rtf_decode_only": round(B * K * world * (512 / 24000.0) / dt, 2),

@@ -117,6 +117,7 @@ struct ctts_gpt {
     unsigned long long* pl_ts = nullptr;         //   diagnostics: per-workgroup phase marks of the last launch ("persistent_timestamps")
     int cur_persist = 0;                         //   the steps being launched use the persistent layer
     int pl_ts_on = 0;
+    int persist_splits = 0;                      //   cap on the attention's key splits per (row, head) (0 = PL_SMAX); "persistent_splits"
     int persist_lpl = 0;                         //   decoder layers per persistent launch (0 = all of them in one launch)
     int persist_sched = 3;                       //   weight request schedule (PersistArgs.sched): 1 and 2 measure the same (389.3 / 389.5 us at batch 1, 436.0 / 436.4 at 2);
                                                  //   3 = paced requests: batch 1 373.0 -> 337.4, 2 425.7 -> 404.0, 3 490.1 -> 467.6 (profiles/r04_ab_persist_options.jsonl)
@@ -299,6 +300,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->persist_lpl = value < 0 ? 0 : value;
     } else if (n == "persistent_schedule") {               // 1 / 2: see persist_layer.hip
         h->persist_sched = (value >= 1 && value <= 3) ? value : 1;
+    } else if (n == "persistent_splits") {
+        h->persist_splits = value < 0 ? 0 : (value > PL_SMAX ? PL_SMAX : value);
     } else if (n == "persistent_pace") {                   // SCHED 3: ~128-cycle units between two paced weight requests of a wave
         h->persist_pace = value < 0 ? 0 : (value > 64 ? 64 : value);
     } else if (n == "persistent_delay_att") {
@@ -812,7 +815,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             pa.w = h->pimg + PL_LAYER_BYTES * l; pa.n_layers = (h->L - l < per) ? h->L - l : per;
             pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
             pa.kv = kv_layer(h, l, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
-            pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1; pa.g_x = pa.g_act + PL_G_ACT;
+            pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1; pa.g_x = pa.g_act + PL_G_ACT; pa.g_part = pa.g_x + PL_G_X; pa.S = h->cur_persist;
             pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched; pa.pace = h->persist_pace; pa.delay_att = h->persist_delay_att; pa.delay = h->persist_delay; pa.delay_act = h->persist_delay_act; pa.delay_x = h->persist_delay_x; pa.nap = h->persist_nap; pa.nap_qkv = h->persist_nap_qkv; pa.poll = (h->persist_poll < 0) ? 0 : h->persist_poll;
             if (launch_persist_layer(R, pa, s)) return 1;
         }
@@ -1050,8 +1053,17 @@ static int advance_rows(ctts_gpt* h, int n_steps) {
 
 // The steps about to be launched run their layers as persistent launches: small fp32 batches without per-utterance adapters whose longest context stays
 // within what one workgroup per (row, head) serves.
+// Returns the key splits per (row, head) (0 = launch chain): as many shares as keep every share within what a workgroup prefetches, at most 64 / (12 B) and
+// PL_SMAX; a context beyond twice that many prefetchable keys goes back to the launch chain (its attention spreads the keys over up to 96 workgroups).
 static inline int decode_persist(const ctts_gpt* h, int B, int L) {
-    return (h->persist_rows > 0 && h->pimg != nullptr && h->cfg.dtype == CTTS_DTYPE_F32 && B <= h->persist_rows && !h->lora_rows && L <= PL_MAX_CONTEXT) ? 1 : 0;
+    if (!(h->persist_rows > 0 && h->pimg != nullptr && h->cfg.dtype == CTTS_DTYPE_F32 && B <= h->persist_rows && B <= PL_MAXR && !h->lora_rows)) return 0;
+    int cap = PL_ATT_BLOCKS / (PL_NH * B);
+    cap = cap > PL_SMAX ? PL_SMAX : (cap < 1 ? 1 : cap);
+    if (h->persist_splits > 0) cap = h->persist_splits < cap ? h->persist_splits : cap;
+    if (L > 2 * PL_SHARE_KEYS * cap + 256) return 0;
+    if (L <= PL_SHARE_KEYS + 128) return 1;                 // (one streamed iteration costs less than the extra hop)
+    const int want = (L + PL_SHARE_KEYS - 1) / PL_SHARE_KEYS;
+    return want > cap ? cap : want;
 }
 
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {

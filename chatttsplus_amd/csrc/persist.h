@@ -10,7 +10,7 @@
 #define PL_I 3072
 #define PL_NH 12
 #define PL_MAXR 4
-#define PL_MAX_CONTEXT 1024                // longest context served (one workgroup per (row, head): 384 keys prefetched, the rest streamed)
+#define PL_SHARE_KEYS 384                  // cached keys a workgroup requests before the query exists; a longer share streams behind the query
 // per-workgroup weight image of one layer: 12 q|k|v rows, 4 o_proj rows, 16 gate|up pairs, 4 down rows (fp32)
 #define PL_QKV_BYTES (12 * 768 * 4)
 #define PL_O_BYTES (4 * 768 * 4)
@@ -24,7 +24,9 @@
 #define PL_G_X1 (PL_MAXR * PL_H)
 #define PL_G_ACT (PL_MAXR * PL_I)
 #define PL_G_X (PL_MAXR * PL_H)
-#define PL_G_TOTAL (PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT + PL_G_X)
+#define PL_SMAX 5                           // key splits per (row, head): 12 rows x heads x splits <= 64 attention workgroups
+#define PL_G_PART (PL_ATT_BLOCKS * 66)
+#define PL_G_TOTAL (PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT + PL_G_X + PL_G_PART)
 
 struct PersistArgs {
     const char* w;                  // layer 0's image [192][PL_BLOCK_BYTES]; layer l at + l * PL_LAYER_BYTES
@@ -40,6 +42,8 @@ struct PersistArgs {
     unsigned long long* g_x1;       // [R][768]
     unsigned long long* g_act;      // [R][3072]
     unsigned long long* g_x;        // [R][768] a layer's output on its way to the next layer
+    unsigned long long* g_part;     // [(row, head) x S][max | sum | o 64] attention partials of the key splits (S > 1)
+    int S;                          // key splits per (row, head), 1..PL_SMAX, 12 R S <= 64
     unsigned* epoch;                // launch counter (never 0)
     int* error;                     // 0, or the edge code of the first wave that gave up
     const int* done;                // DevState.all_done

@@ -526,9 +526,13 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
     }
 
     // ---------------------------------------------------- attention workgroup: one (row, head) in every layer
-    const int item = b - PL_GEMV_BLOCKS;
-    if (item >= PL_NH * R) return;
-    const int r = item / PL_NH, hh = item % PL_NH;
+    // a.S key splits per (row, head) for long contexts (host: decode_persist): split s owns a contiguous share of the cached keys; the splits s > 0 publish
+    // their partial (max, sum, unnormalised output) and split 0 merges them with this step's own key -- one more hop, but every share stays within the
+    // 384 keys a workgroup holds in registers before the query exists (a longer share streams behind the query: +0.6 us per 64 keys and layer)
+    const int item = b - PL_GEMV_BLOCKS, S = a.S;
+    if (item >= PL_NH * R * S) return;
+    const int rh = item / S, sp = item - rh * S;
+    const int r = rh / PL_NH, hh = rh % PL_NH;
     float* const qs = att_s;
     float* const ks = att_s + 64;
     float* const vs = att_s + 128;
@@ -536,7 +540,8 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
     const size_t kv_per = a.kv_per;
     if (wave < 8) {
         const RowMeta m = a.meta[r];
-        const int kv0 = m.kv_start, kv1 = m.slot;             // cached keys [kv0, kv1); this step's key / value arrive with the query
+        const int kvc = (m.slot - m.kv_start + S - 1) / S;      // cached keys [kv_start, slot) in S shares; this step's key / value arrive with the query
+        const int kv0 = m.kv_start + sp * kvc, kv1 = min(kv0 + kvc, m.slot);
         const int grp = lane >> 3, sub = lane & 7;
         const size_t head_off = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
         constexpr int PRE = 6;                                // iterations requested before the query exists: 8 waves x 8 keys x 6 = 384 keys
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
             any_ok[u] = kv0 + 8 * (wave + 8 * u) < kv1;       // wave-uniform: some lane group of this wave has a key in iteration u
         }
 #define PL_LOAD_KV(l_) do { const float* const kb_ = (const float*)a.kv + (size_t)(l_) * 2 * kv_per + head_off; const float* const vb_ = kb_ + kv_per; \
-        _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p_ = kv0 + 8 * (wave + 8 * u) + grp; const int pc_ = ok[u] ? p_ : kv0; \
+        _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p_ = kv0 + 8 * (wave + 8 * u) + grp; const int pc_ = ok[u] ? p_ : m.kv_start; \
             kf[u][0] = *(const f32x4*)(kb_ + (size_t)pc_ * CTTS_HEAD_DIM); kf[u][1] = *(const f32x4*)(kb_ + (size_t)pc_ * CTTS_HEAD_DIM + 4); \
             vf[u][0] = *(const f32x4*)(vb_ + (size_t)pc_ * CTTS_HEAD_DIM); vf[u][1] = *(const f32x4*)(vb_ + (size_t)pc_ * CTTS_HEAD_DIM + 4); } } while (0)
         PL_LOAD_KV(0);
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
             for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64) {       // contexts beyond 256 keys: the rest streams behind the query (wave-uniform bound)
                 const int p = wb0 + grp;
                 const bool live = p < kv1;
-                const int pc = live ? p : kv0;
+                const int pc = live ? p : m.kv_start;
                 const f32x4 k0 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM), k1 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM + 4);
                 const f32x4 v0 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM), v1 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM + 4);
                 float dot = q0[0] * k0[0] + q0[1] * k0[1] + q0[2] * k0[2] + q0[3] * k0[3] + q1[0] * k1[0] + q1[1] * k1[1] + q1[2] * k1[2] + q1[3] * k1[3];
@@ -633,22 +638,22 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
         for (int l = 0; l < NL; ++l) {
             const unsigned tag = tag0 + (unsigned)l;
             float v[3];
-            const bool got = sweep<3>(a.g_qkv, (unsigned)((r * PL_NH + hh) * 192 + lane), [](int k) { return 64 * k; }, tag, v, a.error, 2, abort_s, a.nap_qkv);
+            const bool got = sweep<3>(a.g_qkv, (unsigned)(rh * 192 + lane), [](int k) { return 64 * k; }, tag, v, a.error, 2, abort_s, a.nap_qkv);
             (void)got;
             qs[lane] = v[0] * 0.125f;                         // 1 / sqrt(64) (llama.py:653-661)
             ks[lane] = v[1];
             vs[lane] = v[2];
             if (l + 1 == NL) PL_MARK(1);
             __syncthreads();                                  // B1
-            // this step's own key (slot `m.slot`, the causal end of the row: llama.py:1073-1087): its score, on all 64 lanes
+            // this step's own key (slot `m.slot`, the causal end of the row: llama.py:1073-1087): its score, on all 64 lanes (split 0 merges it)
             const float dnew = wave_sum(qs[lane] * ks[lane]);
             __syncthreads();                                  // B2
-            // lane = output dim: combine the 8 waves' partials and the new key
+            // lane = output dim: combine the 8 waves' partials
             const int sub = lane >> 3, j = lane & 7;
-            float mwv[8], M = dnew;
+            float mwv[8], M = (sp == 0) ? dnew : -INFINITY;
 #pragma unroll
             for (int w = 0; w < 8; ++w) { mwv[w] = merge[(w * 8 + sub) * 10]; M = fmaxf(M, mwv[w]); }
-            const float pe = expf(dnew - M);
+            const float pe = (sp == 0) ? expf(dnew - M) : 0.f;
             float L = pe, O = pe * vs[lane];
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
@@ -656,7 +661,51 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 L += merge[(w * 8 + sub) * 10 + 1] * sw;
                 O += merge[(w * 8 + sub) * 10 + 2 + j] * sw;
             }
-            store_granule(a.g_att + (size_t)r * PL_H + hh * CTTS_HEAD_DIM + lane, tag, O / L);
+            if (S > 1 && sp != 0) {
+                // a share's partial: [max, sum, o[64]] (an empty share publishes max = -inf, sum = 0)
+                u64* const gp = a.g_part + (size_t)(rh * S + sp) * 66;
+                store_granule(gp + 2 + lane, tag, O);
+                if (lane == 0) store_granule(gp, tag, M);
+                if (lane == 1) store_granule(gp + 1, tag, L);
+            } else {
+                if (S > 1) {
+                    // split 0: the other shares' partials (3 granules per lane and share: o[lane], max, sum -- the last two at wave-uniform addresses)
+                    const u64* p = a.g_part + (size_t)(rh * S) * 66;
+                    asm volatile("" : "+v"(p));
+                    float po[4], pm[4], pl[4];
+#pragma unroll 1
+                    for (unsigned spins = 0;; ++spins) {
+                        bool okk = true;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if (t + 1 < S) {
+                                const u64 xo = __hip_atomic_load(p + (t + 1) * 66 + 2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const u64 xm = __hip_atomic_load(p + (t + 1) * 66, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const u64 xl = __hip_atomic_load(p + (t + 1) * 66 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                po[t] = __builtin_bit_cast(float, (unsigned)xo); pm[t] = __builtin_bit_cast(float, (unsigned)xm); pl[t] = __builtin_bit_cast(float, (unsigned)xl);
+                                okk = okk && ((unsigned)(xo >> 32) == tag) && ((unsigned)(xm >> 32) == tag) && ((unsigned)(xl >> 32) == tag);
+                            }
+                        }
+                        if (__all(okk)) break;
+                        typedef __attribute__((address_space(3))) int lds_i;
+                        bool giveup = spins >= PL_SPIN_LIMIT || __hip_atomic_load((lds_i*)abort_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+                        if (!giveup && (spins & 1023u) == 1023u) giveup = __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        if (giveup) { if (lane == 0) { atomicCAS(a.error, 0, 6); __hip_atomic_store((lds_i*)abort_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (t + 1 < S) {
+                            const float mn = fmaxf(M, pm[t]);
+                            const float s1 = pl_exp_diff(M, mn), s2 = pl_exp_diff(pm[t], mn);
+                            L = L * s1 + pl[t] * s2;
+                            O = O * s1 + po[t] * s2;
+                            M = mn;
+                        }
+                    }
+                }
+                store_granule(a.g_att + (size_t)r * PL_H + hh * CTTS_HEAD_DIM + lane, tag, O / L);
+            }
             if (l + 1 == NL) PL_MARK(2);
         }
         if (a.ts != nullptr && lane == 0) {

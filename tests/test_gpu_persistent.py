@@ -20,7 +20,7 @@ LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, nu
 @pytest.fixture(scope="module")
 def gpt():
     from chatttsplus_amd.hip_models import GPT
-    g = GPT(LLAMA, max_batch=8, max_seq_len=1400, weight_dtype="fp32")
+    g = GPT(LLAMA, max_batch=8, max_seq_len=2100, weight_dtype="fp32")
     g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
     yield g
     g.close()
@@ -37,7 +37,8 @@ def _gen(g, B, P, N, pad=None, lp=LP, seed=7):
 def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
     g = gpt
     assert g.get_option("persistent_rows") == 4, "fp32 engines serve up to four decode rows through the persistent launch by default"
-    cases = [(1, 48, 96, None), (1, 600, 24, None), (1, 1000, 40, None),        # ... a context that crosses 1024 keys hands over to the launch path mid-generation
+    # contexts beyond 512 keys split every (row, head) over 2..5 attention workgroups (2 at 600, 3 at 1000, 5 at 1900; two rows: at most 2)
+    cases = [(1, 48, 96, None), (1, 600, 24, None), (1, 1000, 40, None), (1, 1900, 24, None), (2, 700, 16, [0, 150]),
              (2, 40, 32, [0, 9]), (3, 33, 24, [0, 5, 17]), (4, 48, 24, [3, 0, 11, 20])]
     for (B, P, N, pad) in cases:
         g.set_option("persistent_rows", 0)

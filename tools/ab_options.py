@@ -23,11 +23,13 @@ ap.add_argument("--batches", type=int, nargs="+", default=[1])
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--fixed", default="", help="other options held fixed: a=1,b=2")
+ap.add_argument("--prompt", type=int, default=48)
+ap.add_argument("--gen-tokens", type=int, default=512)
 a = ap.parse_args()
 name, vals = a.sweep.split("=")
 vals = [int(v) for v in vals.split(",")]
 dev = torch.device("cuda", 0)
-g = GPT(bench.LLAMA, max_batch=max(a.batches), max_seq_len=48 + 16 + 512 + 16, weight_dtype=a.dtype, device=str(dev))
+g = GPT(bench.LLAMA, max_batch=max(a.batches), max_seq_len=a.prompt + 16 + 512 + 16, weight_dtype=a.dtype, device=str(dev))
 g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
 for kv in [x for x in a.fixed.split(",") if x]:
     k, v = kv.split("=")
@@ -39,8 +41,8 @@ for B in a.batches:
     for rnd in range(a.rounds + 1):
         for v in vals:
             g.set_option(name, v)
-            r = leg.run(B, 48, a.steps, 8, spk=spk)
+            r = leg.run(B, a.prompt, a.steps, 8, spk=spk, gen_tokens=a.gen_tokens)
             if rnd:                      # round 0 captures the graphs
                 times[v].append(r["ev_ms"] / r["K"])
-    print(json.dumps({"dtype": a.dtype, "B": B, "option": name, "fixed": a.fixed,
+    print(json.dumps({"dtype": a.dtype, "B": B, "prompt": a.prompt, "gen_tokens": a.gen_tokens, "option": name, "fixed": a.fixed,
                       "ms_per_step": {str(v): {"median": round(statistics.median(t), 5), "min": round(min(t), 5)} for v, t in times.items()}}), flush=True)
