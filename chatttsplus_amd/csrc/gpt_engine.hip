@@ -235,7 +235,7 @@ static bool persist_device_lock(int dev) {
     for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
     char path[160];
     snprintf(path, sizeof(path), "/tmp/ctts_persist_%s.lock", bus);
-    int fd = open(path, O_CREAT | O_RDWR, 0666);
+    int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);      // (never follows a planted symlink; not inherited by child processes)
     if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); fd = -1; }
     fds[dev] = fd;                                 // (kept for the life of the process)
     return fd >= 0;

@@ -66,7 +66,9 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "valu_rows"           fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (default 2; 0..4)
  *   "persistent_rows"     fp32 engines: decode batches of <= this many rows (<= 4; default 4) run the whole decoder stack of a step as ONE persistent
  *                         launch of 256 resident workgroups (persist_layer.hip; contexts up to 1024 keys, no per-utterance adapters).  0 = off.  The first
- *                         process that loads an fp32 engine on a device holds the mode (advisory lock /tmp/ctts_persist_<pci>.lock); others stay on launches
+ *                         process that loads an fp32 engine on a device holds the mode (advisory lock /tmp/ctts_persist_<pci>.lock); others stay on launches.
+ *                         A persistent launch needs all 256 workgroups resident: run ONE decode at a time per device (two engines of one process decoding
+ *                         concurrently on different streams would have to share the CUs; every wait is bounded and ctts_gpt_progress reports a give-up)
  *   "persistent_layers_per_launch"  0 = the whole stack in one launch (default), n = n layers per launch
  *   "persistent_schedule" weight request schedule of the persistent launch (1 / 2 / 3, default 3 = paced requests)    "persistent_pace"  its pacing interval
  *   "persistent_delay", "persistent_delay_act", "persistent_delay_x", "persistent_delay_att", "persistent_nap", "persistent_nap_qkv"  when and how often the edge waves poll
