@@ -54,6 +54,7 @@ struct PersistArgs {
     int delay_act, delay_x, nap_qkv;   // (x1 edge: delay; act edge: delay_act; layer-output edge: delay_x; poll interval of the attention workgroups' q|k|v sweep)
     int delay_att, delay;           // ~128-cycle units an edge wave sleeps before it starts polling the attention edge / the other edges (the data cannot be there yet)
     int nap;                        // ~128-cycle units between two poll passes of a GEMV edge wave
+    int fault;                      // test hook: > 0 = one workgroup withholds a hand-off in layer fault - 1 (the give-up path must end the step, not hang it)
     int poll;                       // bit 0: watch one sentinel granule per producer before the full sweep of an edge
 };
 

@@ -455,7 +455,8 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     const int i = e & 3, r = e >> 2;
                     const float x1 = xres[4 * r + i] + red[(i * 4) * R + r];                               // llama.py:731
                     xres[4 * r + i] = x1;
-                    store_granule(a.g_x1 + (size_t)r * PL_H + 4 * b + i, tag, x1);
+                    if (!(a.fault > 0 && b == 5 && l + 1 == a.fault))          // (test hook "persistent_fault": workgroup 5 withholds its columns in layer fault - 1)
+                        store_granule(a.g_x1 + (size_t)r * PL_H + 4 * b + i, tag, x1);
                 }
                 if (last) PL_MARK(5);
                 // ---- phase D: x + attention -> RMSNorm, gate | up, SiLU * up

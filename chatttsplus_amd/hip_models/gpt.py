@@ -663,11 +663,13 @@ class GPT:
     @torch.no_grad()
     def generate_many_iter(self, emb, inputs_ids, temperature, eos_token, attention_mask=None, max_new_token=2048, min_new_token=0, logits_warpers=[],
                            logits_processors=[], return_hidden=False, ensure_non_empty=True, context=None, seed=None, max_restarts: int = 64,
-                           utt_ids=None, max_new_tokens_per_row=None, rows=None, admit_min=None, infer_text: bool = False):
+                           utt_ids=None, max_new_tokens_per_row=None, rows=None, admit_min=None, infer_text: bool = False, progress: bool = False):
         """generate_many as a generator: yields [(utterance index, ids [n,4] long, hiddens [n,768] or None)] for the utterances that completed
         since the last yield -- while the rest keeps decoding (what was yielded is final: its rows were written before the report that showed
         the utterance finished) -- and returns (StopIteration.value) the GenerationOutputs of all N utterances.
-        `infer_text=True`: the refine-text pass (gpt.py infer_text: the 21178-way text head, one id per step) through the same row re-use; ids are [n]."""
+        `infer_text=True`: the refine-text pass (gpt.py infer_text: the 21178-way text head, one id per step) through the same row re-use; ids are [n].
+        `progress=True` (streaming): between the completion lists the generator also yields ("progress", [(utterance index, tokens so far n, ids[:n],
+        hiddens[:n] or None)]) for the utterances still decoding -- the first n tokens of an utterance are final once reported."""
         if not self._finalized:
             raise _lib.HipBackendError("weights not loaded")
         if self._busy_token.owner is not None:
@@ -676,12 +678,12 @@ class GPT:
         try:
             return (yield from self._generate_many(emb, inputs_ids, temperature, eos_token, attention_mask, int(max_new_token), min_new_token, logits_warpers,
                                                    logits_processors, return_hidden, ensure_non_empty, context or Context(), seed, max_restarts, utt_ids,
-                                                   max_new_tokens_per_row, rows, admit_min, bool(infer_text)))
+                                                   max_new_tokens_per_row, rows, admit_min, bool(infer_text), bool(progress)))
         finally:
             self._busy_token.owner = None
 
     def _generate_many(self, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token, logits_warpers, logits_processors,
-                       return_hidden, ensure_non_empty, context, seed, max_restarts, utt_ids, row_limits, rows, admit_min, infer_text=False):
+                       return_hidden, ensure_non_empty, context, seed, max_restarts, utt_ids, row_limits, rows, admit_min, infer_text=False, progress=False):
         lib, h, dev = self._lib, self._h, self.device
         N, T = int(inputs_ids.shape[0]), int(inputs_ids.shape[1])
         H, NVQ = self.model_dim, self.num_vq
@@ -746,7 +748,13 @@ class GPT:
                 slot = pending.pop(0)
                 evs[slot].synchronize()
                 lay = layouts[slot]
-                finished_now, again = book.report(lay, pins[slot][:2 * len(lay)].view(-1, 2).tolist(), ensure_non_empty, max_restarts)
+                states = pins[slot][:2 * len(lay)].view(-1, 2).tolist()
+                if progress:
+                    live = [(book.tickets[tk][0], int(end)) for tk, (fin, end) in zip(lay, states) if tk is not None and tk in book.tickets and not fin and end > 0]
+                    if live:
+                        yield ("progress", [(u, n, ids[u, :n, 0].to(torch.long) if infer_text else ids[u, :n].to(torch.long), hid[u, :n] if hid is not None else None)
+                                            for u, n in live])
+                finished_now, again = book.report(lay, states, ensure_non_empty, max_restarts)
                 queue = again + queue                              # first token was EOS (gpt.py:496-525): next noise attempt, ahead of the queue
                 n_done += len(finished_now)
                 if finished_now:

@@ -464,8 +464,8 @@ class ChatTTSPlusPipeline:
         # Lists of waveforms are yielded in input order as prefixes of the request complete.  Not for stream=True (sample windows),
         # per-utterance adapters or caller-supplied noise.
         if kwargs.get("continuous") and len(text_in) > slice_size:
-            if stream or lora_paths is not None or noise_mode not in ("auto", "device"):
-                raise _lib.HipBackendError("continuous=True works with stream=False, device noise and without per-utterance adapters")
+            if lora_paths is not None or noise_mode not in ("auto", "device"):
+                raise _lib.HipBackendError("continuous=True works with device noise and without per-utterance adapters")
             if noise_seed is None:
                 noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             texts_all = list(text_in)
@@ -490,7 +490,35 @@ class ChatTTSPlusPipeline:
                 pic = dataclasses.replace(pic, spk_emb=pic.spk_emb[torch.as_tensor(order, device=pic.spk_emb.device)])
             events = self._infer_code([texts_all[i] for i in order], False, use_decoder, pic, gpt=gpt, continuous=True, seed=noise_seed,
                                       utt_ids=[utt_ids[i] for i in order], rows=slice_size,
-                                      max_new_tokens_per_row=[utt_limits[i] for i in order] if utt_limits is not None else None)
+                                      max_new_tokens_per_row=[utt_limits[i] for i in order] if utt_limits is not None else None, progress=bool(stream))
+            if stream:
+                # stream=True with row re-use (no counterpart in the reference, whose stream branch serves one slice, pipeline:440-463): every yield is a list of
+                # (utterance index, sample window) -- the next [emitted, b) samples of that utterance's prefix waveform, vocoded from the tokens inside the window's
+                # receptive field only (Synth.decode_window) -- as soon as `stream_batch` new tokens of it exist; an utterance's last window comes with its completion
+                syn = self.synth if use_decoder else self._codes_synth()
+                emitted, last_n = {}, {}
+
+                def windows(items, final):
+                    out = []
+                    for k, n, ids_k, hid_k in items:
+                        u = order[k]
+                        src = hid_k if use_decoder else ids_k
+                        total = 256 * (2 * int(n) - 1) if n > 0 else 0
+                        s0 = emitted.get(u, 0)
+                        if total > s0 and (final or n - last_n.get(u, 0) >= pic.stream_batch):
+                            b = total if final else min(s0 + pic.stream_speed, total)
+                            out.append((u, syn.decode_window([src], [s0], [b])[0]))
+                            emitted[u], last_n[u] = b, int(n)
+                    return out
+
+                for ev in events:
+                    if isinstance(ev, tuple) and ev[0] == "progress":
+                        got = windows(ev[1], False)
+                    else:
+                        got = windows([(k, int(ids_k.shape[0]), ids_k, hid_k) for k, ids_k, hid_k in ev], True)
+                    if got:
+                        yield got
+                return
             ready, next_i, first = {}, 0, True
             ids_sink = kwargs.get("_ids_sink")
             for ev in events:

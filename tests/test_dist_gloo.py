@@ -114,6 +114,10 @@ class _FakeGPT:
         ids = [torch.zeros(k, 4, dtype=torch.long) for k in n]
         hid = [torch.full((k, 768), float(k)) for k in n]
         order = sorted(range(N), key=lambda b: (n[b], b))
+        if kw.get("progress"):                       # streaming: half-way reports of every utterance that is long enough, like the engine's chunk reports
+            half = [(b, n[b] // 2, ids[b][:n[b] // 2], hid[b][:n[b] // 2] if return_hidden else None) for b in range(N) if n[b] // 2 >= 2]
+            if half:
+                yield ("progress", half)
         for i in range(0, N, 2):
             yield [(b, ids[b], hid[b] if return_hidden else None) for b in order[i:i + 2]]
         return type("O", (), dict(ids=ids, attentions=[], hiddens=hid if return_hidden else []))
@@ -294,5 +298,22 @@ def test_pipeline_continuous_yields_in_input_order(tmp_path):
     list(pipe._infer(list(TEXTS[:3]), False, None, True, False, True, True, False, True, params_infer_code=InferCodeParams(show_tqdm=False, spk_emb=rows[:3]),
                      slice_size=3, noise="device", noise_seed=9, continuous=True))
     assert gpt.calls == [3] and gpt.many_calls == []
+    # stream=True + continuous (round 4): (utterance index, sample window) pairs; the windows of an utterance are consecutive and add up to its waveform
+    class _WinSynth(_FakeSynth):
+        def decode_window(self, hiddens, s0, s1):
+            assert len(hiddens) == 1 and 0 <= s0[0] < s1[0] <= 256 * (2 * hiddens[0].shape[0] - 1)
+            return [torch.arange(s0[0], s1[0], dtype=torch.float32)]
+    pipe.synth = _WinSynth()
+    ps = InferCodeParams(show_tqdm=False, spk_emb=rows, prompt="[speed_5]", stream_batch=2, stream_speed=100000)
+    got = list(pipe._infer(list(TEXTS), True, None, True, False, True, True, False, True, params_infer_code=ps, slice_size=3, noise_seed=9, continuous=True))
+    per = {}
+    for chunk in got:
+        for u, w in chunk:
+            per.setdefault(u, []).append(w)
+    assert sorted(per) == list(range(10))
+    for u, ws in per.items():
+        full = torch.cat(ws)
+        assert full.shape[0] == 256 * (2 * want[u] - 1) and torch.equal(full, torch.arange(full.shape[0], dtype=torch.float32)), u     # consecutive, gap-free
+    assert any(len(ws) > 1 for ws in per.values()), "no utterance was streamed in more than one window"
     with pytest.raises(_lib.HipBackendError):
-        list(pipe._infer(list(TEXTS), True, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, continuous=True))
+        list(pipe._infer(list(TEXTS), False, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, continuous=True, noise="torch"))

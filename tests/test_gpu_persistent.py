@@ -121,3 +121,22 @@ def test_out_of_range_ids_raise_like_nn_embedding(gpt):
     code[0, 5, 3] = 626
     with pytest.raises(IndexError):
         g(torch.from_numpy(code), tm2)
+
+
+def test_a_withheld_hand_off_ends_the_step_with_an_error_instead_of_hanging(gpt):
+    """Every wait of the persistent launch is bounded: with one workgroup withholding its columns of (x + attention) in layer 7 (test hook), the waiting
+    waves give up after ~0.3 s, the device error word turns the rest of the launch and every later launch into no-ops, and the host gets a
+    HipBackendError naming an edge (whichever starved consumer ran out of passes first) -- then the engine serves the next request normally."""
+    import time
+    from chatttsplus_amd import _lib
+    g = gpt
+    g.set_option("persistent_rows", 4)
+    ref_ids, _ = _gen(g, 1, 24, 12)
+    g.set_option("persistent_fault", 8)
+    t0 = time.perf_counter()
+    with pytest.raises(_lib.HipBackendError, match="gave up waiting on edge [2-5]"):
+        _gen(g, 1, 24, 12)
+    assert time.perf_counter() - t0 < 20.0, "the give-up took too long: a wait is not bounded"
+    g.set_option("persistent_fault", 0)
+    ids, _ = _gen(g, 1, 24, 12)
+    assert torch.equal(ids[0], ref_ids[0]), "the engine did not recover after the reported give-up"

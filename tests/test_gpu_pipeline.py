@@ -150,6 +150,20 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
             assert a.shape == b2.shape, f"slice {key}, utterance {u}: {a.shape} vs {b2.shape} samples (token count differs)"
             assert float(np.sqrt(np.mean((a - b2) ** 2))) <= 1e-4 * float(np.sqrt(np.mean(a ** 2))), f"slice {key}, utterance {u}"
 
+    # stream=True + continuous (round 4): (utterance, sample window) pairs while rows are re-used; per utterance the windows are consecutive, add up to the
+    # utterance's waveform length and the last one (vocoded from the complete utterance) equals the tail of the non-streamed waveform
+    sp3 = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=24, min_new_token=3, show_tqdm=False, stream_batch=6, stream_speed=3000)
+    per = {}
+    for chunk in pipe.infer(list(many), stream=True, skip_refine_text=True, do_text_optimization=False, params_infer_code=sp3, noise_seed=77, slice_size=3, continuous=True):
+        for u, w in chunk:
+            per.setdefault(u, []).append(w.cpu().numpy())
+    assert sorted(per) == list(range(len(many)))
+    for u, ws in per.items():
+        ref = runs[4][u]
+        assert sum(w.shape[0] for w in ws) == ref.shape[0], (u, [w.shape[0] for w in ws], ref.shape)
+        assert np.allclose(ws[-1], ref[ref.shape[0] - ws[-1].shape[0]:], rtol=0, atol=1e-4 * float(np.abs(ref).max())), u
+    assert any(len(ws) > 1 for ws in per.values())
+
     # default infer() path: refine-text pass first (pipeline:399-411), then code inference on the refined text
     from chatttsplus_amd.pipeline import RefineTextParams
     rp = RefineTextParams(max_new_token=6, show_tqdm=False)
