@@ -587,7 +587,7 @@ def main():
             extra["batch32_lora_merged"] = summarize(e, world)
             gl.close()
             # per-utterance adapters: 4 different adapters + "none" spread over the 32 sequences of ONE batch, evaluated as
-            # W x + scale * B (A x) per row (two extra launches per layer); the reference can only merge one adapter per call
+            # W x + scale * B (A x) per row (worker workgroups inside the QKV / o_proj launches, lora_worker.h); the reference can only merge one adapter per call
             for slot in range(4):
                 g.load_adapter(slot, [(l, t, (rl.standard_normal((8, 768)) * 0.02).astype(np.float32), (rl.standard_normal((768, 8)) * 0.02).astype(np.float32), 2.0)
                                       for l in range(LLAMA["num_hidden_layers"]) for t in ("q_proj", "k_proj", "v_proj", "o_proj")])

@@ -135,11 +135,16 @@ struct ctts_gpt {
     DevState* st = nullptr;
     int* last_rows = nullptr;
     int* host_pin = nullptr;
-    // per-utterance LoRA (lora.hip): resident adapters [layer][slot][target][16][768] / [layer][slot][target][768][16] (zero padded to r = 16),
+    // per-utterance LoRA (lora.hip): resident adapters A [layer][slot][target][16][768] and B^T in the same shape (zero padded to r = 16),
     // per-sequence slot table, low-rank terms of the rows being processed
     float *lora_A = nullptr, *lora_B = nullptr, *lora_scale = nullptr, *ln1 = nullptr;
     int* lora_slot_of_seq = nullptr;
+    signed char lora_row_slots[CTTS_MAX_B];      //   the same per decode ROW (rows move when finished rows are compacted away): travels in the kernel arguments of the folded launches
+    std::vector<signed char> lora_rank;          //   [layer][slot][target] rank as loaded (0 = empty)
+    std::vector<int> lora_slot_host;             //   host copy of lora_slot_of_seq
     float *lora_dqkv = nullptr, *lora_do = nullptr;
+    unsigned long long* lora_g = nullptr;        //   decode steps: the same terms as tagged granules from worker workgroups inside the QKV / o_proj launches (lora_worker.h)
+    int lora_fold = 1;                           //   "lora_fold" option: 0 = the two extra launches per layer at decode too
     int lora_rows = 0;                           // 1: the current / next generate() calls carry per-sequence adapters
     int pass_rows = PASS_ROWS_MAX;               // prompt rows per pass of this engine (env CTTS_PASS_ROWS, read once at finalize, lowers it: the
                                                  // one capacity knob of the product library; the multi-pass tests use it)
@@ -280,6 +285,8 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     else if (n == "split_rows") *value = h->split_rows;
     else if (n == "graph_steps") *value = h->graph_steps;
     else if (n == "decode_splits") *value = h->force_splits;
+    else if (n == "lora_fold") *value = h->lora_fold;
+    else if (n == "down_splitk_rows") *value = h->down_sk_rows;
     else { ctts_set_error("get_option: unknown option '%s'", name); return 1; }
     return 0;
 }
@@ -301,6 +308,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->persist_lpl = value < 0 ? 0 : value;
     } else if (n == "persistent_schedule") {               // 1 / 2: see persist_layer.hip
         h->persist_sched = (value >= 1 && value <= 3) ? value : 1;
+    } else if (n == "lora_fold") {                         // per-utterance adapters at decode: 1 = workers inside the QKV / o_proj launches, 0 = two more launches per layer
+        h->lora_fold = (value < 0 || value > 3) ? 1 : value;
     } else if (n == "persistent_fault") {                  // test hook: a withheld hand-off; every wait is bounded, ctts_gpt_progress reports the edge
         h->persist_fault = value < 0 ? 0 : value;
     } else if (n == "persistent_splits") {
@@ -347,7 +356,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
-                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
+                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -424,6 +433,9 @@ static int lora_ensure_storage(ctts_gpt* h) {
         dev_alloc((void**)&h->lora_dqkv, (size_t)h->pass_rows * 3 * h->H * 4) || dev_alloc((void**)&h->lora_do, (size_t)h->pass_rows * h->H * 4))
         return 1;
     CTTS_HIP_CHECK(hipMemset(h->lora_slot_of_seq, 0xFF, CTTS_MAX_B * 4));
+    if (dev_alloc((void**)&h->lora_g, (size_t)CTTS_MAX_B * 4 * h->H * 8)) return 1;           // [rows][3][768] q/k/v | [rows][768] o_proj
+    CTTS_HIP_CHECK(hipMemset(h->lora_g, 0, (size_t)CTTS_MAX_B * 4 * h->H * 8));                 // tag 0 never matches (tags start at 64)
+    if (!h->pl_error) { if (dev_alloc((void**)&h->pl_error, 4)) return 1; CTTS_HIP_CHECK(hipMemset(h->pl_error, 0, 4)); }
     return 0;
 }
 extern "C" int ctts_gpt_set_adapter(ctts_gpt* h, int slot, int layer, const char* target, const float* A, const float* B, int r, float scale) {
@@ -437,11 +449,14 @@ extern "C" int ctts_gpt_set_adapter(ctts_gpt* h, int slot, int layer, const char
     const int H = h->H;
     std::vector<float> a16((size_t)16 * H, 0.f), b16((size_t)H * 16, 0.f);
     for (int k = 0; k < r; ++k) memcpy(&a16[(size_t)k * H], A + (size_t)k * H, (size_t)H * 4);
-    for (int n = 0; n < H; ++n) for (int k = 0; k < r; ++k) b16[(size_t)n * 16 + k] = B[(size_t)n * r + k];
+    for (int n = 0; n < H; ++n) for (int k = 0; k < r; ++k) b16[(size_t)k * H + n] = B[(size_t)n * r + k];       // rank-major like A: rank r reads r rows
     const size_t off = (((size_t)layer * CTTS_MAX_ADAPTERS + slot) * 4 + t) * 16 * H;
     CTTS_HIP_CHECK(hipMemcpy(h->lora_A + off, a16.data(), a16.size() * 4, hipMemcpyHostToDevice));
     CTTS_HIP_CHECK(hipMemcpy(h->lora_B + off, b16.data(), b16.size() * 4, hipMemcpyHostToDevice));
     CTTS_HIP_CHECK(hipMemcpy(h->lora_scale + ((size_t)layer * CTTS_MAX_ADAPTERS + slot) * 4 + t, &scale, 4, hipMemcpyHostToDevice));
+    if (h->lora_rank.empty()) h->lora_rank.assign((size_t)h->L * CTTS_MAX_ADAPTERS * 4, 0);
+    h->lora_rank[((size_t)layer * CTTS_MAX_ADAPTERS + slot) * 4 + t] = (signed char)r;
+    h->opt_gen++;                                   // the ranks are kernel arguments of the folded launches: captured graphs are stale
     return 0;
 }
 extern "C" int ctts_gpt_clear_adapter(ctts_gpt* h, int slot) {
@@ -453,7 +468,9 @@ extern "C" int ctts_gpt_clear_adapter(ctts_gpt* h, int slot) {
         CTTS_HIP_CHECK(hipMemset(h->lora_A + off, 0, per * 4));
         CTTS_HIP_CHECK(hipMemset(h->lora_B + off, 0, per * 4));
         CTTS_HIP_CHECK(hipMemset(h->lora_scale + ((size_t)l * CTTS_MAX_ADAPTERS + slot) * 4, 0, 16));
+        if (!h->lora_rank.empty()) for (int t = 0; t < 4; ++t) h->lora_rank[((size_t)l * CTTS_MAX_ADAPTERS + slot) * 4 + t] = 0;
     }
+    h->opt_gen++;
     return 0;
 }
 extern "C" int ctts_gpt_set_row_adapters(ctts_gpt* h, const int32_t* slots, int B) {
@@ -470,6 +487,8 @@ extern "C" int ctts_gpt_set_row_adapters(ctts_gpt* h, const int32_t* slots, int 
     std::vector<int> tab(CTTS_MAX_B, -1);
     for (int b = 0; b < B; ++b) tab[b] = slots[b] < 0 ? -1 : slots[b];
     CTTS_HIP_CHECK(hipMemcpy(h->lora_slot_of_seq, tab.data(), CTTS_MAX_B * 4, hipMemcpyHostToDevice));
+    h->lora_slot_host = tab;
+    for (int b = 0; b < CTTS_MAX_B; ++b) h->lora_row_slots[b] = (signed char)tab[b];      // rows == sequences until a compaction
     h->lora_rows = 1;
     return 0;
 }
@@ -835,7 +854,16 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         g1.q_out = h->q_buf; g1.k_cache = kv_layer(h, l, 0); g1.v_cache = kv_layer(h, l, 1); g1.rope_rows = rope_rows;
         g1.opart = h->dpart; g1.np = (splitd && l > 0) ? 4 : 0;
         const size_t lora_l = (size_t)l * CTTS_MAX_ADAPTERS * 4 * 16 * h->H;
-        if (lora) {
+        // decode steps: the rows' low-rank terms come from worker workgroups inside the QKV / o_proj launches (lora_worker.h) instead of two more launches
+        const bool lfold = lora && st != nullptr && h->lora_fold && h->lora_g != nullptr && h->H == 768 && R <= CTTS_MAX_B;
+        if (lfold) {
+            LoraFold lf = {};
+            lf.A = h->lora_A + lora_l; lf.B = h->lora_B + lora_l; lf.scale = h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4; lf.lnw = h->ln1 + (size_t)l * h->H;
+            memcpy(lf.slots, h->lora_row_slots, sizeof(lf.slots)); static_assert(sizeof(lf.ranks) == CTTS_MAX_ADAPTERS * 4, "LoraFold.ranks");
+            if (!h->lora_rank.empty()) memcpy(lf.ranks, &h->lora_rank[(size_t)l * CTTS_MAX_ADAPTERS * 4], sizeof(lf.ranks));
+            lf.g = h->lora_g; lf.g_o = h->lora_g + (size_t)CTTS_MAX_B * 3 * h->H; lf.err = h->pl_error; lf.layer = l; lf.diag = h->lora_fold;
+            g1.lf = lf; g1.lora_w = 3 * NB;
+        } else if (lora) {
             if (launch_lora_delta_qkv(x, h->ln1 + (size_t)l * h->H, a.eps, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
                                       h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_dqkv, R, h->H, s)) return 1;
             g1.lora_delta = h->lora_dqkv;
@@ -865,8 +893,9 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         g2.xpacked = h->attn_packed;
         g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;      // the down projection's partial sums are folded into x here
         if (xhm) { g2.xh = h->xh; g2.ssq = h->ssq; g2.scale_in = h->scale_o; }
-        if (lora) {
-            if (S != 1) { ctts_set_error("per-utterance LoRA needs unsplit attention"); return 1; }
+        if (lora && S != 1) { ctts_set_error("per-utterance LoRA needs unsplit attention"); return 1; }
+        if (lfold) { g2.lf = g1.lf; g2.lora_w = NB; }
+        else if (lora) {
             if (launch_lora_delta_o(dt, h->attn_packed, nbg, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
                                     h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_do, R, h->H, s)) return 1;
             g2.lora_delta = h->lora_do;
@@ -901,7 +930,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             if (launch_gemm(dt, nbg, PRO_PACKED, EPI_PART, g4, chunks, s)) return 1;
         } else if (xhm) {                          // (the last layer's copy is for the heads: run_heads)
             g4.xh = h->xh; g4.ssq = h->ssq; g4.scale_in = h->scale_d;
-            if (nbg == 1 && R >= h->down_sk_rows && h->down_sk_rows > 0 && !lora) {
+            if (nbg == 1 && R >= h->down_sk_rows && h->down_sk_rows > 0) {
                 // K sliced 4 ways inside the launch, last arriver combines (EPI_RESID_XH_SK, kernels.h)
                 g4.ktiles_total = h->I / (h->esz == 2 ? 32 : 16); g4.sk_slab = h->sk_slab; g4.sk_cnt = h->sk_cnt;
                 if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH_SK, g4, chunks, s)) return 1;
@@ -990,6 +1019,7 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
     }
     h->row_seq.resize(B); h->row_ctx.assign(B, T); h->row_cap.resize(B);
     for (int b = 0; b < B; ++b) { h->row_seq[b] = b; h->row_cap[b] = T + h->rows_host[b].limit; }
+    if (h->lora_rows) for (int b = 0; b < CTTS_MAX_B; ++b) h->lora_row_slots[b] = (signed char)h->lora_slot_host[b];
     h->pre_T = T;
     h->io.utt_ids = nullptr; h->io.row_limits = nullptr;      // host arrays are consumed here, not kept
     memcpy(h->sc.temperature, sc->temperature, sizeof(sc->temperature));
@@ -1078,7 +1108,8 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
     snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen, h->cur_persist);      // (diagnostic switches are fixed at create)
-    const std::string key(sig);
+    std::string key(sig);
+    if (h->lora_rows) key.append((const char*)h->lora_row_slots, (size_t)h->B);      // the rows' adapter slots are kernel arguments of the folded launches (LoraFold)
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }
     if (h->graphs.size() >= 96) {                  // bounded: a serving process cycles through few (batch, mode) shapes (compaction adds the sizes of compact_size)
@@ -1129,6 +1160,10 @@ extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_
     CTTS_HIP_CHECK(hipStreamSynchronize(s));
     if (steps_done) *steps_done = h->host_pin[0];
     if (all_finished) *all_finished = h->host_pin[2];
+    if (h->host_pin[12] == 7) {
+        ctts_set_error("per-utterance LoRA: a projection tile gave up waiting for its low-rank term (lora_worker.h); use options={'lora_fold': 0}");
+        return 1;
+    }
     if (h->host_pin[12] != 0) {
         ctts_set_error("persistent decode layer: a workgroup gave up waiting on edge %d (2 = q|k|v -> attention, 3 = attention -> o_proj, 4 = o_proj -> gate|up, "
                        "5 = gate|up -> down); is the GPU shared with another process?  Use options={'persistent_rows': 0}", h->host_pin[12]);
@@ -1168,6 +1203,7 @@ extern "C" int ctts_gpt_compact(ctts_gpt* h, const int32_t* keep_rows, int n_kee
     CTTS_HIP_CHECK(hipMemcpyAsync(h->keep_dev, h->keep_host.data(), (size_t)n_keep * 4, hipMemcpyHostToDevice, s));
     if (launch_compact_rows(h->keep_dev, n_keep, h->H, h->x_dec, h->rope_dec, h->meta_dec, h->hist_ring, h->finend, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->st, s)) return 1;
     for (int i = 0; i < n_keep; ++i) { h->row_seq[i] = h->row_seq[keep_rows[i]]; h->row_ctx[i] = h->row_ctx[keep_rows[i]]; h->row_cap[i] = h->row_cap[keep_rows[i]]; }
+    if (h->lora_rows) for (int i = 0; i < n_keep; ++i) h->lora_row_slots[i] = (signed char)h->lora_slot_host[h->row_seq[i]];
     h->B = n_keep;
     return 0;
 }

@@ -13,6 +13,24 @@ enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_P =
 // counter; the LAST arriver adds the slices IN SLICE ORDER (deterministic whatever the arrival order) and runs the residual / packed-copy epilogue.
 #define CTTS_NPART 4       // split-K partial sums of the down projection per row (decode batches <= 4)
 
+// per-utterance LoRA folded into the QKV / o_proj launches of a decode step (lora_worker.h)
+typedef unsigned long long lora_u64;
+struct LoraFold {
+    const float* A;             // this layer's adapters [slot][target 0..3][16][768]
+    const float* B;             //                       [slot][target][16][768] (rank-major, B transposed)
+    const float* scale;         // [slot][4]
+    const float* lnw;           // this layer's input_layernorm weight [768] (q/k/v see the normalised rows, llama.py:726-731)
+    signed char slots[CTTS_MAX_B];   // adapter slot of every decode ROW, -1 = none.  In the kernel arguments on purpose: a worker that first loads its slot from
+                                //   memory issues its A / B loads one round trip late -- behind the whole weight stream of the launch it rides in (measured: +1.4 us
+                                //   per launch).  A captured graph is keyed by these bytes (ensure_graph).
+    signed char ranks[32];      // [slot][target] rank of this layer's adapters (CTTS_MAX_ADAPTERS * 4): the workers skip the zero padding up to 16
+    lora_u64* g;                // granules: q/k/v [rows][3][768], then o_proj [max rows][768] at g_o
+    lora_u64* g_o;
+    int* err;                   // give-up word (shared with the persistent launch's; ctts_gpt_progress reports it)
+    int layer;
+    int diag;                   // timing experiments (option "lora_fold" 2 / 3): 2 = the tiles do not take the terms, 3 = the workers publish zeros at once
+};
+
 // out[R rows][N] = prologue(x)[R][K] . W[N][K]^T  followed by a fused epilogue.
 // W is pre-packed in 16-row x KT-col MFMA-A tiles, [row tile][k tile][lane][16 B] (gpt_engine.cpp).
 struct SamplerDyn;
@@ -53,6 +71,8 @@ struct GemmArgs {
     float* scale_out;       // [rows] PRO_XH / PRO_NORM (block 0): 2^floor(log2(rs)) of this normalisation = the scale of the NEXT xh rows
     // per-utterance LoRA (lora.hip): low-rank term of every row, added in the epilogue.  EPI_QKV: [rows][3][768]; EPI_RESID*: [rows][768]
     const float* lora_delta;
+    LoraFold lf;            // decode steps: the same term from worker workgroups inside the launch, as tagged granules (lora_worker.h); lora_w workers per chunk
+    int lora_w;             //   EPI_QKV: 3 * 16 * NBG, EPI_RESID*: 16 * NBG, 0 = off (lora_delta then holds the term, or null)
     int* sat;               // fp16 engines: counter of saturated / NaN fp16 stores (common.h sat_half); null = do not count
     const RowState* rows;   // heads only: hidden row goes to hiddens[rows[r].out][rows[r].end] while the row is live
     float* sk_slab;         // EPI_RESID_XH_SK: partial tiles [row tile][chunk][slice][256] fp32

@@ -45,20 +45,21 @@ __device__ inline void lora_low_rank(const float* hw, const float* A_t, const fl
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int n = tid + 256 * i;
-        const f32x4* br = (const f32x4*)(B_t + (size_t)n * LORA_RMAX);
-        const f32x4 b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
+        float b[LORA_RMAX];                                   // B is stored rank-major [16][768]
+#pragma unroll
+        for (int k = 0; k < LORA_RMAX; ++k) b[k] = B_t[(size_t)k * H + n];
         float a = 0.f;
-        a += b0[0] * uu[0] + b0[1] * uu[1] + b0[2] * uu[2] + b0[3] * uu[3];
-        a += b1[0] * uu[4] + b1[1] * uu[5] + b1[2] * uu[6] + b1[3] * uu[7];
-        a += b2[0] * uu[8] + b2[1] * uu[9] + b2[2] * uu[10] + b2[3] * uu[11];
-        a += b3[0] * uu[12] + b3[1] * uu[13] + b3[2] * uu[14] + b3[3] * uu[15];
+        a += b[0] * uu[0] + b[1] * uu[1] + b[2] * uu[2] + b[3] * uu[3];
+        a += b[4] * uu[4] + b[5] * uu[5] + b[6] * uu[6] + b[7] * uu[7];
+        a += b[8] * uu[8] + b[9] * uu[9] + b[10] * uu[10] + b[11] * uu[11];
+        a += b[12] * uu[12] + b[13] * uu[13] + b[14] * uu[14] + b[15] * uu[15];
         drow[n] = scale * a;
     }
 }
 
 // q/k/v targets: input = input_layernorm(x) (llama.py:726-731: the projections see the normalised hidden states)
 //   x [rows][768] fp32 residual stream, lnw [768], meta row -> sequence, slot_of_seq [max_batch] (-1 = no adapter),
-//   A_l / B_l: this layer's adapters, [slot][target 0..3][16][768] and [slot][target][768][16] (zero padded to r = 16), scale_l [slot][4]
+//   A_l / B_l: this layer's adapters, [slot][target 0..3][16][768], both rank-major (B transposed; zero padded to r = 16), scale_l [slot][4]
 //   delta [rows][3][768];  grid = (rows, 3 targets)
 __global__ __launch_bounds__(256) void lora_delta_qkv_kernel(const float* x, const float* lnw, float eps, const RowMeta* meta, const int* slot_of_seq,
                                                            const float* A_l, const float* B_l, const float* scale_l, float* delta, int H) {

@@ -16,6 +16,7 @@
 //   EPI_SWIGLU act_fn(gate_proj(x)) * up_proj(x)                  llama.py:214
 //   EPI_LOGITS head_code[i](hidden) for the 4 folded heads        gpt.py:437-447
 #include "kernels.h"
+#include "lora_worker.h"
 
 #define ATT_SMAX 8     // max key splits combined by PRO_ATTN (gpt_engine.hip decode_splits)
 
@@ -88,8 +89,32 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 #define CTTS_EXIT_IF_DONE() if (__builtin_amdgcn_readfirstlane(done_v)) return
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rt0 = blockIdx.x * RT, chunk = blockIdx.y;
+    const int chunk = blockIdx.y;
     const int row0 = chunk * NB;
+    // per-utterance LoRA (lora_worker.h): the first lw blocks of every chunk evaluate the rows' low-rank terms, the tiles behind them pick the terms up in
+    // their epilogues.  (lw rides on the leading scalar `misc` like the other fields the first instructions need.)
+    constexpr bool LORA_QKV = (EPI == EPI_QKV) && (K == 768) && (VR == 0) && (PRO == PRO_NORM || PRO == PRO_XH);
+    constexpr bool LORA_O = (EPI == EPI_RESID || EPI == EPI_RESID_XH) && (K == 768) && (VR == 0) && (PRO == PRO_PACKED);
+    const int lw = (LORA_QKV || LORA_O) ? ((misc >> 24) & 0x7F) : 0;
+    int lora_draw = 0;
+    const unsigned lora_tag_lo = (unsigned)a.lf.layer * 2u + (LORA_O ? 1u : 0u);
+    if constexpr (LORA_QKV || LORA_O) {
+        if (lw != 0) {
+            lora_draw = vload_flag(done_p - 1);                // DevState: draw sits in front of all_done.  Requested now, used where the tag is needed
+            if ((int)blockIdx.x < lw) {                         // (no early exit on `done`: the worker's tiles exit themselves)
+                const int w = blockIdx.x;
+                if constexpr (LORA_QKV) {
+                    const int r = row0 + w / 3;
+                    if (r < R) lora_worker_qkv<WAVES>(a.lf, a.x, a.eps, r, w % 3, lora_draw, lora_tag_lo, (float*)smem, tid);
+                } else {
+                    const int r = row0 + w;
+                    if (r < R) lora_worker_o<WT, WAVES>(a.lf, a.xpacked, NBG, r, lora_draw, lora_tag_lo, (float*)smem, tid);
+                }
+                return;
+            }
+        }
+    }
+    const int rt0 = ((int)blockIdx.x - lw) * RT;
 
     // LOAD ORDER MATTERS: vmcnt retires in order, so a wait on any load issued after the weight stream is a wait on
     // the whole stream.  Everything the prologue needs is therefore requested first, the (non-temporal) weight
@@ -97,7 +122,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     // split-K launches (EPI_PART): this block owns k-tiles [blockIdx.z*KTILES, +KTILES) of a matrix with ktiles_total k-tiles
     const int np_ = misc & 0xFF, S_ = (misc >> 8) & 0xFF;
     constexpr bool SLICED = (EPI == EPI_PART || EPI == EPI_RESID_XH_SK);
-    const int kt_all = SLICED ? (misc >> 16) : KTILES;
+    const int kt_all = SLICED ? ((misc >> 16) & 0xFF) : KTILES;
     const int kt_off = SLICED ? (int)blockIdx.z * KTILES : 0;
     const frag* Wp = (const frag*)Wq + ((size_t)rt0 * kt_all + kt_off + (size_t)wave * KPW) * 64 + lane;
     frag wf[RT][KPW];
@@ -406,6 +431,33 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         }
     }
 
+    // per-utterance LoRA: a first look at the low-rank terms of this thread's epilogue elements -- by now the workers in front of this chunk have normally
+    // published, and the round trip hides behind the cross-wave reduction below
+    constexpr int LPEEK = LORA_QKV ? 2 * RT : (LORA_O ? RITEMS : 1);
+    lora_u64 lpeek[LPEEK];
+#pragma unroll
+    for (int i = 0; i < LPEEK; ++i) lpeek[i] = 0;
+    const bool ltake = (LORA_QKV || LORA_O) && lw != 0 && a.lf.diag != 2;
+    if constexpr (LORA_QKV) {
+        if (ltake && tid < 8 * NB && row0 + (tid >> 3) < R) {
+#pragma unroll
+            for (int ti = 0; ti < RT; ++ti) {
+                const int rt = rt0 + ti, which = rt / (K / 16), within = rt % (K / 16);
+                const lora_u64* gp = a.lf.g + ((size_t)(row0 + (tid >> 3)) * 3 + which) * K + (within >> 2) * CTTS_HEAD_DIM + ((within & 3) << 3) + (tid & 7);
+                lpeek[2 * ti] = lora_peek(gp); lpeek[2 * ti + 1] = lora_peek(gp + 32);
+            }
+        }
+    }
+    if constexpr (LORA_O) {
+        if (ltake) {
+#pragma unroll
+            for (int u = 0; u < RITEMS; ++u) {
+                const int t = tid + u * WAVES * 64, r = row0 + (t >> 4);
+                if (t < 16 * NB && r < R) lpeek[u] = lora_peek(a.lf.g_o + (size_t)r * 768 + rt0 * 16 + (t & 15));
+            }
+        }
+    }
+
     float* red = (float*)(smem + XS_BYTES);                 // [WAVES][NBG][64][4]
 #pragma unroll
     for (int ti = 0; ti < RT; ++ti) {
@@ -492,6 +544,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             float v = (EPI == EPI_RESID_XH_SK) ? sk_v[u] : c_elem(i, n);
             if ((EPI == EPI_RESID || EPI == EPI_RESID_P || EPI == EPI_RESID_XH || EPI == EPI_RESID_XH_SK) && a.lora_delta != nullptr)
                 v += a.lora_delta[(size_t)r * (a.n_row_tiles * 16) + col];          // per-utterance LoRA term of o_proj (lora.hip)
+            if constexpr (LORA_O) {
+                if (ltake) v += lora_take_peeked(lpeek[u], a.lf.g_o + (size_t)r * 768 + col, lora_tag_of(lora_draw, lora_tag_lo), a.lf.err);      // the same term from this launch's workers
+            }
             if (EPI == EPI_PART) {
                 a.part_out[((size_t)r * gridDim.z + blockIdx.z) * (a.n_row_tiles * 16) + col] = v;
             } else if (EPI == EPI_RESID || EPI == EPI_RESID_P) {
@@ -534,6 +589,17 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             if (a.lora_delta != nullptr) {        // per-utterance LoRA term of q/k/v (lora.hip): part of the projection, so before RoPE
                 const float* dl = a.lora_delta + ((size_t)r * 3 + which) * K + h * CTTS_HEAD_DIM + d;
                 ya += dl[0]; yb += dl[32];
+            }
+            if constexpr (LORA_QKV) {
+                if (ltake) {                      // the same term from this launch's workers
+                    const lora_u64* gp = a.lf.g + ((size_t)r * 3 + which) * K + h * CTTS_HEAD_DIM + d;
+                    const unsigned tg = lora_tag_of(lora_draw, lora_tag_lo);
+                    float d0, d1;
+                    if ((unsigned)(lpeek[2 * ti] >> 32) == tg && (unsigned)(lpeek[2 * ti + 1] >> 32) == tg) {
+                        d0 = __builtin_bit_cast(float, (unsigned)lpeek[2 * ti]); d1 = __builtin_bit_cast(float, (unsigned)lpeek[2 * ti + 1]);
+                    } else lora_take2(gp, gp + 32, tg, a.lf.err, d0, d1);
+                    ya += d0; yb += d1;
+                }
             }
             const float va2 = ya, vb2 = yb;
             if (which < 2) {
@@ -582,7 +648,10 @@ template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1
 static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configure_only) {
     constexpr int KTILES = WAVES * KPW;
     constexpr int XS = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * 1024;
-    constexpr int LDS = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4 + 16;
+    constexpr bool LORA_OK = (KTILES * WTraits<WT>::KT == 768) && (VR == 0) &&
+                             ((EPI == EPI_QKV && (PRO == PRO_NORM || PRO == PRO_XH)) || ((EPI == EPI_RESID || EPI == EPI_RESID_XH) && PRO == PRO_PACKED));
+    constexpr int LDS0 = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4 + 16;
+    constexpr int LDS = (LORA_OK && LDS0 < 6272) ? 6272 : LDS0;          // a LoRA worker block keeps the row, the RMSNorm weight and u[16] in LDS (lora_worker.h)
     auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI, RT, VR>;
     if (configure_only) {
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -603,8 +672,12 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
                       (EPI == EPI_RESID_XH || EPI == EPI_RESID_XH_SK) ? (const void*)a.scale_in : nullptr;
     if (EPI == EPI_RESID_XH_SK && (nz > 4 || a.sk_slab == nullptr || a.sk_cnt == nullptr)) { ctts_set_error("skinny_gemm: split-K combine needs <= 4 slices and its slabs"); return 1; }
     const float* resid_arg = (PRO == PRO_XH) ? a.scale_in : (const float*)a.x_out;
-    const int misc = (a.np & 0xFF) | ((a.S & 0xFF) << 8) | (a.ktiles_total << 16);
-    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc, a);
+    if (a.lora_w != 0 && (!LORA_OK || a.lora_w != (EPI == EPI_QKV ? 3 : 1) * 16 * NBG || a.st == nullptr || a.ktiles_total > 255)) {
+        ctts_set_error("skinny_gemm: this launch cannot carry LoRA workers (pro %d epi %d workers %d)", PRO, EPI, a.lora_w);
+        return 1;
+    }
+    const int misc = (a.np & 0xFF) | ((a.S & 0xFF) << 8) | ((a.ktiles_total & 0xFF) << 16) | (a.lora_w << 24);
+    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT + a.lora_w, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }

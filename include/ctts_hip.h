@@ -77,6 +77,9 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection up to this batch size
  *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 17; 0 = never)
  *   "graph_steps"         decode steps captured per hipGraph (default 4)
+ *   "lora_fold"           per-utterance adapters at decode: 1 (default) = the rows' low-rank terms come from worker workgroups inside the QKV / o_proj launches
+ *                         (lora_worker.h), 0 = two more launches per layer (lora.hip; the prompt pass always uses those)
+ *   "persistent_fault"    test hook: one workgroup withholds a hand-off in layer value - 1 (the bounded waits must end the step with an error)
  * Unknown names are an error. */
 int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value);
 int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value);      /* the EFFECTIVE value ("persistent_rows" reads 0 where the mode is unavailable) */

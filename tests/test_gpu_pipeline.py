@@ -427,3 +427,53 @@ def test_per_utterance_lora_matches_per_row_merged_oracle(wd):
         for b in (2, 5):
             assert torch.equal(base.ids[b], out.ids[b])
     g.close()
+
+
+@pytest.mark.parametrize("wd", ["fp32", "fp16"])
+def test_per_utterance_lora_inside_the_projection_launches_equals_the_separate_launches(wd):
+    """Decode steps evaluate the rows' low-rank terms in worker workgroups of the QKV / o_proj launches (lora_worker.h, tagged-granule hand-off inside
+    the launch) instead of two more launches per layer (lora.hip).  Same arithmetic: fp32 token ids identical, hiddens within 2e-5 (the RMSNorm factor is
+    reduced in a different order; fp16: first hidden states within 2e-3), at 3 rows, 20 rows (two 16-row chunks) and 40 rows (32-row chunks), with and without graphs."""
+    from chatttsplus_amd.hip_models import GPT
+    cfg = dict(synth.GPT_REAL); cfg["num_hidden_layers"] = 4
+    llama = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=4)
+    sd = synth.gpt_state_dict(cfg, 1234)
+    rng = np.random.Generator(np.random.Philox(key=78))
+    g = GPT(llama, max_batch=40, max_seq_len=96, weight_dtype=wd)
+    g.load_state_dict(sd)
+    for ai in range(3):
+        ad = []
+        for l in range(4):
+            for t in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                r = (4, 8, 16)[ai]
+                ad.append((l, t, (rng.standard_normal((r, 768)) * 0.05).astype(np.float32), (rng.standard_normal((768, r)) * 0.05).astype(np.float32), 2.0))
+        g.load_adapter(ai, ad)
+    lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+    lp = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+    assert g.get_option("lora_fold") == 1
+    for B in (3, 20, 40):
+        T, N = 12, 24
+        ids, mask = synth.prompt_ids(B, T, cfg["num_text_tokens"], 23, pad_left=[(3 * b) % 7 for b in range(B)])
+        slots = [(b % 4) - 1 for b in range(B)]                         # -1 (none), 0, 1, 2
+        runs = {}
+        for fold, graph in ((0, True), (1, True), (1, False)):
+            g.set_option("lora_fold", fold)
+            g.use_graph = graph
+            g.set_row_adapters(slots)
+            emb = g(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))
+            runs[(fold, graph)] = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N,
+                                                  min_new_token=N, logits_warpers=lw, logits_processors=lp, return_hidden=True, noise="device", seed=3))[-1]
+            g.set_row_adapters(None)
+        g.use_graph = True
+        for key in ((1, True), (1, False)):
+            for b in range(B):
+                if wd == "fp32":
+                    assert torch.equal(runs[key].ids[b], runs[(0, True)].ids[b]), f"{wd} B={B} row {b} {key}: ids differ from the separate launches"
+                    assert float((runs[key].hiddens[b] - runs[(0, True)].hiddens[b]).abs().max()) <= 2e-5, (wd, B, b, key)
+                else:               # fp16 K / V: an ulp in the RMSNorm factor can move a rounding and, steps later, a token -- the first step's hidden states are the statement
+                    h0, r0 = runs[key].hiddens[b][0], runs[(0, True)].hiddens[b][0]
+                    assert float((h0 - r0).pow(2).mean().sqrt() / r0.pow(2).mean().sqrt()) <= 2e-3, (wd, B, b, key)
+            if wd == "fp16":
+                assert torch.equal(torch.stack(list(runs[(1, True)].ids)), torch.stack(list(runs[(1, False)].ids))), "graph replay != eager launches"
+    g.set_option("lora_fold", 1)
+    g.close()
