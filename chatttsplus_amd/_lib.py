@@ -94,6 +94,7 @@ SYMBOLS = [
     ("ctts_gpt_compact", C.c_int, [_P, _P, C.c_int, _P]),
     ("ctts_sampler_noise", C.c_int, [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     ("ctts_gpt_admit", C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    ("ctts_gpt_admit_adapters", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("ctts_gpt_logits", C.c_int, [_P, _P, _P]),
     ("ctts_gpt_force_ids", C.c_int, [_P, _P, _P]),
     ("ctts_sampler_run", C.c_int, [C.POINTER(SamplerCfg), _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

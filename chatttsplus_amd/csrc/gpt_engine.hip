@@ -475,14 +475,21 @@ extern "C" int ctts_gpt_clear_adapter(ctts_gpt* h, int slot) {
 }
 extern "C" int ctts_gpt_set_row_adapters(ctts_gpt* h, const int32_t* slots, int B) {
     if (!h || !h->finalized) { ctts_set_error("set_row_adapters: handle not finalized"); return 1; }
-    if (!slots || B <= 0) { h->lora_rows = 0; return 0; }
+    auto clear_rows = [h]() -> int {              // no row carries an adapter: also forget what an earlier request's rows carried (ctts_gpt_admit_adapters builds on these)
+        h->lora_rows = 0;
+        if (!h->lora_slot_host.empty()) h->lora_slot_host.assign(CTTS_MAX_B, -1);
+        for (int b = 0; b < CTTS_MAX_B; ++b) h->lora_row_slots[b] = -1;
+        if (h->lora_slot_of_seq) CTTS_HIP_CHECK(hipMemset(h->lora_slot_of_seq, 0xFF, CTTS_MAX_B * 4));
+        return 0;
+    };
+    if (!slots || B <= 0) return clear_rows();
     if (B > CTTS_MAX_B) { ctts_set_error("set_row_adapters: B=%d > %d", B, CTTS_MAX_B); return 1; }
     bool any = false;
     for (int b = 0; b < B; ++b) {
         if (slots[b] >= CTTS_MAX_ADAPTERS) { ctts_set_error("set_row_adapters: slot %d out of range", slots[b]); return 1; }
         any = any || slots[b] >= 0;
     }
-    if (!any) { h->lora_rows = 0; return 0; }
+    if (!any) return clear_rows();
     if (lora_ensure_storage(h)) return 1;
     std::vector<int> tab(CTTS_MAX_B, -1);
     for (int b = 0; b < B; ++b) tab[b] = slots[b] < 0 ? -1 : slots[b];
@@ -1192,6 +1199,12 @@ extern "C" int ctts_gpt_rows_enqueue(ctts_gpt* h, int32_t* host_pinned_2B, void*
     return 0;
 }
 
+// per-utterance adapters: the engine keeps the LoRA launches only while a live row carries an adapter
+static void lora_refresh(ctts_gpt* h) {
+    bool any = false;
+    for (int r = 0; r < h->B; ++r) any = any || h->lora_row_slots[r] >= 0;
+    h->lora_rows = any ? 1 : 0;
+}
 extern "C" int ctts_gpt_compact(ctts_gpt* h, const int32_t* keep_rows, int n_keep, void* stream) {
     if (!h || !keep_rows || h->B == 0) { ctts_set_error("compact: call begin first"); return 1; }
     if (n_keep < 1 || n_keep > h->B) { ctts_set_error("compact: n_keep=%d of %d rows", n_keep, h->B); return 1; }
@@ -1203,11 +1216,38 @@ extern "C" int ctts_gpt_compact(ctts_gpt* h, const int32_t* keep_rows, int n_kee
     CTTS_HIP_CHECK(hipMemcpyAsync(h->keep_dev, h->keep_host.data(), (size_t)n_keep * 4, hipMemcpyHostToDevice, s));
     if (launch_compact_rows(h->keep_dev, n_keep, h->H, h->x_dec, h->rope_dec, h->meta_dec, h->hist_ring, h->finend, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->st, s)) return 1;
     for (int i = 0; i < n_keep; ++i) { h->row_seq[i] = h->row_seq[keep_rows[i]]; h->row_ctx[i] = h->row_ctx[keep_rows[i]]; h->row_cap[i] = h->row_cap[keep_rows[i]]; }
-    if (h->lora_rows) for (int i = 0; i < n_keep; ++i) h->lora_row_slots[i] = (signed char)h->lora_slot_host[h->row_seq[i]];
+    if (!h->lora_slot_host.empty()) for (int i = 0; i < n_keep; ++i) h->lora_row_slots[i] = (signed char)h->lora_slot_host[h->row_seq[i]];
     h->B = n_keep;
+    if (h->lora_rows) lora_refresh(h);
     return 0;
 }
 
+
+// Adapter slots of the utterances the NEXT ctts_gpt_admit call seats in `rows` (-1 = none); rows not named keep theirs.  The slot follows the row's KV
+// lane (the prompt pass of the admitted rows looks it up by sequence, lora.hip) and the row itself (the decode launches carry the rows' slots in their
+// arguments, lora_worker.h).  When no live row has an adapter any more the engine drops back to the plain launches.
+extern "C" int ctts_gpt_admit_adapters(ctts_gpt* h, int n, const int32_t* rows, const int32_t* slots, void* stream) {
+    if (!h || h->B == 0 || !rows || !slots) { ctts_set_error("admit_adapters: call begin first / null argument"); return 1; }
+    if (h->lora_slot_host.empty()) {
+        h->lora_slot_host.assign(CTTS_MAX_B, -1);
+        for (int b = 0; b < CTTS_MAX_B; ++b) h->lora_row_slots[b] = -1;
+    }
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        if (rows[i] < 0 || rows[i] >= h->B || slots[i] >= CTTS_MAX_ADAPTERS) { ctts_set_error("admit_adapters: row %d / slot %d out of range", rows[i], slots[i]); return 1; }
+        any = any || slots[i] >= 0;
+    }
+    if (any && lora_ensure_storage(h)) return 1;
+    for (int i = 0; i < n; ++i) {
+        const int sl = slots[i] < 0 ? -1 : slots[i];
+        h->lora_slot_host[h->row_seq[rows[i]]] = sl;
+        h->lora_row_slots[rows[i]] = (signed char)sl;
+    }
+    if (h->lora_slot_of_seq)        // (pageable source: staged before the call returns)
+        CTTS_HIP_CHECK(hipMemcpyAsync(h->lora_slot_of_seq, h->lora_slot_host.data(), CTTS_MAX_B * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+    lora_refresh(h);
+    return 0;
+}
 
 // Continuous batching (no counterpart in the reference, whose slices run to their slowest row, pipeline:391-397 / gpt.py:527-546): `n` new
 // utterances take over decode rows whose utterance has finished.  Their prompts (all tokens but the last) go through an ordinary prompt pass
@@ -1218,7 +1258,6 @@ extern "C" int ctts_gpt_admit(ctts_gpt* h, int n, const int32_t* rows, int T, co
                               const int32_t* row_limits, const int32_t* out_index, const int32_t* attempts, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("admit: call begin first"); return 1; }
     if (!rows || !mask || !emb || !utt_ids || !out_index) { ctts_set_error("admit: null argument"); return 1; }
-    if (h->lora_rows) { ctts_set_error("admit: not with per-utterance adapters"); return 1; }
     if (h->io.noise != nullptr) { ctts_set_error("admit: device noise only (caller-supplied noise is indexed by the batch's draw counter)"); return 1; }
     if (n < 1 || n > h->B || T < 1 || T + h->sc.max_new > h->cfg.max_seq || (long long)n * (T - 1) > h->pass_rows) {
         ctts_set_error("admit: n=%d of %d rows, T=%d (max_seq %d, %d prompt rows per pass)", n, h->B, T, h->cfg.max_seq, h->pass_rows);

@@ -347,7 +347,7 @@ class GPT:
 
     def set_row_adapters(self, slots) -> None:
         """Adapter slot (or -1 / None) per sequence for the following generate() calls; None switches the per-row path off.  With it
-        every q/k/v/o projection evaluates W x + scale * B (A x) per row (two extra launches per layer)."""
+        every q/k/v/o projection evaluates W x + scale * B (A x) per row (decode: inside the projection launches, lora_worker.h; prompt pass: two more launches per layer)."""
         with torch.cuda.device(self.device):
             if slots is None:
                 _lib.check(self._lib.ctts_gpt_set_row_adapters(self._h, None, 0), "set_row_adapters")
@@ -639,7 +639,7 @@ class GPT:
                       attention_mask: Optional[torch.Tensor] = None, max_new_token=2048, min_new_token=0, logits_warpers=[],
                       logits_processors=[], return_hidden=False, ensure_non_empty=True, context=None, seed: Optional[int] = None,
                       max_restarts: int = 64, utt_ids=None, max_new_tokens_per_row=None, rows: Optional[int] = None, admit_min: Optional[int] = None,
-                      on_done=None, infer_text: bool = False) -> GenerationOutputs:
+                      on_done=None, infer_text: bool = False, adapter_slots=None) -> GenerationOutputs:
         """N utterances (left-padded prompts emb[N,T,H], like generate()) through `rows` <= max_batch decode rows: whenever utterances
         finish, queued ones take over their rows (ctts_gpt_admit) instead of the whole slice waiting for its slowest row as the reference's
         slices of 4 do (pipeline:391-397, gpt.py:527-546); once the queue is empty finished rows are compacted away (ctts_gpt_compact).
@@ -647,11 +647,14 @@ class GPT:
         counter / token limit / outputs are its own, so it produces what generate() produces for it in any slice.  ensure_non_empty
         (gpt.py:496-525) acts per utterance: one whose first token is EOS is admitted again with its next attempt, up to `max_restarts`.
         `on_done(list_of_indices)` is called (on the host, while decoding continues) as utterances complete.
+        `adapter_slots` = the resident adapter slot (load_adapter) of every utterance or -1 / None: per-utterance LoRA under row re-use (an admitted
+        utterance brings its own adapter, ctts_gpt_admit_adapters).
         Returns one GenerationOutputs for all N utterances, in input order."""
         gen = self.generate_many_iter(emb, inputs_ids, temperature, eos_token, attention_mask=attention_mask, max_new_token=max_new_token,
                                       min_new_token=min_new_token, logits_warpers=logits_warpers, logits_processors=logits_processors,
                                       return_hidden=return_hidden, ensure_non_empty=ensure_non_empty, context=context, seed=seed, max_restarts=max_restarts,
-                                      utt_ids=utt_ids, max_new_tokens_per_row=max_new_tokens_per_row, rows=rows, admit_min=admit_min, infer_text=infer_text)
+                                      utt_ids=utt_ids, max_new_tokens_per_row=max_new_tokens_per_row, rows=rows, admit_min=admit_min, infer_text=infer_text,
+                                      adapter_slots=adapter_slots)
         try:
             while True:
                 ev = next(gen)
@@ -663,7 +666,8 @@ class GPT:
     @torch.no_grad()
     def generate_many_iter(self, emb, inputs_ids, temperature, eos_token, attention_mask=None, max_new_token=2048, min_new_token=0, logits_warpers=[],
                            logits_processors=[], return_hidden=False, ensure_non_empty=True, context=None, seed=None, max_restarts: int = 64,
-                           utt_ids=None, max_new_tokens_per_row=None, rows=None, admit_min=None, infer_text: bool = False, progress: bool = False):
+                           utt_ids=None, max_new_tokens_per_row=None, rows=None, admit_min=None, infer_text: bool = False, progress: bool = False,
+                           adapter_slots=None):
         """generate_many as a generator: yields [(utterance index, ids [n,4] long, hiddens [n,768] or None)] for the utterances that completed
         since the last yield -- while the rest keeps decoding (what was yielded is final: its rows were written before the report that showed
         the utterance finished) -- and returns (StopIteration.value) the GenerationOutputs of all N utterances.
@@ -678,12 +682,15 @@ class GPT:
         try:
             return (yield from self._generate_many(emb, inputs_ids, temperature, eos_token, attention_mask, int(max_new_token), min_new_token, logits_warpers,
                                                    logits_processors, return_hidden, ensure_non_empty, context or Context(), seed, max_restarts, utt_ids,
-                                                   max_new_tokens_per_row, rows, admit_min, bool(infer_text), bool(progress)))
+                                                   max_new_tokens_per_row, rows, admit_min, bool(infer_text), bool(progress), adapter_slots))
         finally:
+            if adapter_slots is not None:
+                self.set_row_adapters(None)
             self._busy_token.owner = None
 
     def _generate_many(self, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token, logits_warpers, logits_processors,
-                       return_hidden, ensure_non_empty, context, seed, max_restarts, utt_ids, row_limits, rows, admit_min, infer_text=False, progress=False):
+                       return_hidden, ensure_non_empty, context, seed, max_restarts, utt_ids, row_limits, rows, admit_min, infer_text=False, progress=False,
+                       adapter_slots=None):
         lib, h, dev = self._lib, self._h, self.device
         N, T = int(inputs_ids.shape[0]), int(inputs_ids.shape[1])
         H, NVQ = self.model_dim, self.num_vq
@@ -700,6 +707,11 @@ class GPT:
         uids = [int(u) for u in utt_ids] if utt_ids is not None else list(range(N))
         lims = [min(max(int(v), 1), max_new_token) for v in row_limits] if row_limits is not None else [max_new_token] * N
         assert len(uids) == N and len(lims) == N
+        slots = None
+        if adapter_slots is not None:
+            slots = [-1 if a is None or int(a) < 0 else int(a) for a in adapter_slots]
+            if len(slots) != N or infer_text:
+                raise _lib.HipBackendError(f"adapter_slots: {len(slots)} entries for {N} utterances (code mode only)")
         ids = torch.empty(N, max_new_token, NVQ, dtype=torch.int32, device=dev)
         hid = torch.empty(N, max_new_token, H, dtype=torch.float32, device=dev) if return_hidden else None
         finish = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -723,6 +735,8 @@ class GPT:
             io = _lib.GenIO(ids=ids.data_ptr(), hiddens=hid.data_ptr() if hid is not None else None, finish=finish.data_ptr(),
                             end_idx=end_idx.data_ptr(), noise=None, n_draws=max_new_token, seed=int(seed), utt_ids=uid_arr.ctypes.data,
                             row_limits=lim_arr.ctypes.data)
+            if slots is not None:
+                self.set_row_adapters([slots[u] for u in first])
             _lib.check(lib.ctts_gpt_begin(h, R, Ta, mask_a.data_ptr(), C.byref(sc), C.byref(io), st), "begin")
             _lib.check(lib.ctts_gpt_prefill(h, emb_a.data_ptr(), st), "prefill")
             _lib.check(lib.ctts_gpt_sample(h, st), "sample")
@@ -771,6 +785,9 @@ class GPT:
                     lim_arr = np.ascontiguousarray([lims[u] for u in idx], dtype=np.int32)
                     out_arr = np.ascontiguousarray(idx, dtype=np.int32)
                     att_arr = np.ascontiguousarray([a for _, a in take], dtype=np.int32)
+                    if slots is not None:
+                        sl_arr = np.ascontiguousarray([slots[u] for u in idx], dtype=np.int32)
+                        _lib.check(lib.ctts_gpt_admit_adapters(h, k, rows_arr.ctypes.data_as(C.c_void_p), sl_arr.ctypes.data_as(C.c_void_p), st), "admit_adapters")
                     _lib.check(lib.ctts_gpt_admit(h, k, rows_arr.ctypes.data_as(C.c_void_p), Ta, mask_a.data_ptr(), emb_a.data_ptr(),
                                                   uid_arr.ctypes.data_as(C.c_void_p), lim_arr.ctypes.data_as(C.c_void_p),
                                                   out_arr.ctypes.data_as(C.c_void_p), att_arr.ctypes.data_as(C.c_void_p), st), "admit")

@@ -461,11 +461,18 @@ class ChatTTSPlusPipeline:
         # `continuous=True` (no counterpart in the reference): the request's utterances are NOT cut into slices that each wait for their slowest
         # row (pipeline:391-397); slice_size decode rows are kept busy -- queued utterances take over the rows of finished ones
         # (GPT.generate_many_iter, ctts_gpt_admit).  Device noise keyed by utterance id: every utterance gets the waveform the sliced path gives it.
-        # Lists of waveforms are yielded in input order as prefixes of the request complete.  Not for stream=True (sample windows),
-        # per-utterance adapters or caller-supplied noise.
+        # Lists of waveforms are yielded in input order as prefixes of the request complete.  Not for caller-supplied noise.
         if kwargs.get("continuous") and len(text_in) > slice_size:
-            if lora_paths is not None or noise_mode not in ("auto", "device"):
-                raise _lib.HipBackendError("continuous=True works with device noise and without per-utterance adapters")
+            if noise_mode not in ("auto", "device"):
+                raise _lib.HipBackendError("continuous=True works with device noise")
+            adapter_slots = None
+            if lora_paths is not None:
+                # per-utterance adapters under row re-use: an admitted utterance brings its own adapter (ctts_gpt_admit_adapters).  All adapters of the request
+                # must be resident at once (the engine holds _lib.MAX_ADAPTERS)
+                if len({p for p in lora_paths if p}) > _lib.MAX_ADAPTERS:
+                    raise _lib.HipBackendError(f"continuous=True: {len({p for p in lora_paths if p})} distinct adapters in the request; the engine holds "
+                                               f"{_lib.MAX_ADAPTERS} (use slices: continuous=False)")
+                adapter_slots = self._adapter_slots(gpt, lora_paths)
             if noise_seed is None:
                 noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             texts_all = list(text_in)
@@ -490,7 +497,8 @@ class ChatTTSPlusPipeline:
                 pic = dataclasses.replace(pic, spk_emb=pic.spk_emb[torch.as_tensor(order, device=pic.spk_emb.device)])
             events = self._infer_code([texts_all[i] for i in order], False, use_decoder, pic, gpt=gpt, continuous=True, seed=noise_seed,
                                       utt_ids=[utt_ids[i] for i in order], rows=slice_size,
-                                      max_new_tokens_per_row=[utt_limits[i] for i in order] if utt_limits is not None else None, progress=bool(stream))
+                                      max_new_tokens_per_row=[utt_limits[i] for i in order] if utt_limits is not None else None, progress=bool(stream),
+                                      **({"adapter_slots": [adapter_slots[i] for i in order]} if adapter_slots is not None else {}))
             if stream:
                 # stream=True with row re-use (no counterpart in the reference, whose stream branch serves one slice, pipeline:440-463): every yield is a list of
                 # (utterance index, sample window) -- the next [emitted, b) samples of that utterance's prefix waveform, vocoded from the tokens inside the window's

@@ -232,9 +232,14 @@ int ctts_gpt_compact(ctts_gpt* h, const int32_t* keep_rows, int n_keep, void* st
  *               row), regenerate attempt (ensure_non_empty: an utterance whose first token was EOS is admitted again with attempt + 1)
  * The prompt but its last token goes through a prompt pass into the rows' KV lanes; the last token becomes the rows' next decode input, so
  * the next decode step samples the utterance's first token.  Step counter, noise stream, limit and outputs are per row, so an utterance's
- * result does not depend on when or where it is admitted.  Code mode, device noise, no per-utterance adapters.  Asynchronous. */
+ * result does not depend on when or where it is admitted.  Device noise only.  Per-utterance adapters: name the new utterances' slots with
+ * ctts_gpt_admit_adapters first.  Asynchronous. */
 int ctts_gpt_admit(ctts_gpt* h, int n, const int32_t* rows, int T, const int32_t* mask, const float* emb, const uint64_t* utt_ids,
                    const int32_t* row_limits, const int32_t* out_index, const int32_t* attempts, void* stream);
+
+/* Adapter slots (ctts_gpt_set_adapter; -1 = none) of the utterances the NEXT ctts_gpt_admit call seats in `rows`; rows not named keep theirs.  When no
+ * live row carries an adapter any more the engine drops back to the plain launches. */
+int ctts_gpt_admit_adapters(ctts_gpt* h, int n, const int32_t* rows, const int32_t* slots, void* stream);
 
 /* Non-blocking variant: enqueues a copy of {steps_done, draws, all_finished, -} into 4 int32 of PINNED host memory; the
  * caller records an event after it and reads the words once the event has completed -- lets the host keep one chunk of

@@ -350,6 +350,22 @@ def test_pipeline_lora_path_end_to_end_batch32(tmp_path):
             rms = float(np.sqrt(np.mean((w - wav_ref) ** 2))) / float(np.sqrt(np.mean(wav_ref ** 2)))
             assert rms <= 1e-3, f"adapter {ai} utterance {b}: waveform rms-rel {rms}"
     assert len(pipe._lora_models) == 1                               # LRU of one: adapter 0's engine was destroyed when adapter 1 came in
+    # per-utterance adapters (lora_paths) in slices of 4 vs continuous batching on 4 rows: an admitted utterance brings its own adapter
+    # (ctts_gpt_admit_adapters) and gets the waveform the sliced path gives it
+    paths = [(str(tmp_path / "lora0"), None, str(tmp_path / "lora1"))[i % 3] for i in range(14)]
+    p2 = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=20, min_new_token=3, show_tqdm=False)
+    kw = dict(skip_refine_text=True, do_text_optimization=False, params_infer_code=p2, lora_paths=paths, slice_size=4, noise="device", noise_seed=9,
+              max_new_tokens_per_utterance=[4 + (5 * i) % 17 for i in range(14)])          # ragged ends: rows free up at different steps
+    sliced = [w for chunk in pipe.infer(list(texts[:14]), **kw) for w in chunk]
+    cont = [w for chunk in pipe.infer(list(texts[:14]), continuous=True, **kw) for w in chunk]
+    plain = [w for chunk in pipe.infer(list(texts[:14]), **dict(kw, lora_paths=None)) for w in chunk]
+    assert len(sliced) == len(cont) == 14 and len({w.shape[0] for w in sliced}) > 1
+    for u in range(14):
+        assert sliced[u].shape == cont[u].shape, f"utterance {u}: {cont[u].shape[0]} samples with row re-use, {sliced[u].shape[0]} in slices"
+        assert float((sliced[u] - cont[u]).abs().max()) <= 1e-4 * float(sliced[u].abs().max()), u
+    assert any(sliced[u].shape != plain[u].shape or float((sliced[u] - plain[u]).abs().max()) > 1e-3 * float(plain[u].abs().max()) for u in range(14) if paths[u]), "the adapters change nothing"
+    for u in (1, 4, 7):                                              # utterances without an adapter are the base model's
+        assert sliced[u].shape == plain[u].shape and float((sliced[u] - plain[u]).abs().max()) <= 1e-4 * float(plain[u].abs().max())
     # the base engine is untouched: same result as an engine that never saw an adapter
     base = run(None)
     o = ref_cpu.OracleGPT(gsd, 12)
@@ -476,4 +492,37 @@ def test_per_utterance_lora_inside_the_projection_launches_equals_the_separate_l
             if wd == "fp16":
                 assert torch.equal(torch.stack(list(runs[(1, True)].ids)), torch.stack(list(runs[(1, False)].ids))), "graph replay != eager launches"
     g.set_option("lora_fold", 1)
+    # row re-use with adapters: 12 utterances through 3 rows, each with its own slot (an admitted utterance brings its adapter: ctts_gpt_admit_adapters).
+    # Folded and separate launches see the same admissions: identical tokens.  Against slices: the admitted utterance's LAST prompt token takes the decode
+    # kernels instead of the prompt-pass ones (ulp-level differences, with or without adapters), so the statement is the first hidden state within 1e-5 --
+    # a wrong or missing adapter moves it by O(1) -- and the first tokens.
+    if wd == "fp32":
+        NU, T, N = 12, 10, 18
+        ids, mask = synth.prompt_ids(NU, T, cfg["num_text_tokens"], 29, pad_left=[(2 * b) % 5 for b in range(NU)])
+        slots = [(b % 4) - 1 for b in range(NU)]
+        emb = g(torch.from_numpy(ids), torch.ones(NU, T, dtype=torch.bool))
+        kw = dict(max_new_token=N, min_new_token=2, logits_warpers=lw, logits_processors=lp, return_hidden=True, seed=11)
+        many = {}
+        for fold in (1, 0):
+            g.set_option("lora_fold", fold)
+            many[fold] = g.generate_many(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), utt_ids=list(range(NU)), rows=3,
+                                         adapter_slots=slots, **kw)
+            assert g.admissions, "no utterance was admitted into a freed row"
+        g.set_option("lora_fold", 1)
+        plain = g.generate_many(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), utt_ids=list(range(NU)), rows=3, **kw)
+        for u in range(NU):
+            assert torch.equal(many[1].ids[u], many[0].ids[u]) and float((many[1].hiddens[u] - many[0].hiddens[u]).abs().max()) <= 2e-5, u
+        for i in range(0, NU, 3):
+            sl = slice(i, i + 3)
+            g.set_row_adapters(slots[sl])
+            ref = list(g.generate(emb[sl].contiguous(), torch.from_numpy(ids[sl]), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask[sl]), noise="device",
+                                  utt_ids=list(range(NU))[sl], **kw))[-1]
+            g.set_row_adapters(None)
+            for j, u in enumerate(range(i, i + 3)):
+                assert float((many[1].hiddens[u][0] - ref.hiddens[j][0]).abs().max()) <= 1e-5, f"utterance {u} (slot {slots[u]}): not the adapter a slice gives it"
+                assert torch.equal(many[1].ids[u][:4], ref.ids[j][:4]), u
+                if slots[u] >= 0:
+                    assert float((many[1].hiddens[u][0] - plain.hiddens[u][0]).abs().max()) > 1e-3, f"utterance {u}: its adapter changes nothing"
+                else:
+                    assert torch.equal(many[1].ids[u], plain.ids[u]), u
     g.close()
