@@ -143,9 +143,6 @@ struct ctts_gpt {
     std::vector<signed char> lora_rank;          //   [layer][slot][target] rank as loaded (0 = empty)
     std::vector<int> lora_slot_host;             //   host copy of lora_slot_of_seq
     float *lora_dqkv = nullptr, *lora_do = nullptr;
-    unsigned* att_flags = nullptr;               // attention inside the o_proj launch (skinny_gemm.hip): completion tag per (row, head)
-    int attn_fuse = 1;                           //   "attn_oproj_fuse" option
-    int attn_nap0 = 0, attn_nap = 1;             //   "attn_oproj_nap0" / "attn_oproj_nap": see GemmArgs.att_nap0
     unsigned long long* lora_g = nullptr;        //   decode steps: the same terms as tagged granules from worker workgroups inside the QKV / o_proj launches (lora_worker.h)
     int lora_fold = 1;                           //   "lora_fold" option: 0 = the two extra launches per layer at decode too
     int lora_rows = 0;                           // 1: the current / next generate() calls carry per-sequence adapters
@@ -270,7 +267,7 @@ static int ensure_persist(ctts_gpt* h, bool required) {
     }
     if (persist_configure()) return 1;
     if (dev_alloc((void**)&h->pimg, PL_LAYER_BYTES * h->L) || dev_alloc((void**)&h->pl_g, (size_t)PL_G_TOTAL * 8) ||
-        dev_alloc((void**)&h->pl_epoch, 4) || (h->pl_error == nullptr && dev_alloc((void**)&h->pl_error, 4))) return 1;
+        dev_alloc((void**)&h->pl_epoch, 4) || dev_alloc((void**)&h->pl_error, 4)) return 1;
     const unsigned one = 1;
     CTTS_HIP_CHECK(hipMemcpy(h->pl_epoch, &one, 4, hipMemcpyHostToDevice));
     for (int l = 0; l < h->L; ++l)
@@ -289,7 +286,6 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     else if (n == "graph_steps") *value = h->graph_steps;
     else if (n == "decode_splits") *value = h->force_splits;
     else if (n == "lora_fold") *value = h->lora_fold;
-    else if (n == "attn_oproj_fuse") *value = h->attn_fuse;
     else if (n == "down_splitk_rows") *value = h->down_sk_rows;
     else { ctts_set_error("get_option: unknown option '%s'", name); return 1; }
     return 0;
@@ -312,12 +308,6 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->persist_lpl = value < 0 ? 0 : value;
     } else if (n == "persistent_schedule") {               // 1 / 2: see persist_layer.hip
         h->persist_sched = (value >= 1 && value <= 3) ? value : 1;
-    } else if (n == "attn_oproj_fuse") {                   // decode, unsplit attention, 16-row chunks: the attention workgroups ride in front of the o_proj tiles of ONE launch
-        h->attn_fuse = value ? 1 : 0;
-    } else if (n == "attn_oproj_nap0") {
-        h->attn_nap0 = value < 0 ? 0 : (value > 4096 ? 4096 : value);
-    } else if (n == "attn_oproj_nap") {
-        h->attn_nap = value < 0 ? 0 : (value > 4096 ? 4096 : value);
     } else if (n == "lora_fold") {                         // per-utterance adapters at decode: 1 = workers inside the QKV / o_proj launches, 0 = two more launches per layer
         h->lora_fold = (value < 0 || value > 3) ? 1 : value;
     } else if (n == "persistent_fault") {                  // test hook: a withheld hand-off; every wait is bounded, ctts_gpt_progress reports the edge
@@ -366,7 +356,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
-                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->att_flags, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
+                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -741,11 +731,8 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
         dev_alloc((void**)&h->cmeta, CTTS_MAX_B * sizeof(RowMeta)) || dev_alloc((void**)&h->cring, (size_t)CTTS_MAX_B * CTTS_NUM_VQ * 16 * 4) ||
         dev_alloc((void**)&h->cfin, (size_t)CTTS_MAX_B * sizeof(RowState)) || dev_alloc((void**)&h->keep_dev, CTTS_MAX_B * 4) ||
         dev_alloc(&h->xh, (size_t)((CTTS_MAX_B + 32) / 16) * (H / (h->esz == 2 ? 32 : 16)) * 1024) || dev_alloc((void**)&h->ssq, (size_t)(CTTS_MAX_B + 32) * (H / 16) * 4) ||
-        dev_alloc((void**)&h->scale_o, (size_t)(CTTS_MAX_B + 32) * 4) || dev_alloc((void**)&h->scale_d, (size_t)(CTTS_MAX_B + 32) * 4) ||
-        dev_alloc((void**)&h->att_flags, (size_t)CTTS_MAX_B * 16 * 4))
+        dev_alloc((void**)&h->scale_o, (size_t)(CTTS_MAX_B + 32) * 4) || dev_alloc((void**)&h->scale_d, (size_t)(CTTS_MAX_B + 32) * 4))
         return 1;
-    CTTS_HIP_CHECK(hipMemset(h->att_flags, 0, (size_t)CTTS_MAX_B * 16 * 4));       // tag 0 never matches (tags start at 64)
-    if (!h->pl_error) { if (dev_alloc((void**)&h->pl_error, 4)) return 1; CTTS_HIP_CHECK(hipMemset(h->pl_error, 0, 4)); }
     if (h->wsplit) {     // operand images of the prompt rows for the split GEMMs: heads / tails of the normalised rows | attention outputs (K = 768) and of the SwiGLU outputs (K = 3072)
         const size_t rows = (size_t)PASS_ROWS + PASS_PAD;
         if (dev_alloc(&h->sp_x_hi, rows * H * 2) || dev_alloc(&h->sp_x_lo, rows * H * 2) || dev_alloc(&h->sp_act_hi, rows * h->I * 2) || dev_alloc(&h->sp_act_lo, rows * h->I * 2)) return 1;
@@ -905,11 +892,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
         if (st == nullptr) { at.T = h->pre_T; at.row0 = (int)(meta - h->meta_pre); }       // prompt pass: position of this pass in the flattened [B][T] prompt
         at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
-        // decode, unsplit attention, 16-row chunks, no adapters: the attention workgroups ride in front of the o_proj tiles in ONE launch (skinny_gemm.hip)
-        const bool afuse = (st != nullptr) && (S == 1) && !lora && (nbg == 1) && !splitd && h->attn_fuse && h->att_flags != nullptr && h->NH == 12 && h->H == 768 &&
-                           (dt == CTTS_DTYPE_F32 || R * h->NH >= 256);      // (fp16 o_proj blocks have 4 waves: they can only host the 4-wave attention of >= 22 rows)
         if (pfs && S == 1) { if (launch_attention_split(at, h->sp_x_hi, h->sp_x_lo, s)) return 1; }      // writes o_proj's head / tail operand images directly
-        else if (afuse) { /* launched with o_proj below */ }
         else if (launch_attention(dt, at, s)) return 1;
         // softmax combine + o_proj + residual (S == 1: attention already wrote the normalised, packed B operand)
         GemmArgs g2 = a;
@@ -917,7 +900,6 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         g2.xpacked = h->attn_packed;
         g2.opart = h->dpart; g2.np = (splitd && l > 0) ? 4 : 0;      // the down projection's partial sums are folded into x here
         if (xhm) { g2.xh = h->xh; g2.ssq = h->ssq; g2.scale_in = h->scale_o; }
-        if (afuse) { g2.att = at; g2.att_flags = h->att_flags; g2.att_wide = (R * h->NH < 256) ? 1 : 0; g2.att_layer = l; g2.att_nap0 = h->attn_nap0; g2.att_nap = h->attn_nap; g2.err = h->pl_error; }
         if (lora && S != 1) { ctts_set_error("per-utterance LoRA needs unsplit attention"); return 1; }
         if (lfold) { g2.lf = g1.lf; g2.lora_w = NB; }
         else if (lora) {
@@ -1185,10 +1167,6 @@ extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_
     CTTS_HIP_CHECK(hipStreamSynchronize(s));
     if (steps_done) *steps_done = h->host_pin[0];
     if (all_finished) *all_finished = h->host_pin[2];
-    if (h->host_pin[12] == 8) {
-        ctts_set_error("attention inside the o_proj launch: a tile gave up waiting for its rows' attention workgroups; use options={'attn_oproj_fuse': 0}");
-        return 1;
-    }
     if (h->host_pin[12] == 7) {
         ctts_set_error("per-utterance LoRA: a projection tile gave up waiting for its low-rank term (lora_worker.h); use options={'lora_fold': 0}");
         return 1;

@@ -31,23 +31,6 @@ struct LoraFold {
     int diag;                   // timing experiments (option "lora_fold" 2 / 3): 2 = the tiles do not take the terms, 3 = the workers publish zeros at once
 };
 
-struct AttnArgs {
-    const float* q;         // [R][NH][64]
-    const void* k_cache;    // this layer
-    const void* v_cache;
-    int Lmax;
-    int NH;
-    int R;
-    int S;                  // key splits (grid.y)
-    const RowMeta* meta;
-    const DevState* st;
-    float* part_ml;         // [R][NH][S][2]
-    float* part_o;          // [R][NH][S][64]
-    void* packed_out;       // S == 1 only: normalised output written straight into the o_proj kernel's fragment-major B operand
-    int nbg;                //   rows per chunk = 16*nbg
-    int T, row0;            // prompt pass (MFMA flash kernel): prompt length and the flattened index b*T + t of the pass's first row
-};
-
 // out[R rows][N] = prologue(x)[R][K] . W[N][K]^T  followed by a fused epilogue.
 // W is pre-packed in 16-row x KT-col MFMA-A tiles, [row tile][k tile][lane][16 B] (gpt_engine.cpp).
 struct SamplerDyn;
@@ -94,17 +77,25 @@ struct GemmArgs {
     const RowState* rows;   // heads only: hidden row goes to hiddens[rows[r].out][rows[r].end] while the row is live
     float* sk_slab;         // EPI_RESID_XH_SK: partial tiles [row tile][chunk][slice][256] fp32
     int* sk_cnt;            //                  arrival tickets [row tile][chunk], zero between launches (the last arriver resets its counter)
-    // attention inside the o_proj launch (decode steps, unsplit attention; skinny_gemm.hip): the first R * NH workgroups of the launch run attention.hip's
-    // body and hand their rows to the tiles behind them through write-through stores + one flag word per (row, head)
-    AttnArgs att;
-    unsigned* att_flags;    // [max rows][NH], tag of the step / layer that last completed the (row, head); null = the attention is its own launch
-    int att_wide;           // 8-wave attention workgroups (launch_attention's rule) where the block size allows
-    int att_layer;
-    int att_nap0, att_nap;  // the tiles' poller: initial nap (x 64 sleep units) and nap between passes (x 16)
-    int* err;               // give-up word of the bounded waits (code 8)
     int valu;               // fp32 decode, <= 4 rows: products on the VALU instead of exact-f32 MFMA (skinny_gemm.hip, VR; ctts_gpt_set_option "valu_rows")
 };
 
+struct AttnArgs {
+    const float* q;         // [R][NH][64]
+    const void* k_cache;    // this layer
+    const void* v_cache;
+    int Lmax;
+    int NH;
+    int R;
+    int S;                  // key splits (grid.y)
+    const RowMeta* meta;
+    const DevState* st;
+    float* part_ml;         // [R][NH][S][2]
+    float* part_o;          // [R][NH][S][64]
+    void* packed_out;       // S == 1 only: normalised output written straight into the o_proj kernel's fragment-major B operand
+    int nbg;                //   rows per chunk = 16*nbg
+    int T, row0;            // prompt pass (MFMA flash kernel): prompt length and the flattened index b*T + t of the pass's first row
+};
 
 struct SamplerCfgDev {      // mirrors ctts_sampler_cfg
     float temperature[CTTS_NUM_VQ];

@@ -17,7 +17,6 @@
 //   EPI_LOGITS head_code[i](hidden) for the 4 folded heads        gpt.py:437-447
 #include "kernels.h"
 #include "lora_worker.h"
-#include "attention_body.h"
 
 #define ATT_SMAX 8     // max key splits combined by PRO_ATTN (gpt_engine.hip decode_splits)
 
@@ -90,8 +89,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 #define CTTS_EXIT_IF_DONE() if (__builtin_amdgcn_readfirstlane(done_v)) return
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int chunk = blockIdx.y;
-    int row0 = chunk * NB;
+    const int chunk = blockIdx.y;
+    const int row0 = chunk * NB;
     // per-utterance LoRA (lora_worker.h): the first lw blocks of every chunk evaluate the rows' low-rank terms, the tiles behind them pick the terms up in
     // their epilogues.  (lw rides on the leading scalar `misc` like the other fields the first instructions need.)
     constexpr bool LORA_QKV = (EPI == EPI_QKV) && (K == 768) && (VR == 0) && (PRO == PRO_NORM || PRO == PRO_XH);
@@ -115,35 +114,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             }
         }
     }
-    // Attention inside the o_proj launch (misc bit 31): workgroups [0, R * 12) run the decode attention of their (row, head), the o_proj tiles sit behind them in
-    // the grid -- a tile has a higher linear index than every workgroup it waits for, so its producers are resident or done before it starts -- request their
-    // weights at entry, wait for the flags of their chunk's rows and only then load the B operand the attention workgroups wrote (write-through stores, sc1
-    // loads: no fences).  What it saves per layer: one launch boundary and the round trip of the o_proj weights, which now overlaps the attention.
-    constexpr bool AFUSE = (PRO == PRO_PACKED) && (EPI == EPI_RESID || EPI == EPI_RESID_XH) && (K == 768) && (VR == 0) && (NBG == 1) && (RT == 1);
-    bool afused = false;
-    int att_draw = 0;
-    int chunk_f = chunk, bx_f = (int)blockIdx.x - lw;
-    if constexpr (AFUSE) {
-        if (misc < 0) {
-            afused = true;
-            att_draw = vload_flag(done_p - 1);                  // DevState.draw (see lora_worker.h): the step's tag
-            const int natt = R * 12;
-            if ((int)blockIdx.x < natt) {
-                float (*mg)[8][10] = (float (*)[8][10])smem;
-                bool wide = false;
-                if constexpr (WAVES >= 8) wide = a.att_wide != 0;
-                if constexpr (WAVES >= 8) {
-                    if (wide && tid < 512) attn_decode_body<WT, 8>(blockIdx.x, 0, done_p, a.att.meta, a.att.q, a.att.k_cache, a.att.v_cache, 12, 1, a.att, mg, a.att_flags, att_draw, (unsigned)a.att_layer * 2u);
-                }
-                if (!wide && tid < 256) attn_decode_body<WT, 4>(blockIdx.x, 0, done_p, a.att.meta, a.att.q, a.att.k_cache, a.att.v_cache, 12, 1, a.att, mg, a.att_flags, att_draw, (unsigned)a.att_layer * 2u);
-                return;
-            }
-            const int t = (int)blockIdx.x - natt;
-            chunk_f = t / 48; bx_f = t % 48;                    // o_proj: 768 / 16 row tiles per chunk
-        }
-    }
-    const int rt0 = bx_f * RT;
-    if (AFUSE && afused) { chunk = chunk_f; row0 = chunk * NB; }
+    const int rt0 = ((int)blockIdx.x - lw) * RT;
 
     // LOAD ORDER MATTERS: vmcnt retires in order, so a wait on any load issued after the weight stream is a wait on
     // the whole stream.  Everything the prologue needs is therefore requested first, the (non-temporal) weight
@@ -361,7 +332,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 #pragma unroll
                 for (int i = 0; i < KPW; ++i) bv[n][i] = xq[(size_t)(kt_off + wave * KPW + i) * 64 + n];
         }
-        if (PREB && !(AFUSE && afused)) {
+        if (PREB) {
             const frag* xq = (const frag*)in0 + (size_t)chunk * NBG * kt_all * 64 + lane;
 #pragma unroll
             for (int g = 0; g < NBG; ++g)
@@ -370,42 +341,6 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         }
         CTTS_ISSUE_WEIGHT_LOADS();
         CTTS_EXIT_IF_DONE();
-        if constexpr (AFUSE) {
-            static_assert(!AFUSE || PREB, "the fused o_proj tiles keep their B fragments in registers");
-            if (afused) {
-                // the attention workgroups of this chunk's rows: one flag per (row, head), one poller each; every wait is bounded
-                // (ONE wave polls, three flags per lane, with long naps: 96 tiles x 192 pollers re-reading their flags every 0.1 us took 35 us from a
-                //  batch-32 step -- the attention they wait for is the one kernel of the step that runs at the HBM rate)
-                const int nfl = min(NB, R - row0) * 12;
-                if (wave == 0) {
-                    const unsigned tg = ((unsigned)att_draw + 1u) * 64u + (unsigned)a.att_layer * 2u;
-                    const unsigned* fp = a.att_flags + (size_t)row0 * 12;
-                    for (int z = 0; z < a.att_nap0; ++z) __builtin_amdgcn_s_sleep(64);          // the attention cannot be done earlier than this
-#pragma unroll 1
-                    for (unsigned spins = 0;; ++spins) {
-                        bool ok = true;
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const int f = lane + 64 * j;
-                            if (f < nfl) ok = ok && (__hip_atomic_load(fp + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tg);
-                        }
-                        if (__all(ok)) break;
-                        if (spins > (1u << 20)) { if (lane == 0 && a.err != nullptr) atomicCAS(a.err, 0, 8); break; }
-                        for (int z = 0; z < a.att_nap; ++z) __builtin_amdgcn_s_sleep(16);
-                    }
-                }
-                __syncthreads();
-                const unsigned long long* xq = (const unsigned long long*)((const frag*)in0 + (size_t)chunk * NBG * kt_all * 64 + lane);
-#pragma unroll
-                for (int i = 0; i < KPW; ++i) {
-                    const unsigned long long* p8 = xq + (size_t)(kt_off + wave * KPW + i) * 64 * 2;      // one 16-byte fragment = two write-through granules
-                    unsigned long long w[2];
-                    w[0] = __hip_atomic_load(p8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w[1] = __hip_atomic_load(p8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_memcpy(&bpre[0][i], w, 16);
-                }
-            }
-        }
     }
     float* fac_s = (float*)(smem + XS_BYTES + WAVES * NBG * 1024);      // PRO_XH: [NB] rs / scale of each row of the chunk
     if (PRO == PRO_XH) {
@@ -740,18 +675,6 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
     if (a.lora_w != 0 && (!LORA_OK || a.lora_w != (EPI == EPI_QKV ? 3 : 1) * 16 * NBG || a.st == nullptr || a.ktiles_total > 255)) {
         ctts_set_error("skinny_gemm: this launch cannot carry LoRA workers (pro %d epi %d workers %d)", PRO, EPI, a.lora_w);
         return 1;
-    }
-    constexpr bool AFUSE_OK = (PRO == PRO_PACKED) && (EPI == EPI_RESID || EPI == EPI_RESID_XH) && (KTILES * WTraits<WT>::KT == 768) && (VR == 0) && (NBG == 1) && (RT == 1);
-    if (a.att_flags != nullptr) {          // attention inside this launch: 1-D grid, the R * 12 attention workgroups first
-        if (!AFUSE_OK || a.st == nullptr || a.lora_w != 0 || a.n_row_tiles != 48 || a.att.NH != 12 || a.att.S != 1 || a.att.packed_out == nullptr || nz != 1 ||
-            LDS < 8 * 8 * 10 * 4) {
-            ctts_set_error("skinny_gemm: this launch cannot carry the attention (pro %d epi %d)", PRO, EPI);
-            return 1;
-        }
-        const int misc_f = (int)(((unsigned)(a.np & 0xFF)) | ((unsigned)(a.S & 0xFF) << 8) | ((unsigned)(a.ktiles_total & 0xFF) << 16) | 0x80000000u);
-        hipLaunchKernelGGL(kern, dim3(a.R * 12 + 48 * chunks), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc_f, a);
-        CTTS_HIP_CHECK(hipGetLastError());
-        return 0;
     }
     const int misc = (a.np & 0xFF) | ((a.S & 0xFF) << 8) | ((a.ktiles_total & 0xFF) << 16) | (a.lora_w << 24);
     hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT + a.lora_w, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc, a);

@@ -140,30 +140,3 @@ def test_a_withheld_hand_off_ends_the_step_with_an_error_instead_of_hanging(gpt)
     g.set_option("persistent_fault", 0)
     ids, _ = _gen(g, 1, 24, 12)
     assert torch.equal(ids[0], ref_ids[0]), "the engine did not recover after the reported give-up"
-
-
-@pytest.mark.parametrize("wd", ["fp32", "fp16"])
-def test_attention_inside_the_o_proj_launch_is_bitwise_the_two_launches(wd):
-    """Decode steps with unsplit attention and 16-row chunks run the attention workgroups in front of the o_proj tiles of ONE launch (skinny_gemm.hip: flags +
-    write-through hand-off inside the launch).  Same workgroup bodies, same arithmetic: tokens AND hidden states are bitwise those of the two separate launches,
-    with graphs and eagerly, at 5 ... 32 rows (ragged left padding)."""
-    from chatttsplus_amd.hip_models import GPT
-    llama = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=4)
-    cfg = dict(synth.GPT_REAL); cfg["num_hidden_layers"] = 4
-    g = GPT(llama, max_batch=32, max_seq_len=160, weight_dtype=wd)
-    g.load_state_dict(synth.gpt_state_dict(cfg, 1234))
-    assert g.get_option("attn_oproj_fuse") == 1
-    for B in (5, 8, 16, 21, 22, 32):
-        pad = [(5 * b) % 11 for b in range(B)]
-        runs = {}
-        for fuse, graph in ((0, True), (1, True), (1, False)):
-            g.set_option("attn_oproj_fuse", fuse)
-            g.use_graph = graph
-            runs[(fuse, graph)] = _gen(g, B, 40, 48, pad)
-        g.use_graph = True
-        for key in ((1, True), (1, False)):
-            for b in range(B):
-                assert torch.equal(runs[key][0][b], runs[(0, True)][0][b]), f"{wd} B={B} row {b} {key}: tokens differ"
-                assert torch.equal(runs[key][1][b], runs[(0, True)][1][b]), f"{wd} B={B} row {b} {key}: hidden states differ"
-    g.set_option("attn_oproj_fuse", 1)
-    g.close()
