@@ -317,3 +317,39 @@ def test_pipeline_continuous_yields_in_input_order(tmp_path):
     assert any(len(ws) > 1 for ws in per.values()), "no utterance was streamed in more than one window"
     with pytest.raises(_lib.HipBackendError):
         list(pipe._infer(list(TEXTS), False, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, continuous=True, noise="torch"))
+
+
+def test_pipeline_continuous_with_per_utterance_adapters_host_logic(tmp_path, monkeypatch):
+    """infer(continuous=True, lora_paths=[...]) host logic with the fake engine: every adapter of the request is loaded into its own resident slot once, the
+    engine gets one slot (or -1) per utterance IN THE ORDER it gets the utterances (continuous="throughput" reorders them), and a request with more
+    distinct adapters than the engine holds is refused with a message that names the way out."""
+    from chatttsplus_amd.pipeline import InferCodeParams
+    import chatttsplus_amd.pipeline as pl
+    from chatttsplus_amd import _lib
+    pipe = _fake_pipeline(str(tmp_path))
+    gpt = pipe.models_dict["gpt"]
+    loaded = []
+    gpt.load_adapter = lambda slot, ad: loaded.append((slot, ad))
+    monkeypatch.setattr(pl, "load_lora_adapter", lambda path: f"adapter:{path}")
+    seen = {}
+    many0 = gpt.generate_many_iter
+
+    def many(*a, **kw):
+        seen["slots"], seen["utt_ids"] = list(kw.pop("adapter_slots")), list(kw["utt_ids"])
+        return many0(*a, **kw)
+    gpt.generate_many_iter = many
+    table = (torch.arange(3, dtype=torch.float32)[:, None] * 3 + 1).expand(3, 8).contiguous()
+    p = InferCodeParams(show_tqdm=False, spk_emb=table[torch.tensor(SPK_IDX)], prompt="[speed_5]")
+    paths = [("A", None, "B", "A", None)[i % 5] for i in range(10)]
+    for mode in (True, "throughput"):
+        loaded.clear(); pipe.__dict__.pop("_slot_of_path", None)
+        lists = list(pipe._infer(list(TEXTS), False, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, utt_ids=list(range(100, 110)),
+                                 noise_seed=9, continuous=mode, lora_paths=paths))
+        assert sum(len(l) for l in lists) == 10
+        assert sorted(ad for _, ad in loaded) == ["adapter:A", "adapter:B"] and len({s for s, _ in loaded}) == 2       # each adapter once, own slot
+        slot_of = {ad.split(":")[1]: s for s, ad in loaded}
+        assert seen["slots"] == [(-1 if paths[u - 100] is None else slot_of[paths[u - 100]]) for u in seen["utt_ids"]], mode
+    too_many = [f"P{i}" for i in range(_lib.MAX_ADAPTERS + 1)] + [None] * (10 - _lib.MAX_ADAPTERS - 1)
+    with pytest.raises(_lib.HipBackendError, match="continuous=False"):
+        list(pipe._infer(list(TEXTS), False, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, noise_seed=9, continuous=True,
+                         lora_paths=too_many))
