@@ -61,7 +61,7 @@ __device__ inline void store_x4<float>(void* base, int n, int k, int ktiles, flo
 // that for the 128 CUs that hold two gate|up blocks) -- while the same weight fragment times VR activation rows is 4 * VR v_fma per lane.  A lane keeps its
 // own weight row (lane & 15) and k-group (lane >> 4) of the MFMA-A image, so the packed weights are shared with the MFMA kernels; the four k-groups
 // are summed through the LDS crossbar and the waves' partials through `red`, in wave order (deterministic).
-template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1, int VR = 0>
+template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1, int VR = 0, bool LORA = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done_p, const void* Wq, const void* in0, const void* in1,
                                                                   const float* resid_in, const int R, const int misc, const GemmArgs a) {
     // misc = np | S << 8 | ktiles_total << 16: the three struct fields that address the first loads of some variants (partial
@@ -93,8 +93,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     const int row0 = chunk * NB;
     // per-utterance LoRA (lora_worker.h): the first lw blocks of every chunk evaluate the rows' low-rank terms, the tiles behind them pick the terms up in
     // their epilogues.  (lw rides on the leading scalar `misc` like the other fields the first instructions need.)
-    constexpr bool LORA_QKV = (EPI == EPI_QKV) && (K == 768) && (VR == 0) && (PRO == PRO_NORM || PRO == PRO_XH);
-    constexpr bool LORA_O = (EPI == EPI_RESID || EPI == EPI_RESID_XH) && (K == 768) && (VR == 0) && (PRO == PRO_PACKED);
+    // (LORA is a template argument: compiled into every capable launch, the worker branch and the look-ahead cost the adapter-less step 0.5 % in fp32 and 2 % in fp16)
+    constexpr bool LORA_QKV = LORA && (EPI == EPI_QKV) && (K == 768) && (VR == 0) && (PRO == PRO_NORM || PRO == PRO_XH);
+    constexpr bool LORA_O = LORA && (EPI == EPI_RESID || EPI == EPI_RESID_XH) && (K == 768) && (VR == 0) && (PRO == PRO_PACKED);
+    static_assert(!LORA || LORA_QKV || LORA_O, "LoRA workers: the q/k/v and o_proj launches of a decode step");
     const int lw = (LORA_QKV || LORA_O) ? ((misc >> 24) & 0x7F) : 0;
     int lora_draw = 0;
     // (the layer index is read where the tag is formed: an unconditional read of the argument struct at entry cost the adapter-less launches 0.2 us)
@@ -645,15 +647,15 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1, int VR = 0>
+template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1, int VR = 0, bool LORA = false>
 static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configure_only) {
     constexpr int KTILES = WAVES * KPW;
     constexpr int XS = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * 1024;
-    constexpr bool LORA_OK = (KTILES * WTraits<WT>::KT == 768) && (VR == 0) &&
+    constexpr bool LORA_OK = LORA && (KTILES * WTraits<WT>::KT == 768) && (VR == 0) &&
                              ((EPI == EPI_QKV && (PRO == PRO_NORM || PRO == PRO_XH)) || ((EPI == EPI_RESID || EPI == EPI_RESID_XH) && PRO == PRO_PACKED));
     constexpr int LDS0 = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4 + 16;
     constexpr int LDS = (LORA_OK && LDS0 < 6272) ? 6272 : LDS0;          // a LoRA worker block keeps the row, the RMSNorm weight and u[16] in LDS (lora_worker.h)
-    auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI, RT, VR>;
+    auto kern = skinny_gemm_kernel<WT, NBG, WAVES, KPW, PRO, EPI, RT, VR, LORA>;
     if (configure_only) {
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         return 0;
@@ -722,6 +724,11 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
             rc |= launch_one<WT, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
             if constexpr (NBG == 1) rc |= launch_one<WT, 1, W768, P768, PRO_PACKED, EPI_RESID_XH_SK>(a, chunks, s, true);
         }
+        // the same four launches with LoRA workers (lora_worker.h)
+        rc |= launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV, RT_NORM_C, 0, true>(a, chunks, s, true);
+        rc |= launch_one<WT, NBG, W768, P768, PRO_XH, EPI_QKV, RT_XH, 0, true>(a, chunks, s, true);
+        rc |= launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID, 1, 0, true>(a, chunks, s, true);
+        rc |= launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH, 1, 0, true>(a, chunks, s, true);
         if constexpr (!F16 && NBG == 1) {
 #define CTTS_VALU_CFG(VRN) rc |= launch_one<float, 1, W768, P768, PRO_NORM_P, EPI_QKV, 1, VRN>(a, chunks, s, true); rc |= launch_one<float, 1, W768, P768, PRO_NORM, EPI_QKV, 1, VRN>(a, chunks, s, true); \
             rc |= launch_one<float, 1, W768, P768, PRO_ATTN, EPI_RESID_P, 1, VRN>(a, chunks, s, true); rc |= launch_one<float, 1, W768, P768, PRO_NORM, EPI_SWIGLU, 1, VRN>(a, chunks, s, true); \
@@ -757,6 +764,14 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     }
     // 17-32 rows: RT_NORM weight row tiles per block for the two kernels whose prologue re-normalises every row in every block
     constexpr int RT_NORM = (NBG == 2) ? CTTS_RT_NORM : 1;
+    if (a.lora_w != 0) {          // per-utterance LoRA at decode: the launches that carry the workers
+        if (pro == PRO_NORM && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV, RT_NORM, 0, true>(a, chunks, s, false);
+        if (pro == PRO_XH && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_XH, EPI_QKV, RT_XH, 0, true>(a, chunks, s, false);
+        if (pro == PRO_PACKED && epi == EPI_RESID && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID, 1, 0, true>(a, chunks, s, false);
+        if (pro == PRO_PACKED && epi == EPI_RESID_XH && a.K == 768) return launch_one<WT, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH, 1, 0, true>(a, chunks, s, false);
+        ctts_set_error("skinny_gemm: prologue/epilogue %d/%d cannot carry LoRA workers", pro, epi);
+        return 1;
+    }
     if (pro == PRO_NORM && epi == EPI_QKV) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_QKV, RT_NORM>(a, chunks, s, false);
     if (pro == PRO_ATTN && epi == EPI_RESID) return launch_one<WT, NBG, W768, P768, PRO_ATTN, EPI_RESID>(a, chunks, s, false);
     if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_one<WT, NBG, W768, P768, PRO_NORM, EPI_SWIGLU, RT_NORM>(a, chunks, s, false);
