@@ -684,6 +684,9 @@ class ChatTTSPlusPipeline:
         limits_all = kwargs.pop("max_new_tokens_per_utterance", None)          # per GLOBAL utterance; each slice gets its own entries
         if limits_all is not None and len(limits_all) != len(texts):
             raise _lib.HipBackendError(f"max_new_tokens_per_utterance: {len(limits_all)} entries for {len(texts)} utterances")
+        lora_all = kwargs.pop("lora_paths", None)                              # one adapter directory (or None) per GLOBAL utterance; each slice gets its own entries
+        if lora_all is not None and len(lora_all) != len(texts):
+            raise _lib.HipBackendError(f"lora_paths: {len(lora_all)} entries for {len(texts)} utterances")
         ids_out = kwargs.pop("ids_out", None)                                  # optional list: receives this rank's generated ids, in `mine` order
         sink = [] if ids_out is not None else None
 
@@ -698,6 +701,8 @@ class ChatTTSPlusPipeline:
                 kw_sl = dict(kwargs)
                 if limits_all is not None:
                     kw_sl["max_new_tokens_per_utterance"] = [int(limits_all[i]) for i in sl]
+                if lora_all is not None:
+                    kw_sl["lora_paths"] = [lora_all[i] for i in sl]
                 if sink is not None:
                     kw_sl["_ids_sink"] = sink
                 for wavs in self._infer([texts[i] for i in sl], False, None, skip_refine_text, False, True, True, False, True,

@@ -260,6 +260,26 @@ def test_pipeline_infer_sharded_single_process(tmp_path):
     with pytest.raises(Exception, match="speaker_table"):                                          # index without a table: a clear error, not an AttributeError
         pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=None)
     assert [int(w.shape[0]) for w in wavs] == [256 * (2 * n - 1) for n in all_lens]
+    # per-utterance adapters of a sharded request: `lora_paths` names one adapter (or None) per GLOBAL utterance, every slice gets its own entries
+    import chatttsplus_amd.pipeline as pl
+    gpt = pipe.models_dict["gpt"]
+    loaded, row_tables = [], []
+    gpt.load_adapter = lambda slot, ad: loaded.append((slot, ad))
+    gpt.set_row_adapters = lambda slots: row_tables.append(None if slots is None else list(slots))
+    orig = pl.load_lora_adapter
+    pl.load_lora_adapter = lambda path: f"adapter:{path}"
+    try:
+        paths = [("A", None, "B")[i % 3] for i in range(len(TEXTS))]
+        mine2, wavs2, lens2 = pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=table, params_infer_code=InferCodeParams(show_tqdm=False),
+                                                 noise_seed=4242, lora_paths=paths)
+        with pytest.raises(Exception, match="lora_paths"):
+            pipe.infer_sharded(list(TEXTS), speaker_index=SPK_IDX, speaker_table=table, lora_paths=paths[:3])
+    finally:
+        pl.load_lora_adapter = orig
+    assert lens2 == all_lens and sorted(ad for _, ad in loaded) == ["adapter:A", "adapter:B"]
+    slot_of = {ad.split(":")[1]: s_ for s_, ad in loaded}
+    given = [t for t in row_tables if t is not None]
+    assert [x for t in given for x in t] == [(-1 if paths[i] is None else slot_of[paths[i]]) for i in mine2]       # slices of 3 rows, in this rank's order
 
 
 def test_pipeline_continuous_yields_in_input_order(tmp_path):
