@@ -90,6 +90,9 @@ struct ctts_gpt {
                                                  // 16 766 -> 712: 48 blocks pulling 9.4 MB of fp32 weights + as many bytes of fp32 activations through 48 CUs were
                                                  // the slowest launch of the layer; with two 16-row chunks the partial sums cost the next QKV prologue what the
                                                  // split saves: batch 20 / 24 / 28 / 32 835 / 892 / 914 / 941 either way)
+                                                 // Round 4: fp32 8 as well -- with the in-launch split-K combine (down_sk_rows) the packed-residual path wins from 9 rows on:
+                                                 // ms/step launch slices / packed + combine: batch 8 0.599 / 0.613, 9 0.632 / 0.623, 10 0.641 / 0.627, 12 0.664 / 0.637,
+                                                 // 14 0.687 / 0.648, 16 0.709 / 0.661; launch slices beyond 16 rows lose (17 0.765 -> 0.812, 32 0.860 -> 0.939)
     float* dpart = nullptr;                      // [rows<=32][4][768]
     int cur_splits = 1;                          // key splits of the decode attention for the steps being launched (decode_splits)
     int launched = 0;                            // decode steps enqueued since begin / restart: host-side bound on the context length
@@ -98,7 +101,7 @@ struct ctts_gpt {
                                                  // 640 vs 660 us/step) -- per-block prologue latency, not L2 traffic, is what these launches pay for;
                                                  // the prompt pass keeps 32-row blocks
     int force_splits = 0;                        // key splits of the decode attention (0 = decode_splits policy); ctts_gpt_set_option("decode_splits")
-    int down_sk_rows = 17;                       // xh-mode decode batches of >= this many rows (one 16-row chunk per block) slice the down projection's K four ways inside the
+    int down_sk_rows = 9;                        // xh-mode decode batches of >= this many rows (one 16-row chunk per block) slice the down projection's K four ways inside the
                                                  // launch (EPI_RESID_XH_SK); 0 = never.  "down_splitk_rows".  us/step without -> with (profiles/r04_ab_down_splitk.jsonl):
                                                  // fp32 batch 17 795 -> 767, 24 862 -> 833, 32 894 -> 868; fp16 batch 9 475 -> 465, 16 507 -> 496, 24 / 32 unchanged
     float* sk_slab = nullptr; int* sk_cnt = nullptr;
@@ -204,9 +207,9 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->cfg = *c;
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
-    h->split_rows = (c->dtype == CTTS_DTYPE_F16) ? 8 : 16;
+    h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
     h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 4 : 0;
-    h->down_sk_rows = (c->dtype == CTTS_DTYPE_F16) ? 9 : 17;     // = the first batch size of the packed-residual path (split_rows + 1)
+    h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
     // product library takes no behaviour from the environment on its launch paths (diag_env() is a constant null there).
     if (const char* sr = diag_env("CTTS_SPLIT_ROWS")) { h->split_rows = atoi(sr); if (h->split_rows > 32) h->split_rows = 32; }

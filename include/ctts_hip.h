@@ -74,8 +74,8 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "persistent_delay", "persistent_delay_act", "persistent_delay_x", "persistent_delay_att", "persistent_nap", "persistent_nap_qkv"  when and how often the edge waves poll
  *   "persistent_poll"     0 / 1: sentinel granules before the full sweeps (default 0)
  *   "persistent_timestamps" diagnostics: the persistent launches record per-workgroup phase marks
- *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection up to this batch size
- *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 17; 0 = never)
+ *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection as launch slices up to this batch size (default 8)
+ *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 9; 0 = never)
  *   "graph_steps"         decode steps captured per hipGraph (default 4)
  *   "lora_fold"           per-utterance adapters at decode: 1 (default) = the rows' low-rank terms come from worker workgroups inside the QKV / o_proj launches
  *                         (lora_worker.h), 0 = two more launches per layer (lora.hip; the prompt pass always uses those)
