@@ -100,6 +100,9 @@ struct ctts_gpt {
                                                  // Measured: two 16-row chunks beat one 32-row block at batch 24 / 32 (598 vs 624,
                                                  // 640 vs 660 us/step) -- per-block prologue latency, not L2 traffic, is what these launches pay for;
                                                  // the prompt pass keeps 32-row blocks
+                                                 // Round 4 (with the in-launch split-K combine of the 16-row chunks): ms/step 32-row blocks / 16-row chunks, fp32: batch 40 1.176 / 1.012,
+                                                 // 48 1.266 / 1.100, 64 1.343 / 1.259, 96 1.717 / 1.754, 128 2.081 / 2.159; fp16: 40 0.676 / 0.652, 64 0.767 / 0.768, 128 1.099 / 1.169
+                                                 // -> 32-row blocks from 81 (fp32) / 57 (fp16) rows ("nbg2_rows")
     int force_splits = 0;                        // key splits of the decode attention (0 = decode_splits policy); ctts_gpt_set_option("decode_splits")
     int down_sk_rows = 9;                        // xh-mode decode batches of >= this many rows (one 16-row chunk per block) slice the down projection's K four ways inside the
                                                  // launch (EPI_RESID_XH_SK); 0 = never.  "down_splitk_rows".  us/step without -> with (profiles/r04_ab_down_splitk.jsonl):
@@ -209,6 +212,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
     h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 4 : 0;
+    h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
     // product library takes no behaviour from the environment on its launch paths (diag_env() is a constant null there).
@@ -341,6 +345,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->force_splits = value;
     } else if (n == "split_rows") {              // decode batches up to this size run the down projection as split-K launch slices
         h->split_rows = value < 0 ? 0 : (value > 32 ? 32 : value);
+    } else if (n == "nbg2_rows") {               // decode batches of >= this many rows use 32-row blocks (see nbg2_rows)
+        h->nbg2_rows = value < 17 ? 17 : value;
     } else if (n == "down_splitk_rows") {        // see down_sk_rows
         h->down_sk_rows = value < 0 ? 0 : value;
     } else if (n == "graph_steps") {

@@ -76,6 +76,7 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "persistent_timestamps" diagnostics: the persistent launches record per-workgroup phase marks
  *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection as launch slices up to this batch size (default 8)
  *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 9; 0 = never)
+ *   "nbg2_rows"           decode batches of >= this many rows use 32-row blocks instead of 16-row chunks (default 81 fp32 / 57 fp16)
  *   "graph_steps"         decode steps captured per hipGraph (default 4)
  *   "lora_fold"           per-utterance adapters at decode: 1 (default) = the rows' low-rank terms come from worker workgroups inside the QKV / o_proj launches
  *                         (lora_worker.h), 0 = two more launches per layer (lora.hip; the prompt pass always uses those)
