@@ -61,7 +61,7 @@ def cpu_baseline(prompt_len: int, sample_steps: int):
         o.generate(emb, torch.from_numpy(ids), sp, attention_mask=torch.from_numpy(mask), max_new_token=n,
                    noise=ref_cpu.SeededNoise(1234))
         times[n] = time.perf_counter() - t0
-    dt = times[4 + sample_steps] - times[4]
+    dt = max(times[4 + sample_steps] - times[4], 1e-9)
     return dict(value=round(sample_steps / dt, 3), unit="tokens/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"oracle/ref_cpu.OracleGPT (torch fp32) batch 1, prompt {prompt_len}, {sample_steps} decode steps "
                        f"after a 4-step run is subtracted, same synthetic weights; host has {os.cpu_count()} logical CPUs")
@@ -112,23 +112,25 @@ def sharded_request_leg(pipe, dev, rank, world, n_utt=256, rows=32, reps=2, max_
     table = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])) if rank == 0 else None
     params = InferCodeParams(prompt="[speed_5]", max_new_token=max_new, min_new_token=max_new, show_tqdm=False)   # EOS masked: every row runs to its own limit
     cpu = dev.type == "cpu"
+    grouped = dist.is_available() and dist.is_initialized()          # (--force-pg: a one-rank group runs every rendezvous too)
 
     def sync():
         if not cpu:
             torch.cuda.synchronize(dev)
 
     best = None
+    walls = []
     for rep in range(reps + 1):
         ids = []
         sync()
-        if world > 1:
+        if grouped:
             dist.barrier()
         t0 = time.perf_counter()
         mine, wavs, lens = pipe.infer_sharded(list(texts), speaker_index=spk_index, speaker_table=table, params_infer_code=params, noise_seed=4242,
                                               slice_size=rows, continuous=True, max_new_tokens_per_utterance=limits, ids_out=ids)
         sync()
         t_mine = time.perf_counter() - t0
-        if world > 1:
+        if grouped:
             dist.barrier()
         dt = time.perf_counter() - t0
         if lens != limits:
@@ -145,13 +147,14 @@ def sharded_request_leg(pipe, dev, rank, world, n_utt=256, rows=32, reps=2, max_
             tt = t.to(torch.int64).cpu()
             w = (torch.arange(tt.numel(), dtype=torch.int64) % 8191 + 1).view(tt.shape)
             chk[u] = int((tt * w).sum())
-        if world > 1:
+        if grouped:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(per, op=dist.ReduceOp.SUM)
             dist.all_reduce(chk, op=dist.ReduceOp.SUM)
         if rep == 0:
             continue
         wall = float(tmax.item())
+        walls.append(wall)
         if best is None or wall < best["wall_s"]:
             tok = per[:, 0].cpu().tolist()
             best = dict(wall_s=wall, per_rank_useful_tokens=[int(x) for x in tok], per_rank_busy_s=[round(x, 4) for x in per[:, 1].cpu().tolist()],
@@ -161,7 +164,7 @@ def sharded_request_leg(pipe, dev, rank, world, n_utt=256, rows=32, reps=2, max_
     tok = best["per_rank_useful_tokens"]
     return {"utterances": n_utt, "decode_rows_per_gpu": rows, "prompt_lengths": "U{16..96} tokens", "target_lengths": "U{128..512} tokens", "speakers": 4,
             "path": "ChatTTSPlusPipeline.infer_sharded(continuous=True): partition + speaker/seed broadcast + GPT (continuous batching) + DVAE decoder + Vocos + length all-reduce",
-            "wall_ms": round(best["wall_s"] * 1e3, 2), "useful_tokens": int(total), "useful_tokens_per_s": round(total / best["wall_s"], 1),
+            "wall_ms": round(best["wall_s"] * 1e3, 2), "wall_ms_reps": [round(w * 1e3, 2) for w in walls], "useful_tokens": int(total), "useful_tokens_per_s": round(total / best["wall_s"], 1),
             "audio_seconds": round(audio_s, 2), "rtf_audio_s_per_wall_s": round(audio_s / best["wall_s"], 2),
             "per_rank_useful_tokens": tok, "per_rank_busy_s": best["per_rank_busy_s"],
             "load_imbalance_max_over_mean": round(max(tok) / (sum(tok) / len(tok)), 4) if sum(tok) else None,
@@ -201,55 +204,73 @@ class _DrySynth:
         return [torch.zeros(256 * (2 * h.shape[0] - 1)) if h.shape[0] else torch.zeros(0) for h in hiddens]
 
 def dry_run(args, world, rank):
-    """Same collective sequence as the real run (speaker broadcast, barrier, timed region, barrier, MAX all-reduce, per-rank
-    gather, rank-0 JSON) on the gloo backend with a sleep instead of the decode loop -- validates the N>1 control flow on CPU."""
+    """Same rendezvous sequence as the real run -- speaker broadcast; per leg: barrier, timed region, barrier, MAX all-reduce, per-rank gather; the legs
+    in the real order (headline, batch 32, the sharded request, 512-token prompts); group destroyed; CPU baseline on rank 0; ONE JSON line from rank 0 --
+    on the gloo backend with a sleep instead of the decode loop: validates the N > 1 control flow on CPU."""
     import torch.distributed as dist
     from chatttsplus_amd import synth
     from chatttsplus_amd.dist import broadcast_speakers
-    if world > 1:
+    grouped = world > 1 or args.force_pg
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("gloo", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
     table = torch.from_numpy(synth.speaker_vector(1234))[None] if rank == 0 else None
     spk = broadcast_speakers(table, 1, 768, torch.device("cpu"))
     assert abs(float(spk.norm()) - float(torch.from_numpy(synth.speaker_vector(1234)).norm())) < 1e-4
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    time.sleep(0.05 * (1 + rank))            # ranks finish at different times: the MAX must win
-    mine = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    per = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-    if world > 1:
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        dist.all_gather(per, torch.tensor([mine], dtype=torch.float64))
-    else:
+
+    def leg(batch, steps, nap):
+        if grouped:
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(nap * (1 + rank))             # ranks finish at different times: the MAX must win
+        mine = time.perf_counter() - t0
+        if grouped:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         per = [torch.tensor([mine], dtype=torch.float64)]
+        if grouped:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            per = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(per, torch.tensor([mine], dtype=torch.float64))
+        return float(dt), [float(p) for p in per]
+
+    dt, per = leg(args.batch, args.steps, 0.05)
+    extra = {}
+    d32, p32 = leg(32, args.steps, 0.01)
+    extra["batch32"] = {"tokens_per_s": round(32 * args.steps * world / d32, 1), "per_rank_tokens_per_s": [round(32 * args.steps / p, 1) for p in p32],
+                        "rtf_end_to_end": round(32 * args.steps * world * (512 / 24000.0) / d32, 2)}
     # the sharded-request leg on the same control flow: real ChatTTSPlusPipeline.infer_sharded host code (partition, speaker + seed broadcast, per-rank
     # slices / continuous batching, length all-reduce) around CPU stand-ins for the engines
     import tempfile
     from chatttsplus_amd.pipeline import ChatTTSPlusPipeline
     with tempfile.TemporaryDirectory() as td:
         pipe = ChatTTSPlusPipeline.from_components(_DryGPT(), _DrySynth(), synth.toy_tokenizer(td), "cpu")
-        sharded = sharded_request_leg(pipe, torch.device("cpu"), rank, world, n_utt=48, rows=8, reps=1, max_new=160)
-    if rank == 0:
-        print(json.dumps({"metric": "decode tokens/s", "value": round(args.batch * args.steps * world / float(dt), 2), "unit": "tokens/s",
-                          "extra": {"sharded_request": sharded},
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(dt) / args.steps * 1e3, 5),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-                          "world_size": world, "per_rank_tokens_per_s": [round(args.batch * args.steps / float(p), 2) for p in per],
-                          "config": {"workload": "DRY RUN (no GPU work)"}}))
-    if world > 1:
+        extra["sharded_request"] = sharded_request_leg(pipe, torch.device("cpu"), rank, world, n_utt=48, rows=8, reps=1, max_new=160)
+    d5, p5 = leg(1, args.steps, 0.01)
+    extra["prompt512_batch1"] = {"tokens_per_s": round(args.steps * world / d5, 1), "per_rank_tokens_per_s": [round(args.steps / p, 1) for p in p5]}
+    pg = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_at_world_1": bool(args.force_pg and world == 1)} if grouped else None
+    if grouped:
         dist.destroy_process_group()
+    if rank == 0:
+        # rank 0 alone, after the last rendezvous -- as in the real run (a tiny sample here: the dry run checks the control flow, not the number)
+        cpu = cpu_baseline(8, 8) if args.cpu_steps > 0 else None
+        print(json.dumps({"metric": "decode tokens/s", "value": round(args.batch * args.steps * world / dt, 2), "unit": "tokens/s",
+                          "extra": extra, "cpu_baseline": cpu, "process_group": pg,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                          "world_size": world, "per_rank_tokens_per_s": [round(args.batch * args.steps / p, 2) for p in per],
+                          "config": {"workload": "DRY RUN (no GPU work)"}}))
 
 
 class Leg:
     """One timed decode leg on an engine: begin -> prompt pass -> first sample -> untimed steps up to the window -> K timed steps."""
 
-    def __init__(self, g, dev, rank, world):
+    def __init__(self, g, dev, rank, world, grouped=None):
         self.g, self.dev, self.rank, self.world = g, dev, rank, world
+        self.grouped = (world > 1) if grouped is None else bool(grouped)      # a process group exists (--force-pg: also at world 1): every rendezvous of the N > 1 path runs
 
     def run(self, B, P, K, W, pad_left=None, spk=None, gen_tokens=GEN_TOKENS, use_graph=1, keep_hidden=False):
         import torch.distributed as dist
@@ -292,7 +313,7 @@ class Leg:
             _lib.check(lib.ctts_gpt_decode(h, n, use_graph, st), "decode (untimed)")
             left -= n
         torch.cuda.synchronize(dev)
-        if self.world > 1:
+        if self.grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
         # timed: exactly K steps; the same region is bracketed by HIP events on the launch stream
@@ -303,7 +324,7 @@ class Leg:
         ev1.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         mine = time.perf_counter() - t0
-        if self.world > 1:
+        if self.grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
@@ -315,7 +336,7 @@ class Leg:
             raise SystemExit(f"bench invalid: {steps_done.value} steps executed, expected {expect} (end_idx min {int(end.min().item())})")
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         per = [torch.tensor([mine], device=dev, dtype=torch.float64)]
-        if self.world > 1:
+        if self.grouped:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             per = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(self.world)]
             dist.all_gather(per, torch.tensor([mine], device=dev, dtype=torch.float64))
@@ -323,6 +344,18 @@ class Leg:
         mean_ctx = float(valid.mean()) + s0 + K / 2.0
         return dict(B=B, P=P, K=K, s0=s0, dt=float(tmax.item()), ev_ms=ev_ms, prefill_ms=prefill_ms, hid=hid, expect=expect, mean_ctx=mean_ctx,
                     per_rank_s=[float(p.item()) for p in per], step_bytes=g.step_bytes(B, mean_ctx))
+
+
+def run_reps(leg, reps, *a, **kw):
+    """The same leg `reps` times (each a fresh begin -> prompt pass -> steps up to the window -> K timed steps); returns the MEDIAN rep (by HIP-event
+    time) with the spread of all reps attached: one rep cannot tell a slow box or a slow allocation from a slow kernel (the driver's
+    single-rep `batch32_lora_merged` line sat 19 % above `batch32` with nothing to tell why)."""
+    rs = [leg.run(*a, **kw) for _ in range(max(1, reps))]
+    order = sorted(range(len(rs)), key=lambda i: rs[i]["ev_ms"])
+    r = rs[order[len(order) // 2]]
+    ms = sorted(x["dt"] / x["K"] * 1e3 for x in rs)
+    r["spread_ms_per_step"] = {"reps": len(rs), "min": round(ms[0], 5), "median": round(ms[len(ms) // 2], 5), "max": round(ms[-1], 5)}
+    return r
 
 
 def ragged_leg(g, dev, spk, rank, B=32, seed=2024):
@@ -445,6 +478,13 @@ def queue_leg(g, dev, spk, rank, NU=128, rows=32, seed=4048, admit_min=None, mod
 def summarize(r, world):
     step_ms = r["ev_ms"] / r["K"]
     ach = r["step_bytes"] / (step_ms * 1e-3) / 1e9
+    out = _summary(r, world, step_ms, ach)
+    if "spread_ms_per_step" in r:
+        out["spread_ms_per_step"] = r["spread_ms_per_step"]
+    return out
+
+
+def _summary(r, world, step_ms, ach):
     return {"tokens_per_s": round(r["B"] * r["K"] * world / r["dt"], 1), "ms_per_step": round(r["dt"] / r["K"] * 1e3, 5),
             "step_ms_hip_events": round(step_ms, 5), "batch_per_gpu": r["B"], "prompt_len": r["P"], "steps": r["K"],
             "mean_context": round(r["mean_ctx"], 1), "algorithmic_bytes_per_step": int(r["step_bytes"]),
@@ -466,6 +506,9 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=128, help="timed steps of each extra leg")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="engine option (ctts_gpt_set_option) for A/B runs, e.g. --option persistent_rows=0")
     ap.add_argument("--request-utterances", type=int, default=256, help="utterances of the sharded-request leg (BASELINE configs[3]: 256)")
+    ap.add_argument("--extra-reps", type=int, default=3, help="repetitions of every extra leg (median reported, min / max beside it)")
+    ap.add_argument("--force-pg", action="store_true", help="create the RCCL process group also at --gpus 1 and take the N > 1 code path end to end "
+                    "(barriers, MAX all-reduce, per-rank gather, speaker broadcast, the sharded request with a group): rehearses on a one-GPU box what the 8-GPU run does")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank control flow (no HIP work, fake timing); used by tests/test_bench_dryrun.py")
     args = ap.parse_args()
 
@@ -482,9 +525,12 @@ def main():
         return dry_run(args, world, rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    grouped = world > 1 or args.force_pg
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
         assert dist.get_world_size() == args.gpus
 
@@ -495,7 +541,7 @@ def main():
     extras = not args.no_extras
     EB, EK = 32, args.extra_steps
     sd = synth.gpt_state_dict(synth.GPT_REAL, 1234)                    # every rank holds a full replica (0.45 GB fp16)
-    need_seq = max(P, 512 if (extras and world == 1) else (96 if extras else 0)) + W + max(GEN_TOKENS, args.gen_tokens, K) + 16     # (96: the sharded request's longest prompt)
+    need_seq = max(P, 512 if extras else 0) + W + max(GEN_TOKENS, args.gen_tokens, K) + 16     # (96: the sharded request's longest prompt)
     g = GPT(LLAMA, max_batch=max(B, EB if extras else 1), max_seq_len=need_seq, weight_dtype=args.dtype, device=str(dev))
     g.load_state_dict(sd)
     for kv in args.option:
@@ -504,11 +550,12 @@ def main():
     # speaker table (4 distinct speakers) lives on rank 0 and is broadcast over xGMI -- the path's only collective;
     # sequence b of every batch speaks with speaker b % 4
     spk = (torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev) if rank == 0 else torch.zeros(4, 768, device=dev))
-    if world > 1:
+    if grouped:
         dist.broadcast(spk, src=0)
     use_graph = 0 if args.no_graph else 1
     persist_rows = g.get_option("persistent_rows")             # effective value: 1 on fp32 engines that hold the device's persistent-launch lock
-    leg = Leg(g, dev, rank, world)
+    leg = Leg(g, dev, rank, world, grouped)
+    XR = max(1, args.extra_reps)
     r = leg.run(B, P, K, W, spk=spk, use_graph=use_graph, keep_hidden=True, gen_tokens=args.gen_tokens)
     dt, expect, hid = r["dt"], r["expect"], r["hid"]
 
@@ -537,21 +584,42 @@ def main():
     if extras:
         try:
             # configs[2] / configs[3]: batch 32 per GPU, uniform prompts; aggregated over the ranks (MAX time)
-            e = leg.run(EB, P, EK, W, spk=spk, use_graph=use_graph)
-            extra["batch32"] = summarize(e, world)
-            extra["batch32"]["per_rank_tokens_per_s"] = [round(EB * EK / p, 1) for p in e["per_rank_s"]]
-            # configs[3]: ONE request of 256 ragged utterances sharded over the ranks through the pipeline's own entry point
-            #             (at N = 1 the same request on one GPU: the number the N-GPU lines are compared with)
             import tempfile
             from chatttsplus_amd.hip_models import Synth
             from chatttsplus_amd.pipeline import ChatTTSPlusPipeline
+            syn_r = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2 * 512 + 64, device=str(dev), max_batch=32)
+            syn_r.load("dvae.", synth.dvae_state_dict(synth.DVAE_REAL, 1234))
+            syn_r.load("vocos.", synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
+            e = run_reps(leg, XR, EB, P, EK, W, spk=spk, use_graph=use_graph, keep_hidden=True)
+            extra["batch32"] = summarize(e, world)
+            extra["batch32"]["per_rank_tokens_per_s"] = [round(EB * EK / p, 1) for p in e["per_rank_s"]]
+            # BASELINE's metric asks RTF at batch 32 too: audio seconds of the 32 utterances / (prompt pass + decode steps at the measured rate + one
+            # batched DVAE-decoder + Vocos call on their hidden states), rank 0's clock
+            try:
+                ex32 = e["expect"]
+                batch = [e["hid"][b, :ex32] for b in range(EB)]
+                syn_r.decode_batch(batch)
+                torch.cuda.synchronize(dev)
+                tv = time.perf_counter()
+                wv = syn_r.decode_batch(batch)
+                torch.cuda.synchronize(dev)
+                v32 = (time.perf_counter() - tv) * 1e3
+                assert len(wv) == EB and all(int(w.shape[0]) == 256 * (2 * ex32 - 1) for w in wv)
+                extra["batch32"]["vocoder_ms_for_batch"] = round(v32, 3)
+                extra["batch32"]["rtf_end_to_end"] = round(EB * 256 * (2 * ex32 - 1) / 24000.0 / ((e["prefill_ms"] + (e["dt"] / EK) * 1e3 * (ex32 - 1) + v32) / 1e3), 2)
+            except Exception as exv:
+                extra["batch32"]["rtf_end_to_end"] = f"failed: {exv}"
+            e["hid"] = None
+            # configs[3]: ONE request of 256 ragged utterances sharded over the ranks through the pipeline's own entry point
+            #             (at N = 1 the same request on one GPU: the number the N-GPU lines are compared with)
             with tempfile.TemporaryDirectory() as td:
-                syn_r = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2 * 512 + 64, device=str(dev), max_batch=32)
-                syn_r.load("dvae.", synth.dvae_state_dict(synth.DVAE_REAL, 1234))
-                syn_r.load("vocos.", synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
                 pipe = ChatTTSPlusPipeline.from_components(g, syn_r, synth.toy_tokenizer(td), dev)
                 extra["sharded_request"] = sharded_request_leg(pipe, dev, rank, world, n_utt=args.request_utterances, rows=EB)
                 del pipe, syn_r
+            # north_star: "decode tokens/s on synthetic 512-token prompts ... at 1/2/4/8 GPUs", batch 1 per GPU
+            e = run_reps(leg, XR, 1, 512, EK, W, spk=spk, use_graph=use_graph)
+            extra["prompt512_batch1"] = summarize(e, world)
+            extra["prompt512_batch1"]["per_rank_tokens_per_s"] = [round(EK / p, 1) for p in e["per_rank_s"]]
             if world > 1:
                 # multi-rank runs stop here: the remaining legs characterise one GPU (measured at N = 1) and every leg is a rendezvous --
                 # a rank failing inside one of them would leave the others waiting at its barrier
@@ -560,7 +628,7 @@ def main():
             rng = np.random.Generator(np.random.Philox(key=77 + rank))
             plen = rng.integers(16, 97, size=EB)
             plen[0] = 96
-            e = leg.run(EB, 96, EK, W, pad_left=[int(96 - p) for p in plen], spk=spk, use_graph=use_graph)
+            e = run_reps(leg, XR, EB, 96, EK, W, pad_left=[int(96 - p) for p in plen], spk=spk, use_graph=use_graph)
             extra["batch32_mixed_prompts"] = summarize(e, world)
             extra["batch32_mixed_prompts"]["prompt_lengths"] = "U{16..96} left-padded to 96"
             # SURVEY 8d C3 with ragged TARGET lengths: useful vs padded tokens/s, finished-row compaction off / on
@@ -570,29 +638,30 @@ def main():
             if persist_rows >= 1:
                 # the headline workload on the launch chain (102 dependent launches per step) -- what the persistent launch replaces
                 g.set_option("persistent_rows", 0)
-                e = leg.run(1, P, min(K, 256), W, spk=spk, use_graph=use_graph, gen_tokens=args.gen_tokens)
+                e = run_reps(leg, XR, 1, P, min(K, 256), W, spk=spk, use_graph=use_graph, gen_tokens=args.gen_tokens)
                 g.set_option("persistent_rows", persist_rows)
                 extra["batch1_launch_chain"] = summarize(e, world)
-            # north_star: "decode tokens/s on synthetic 512-token prompts", batch 1
-            e = leg.run(1, 512, EK, W, spk=spk, use_graph=use_graph)
-            extra["prompt512_batch1"] = summarize(e, world)
-            e = leg.run(EB, 512, EK, W, spk=spk, use_graph=use_graph, gen_tokens=2 * EK)
+            e = run_reps(leg, XR, EB, 512, EK, W, spk=spk, use_graph=use_graph, gen_tokens=2 * EK)
             extra["prompt512_batch32"] = summarize(e, world)
             # configs[4]: LoRA (r=8, alpha=16 on q/k/v/o of all layers, train_voice_clone_lora.yaml:72-80) merged into the packed weights
             rl = np.random.Generator(np.random.Philox(key=31))
             adapters = [(l, t, (rl.standard_normal((8, 768)) * 0.02).astype(np.float32), (rl.standard_normal((768, 8)) * 0.02).astype(np.float32), 2.0)
                         for l in range(LLAMA["num_hidden_layers"]) for t in ("q_proj", "k_proj", "v_proj", "o_proj")]
             gl = g.with_lora(adapters)
-            e = Leg(gl, dev, rank, world).run(EB, P, EK, W, spk=spk, use_graph=use_graph)
+            e = run_reps(Leg(gl, dev, rank, world, grouped), XR, EB, P, EK, W, spk=spk, use_graph=use_graph)
             extra["batch32_lora_merged"] = summarize(e, world)
             gl.close()
+            # the base engine again, right after: tells a drifting box from something the merged sibling does (its kernels and bytes are the base engine's)
+            e = run_reps(leg, XR, EB, P, EK, W, spk=spk, use_graph=use_graph)
+            extra["batch32_again_after_lora_merged"] = summarize(e, world)
+            extra["batch32_lora_merged"]["vs_batch32_same_minute"] = round(extra["batch32_lora_merged"]["ms_per_step"] / extra["batch32_again_after_lora_merged"]["ms_per_step"], 4)
             # per-utterance adapters: 4 different adapters + "none" spread over the 32 sequences of ONE batch, evaluated as
             # W x + scale * B (A x) per row (worker workgroups inside the QKV / o_proj launches, lora_worker.h); the reference can only merge one adapter per call
             for slot in range(4):
                 g.load_adapter(slot, [(l, t, (rl.standard_normal((8, 768)) * 0.02).astype(np.float32), (rl.standard_normal((768, 8)) * 0.02).astype(np.float32), 2.0)
                                       for l in range(LLAMA["num_hidden_layers"]) for t in ("q_proj", "k_proj", "v_proj", "o_proj")])
             g.set_row_adapters([(b % 5) - 1 for b in range(EB)])
-            e = leg.run(EB, P, EK, W, spk=spk, use_graph=use_graph)
+            e = run_reps(leg, XR, EB, P, EK, W, spk=spk, use_graph=use_graph)
             g.set_row_adapters(None)
             extra["batch32_lora_per_utterance"] = summarize(e, world)
             if args.dtype == "fp16":
@@ -600,7 +669,7 @@ def main():
                 # <= 1e-3 -- DESIGN.md section 2) on the headline workload, same window
                 g32 = GPT(LLAMA, max_batch=1, max_seq_len=P + W + max(GEN_TOKENS, K) + 16, weight_dtype="fp32", device=str(dev))
                 g32.load_state_dict(sd)
-                e = Leg(g32, dev, rank, world).run(1, P, min(K, 256), W, spk=spk, use_graph=use_graph)
+                e = run_reps(Leg(g32, dev, rank, world, grouped), XR, 1, P, min(K, 256), W, spk=spk, use_graph=use_graph)
                 extra["parity_mode_fp32_batch1"] = summarize(e, world)
                 g32.close()
             else:
@@ -608,9 +677,9 @@ def main():
                 # 1.2-1.75e-3 vs the fp32 CPU path (asserted <= 2e-3, tests/test_gpu_fp16_parity.py), token ids not guaranteed; same windows
                 g16 = GPT(LLAMA, max_batch=EB, max_seq_len=P + W + max(GEN_TOKENS, K) + 16, weight_dtype="fp16", device=str(dev))
                 g16.load_state_dict(sd)
-                l16 = Leg(g16, dev, rank, world)
-                extra["fast_mode_fp16_batch1"] = summarize(l16.run(1, P, min(K, 256), W, spk=spk, use_graph=use_graph), world)
-                extra["fast_mode_fp16_batch32"] = summarize(l16.run(EB, P, EK, W, spk=spk, use_graph=use_graph), world)
+                l16 = Leg(g16, dev, rank, world, grouped)
+                extra["fast_mode_fp16_batch1"] = summarize(run_reps(l16, XR, 1, P, min(K, 256), W, spk=spk, use_graph=use_graph), world)
+                extra["fast_mode_fp16_batch32"] = summarize(run_reps(l16, XR, EB, P, EK, W, spk=spk, use_graph=use_graph), world)
                 extra["fast_mode_fp16_note"] = "mel / waveform rel-RMS 1.2-1.75e-3 vs the fp32 CPU path (north_star asks 1e-3): not the shipped default"
                 g16.close()
         except (SystemExit, KeyboardInterrupt):
@@ -618,7 +687,7 @@ def main():
         except StopIteration:
             pass
         except Exception as ex:
-            if world > 1:
+            if grouped:
                 raise                                  # fail loudly rather than desynchronise the ranks
             extra["error"] = f"{type(ex).__name__}: {ex}"
 
@@ -664,13 +733,14 @@ def main():
             "reference_published_tok_s": {"tensorrt_fp16_rtx3060": 110, "pytorch_fp16_rtx3060": 28},
             "extra": extra if extras else None,
         }
-        if args.cpu_steps > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(P, args.cpu_steps)
-        elif world > 1:
-            res["cpu_baseline"] = None
-        print(json.dumps(res))
-    if world > 1:
+        res["process_group"] = ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_at_world_1": bool(args.force_pg and world == 1)}
+                                if grouped else None)
+    if grouped:
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU baseline runs on rank 0 only, AFTER the last rendezvous (the other ranks are done): an N > 1 line carries it too
+        res["cpu_baseline"] = cpu_baseline(P, args.cpu_steps) if args.cpu_steps > 0 else None
+        print(json.dumps(res))
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <map>
@@ -30,6 +31,7 @@
 #include "../../include/ctts_hip.h"
 #include "kernels.h"
 #include "persist.h"
+#include "persist_mfma.h"
 #include "roctx_range.h"
 
 static thread_local char g_err[512] = "";
@@ -109,6 +111,7 @@ struct ctts_gpt {
                                                  // fp32 batch 17 795 -> 767, 24 862 -> 833, 32 894 -> 868; fp16 batch 9 475 -> 465, 16 507 -> 496, 24 / 32 unchanged
     float* sk_slab = nullptr; int* sk_cnt = nullptr;
     int opt_gen = 0;                             // bumped by ctts_gpt_set_option: part of the decode-graph key
+    int graph_gen = 0;                           //   the opt_gen the cached graphs were captured under: graphs of an older generation can never be selected again and are dropped
     int valu_rows = 2;                           // fp32 engines: decode batches of <= this many rows multiply on the VALU (skinny_gemm.hip, VR template argument):
                                                  // an exact-f32 MFMA costs 32 cycles whatever the number of live columns, 48 of them per SIMD and launch.
                                                  // Measured (us/step, MFMA -> VALU, profiles/r04_ab_valu_rows.jsonl): batch 1 481.9 -> 450.8, 2 491.7 -> 477.5,
@@ -136,6 +139,17 @@ struct ctts_gpt {
     int persist_delay_att = 0, persist_delay = 12, persist_delay_act = 16, persist_delay_x = 15, persist_nap = 1, persist_nap_qkv = 1;
     int persist_poll = -1;                       //   PersistArgs.poll; -1 = by row count: the sentinel pass costs one serial poll at 1-2 rows (batch 1 379.2 -> 387.1 us,
                                                  //   batch 2 430.7 -> 437.8) and pays from 3 rows on, where a full sweep re-reads up to 96 granules per lane (batch 4 547.5 -> 537.6)
+    // fp32 engines, pm_rows_min..pm_rows_max decode rows: the decoder stack of a step is ONE persistent launch with MFMA projections (persist_mfma.hip), reading
+    // the SAME packed tile images as the launch chain (no second weight copy).  "mfma_rows" / "mfma_rows_min"; 0 = off
+    int pm_rows_max = 0, pm_rows_min = PM_MINR;
+    unsigned* pm_flags = nullptr;                //   [5][256] flag words
+    unsigned* pm_epoch = nullptr;                //   launch counter
+    float* pm_slab = nullptr; int* pm_cnt = nullptr;      //   split-K slabs + tickets of the down projection
+    float* scale_one = nullptr;                  //   [rows] 1.0f: the heads' PRO_XH kernel divides by the packed rows' scale, which this path does not apply
+    unsigned long long* pm_ts = nullptr; int pm_ts_on = 0;
+    int cur_pm = 0;                              //   the steps being launched use it
+    int pm_nap = 1, pm_fault = 0;
+    int pm_delay[PM_NPHASE] = {8, 8, 8, 8, 8};   //   ~128-cycle units the poller sleeps before its first pass of each wait
     int no_prepack = 0, prefill_gemm_rows = 1536, xh_heads = 1;   // diagnostic builds only: see run_layers / run_decode_step
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
     DevState* st = nullptr;
@@ -148,6 +162,8 @@ struct ctts_gpt {
     signed char lora_row_slots[CTTS_MAX_B];      //   the same per decode ROW (rows move when finished rows are compacted away): travels in the kernel arguments of the folded launches
     std::vector<signed char> lora_rank;          //   [layer][slot][target] rank as loaded (0 = empty)
     std::vector<int> lora_slot_host;             //   host copy of lora_slot_of_seq
+    std::vector<int> lora_req_host;              //   what ctts_gpt_set_row_adapters asked for ("the following generate() calls"): every begin() starts from it again, whatever
+                                                 //   compaction (lora_refresh) and ctts_gpt_admit_adapters did to the live tables of the previous call
     float *lora_dqkv = nullptr, *lora_do = nullptr;
     unsigned long long* lora_g = nullptr;        //   decode steps: the same terms as tagged granules from worker workgroups inside the QKV / o_proj launches (lora_worker.h)
     int lora_fold = 1;                           //   "lora_fold" option: 0 = the two extra launches per layer at decode too
@@ -212,6 +228,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
     h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 4 : 0;
+    h->pm_rows_max = (c->dtype == CTTS_DTYPE_F32) ? PM_MAXR : 0;
     h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
@@ -249,6 +266,8 @@ static bool persist_device_lock(int dev) {
     char path[160];
     snprintf(path, sizeof(path), "/tmp/ctts_persist_%s.lock", bus);
     int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);      // (never follows a planted symlink; not inherited by child processes)
+    if (fd >= 0) (void)fchmod(fd, 0666);             // (the umask must not make the file another user's obstacle)
+    else fd = open(path, O_RDONLY | O_CLOEXEC | O_NOFOLLOW);      // a file left by another user: flock works on a read-only descriptor too
     if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); fd = -1; }
     fds[dev] = fd;                                 // (kept for the life of the process)
     return fd >= 0;
@@ -283,10 +302,42 @@ static int ensure_persist(ctts_gpt* h, bool required) {
     return 0;
 }
 
+// The persistent MFMA stack's device state: flag words, launch counter, split-K slabs.  Same residency precondition as the <= 4-row launch (256 workgroups, one
+// per CU, all resident): the per-device advisory lock keeps the mode to one process.
+static int ensure_persist_mfma(ctts_gpt* h, bool required) {
+    if (h->pm_flags != nullptr || !h->finalized) return 0;
+    int dev = 0, cus = 0;
+    CTTS_HIP_CHECK(hipGetDevice(&dev));
+    CTTS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const char* why = nullptr;
+    const size_t kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM;
+    if (h->cfg.dtype != CTTS_DTYPE_F32) why = "fp32 engines only";
+    else if (h->L > 31) why = "at most 31 decoder layers";
+    else if (cus < PM_BLOCKS) why = "the device has fewer than 256 compute units";
+    else if (kv_per * 4 >= ((size_t)1 << 32)) why = "a layer's K block exceeds 4 GB (32-bit buffer offsets)";
+    else if (!persist_device_lock(dev)) why = "another process already runs persistent launches on this device";
+    if (why) {
+        h->pm_rows_max = 0;
+        if (required) { ctts_set_error("persistent MFMA stack unavailable: %s", why); return 1; }
+        return 0;
+    }
+    if (persist_mfma_configure()) return 1;
+    if (dev_alloc((void**)&h->pm_flags, (size_t)PM_NPHASE * 256 * 4) || dev_alloc((void**)&h->pm_epoch, 4) || dev_alloc((void**)&h->pm_slab, persist_mfma_slab_floats() * 4) ||
+        dev_alloc((void**)&h->pm_cnt, 48 * 4) || dev_alloc((void**)&h->scale_one, (size_t)(CTTS_MAX_B + 32) * 4)) return 1;
+    if (!h->pl_error && dev_alloc((void**)&h->pl_error, 4)) return 1;
+    const unsigned one = 1;
+    CTTS_HIP_CHECK(hipMemcpy(h->pm_epoch, &one, 4, hipMemcpyHostToDevice));
+    std::vector<float> ones(CTTS_MAX_B + 32, 1.0f);
+    CTTS_HIP_CHECK(hipMemcpy(h->scale_one, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
 extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     if (!h || !name || !value) { ctts_set_error("get_option: null argument"); return 1; }
     const std::string n(name);
     if (n == "persistent_rows") *value = (h->pimg != nullptr || !h->finalized) ? h->persist_rows : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
+    else if (n == "mfma_rows") *value = (h->pm_flags != nullptr || !h->finalized) ? h->pm_rows_max : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
+    else if (n == "mfma_rows_min") *value = h->pm_rows_min;
     else if (n == "valu_rows") *value = h->valu_rows;
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
     else if (n == "split_rows") *value = h->split_rows;
@@ -311,6 +362,20 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
     } else if (n == "persistent_rows") {         // fp32 engines: decode batches of <= this many rows run each layer as ONE persistent launch (0 = off)
         h->persist_rows = value < 0 ? 0 : (value > CTTS_PERSIST_MAX_ROWS ? CTTS_PERSIST_MAX_ROWS : value);
         if (h->persist_rows > 0 && ensure_persist(h, true)) { h->persist_rows = 0; return 1; }
+    } else if (n == "mfma_rows") {               // fp32 engines: decode batches of mfma_rows_min..mfma_rows rows run the decoder stack as ONE persistent MFMA launch (0 = off)
+        h->pm_rows_max = value < 0 ? 0 : (value > PM_MAXR ? PM_MAXR : value);
+        if (h->pm_rows_max > 0 && ensure_persist_mfma(h, true)) { h->pm_rows_max = 0; return 1; }
+    } else if (n == "mfma_rows_min") {           // (below it the VALU persistent launch / the launch chain serve the batch; 1 lets the MFMA stack take every batch up to mfma_rows)
+        h->pm_rows_min = value < 1 ? 1 : value;
+    } else if (n == "mfma_nap") {
+        h->pm_nap = value < 0 ? 0 : (value > 256 ? 256 : value);
+    } else if (n == "mfma_fault") {              // test hook: a withheld flag; every wait is bounded, ctts_gpt_progress reports the edge
+        h->pm_fault = value < 0 ? 0 : value;
+    } else if (n.rfind("mfma_delay_", 0) == 0 && n.size() == 12 && n[11] >= '0' && n[11] < '0' + PM_NPHASE) {      // mfma_delay_0 .. _4
+        h->pm_delay[n[11] - '0'] = value < 0 ? 0 : (value > 1024 ? 1024 : value);
+    } else if (n == "mfma_timestamps") {         // diagnostics: the poller of every workgroup records wall_clock64 marks of the last layer (ctts_gpt_debug_read "pm_ts")
+        if (value && !h->pm_ts && dev_alloc((void**)&h->pm_ts, (size_t)PM_BLOCKS * PM_NTS * 8)) return 1;
+        h->pm_ts_on = value ? 1 : 0;
     } else if (n == "persistent_layers_per_launch") {      // 0 = the whole stack in one launch (default); 1 = one launch per layer
         h->persist_lpl = value < 0 ? 0 : value;
     } else if (n == "persistent_schedule") {               // 1 / 2: see persist_layer.hip
@@ -365,7 +430,8 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
-                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
+                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt,
+                    h->pm_flags, h->pm_epoch, h->pm_slab, h->pm_cnt, h->scale_one, h->pm_ts};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -486,6 +552,7 @@ extern "C" int ctts_gpt_set_row_adapters(ctts_gpt* h, const int32_t* slots, int 
     if (!h || !h->finalized) { ctts_set_error("set_row_adapters: handle not finalized"); return 1; }
     auto clear_rows = [h]() -> int {              // no row carries an adapter: also forget what an earlier request's rows carried (ctts_gpt_admit_adapters builds on these)
         h->lora_rows = 0;
+        h->lora_req_host.clear();
         if (!h->lora_slot_host.empty()) h->lora_slot_host.assign(CTTS_MAX_B, -1);
         for (int b = 0; b < CTTS_MAX_B; ++b) h->lora_row_slots[b] = -1;
         if (h->lora_slot_of_seq) CTTS_HIP_CHECK(hipMemset(h->lora_slot_of_seq, 0xFF, CTTS_MAX_B * 4));
@@ -504,6 +571,7 @@ extern "C" int ctts_gpt_set_row_adapters(ctts_gpt* h, const int32_t* slots, int 
     for (int b = 0; b < B; ++b) tab[b] = slots[b] < 0 ? -1 : slots[b];
     CTTS_HIP_CHECK(hipMemcpy(h->lora_slot_of_seq, tab.data(), CTTS_MAX_B * 4, hipMemcpyHostToDevice));
     h->lora_slot_host = tab;
+    h->lora_req_host = tab;
     for (int b = 0; b < CTTS_MAX_B; ++b) h->lora_row_slots[b] = (signed char)tab[b];      // rows == sequences until a compaction
     h->lora_rows = 1;
     return 0;
@@ -763,6 +831,7 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
     h->host.clear();
     h->finalized = true;
     if (h->persist_rows > 0 && ensure_persist(h, false)) return 1;
+    if (h->pm_rows_max > 0 && ensure_persist_mfma(h, false)) return 1;
     return 0;
 }
 
@@ -858,6 +927,20 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             if (launch_persist_layer(R, pa, s)) return 1;
         }
         return 0;
+    }
+    if (st != nullptr && h->cur_pm && h->pm_flags != nullptr && dt == CTTS_DTYPE_F32 && R <= PM_MAXR && !lora) {
+        // ONE persistent launch with MFMA projections (persist_mfma.hip): leaves x, and the packed copy + sums of squares the heads' PRO_XH kernel reads
+        if (form) { form->parts = false; form->xh = true; }
+        PmArgs pa = {};
+        pa.wqkv = (const char*)h->lw[0].qkv; pa.wo = (const char*)h->lw[0].o; pa.wgu = (const char*)h->lw[0].gu; pa.wd = (const char*)h->lw[0].d;
+        pa.w_stride = h->L > 1 ? (size_t)((const char*)h->lw[1].qkv - (const char*)h->lw[0].qkv) : 0;
+        pa.n_layers = h->L; pa.R = R; pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
+        pa.kv = kv_layer(h, 0, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
+        pa.q_buf = h->q_buf; pa.attn_packed = (float*)h->attn_packed; pa.xh = (float*)h->xh; pa.ssq = h->ssq; pa.act = (float*)h->act;
+        pa.slab = h->pm_slab; pa.cnt = h->pm_cnt; pa.flags = h->pm_flags; pa.epoch = h->pm_epoch; pa.error = h->pl_error; pa.done = &st->all_done;
+        pa.ts = h->pm_ts_on ? h->pm_ts : nullptr; pa.eps = 1e-6f; pa.nap = h->pm_nap; pa.fault = h->pm_fault;
+        for (int i = 0; i < PM_NPHASE; ++i) pa.delay[i] = h->pm_delay[i];
+        return launch_persist_mfma(pa, s);
     }
     if (form) { form->parts = splitd; form->xh = xhm; }
     for (int l = 0; l < h->L; ++l) {
@@ -972,7 +1055,7 @@ static int run_heads(ctts_gpt* h, bool write_hidden, StreamForm form, hipStream_
     // the last down projection left the rows as packed fp16 + sums of squares (PRO_XH): no fp32 re-normalisation per block.  The text head is a
     // different launch shape (not measured): it keeps the fp32 prologue
     if (form.xh && !h->text_mode && h->xh_heads) {
-        a.xh = h->xh; a.ssq = h->ssq; a.scale_in = h->scale_d;
+        a.xh = h->xh; a.ssq = h->ssq; a.scale_in = h->cur_pm ? h->scale_one : h->scale_d;      // (the persistent MFMA stack leaves the packed rows unscaled)
         return launch_gemm(h->cfg.dtype, nbg, PRO_XH, EPI_LOGITS, a, chunks, s);
     }
     return launch_gemm(h->cfg.dtype, nbg, (nbg == 1) ? PRO_NORM_P : PRO_NORM, EPI_LOGITS, a, chunks, s);
@@ -1035,7 +1118,21 @@ extern "C" int ctts_gpt_begin(ctts_gpt* h, int B, int T, const int32_t* mask, co
     }
     h->row_seq.resize(B); h->row_ctx.assign(B, T); h->row_cap.resize(B);
     for (int b = 0; b < B; ++b) { h->row_seq[b] = b; h->row_cap[b] = T + h->rows_host[b].limit; }
-    if (h->lora_rows) for (int b = 0; b < CTTS_MAX_B; ++b) h->lora_row_slots[b] = (signed char)h->lora_slot_host[b];
+    if (!h->lora_slot_host.empty()) {
+        // per-utterance adapters: the call starts from what ctts_gpt_set_row_adapters requested.  (lora_rows is the LIVE state: ctts_gpt_compact clears it once every
+        // adapter-carrying row has left the batch and ctts_gpt_admit_adapters rewrites the tables -- a second generate() after ONE set_row_adapters() call used to
+        // run without its adapters, silently)
+        if (h->lora_req_host.empty()) h->lora_slot_host.assign(CTTS_MAX_B, -1);
+        else h->lora_slot_host = h->lora_req_host;
+        bool any = false;
+        for (int b = 0; b < CTTS_MAX_B; ++b) { h->lora_row_slots[b] = (signed char)h->lora_slot_host[b]; any = any || (b < B && h->lora_slot_host[b] >= 0); }
+        h->lora_rows = any ? 1 : 0;
+        if (h->lora_slot_of_seq)        // (pageable source: staged before the call returns)
+            CTTS_HIP_CHECK(hipMemcpyAsync(h->lora_slot_of_seq, h->lora_slot_host.data(), CTTS_MAX_B * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+        // the folded launches tag their granules with the sampler's draw counter, which restarts at every begin(): forget the previous call's granules, or a tile could
+        // accept a stale term whose tag happens to match (a previous call of exactly as many steps)
+        if (h->lora_rows && h->lora_g) CTTS_HIP_CHECK(hipMemsetAsync(h->lora_g, 0, (size_t)CTTS_MAX_B * 4 * h->H * 8, (hipStream_t)stream));
+    }
     h->pre_T = T;
     h->io.utt_ids = nullptr; h->io.row_limits = nullptr;      // host arrays are consumed here, not kept
     memcpy(h->sc.temperature, sc->temperature, sizeof(sc->temperature));
@@ -1115,6 +1212,17 @@ static inline int decode_persist(const ctts_gpt* h, int B, int L) {
     return want > cap ? cap : want;
 }
 
+// ... or as ONE persistent launch with MFMA projections (persist_mfma.hip): fp32, mfma_rows_min..mfma_rows rows, no per-utterance adapters.  Takes precedence over the
+// VALU persistent launch where both would serve the batch (mfma_rows_min <= 4).
+static inline int decode_pm(const ctts_gpt* h, int B) {
+    return (h->pm_rows_max > 0 && h->pm_flags != nullptr && h->cfg.dtype == CTTS_DTYPE_F32 && B >= h->pm_rows_min && B <= h->pm_rows_max && B <= PM_MAXR && !h->lora_rows) ? 1 : 0;
+}
+static inline void pick_decode_path(ctts_gpt* h, int longest) {
+    h->cur_splits = decode_splits(h, h->B, longest);
+    h->cur_pm = decode_pm(h, h->B);
+    h->cur_persist = h->cur_pm ? 0 : decode_persist(h, h->B, longest);
+}
+
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
     StreamForm form = {false, false};
     if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s, &form)) return 1;
@@ -1123,15 +1231,21 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
 
 static int ensure_graph(ctts_gpt* h) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen, h->cur_persist);      // (diagnostic switches are fixed at create)
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen, h->cur_persist, h->cur_pm);      // (diagnostic switches are fixed at create)
     std::string key(sig);
     if (h->lora_rows) key.append((const char*)h->lora_row_slots, (size_t)h->B);      // the rows' adapter slots are kernel arguments of the folded launches (LoraFold)
+    if (h->graph_gen != h->opt_gen || h->graphs.size() >= 96) {
+        // graphs captured under other option / adapter settings are dead weight (loading one adapter bumps opt_gen ~80 times), and the cache is bounded: a serving
+        // process cycles through few (batch, mode) shapes.  Replays of the dropped graphs may still be in flight (generate() keeps two chunks enqueued): drain first.
+        if (!h->graphs.empty()) {
+            CTTS_HIP_CHECK(hipDeviceSynchronize());
+            for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+            h->graphs.clear(); h->gexec = nullptr;
+        }
+        h->graph_gen = h->opt_gen;
+    }
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { h->gexec = it->second.exec; return 0; }
-    if (h->graphs.size() >= 96) {                  // bounded: a serving process cycles through few (batch, mode) shapes (compaction adds the sizes of compact_size)
-        for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
-        h->graphs.clear(); h->gexec = nullptr;
-    }
     ctts_gpt::GraphEntry ge = {nullptr, nullptr};
     CTTS_HIP_CHECK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = 0;
@@ -1152,8 +1266,7 @@ extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* st
     hipStream_t s = (hipStream_t)stream;
     {
         const int longest = advance_rows(h, n_steps) + 1;
-        h->cur_splits = decode_splits(h, h->B, longest);
-        h->cur_persist = decode_persist(h, h->B, longest);
+        pick_decode_path(h, longest);
     }
     h->launched += n_steps;
     if (use_graph) {
@@ -1178,6 +1291,11 @@ extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_
     if (all_finished) *all_finished = h->host_pin[2];
     if (h->host_pin[12] == 7) {
         ctts_set_error("per-utterance LoRA: a projection tile gave up waiting for its low-rank term (lora_worker.h); use options={'lora_fold': 0}");
+        return 1;
+    }
+    if (h->host_pin[12] >= 8) {
+        ctts_set_error("persistent MFMA decode stack: a workgroup gave up waiting on edge %d (8 = down -> q|k|v, 9 = q|k|v -> attention, 10 = attention -> o_proj, "
+                       "11 = o_proj -> gate|up, 12 = gate|up -> down); is the GPU shared with another process?  Use options={'mfma_rows': 0}", h->host_pin[12]);
         return 1;
     }
     if (h->host_pin[12] != 0) {
@@ -1327,6 +1445,9 @@ extern "C" int ctts_gpt_debug_read(ctts_gpt* h, const char* name, void* out, siz
     else if (n == "logits") { src = h->logits; nb = (size_t)CTTS_MAX_B * h->NVQ * h->V * 4; }
     else if (n == "pl_g" && h->pl_g) { src = h->pl_g; nb = (size_t)PL_G_TOTAL * 8; }
     else if (n == "pl_ts" && h->pl_ts) { src = h->pl_ts; nb = (size_t)PL_BLOCKS * 10 * 8; }
+    else if (n == "pm_ts" && h->pm_ts) { src = h->pm_ts; nb = (size_t)PM_BLOCKS * PM_NTS * 8; }
+    else if (n == "xh") { src = h->xh; nb = (size_t)2 * 48 * 1024; }
+    else if (n == "ssq") { src = h->ssq; nb = (size_t)32 * 48 * 4; }
     else if (n == "pl_state" && h->pl_epoch) {
         unsigned* o = (unsigned*)out;
         if (max_bytes < 8) { ctts_set_error("debug_read: buffer too small"); return 1; }
@@ -1398,8 +1519,7 @@ extern "C" int ctts_gpt_time_decode(ctts_gpt* h, int n_steps, float* ms_per_step
             const int n = (n_steps - i < CH) ? n_steps - i : CH;
             int longest = 1;
             for (int r = 0; r < h->B; ++r) { const int c = std::min(h->row_ctx[r] + (launched - h->launched) + n, h->row_cap[r]); if (c > longest) longest = c; }
-            h->cur_splits = decode_splits(h, h->B, longest + 1);
-            h->cur_persist = decode_persist(h, h->B, longest + 1);
+            pick_decode_path(h, longest + 1);
             launched += n;
             if (ensure_graph(h)) return 1;
             if (pass == 1) for (int j = 0; j < n; j += h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));

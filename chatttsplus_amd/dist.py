@@ -3,6 +3,10 @@ cross-slice state, pipelines/chattts_plus_pipeline.py:391-397), so the path shar
 one process per GPU and NO data-path collective.  The only exchange is one broadcast of the
 speaker-embedding table from rank 0 per request (RCCL over xGMI when the backend is "nccl"; gloo on CPU
 in the tests) plus an optional gather of per-utterance lengths for aggregate throughput.
+
+Whenever a process group is initialised the collectives RUN, also at world size 1: a one-rank "nccl" group takes the same RCCL code
+path (communicator creation, device-tensor broadcast / all-reduce) as an eight-rank one, so it can be exercised on a one-GPU box
+(tests/test_gpu_rccl.py, `bench.py --force-pg`).  Without a group the functions are plain local copies.
 """
 from __future__ import annotations
 
@@ -27,7 +31,7 @@ def partition(lengths: Sequence[int], world: int) -> List[List[int]]:
 def broadcast_speakers(table: Optional[torch.Tensor], n_spk: int, dim: int, device, src: int = 0) -> torch.Tensor:
     """rank `src` holds table [n_spk, dim] fp32; every rank returns a copy on `device`.  <= 786 KB even for
     256 distinct speakers: latency-bound on xGMI, done once per request before the decode loop."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         assert table is not None
         return table.to(device=device, dtype=torch.float32)
     if dist.get_rank() == src:
@@ -41,7 +45,7 @@ def broadcast_speakers(table: Optional[torch.Tensor], n_spk: int, dim: int, devi
 
 def broadcast_seed(seed: int, device, src: int = 0) -> int:
     """The request's noise seed as drawn on rank `src` (8 bytes, same process group as the speaker table); world 1: the local draw."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return int(seed)
     buf = torch.tensor([int(seed)], dtype=torch.int64, device=device)
     dist.broadcast(buf, src=src)
@@ -65,6 +69,6 @@ def sharded_generate(lengths: Sequence[int], speaker_index: Sequence[int], speak
     full = torch.zeros(total, dtype=torch.int64, device=device)
     if mine:
         full[torch.as_tensor(mine, dtype=torch.long, device=device)] = torch.as_tensor(out_len, dtype=torch.int64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(full, op=dist.ReduceOp.SUM)          # disjoint supports -> gather of lengths
     return mine, full.cpu().tolist()

@@ -805,6 +805,10 @@ class GPT:
                         book.compact(keep)
                         self.compactions.append((launched, len(book.row_tk)))
             torch.cuda.current_stream(dev).synchronize()
+            # the device give-up word (a persistent launch's bounded wait ran out, or a projection tile never got its low-rank term): every later launch of the
+            # request was a no-op and the sampler kept drawing from stale rows -- an error, not audio (ctts_gpt_progress raises it, as in generate())
+            steps, alld = C.c_int32(0), C.c_int32(0)
+            _lib.check(lib.ctts_gpt_progress(h, C.byref(steps), C.byref(alld), st), "progress")
             self.saturations = self._report_saturations(h, st, "generate_many()")
             return self._outputs(ids, hid, end_idx, infer_text)
 

@@ -25,6 +25,11 @@ def test_bench_dry_run_world2():
     assert d["ms_per_step"] * 8 / 1e3 >= 0.09            # the slower rank (0.1 s) defines the time
     # the sharded-request leg (BASELINE configs[3]) rehearsed through the real ChatTTSPlusPipeline.infer_sharded host code: both ranks serve a
     # share, every utterance keeps its tokens (digest == the world-1 digest), the lengths are the targets
+    # what an N > 1 line must carry: the CPU baseline (rank 0, after the group is gone), north_star's 512-token-prompt leg
+    # and the batch-32 RTF
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert len(d["extra"]["prompt512_batch1"]["per_rank_tokens_per_s"]) == 2 and d["extra"]["batch32"]["rtf_end_to_end"] > 0
+    assert d["process_group"] == {"backend": "gloo", "world_size": 2, "forced_at_world_1": False}
     sr = d["extra"]["sharded_request"]
     assert sr["utterances"] == 48 and len(sr["per_rank_useful_tokens"]) == 2 and all(t > 0 for t in sr["per_rank_useful_tokens"])
     assert sum(sr["per_rank_useful_tokens"]) == sr["useful_tokens"] and sr["load_imbalance_max_over_mean"] < 1.2
@@ -37,7 +42,19 @@ def test_bench_dry_run_world2():
 def test_bench_dry_run_single():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "4"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["process_group"] is None
+
+
+def test_bench_force_pg_takes_the_group_path_at_world_1():
+    """`--force-pg`: a one-rank process group and every rendezvous of the N > 1 path at --gpus 1 (gloo here; "nccl" = RCCL on the GPU box, where the same
+    switch makes the first contact with RCCL a one-GPU run instead of the driver's 8-GPU one)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "4", "--force-pg"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["process_group"] == {"backend": "gloo", "world_size": 1, "forced_at_world_1": True}
+    assert d["extra"]["sharded_request"]["utterances"] == 48 and d["cpu_baseline"]["value"] > 0
 
 
 def test_bench_self_spawns_ranks_without_launcher():
