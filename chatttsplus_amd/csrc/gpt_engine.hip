@@ -140,7 +140,9 @@ struct ctts_gpt {
     int persist_poll = -1;                       //   PersistArgs.poll; -1 = by row count: the sentinel pass costs one serial poll at 1-2 rows (batch 1 379.2 -> 387.1 us,
                                                  //   batch 2 430.7 -> 437.8) and pays from 3 rows on, where a full sweep re-reads up to 96 granules per lane (batch 4 547.5 -> 537.6)
     // fp32 engines, pm_rows_min..pm_rows_max decode rows: the decoder stack of a step is ONE persistent launch with MFMA projections (persist_mfma.hip), reading
-    // the SAME packed tile images as the launch chain (no second weight copy).  "mfma_rows" / "mfma_rows_min"; 0 = off
+    // the SAME packed tile images as the launch chain (no second weight copy).  "mfma_rows" / "mfma_rows_min"; 0 = off = the DEFAULT: measured slower than the
+    // launch chain at every batch size it serves (ms/step chain / this: batch 8 0.600 / 0.798, 32 0.869 / 1.082, profiles/r05_pm_probe_v2_*.jsonl) -- a hand-off
+    // of a 98 KB operand (write-through stores, drain, flag, poll, coherent loads) costs what a launch boundary costs, DESIGN.md section 0
     int pm_rows_max = 0, pm_rows_min = PM_MINR;
     unsigned* pm_flags = nullptr;                //   [5][256] flag words
     unsigned* pm_epoch = nullptr;                //   launch counter
@@ -228,7 +230,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
     h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 4 : 0;
-    h->pm_rows_max = (c->dtype == CTTS_DTYPE_F32) ? PM_MAXR : 0;
+    h->pm_rows_max = 0;                                          // opt-in: ctts_gpt_set_option("mfma_rows", 5..32)
     h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the

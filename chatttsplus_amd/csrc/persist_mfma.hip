@@ -77,6 +77,103 @@ __device__ inline float pm_c(const float* red, int i, int n, int g) {
     return sum;
 }
 
+// One (row, head) attention item on a group of 4 waves: attn_decode_kernel<float, 4> (attention.hip) -- wave aw, lane group grp handle keys kv0 + 8 (4 i + aw) + grp,
+// online softmax per lane group, the wave's 8 groups merged by shuffles, the wave's partial (max, sum, o[8] per sub) parked in LDS (mg: [4 waves][8][10]).
+// UN = keys per lane group and loop iteration (loads in flight only: the arithmetic and its order do not depend on it).
+template <int UN>
+__device__ __forceinline__ void pm_attn_item(const PmArgs& a, const pm_rsrc_t rk, const pm_rsrc_t rv, const pm_rsrc_t rs_q, const int r, const int h,
+                                             const int aw, const int lane, float* const mg) {
+    const int grp = lane >> 3, sub = lane & 7;
+    const RowMeta m = a.meta[r];
+    const int kv0 = m.kv_start, kv1 = m.slot + 1;
+    float q[8];
+    {
+        const unsigned qo = (unsigned)((((size_t)r * PM_NH + h) * CTTS_HEAD_DIM + 8 * sub) * 4);
+        const f32x4 q0 = pm_ld16(rs_q, qo), q1 = pm_ld16(rs_q, qo + 16);
+        q[0] = q0[0] * 0.125f; q[1] = q0[1] * 0.125f; q[2] = q0[2] * 0.125f; q[3] = q0[3] * 0.125f;
+        q[4] = q1[0] * 0.125f; q[5] = q1[1] * 0.125f; q[6] = q1[2] * 0.125f; q[7] = q1[3] * 0.125f;
+    }
+    const unsigned head_off = (unsigned)(((((size_t)m.seq * PM_NH + h) * a.Lmax) * CTTS_HEAD_DIM + 8 * sub) * 4);     // bytes
+    float mrun = -INFINITY, lrun = 0.f, o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int wb = kv0 + 8 * aw; wb < kv1; wb += 8 * PM_ATT_WAVES * UN) {
+        const int base = wb + grp;
+        float kf[UN][8], vf[UN][8];
+        bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int p = base + 8 * PM_ATT_WAVES * u;
+            ok[u] = p < kv1;
+            const unsigned off = head_off + (unsigned)(ok[u] ? p : kv0) * (CTTS_HEAD_DIM * 4);      // clamp: always a valid address
+            const f32x4 k0 = pm_ld16(rk, off), k1 = pm_ld16(rk, off + 16), v0 = pm_ld16(rv, off), v1 = pm_ld16(rv, off + 16);
+            kf[u][0] = k0[0]; kf[u][1] = k0[1]; kf[u][2] = k0[2]; kf[u][3] = k0[3]; kf[u][4] = k1[0]; kf[u][5] = k1[1]; kf[u][6] = k1[2]; kf[u][7] = k1[3];
+            vf[u][0] = v0[0]; vf[u][1] = v0[1]; vf[u][2] = v0[2]; vf[u][3] = v0[3]; vf[u][4] = v1[0]; vf[u][5] = v1[1]; vf[u][6] = v1[2]; vf[u][7] = v1[3];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += q[j] * kf[u][j];
+            dot += dpp_f<DPP_XOR1>(dot);                    // 8-lane group sum on DPP (quad xor1, xor2, half-mirror)
+            dot += dpp_f<DPP_XOR2>(dot);
+            dot += dpp_f<DPP_HALF_MIRROR>(dot);
+            if (ok[u]) {
+                const float mn = fmaxf(mrun, dot);
+                const float sc = pm_exp_diff(mrun, mn);
+                const float pe = expf(dot - mn);
+                lrun = lrun * sc + pe;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = o[j] * sc + pe * vf[u][j];
+                mrun = mn;
+            }
+        }
+    }
+    // merge the 8 key groups of this wave (lanes with equal `sub`)
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(mrun, off), l2 = __shfl_xor(lrun, off);
+        const float mn = fmaxf(mrun, m2);
+        const float s1 = pm_exp_diff(mrun, mn), s2 = pm_exp_diff(m2, mn);
+        lrun = lrun * s1 + l2 * s2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float o2 = __shfl_xor(o[j], off);
+            o[j] = o[j] * s1 + o2 * s2;
+        }
+        mrun = mn;
+    }
+    if (grp == 0) {
+        float* mp = mg + (aw * 8 + sub) * 10;
+        mp[0] = mrun; mp[1] = lrun;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mp[2 + j] = o[j];
+    }
+}
+// ... and its end on the group's first wave, lanes 0..7: the 4 waves' partials in wave order, the softmax finished, the row written into o_proj's fragment-major
+// B operand (attention.hip packed_out)
+__device__ __forceinline__ void pm_attn_finish(const PmArgs& a, const int r, const int h, const int lane, const float* const mg) {
+    float M = mg[lane * 10], L = mg[lane * 10 + 1], O[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) O[j] = mg[lane * 10 + 2 + j];
+#pragma unroll
+    for (int w = 1; w < PM_ATT_WAVES; ++w) {
+        const float* mw = mg + (w * 8 + lane) * 10;
+        const float m2 = mw[0], l2 = mw[1];
+        const float mn = fmaxf(M, m2);
+        const float s1 = pm_exp_diff(M, mn), s2 = pm_exp_diff(m2, mn);
+        L = L * s1 + l2 * s2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) O[j] = O[j] * s1 + mw[2 + j] * s2;
+        M = mn;
+    }
+    const float inv = 1.0f / L;
+    float* dst = a.attn_packed + (size_t)(r >> 4) * 48 * 256;
+    const int k = h * CTTS_HEAD_DIM + 8 * lane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pm_st4(dst + xfrag_index<float>(r & 15, k + j, 48), O[j] * inv);
+}
+
 #define PM_BAR() __syncthreads()
 #define PM_PUBLISH(flagp_, tag_) __hip_atomic_store((flagp_), (tag_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 // after the barrier that follows a poll: has the poller given up?  (uniform: the flag was written before the barrier)
@@ -108,8 +205,9 @@ struct PmRole {
 // "ready" = the poller (wave 8) has seen every flag of the producing phase; the give-up flag is tested right behind it by everybody.
 
 // ---------------------------------------------------------------------------------------------------- waves 0..7: weight tiles in registers, MFMA, epilogues
+// (phase 2: GEMM waves 0..3 serve the workgroup's second attention item)
 template <int NCH>
-__device__ __forceinline__ void pm_gemm_role(const PmArgs& a, float* const bx, float* const red, float* const fac, pm_lds_int* const ctl,
+__device__ __forceinline__ void pm_gemm_role(const PmArgs& a, float* const bx, float* const red, float* const fac, float* const merge, pm_lds_int* const ctl,
                                              const int tid0, const int lane0, const int wave, const int b) {
     int tid = tid0, lane = lane0;
     const PmRole ro(b);
@@ -241,12 +339,22 @@ __device__ __forceinline__ void pm_gemm_role(const PmArgs& a, float* const bx, f
             PM_BAR();
             if (more) PM_LOAD_W0(l + 1);
         }
-        // ================================================================ phase 2: the attention waves' (idle here: barriers only)
+        // ================================================================ phase 2: attention.  The workgroup's first item runs on the attention waves; its second one
+        // (17..32 rows: items b + 256) on GEMM waves 0..3, which idle here anyway -- both at once, so the phase lasts ONE item whatever the workgroup's share
         if (b < R * PM_NH) {
             PM_BAR();
             PM_ABORT_CHECK();
-            const int n_it = (R * PM_NH - b + PM_BLOCKS - 1) / PM_BLOCKS;
-            for (int it = 0; it < n_it; ++it) PM_BAR();
+            const int item2 = b + PM_BLOCKS;
+            const bool mine = item2 < R * PM_NH && wave < PM_ATT_WAVES;
+            if (mine) {
+                float* const kbase = (float*)a.kv + (size_t)l * 2 * a.kv_per;
+                pm_attn_item<3>(a, pm_rsrc(kbase), pm_rsrc(kbase + a.kv_per), pm_rsrc(a.q_buf), item2 / PM_NH, item2 % PM_NH, wave, lane, merge + PM_ATT_WAVES * 80);
+            }
+            PM_BAR();
+            if (mine && wave == 0) {
+                if (lane < 8) pm_attn_finish(a, item2 / PM_NH, item2 % PM_NH, lane, merge + PM_ATT_WAVES * 80);
+                pm_drain();
+            }
             PM_BAR();
         }
         // ================================================================ phase 3: o_proj + residual (llama.py:666,731) -> x, per-tile sums of squares, packed copy
@@ -387,7 +495,7 @@ __device__ __forceinline__ void pm_att_role(const PmArgs& a, float* const merge,
     const PmRole ro(b);
     const int R = a.R, NL = a.n_layers;
     const bool poller = wave == PM_GEMM_WAVES;
-    const int aw = wave - PM_GEMM_WAVES, grp = lane >> 3, sub = lane & 7;
+    const int aw = wave - PM_GEMM_WAVES;
     unsigned* const f_qkv = a.flags, * const f_att = a.flags + 256, * const f_o = a.flags + 512, * const f_gu = a.flags + 768, * const f_d = a.flags + 1024;
     const int n_items = R * PM_NH, n_att_wg = n_items < PM_BLOCKS ? n_items : PM_BLOCKS;
     // diagnostics: the poller's lane 0 stamps the last layer's phase boundaries straight into a.ts (no registers held)
@@ -413,105 +521,10 @@ __device__ __forceinline__ void pm_att_role(const PmArgs& a, float* const merge,
             PM_MARK(2);
             PM_BAR();
             PM_ABORT_CHECK();
-            const int n_it = (n_items - b + PM_BLOCKS - 1) / PM_BLOCKS;
             float* const kbase = (float*)a.kv + (size_t)l * 2 * a.kv_per;          // this layer's K block; V at + kv_per
-            const pm_rsrc_t rk = pm_rsrc(kbase), rv = pm_rsrc(kbase + a.kv_per), rs_q = pm_rsrc(a.q_buf);
-            for (int it = 0; it < n_it; ++it) {
-                const int item = b + it * PM_BLOCKS;
-                const int r = item / PM_NH, h = item % PM_NH;
-                float* const mg = merge + (it & 1) * (PM_ATT_WAVES * 80);
-                {
-                    // attn_decode_kernel<float, 4> (attention.hip): wave aw, lane group grp handle keys kv0 + 8 (4 i + aw) + grp
-                    const RowMeta m = a.meta[r];
-                    const int kv0 = m.kv_start, kv1 = m.slot + 1;
-                    float q[8];
-                    {
-                        const unsigned qo = (unsigned)((((size_t)r * PM_NH + h) * CTTS_HEAD_DIM + 8 * sub) * 4);
-                        const f32x4 q0 = pm_ld16(rs_q, qo), q1 = pm_ld16(rs_q, qo + 16);
-                        q[0] = q0[0] * 0.125f; q[1] = q0[1] * 0.125f; q[2] = q0[2] * 0.125f; q[3] = q0[3] * 0.125f;
-                        q[4] = q1[0] * 0.125f; q[5] = q1[1] * 0.125f; q[6] = q1[2] * 0.125f; q[7] = q1[3] * 0.125f;
-                    }
-                    const unsigned head_off = (unsigned)(((((size_t)m.seq * PM_NH + h) * a.Lmax) * CTTS_HEAD_DIM + 8 * sub) * 4);     // bytes
-                    float mrun = -INFINITY, lrun = 0.f, o[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-                    for (int wb = kv0 + 8 * aw; wb < kv1; wb += 8 * PM_ATT_WAVES * PM_UN) {
-                        const int base = wb + grp;
-                        float kf[PM_UN][8], vf[PM_UN][8];
-                        bool ok[PM_UN];
-#pragma unroll
-                        for (int u = 0; u < PM_UN; ++u) {
-                            const int p = base + 8 * PM_ATT_WAVES * u;
-                            ok[u] = p < kv1;
-                            const unsigned off = head_off + (unsigned)(ok[u] ? p : kv0) * (CTTS_HEAD_DIM * 4);      // clamp: always a valid address
-                            const f32x4 k0 = pm_ld16(rk, off), k1 = pm_ld16(rk, off + 16), v0 = pm_ld16(rv, off), v1 = pm_ld16(rv, off + 16);
-                            kf[u][0] = k0[0]; kf[u][1] = k0[1]; kf[u][2] = k0[2]; kf[u][3] = k0[3]; kf[u][4] = k1[0]; kf[u][5] = k1[1]; kf[u][6] = k1[2]; kf[u][7] = k1[3];
-                            vf[u][0] = v0[0]; vf[u][1] = v0[1]; vf[u][2] = v0[2]; vf[u][3] = v0[3]; vf[u][4] = v1[0]; vf[u][5] = v1[1]; vf[u][6] = v1[2]; vf[u][7] = v1[3];
-                        }
-#pragma unroll
-                        for (int u = 0; u < PM_UN; ++u) {
-                            float dot = 0.f;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) dot += q[j] * kf[u][j];
-                            dot += dpp_f<DPP_XOR1>(dot);                    // 8-lane group sum on DPP (quad xor1, xor2, half-mirror)
-                            dot += dpp_f<DPP_XOR2>(dot);
-                            dot += dpp_f<DPP_HALF_MIRROR>(dot);
-                            if (ok[u]) {
-                                const float mn = fmaxf(mrun, dot);
-                                const float sc = pm_exp_diff(mrun, mn);
-                                const float pe = expf(dot - mn);
-                                lrun = lrun * sc + pe;
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) o[j] = o[j] * sc + pe * vf[u][j];
-                                mrun = mn;
-                            }
-                        }
-                    }
-                    // merge the 8 key groups of this wave (lanes with equal `sub`)
-#pragma unroll
-                    for (int off = 8; off < 64; off <<= 1) {
-                        const float m2 = __shfl_xor(mrun, off), l2 = __shfl_xor(lrun, off);
-                        const float mn = fmaxf(mrun, m2);
-                        const float s1 = pm_exp_diff(mrun, mn), s2 = pm_exp_diff(m2, mn);
-                        lrun = lrun * s1 + l2 * s2;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float o2 = __shfl_xor(o[j], off);
-                            o[j] = o[j] * s1 + o2 * s2;
-                        }
-                        mrun = mn;
-                    }
-                    if (grp == 0) {
-                        float* mp = mg + (aw * 8 + sub) * 10;
-                        mp[0] = mrun; mp[1] = lrun;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) mp[2 + j] = o[j];
-                    }
-                }
-                PM_BAR();
-                if (poller && lane < 8) {
-                    float M = mg[lane * 10], L = mg[lane * 10 + 1], O[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) O[j] = mg[lane * 10 + 2 + j];
-#pragma unroll
-                    for (int w = 1; w < PM_ATT_WAVES; ++w) {
-                        const float* mw = mg + (w * 8 + lane) * 10;
-                        const float m2 = mw[0], l2 = mw[1];
-                        const float mn = fmaxf(M, m2);
-                        const float s1 = pm_exp_diff(M, mn), s2 = pm_exp_diff(m2, mn);
-                        L = L * s1 + l2 * s2;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) O[j] = O[j] * s1 + mw[2 + j] * s2;
-                        M = mn;
-                    }
-                    // the softmax finishes here: o_proj's B operand, fragment-major (attention.hip packed_out)
-                    const float inv = 1.0f / L;
-                    float* dst = a.attn_packed + (size_t)(r >> 4) * 48 * 256;
-                    const int k = h * CTTS_HEAD_DIM + 8 * lane;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pm_st4(dst + xfrag_index<float>(r & 15, k + j, 48), O[j] * inv);
-                }
-            }
+            pm_attn_item<PM_UN>(a, pm_rsrc(kbase), pm_rsrc(kbase + a.kv_per), pm_rsrc(a.q_buf), b / PM_NH, b % PM_NH, aw, lane, merge);
+            PM_BAR();
+            if (poller && lane < 8) pm_attn_finish(a, b / PM_NH, b % PM_NH, lane, merge);
             if (poller) pm_drain();
             PM_BAR();
             if (poller && lane == 0) PM_PUBLISH(f_att + b, tag + 2u);
@@ -574,7 +587,7 @@ __global__ __launch_bounds__(PM_THREADS) void persist_mfma_kernel(const PmArgs a
     const int done_v = vload_flag(a.done), err_v = vload_flag(a.error), ep_v = vload_flag((const int*)a.epoch);
     if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;      // every sequence finished (gpt.py:545) / an earlier launch gave up: the same for every workgroup
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
-    if (wave < PM_GEMM_WAVES) pm_gemm_role<NCH>(a, bx, red, fac, ctl, tid, lane, wave, b);
+    if (wave < PM_GEMM_WAVES) pm_gemm_role<NCH>(a, bx, red, fac, merge, ctl, tid, lane, wave, b);
     else pm_att_role<NCH>(a, merge, ctl, tid, lane, wave, b, (unsigned)ep_v << 8);      // tag = launch counter << 8 | layer * 8 + phase + 1
     // Advance the launch counter.  Safe although other workgroups may still be running: workgroup 0 owns a down item, i.e. it has seen every
     // workgroup's gate|up flag of the last layer, i.e. every workgroup has long read its copy at entry.

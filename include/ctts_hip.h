@@ -81,12 +81,18 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "lora_fold"           per-utterance adapters at decode: 1 (default) = the rows' low-rank terms come from worker workgroups inside the QKV / o_proj launches
  *                         (lora_worker.h), 0 = two more launches per layer (lora.hip; the prompt pass always uses those)
  *   "persistent_fault"    test hook: one workgroup withholds a hand-off in layer value - 1 (the bounded waits must end the step with an error)
+ *   "mfma_rows"           fp32 engines, OPT-IN (default 0 = off): decode batches of "mfma_rows_min" (default 5) .. this many rows (<= 32) run the decoder stack of a
+ *                         step as ONE persistent launch with MFMA projections (persist_mfma.hip; same packed weight images, same sums as the launch chain).  Measured
+ *                         slower than the launch chain on MI355X, hence off; same residency rule and device lock as "persistent_rows"
+ *   "mfma_nap", "mfma_delay_0" .. "mfma_delay_4"  how often / how long after a phase starts its poller looks at the producing phase's flag words
+ *   "mfma_timestamps"     diagnostics: per-workgroup phase marks of the last layer ("pm_ts" of ctts_gpt_debug_read)      "mfma_fault"  test hook like "persistent_fault"
  * Unknown names are an error. */
 int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value);
 int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value);      /* the EFFECTIVE value ("persistent_rows" reads 0 where the mode is unavailable) */
 
 /* Diagnostics (tools/persist_probe.py): copies a named internal buffer to HOST memory -- "x_dec", "q_buf", "logits", "pl_g" (the persistent
- * layer's granule buffers), "pl_ts" (its per-workgroup phase marks, option "persistent_timestamps"), "pl_state" ({epoch, error}).  Synchronises. */
+ * layer's granule buffers), "pl_ts" (its per-workgroup phase marks, option "persistent_timestamps"), "pl_state" ({epoch, error}), "pm_ts" (phase marks of the persistent MFMA stack,
+ * option "mfma_timestamps"), "xh" / "ssq" (the packed residual copy and its per-tile sums of squares).  Synchronises. */
 int ctts_gpt_debug_read(ctts_gpt* h, const char* name, void* out, size_t max_bytes, size_t* bytes, void* stream);
 
 /* replaces GPT.from_pretrained -> load_state_dict (gpt.py:84-85).  `name` is the reference

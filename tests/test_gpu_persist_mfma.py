@@ -1,0 +1,125 @@
+"""The persistent MFMA decode stack (persist_mfma.hip: the 20-layer stack of a 5..32-row decode step as ONE launch of 256 resident workgroups -- weight tiles in
+registers a layer ahead, exact-f32 MFMA projections in the launch chain's summation order, hand-offs by write-through stores + flag words) against the launch
+chain it can replace -- the loop both serve is the reference's gpt.py:389-546 over llama.py:719-749.
+
+The mode is opt-in (`options={"mfma_rows": 32}`): it is correct (token ids identical to the launch chain and to the reference's goldens, below) but measured slower
+(DESIGN.md section 0), so the launch chain stays the default for these batch sizes."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from chatttsplus_amd import synth
+from tests.helpers import gen_case_inputs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+LP = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20)
+
+
+@pytest.fixture(scope="module")
+def gpt():
+    from chatttsplus_amd.hip_models import GPT
+    g = GPT(LLAMA, max_batch=32, max_seq_len=700, weight_dtype="fp32")
+    g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+    yield g
+    g.close()
+
+
+def _gen(g, B, P, N, pad=None, seed=7):
+    ids, mask = synth.prompt_ids(B, P, 21178, 4321, pad_left=pad)
+    emb = g(torch.from_numpy(ids), torch.ones(B, P, dtype=torch.bool))
+    res = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=N,
+                          logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="device", seed=seed))[-1]
+    return res.ids, res.hiddens
+
+
+def test_mfma_stack_is_opt_in_and_matches_the_launch_chain(gpt):
+    g = gpt
+    assert g.get_option("mfma_rows") == 0, "the persistent MFMA stack is opt-in"
+    # the reference run = the launch chain on the same arithmetic: packed-residual path with the in-launch split-K combine from 5 rows on (its defaults start at 9)
+    g.set_option("split_rows", 4); g.set_option("down_splitk_rows", 5)
+    try:
+        for (B, P, N) in [(5, 40, 12), (8, 33, 12), (13, 40, 10), (16, 48, 10), (17, 40, 10), (22, 36, 10), (32, 40, 12), (32, 600, 6)]:
+            pad = [(7 * b) % 13 for b in range(B)]
+            g.set_option("mfma_rows", 0)
+            ref_ids, ref_h = _gen(g, B, P, N, pad)
+            g.set_option("mfma_rows", 32)
+            ids, hid = _gen(g, B, P, N, pad)
+            for b in range(B):
+                assert torch.equal(ids[b], ref_ids[b]), f"B={B} P={P}: row {b} tokens differ from the launch chain"
+                assert float((hid[b] - ref_h[b]).abs().max()) <= 5e-5, (B, P, b)
+            assert all(torch.equal(hid[b][0], ref_h[b][0]) for b in range(B)) or B < 22, "first step: same sums in the same order from 22 rows on (4-wave attention blocks on both paths)"
+    finally:
+        g.set_option("mfma_rows", 0); g.set_option("split_rows", 8); g.set_option("down_splitk_rows", 9)
+
+
+def test_mfma_stack_replay_is_bitwise_reproducible_and_graph_equals_eager(gpt):
+    g = gpt
+    g.set_option("mfma_rows", 32)
+    try:
+        a_ids, a_h = _gen(g, 24, 48, 40)
+        b_ids, b_h = _gen(g, 24, 48, 40)
+        g.use_graph = False
+        try:
+            c_ids, c_h = _gen(g, 24, 48, 40)
+        finally:
+            g.use_graph = True
+        for r in range(24):
+            assert torch.equal(a_ids[r], b_ids[r]) and torch.equal(a_h[r], b_h[r]), "two replays differ (fixed reduction orders, no atomics on the data path)"
+            assert torch.equal(a_ids[r], c_ids[r]) and torch.equal(a_h[r], c_h[r]), "hipGraph replay != eager launches"
+    finally:
+        g.set_option("mfma_rows", 0)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_mfma_stack_reproduces_the_reference_b32_ragged_golden(compact):
+    """gpt_real_b32_ragged was minted by the reference's own GPT.generate (32 sequences, 23 left paddings, rows ending after 2 .. 96 tokens): with the persistent MFMA
+    stack serving every step of 5..32 rows -- and, under compaction, handing the shrinking batch to the <= 4-row persistent launch -- every row's ids are the reference's."""
+    from chatttsplus_amd.hip_models import GPT
+    z, meta = load_golden("gpt_real_b32_ragged")
+    sd, ids, mask, _ = gen_case_inputs(meta, synth.GPT_REAL)
+    g = GPT(LLAMA, max_batch=32, max_seq_len=128, weight_dtype="fp32", options={"mfma_rows": 32})
+    try:
+        g.load_state_dict(sd)
+        assert g.get_option("mfma_rows") == 32
+        ids_t = torch.from_numpy(ids)
+        emb = g(ids_t, torch.ones(ids.shape[:2], dtype=torch.bool))
+        g.compact = compact
+        torch.manual_seed(int(meta["torch_seed"]))
+        out = list(g.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=int(meta["max_new"]),
+                              min_new_token=int(meta["min_new"]), logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="torch"))[-1]
+        lens = z["lens"]
+        assert [int(i.shape[0]) for i in out.ids] == lens.tolist()
+        for b, n in enumerate(lens):
+            assert np.array_equal(out.ids[b].cpu().numpy(), z["ids"][b, :n].astype(np.int64)), f"row {b}: token ids differ"
+        for k, r in enumerate(int(x) for x in meta["hidden_rows"]):
+            n = int(lens[r])
+            assert np.abs(out.hiddens[r].cpu().numpy() - z["hiddens"][k, :n]).max() <= 1e-4, r
+    finally:
+        g.close()
+
+
+def test_a_withheld_flag_ends_the_step_with_an_error_instead_of_hanging(gpt):
+    """Every wait of the persistent MFMA stack is bounded: with one workgroup withholding its q|k|v flag in layer 7 (test hook), the pollers give up after ~0.3 s, the
+    device error word turns the rest of the launch and every later launch into no-ops, the host gets a HipBackendError naming the edge -- and the next request is
+    served normally."""
+    from chatttsplus_amd import _lib
+    g = gpt
+    g.set_option("mfma_rows", 32)
+    try:
+        ref_ids, _ = _gen(g, 12, 24, 10)
+        g.set_option("mfma_fault", 8)
+        t0 = time.perf_counter()
+        with pytest.raises(_lib.HipBackendError, match=r"persistent MFMA decode stack: a workgroup gave up waiting on edge (8|9|1[0-2])"):
+            _gen(g, 12, 24, 10)
+        assert time.perf_counter() - t0 < 20.0, "the give-up took too long: a wait is not bounded"
+        g.set_option("mfma_fault", 0)
+        ids, _ = _gen(g, 12, 24, 10)
+        for r in range(12):
+            assert torch.equal(ids[r], ref_ids[r]), "the engine did not recover after the reported give-up"
+    finally:
+        g.set_option("mfma_fault", 0); g.set_option("mfma_rows", 0)

@@ -48,7 +48,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         g.set_option(k, int(v))
-    rows_max = g.get_option("mfma_rows")
+    rows_max = g.get_option("mfma_rows") or 32          # (the mode is opt-in: off by default)
+    g.set_option("mfma_rows", rows_max)
     print(json.dumps({"mfma_rows": rows_max, "mfma_rows_min": g.get_option("mfma_rows_min"), "persistent_rows": g.get_option("persistent_rows")}), flush=True)
     spk = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
     if not args.no_check:
