@@ -119,7 +119,10 @@ struct ctts_gpt {
     int persist_rows = 0;                        // fp32 engines (default 4, set at create): decode batches of <= this many rows run the decoder stack as ONE persistent
                                                  // launch (persist_layer.hip).  us/step, launch chain -> persistent (profiles/r04_ab_persist_options.jsonl):
                                                  // batch 1 452 -> 285, batch 2 480 -> 347, batch 4 540 -> 467
-    char* pimg = nullptr;                        //   per-workgroup register images of the layer weights [L][192][192 KB], built on the device from the packed tiles
+    bool persist_ok = false;                     //   the mode's preconditions hold and this process holds the device's lock (ensure_persist)
+    char* pimg = nullptr;                        //   per-workgroup register images of the layer weights [L][192][192 KB], built on the device from the packed tiles -- on the FIRST
+                                                 //   decode call of <= persistent_rows rows (persist_images): an engine that only ever decodes larger batches (a LoRA-merged
+                                                 //   sibling serving batch 32) never pays the second 755 MB weight copy
     unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
     unsigned* pl_epoch = nullptr;                //   launch counter = granule tag
     int* pl_error = nullptr;                     //   first give-up code (0 = none); reported by ctts_gpt_progress
@@ -279,7 +282,7 @@ static bool persist_device_lock(int dev) {
 // needed after finalize), granule buffers, launch counter, error word.  `required`: the caller asked for the mode explicitly (an unmet precondition is
 // an error); otherwise the mode is simply left off.
 static int ensure_persist(ctts_gpt* h, bool required) {
-    if (h->pimg != nullptr || !h->finalized) return 0;          // (before finalize: built by finalize)
+    if (h->persist_ok || !h->finalized) return 0;               // (before finalize: checked by finalize)
     int dev = 0, cus = 0;
     CTTS_HIP_CHECK(hipGetDevice(&dev));
     CTTS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -294,10 +297,17 @@ static int ensure_persist(ctts_gpt* h, bool required) {
         return 0;
     }
     if (persist_configure()) return 1;
-    if (dev_alloc((void**)&h->pimg, PL_LAYER_BYTES * h->L) || dev_alloc((void**)&h->pl_g, (size_t)PL_G_TOTAL * 8) ||
-        dev_alloc((void**)&h->pl_epoch, 4) || dev_alloc((void**)&h->pl_error, 4)) return 1;
+    if (dev_alloc((void**)&h->pl_g, (size_t)PL_G_TOTAL * 8) || dev_alloc((void**)&h->pl_epoch, 4)) return 1;
+    if (!h->pl_error && dev_alloc((void**)&h->pl_error, 4)) return 1;
     const unsigned one = 1;
     CTTS_HIP_CHECK(hipMemcpy(h->pl_epoch, &one, 4, hipMemcpyHostToDevice));
+    h->persist_ok = true;
+    return 0;
+}
+// the weight images, on first need (called outside stream capture: allocates, launches on the null stream, synchronises)
+static int persist_images(ctts_gpt* h) {
+    if (h->pimg != nullptr || !h->persist_ok) return 0;
+    if (dev_alloc((void**)&h->pimg, PL_LAYER_BYTES * h->L)) return 1;
     for (int l = 0; l < h->L; ++l)
         if (launch_persist_repack(h->lw[l].qkv, h->lw[l].o, h->lw[l].gu, h->lw[l].d, h->pimg + PL_LAYER_BYTES * l, nullptr)) return 1;
     CTTS_HIP_CHECK(hipDeviceSynchronize());
@@ -337,7 +347,7 @@ static int ensure_persist_mfma(ctts_gpt* h, bool required) {
 extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     if (!h || !name || !value) { ctts_set_error("get_option: null argument"); return 1; }
     const std::string n(name);
-    if (n == "persistent_rows") *value = (h->pimg != nullptr || !h->finalized) ? h->persist_rows : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
+    if (n == "persistent_rows") *value = (h->persist_ok || !h->finalized) ? h->persist_rows : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
     else if (n == "mfma_rows") *value = (h->pm_flags != nullptr || !h->finalized) ? h->pm_rows_max : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
     else if (n == "mfma_rows_min") *value = h->pm_rows_min;
     else if (n == "valu_rows") *value = h->valu_rows;
@@ -1219,11 +1229,54 @@ static inline int decode_persist(const ctts_gpt* h, int B, int L) {
 static inline int decode_pm(const ctts_gpt* h, int B) {
     return (h->pm_rows_max > 0 && h->pm_flags != nullptr && h->cfg.dtype == CTTS_DTYPE_F32 && B >= h->pm_rows_min && B <= h->pm_rows_max && B <= PM_MAXR && !h->lora_rows) ? 1 : 0;
 }
-static inline void pick_decode_path(ctts_gpt* h, int longest) {
+static inline int pick_decode_path(ctts_gpt* h, int longest) {
     h->cur_splits = decode_splits(h, h->B, longest);
     h->cur_pm = decode_pm(h, h->B);
+    if (!h->cur_pm && h->persist_ok && h->pimg == nullptr && h->persist_rows > 0 && h->B <= h->persist_rows && h->cfg.dtype == CTTS_DTYPE_F32 && !h->lora_rows && persist_images(h)) return 1;
     h->cur_persist = h->cur_pm ? 0 : decode_persist(h, h->B, longest);
+    return 0;
 }
+
+// Persistent launches of ONE process on one device take turns.  Each needs all 256 workgroups resident; two of them enqueued on different streams (two engines, two
+// threads: a base engine and a LoRA-merged sibling, two pipelines) could each be given a share of the CUs and wait for the other's until both give up.  The
+// per-device file lock keeps OTHER processes off the mode; this keeps the process's own streams apart: a decode call that launches persistent kernels first makes its
+// stream wait for the previous such call's last launch (an event, no host wait), then records its own.  Calls on one stream are ordered anyway.
+struct PersistTurn {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool pending = false;
+};
+static PersistTurn* persist_turn() {
+    static std::mutex mu;
+    static std::map<int, PersistTurn*> turns;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = turns.find(dev);
+    if (it != turns.end()) return it->second;
+    PersistTurn* t = new PersistTurn();
+    if (hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess) { delete t; return nullptr; }
+    turns[dev] = t;
+    return t;
+}
+struct PersistTurnGuard {
+    PersistTurn* t = nullptr;
+    hipStream_t s = nullptr;
+    int rc = 0;
+    PersistTurnGuard(bool persistent, hipStream_t stream) : s(stream) {
+        if (!persistent) return;
+        t = persist_turn();
+        if (!t) return;
+        t->mu.lock();
+        if (t->pending && t->last != s && hipStreamWaitEvent(s, t->ev, 0) != hipSuccess) rc = 1;
+    }
+    ~PersistTurnGuard() {
+        if (!t) return;
+        if (hipEventRecord(t->ev, s) == hipSuccess) { t->last = s; t->pending = true; }
+        t->mu.unlock();
+    }
+};
 
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
     StreamForm form = {false, false};
@@ -1268,9 +1321,11 @@ extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* st
     hipStream_t s = (hipStream_t)stream;
     {
         const int longest = advance_rows(h, n_steps) + 1;
-        pick_decode_path(h, longest);
+        if (pick_decode_path(h, longest)) return 1;
     }
     h->launched += n_steps;
+    PersistTurnGuard turn(h->cur_persist != 0 || h->cur_pm != 0, s);
+    if (turn.rc) { ctts_set_error("decode: hipStreamWaitEvent failed"); return 1; }
     if (use_graph) {
         if (ensure_graph(h)) return 1;
         int left = n_steps;
@@ -1521,7 +1576,7 @@ extern "C" int ctts_gpt_time_decode(ctts_gpt* h, int n_steps, float* ms_per_step
             const int n = (n_steps - i < CH) ? n_steps - i : CH;
             int longest = 1;
             for (int r = 0; r < h->B; ++r) { const int c = std::min(h->row_ctx[r] + (launched - h->launched) + n, h->row_cap[r]); if (c > longest) longest = c; }
-            pick_decode_path(h, longest + 1);
+            if (pick_decode_path(h, longest + 1)) return 1;
             launched += n;
             if (ensure_graph(h)) return 1;
             if (pass == 1) for (int j = 0; j < n; j += h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));

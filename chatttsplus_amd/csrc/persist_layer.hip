@@ -1,22 +1,26 @@
-// One decoder layer of a small decode batch (<= 4 rows, fp32 engine) as ONE persistent launch (gfx950).
+// The decoder stack of a small decode batch (<= 4 rows, fp32 engine) as ONE persistent launch (gfx950): all 20 layers of a step, or `n_layers` of them per
+// launch (option "persistent_layers_per_launch"; the first version of the structure ran one layer per launch).
 //
 // Reference arithmetic: LlamaDecoderLayer.forward, chattts_plus/models/llama.py:719-749 (RMSNorm :82-87, q/k/v + RoPE + cache append :619-633,
 // SDPA :653-661, o_proj + residual :666,731, SwiGLU MLP + residual :214,737-739) -- the loop it serves is gpt.py:389-546.
 //
-// Why: a batch-1 decode step of the launch path is 102 dependent launches of ~4.8 us each although the layer's 37.7 MB of fp32 weights stream
-// in ~6 us: every launch pays boundary + ramp + one load round trip + drain.  Here a layer is ONE launch of 256 resident workgroups:
-//   * 192 GEMV workgroups own a fixed slice of every projection (12 q/k/v rows, 4 o_proj rows, 16 gate|up pairs, 4 down rows = 192 KB of
-//     weights); their 8 compute waves request the whole slice with non-temporal loads at kernel entry, so the weight stream runs AHEAD of
-//     the layer's dependency edges (MI355X_MICROARCH.md price list, row prefetch-credit) and every product is VALU work on registers;
-//   * 64 attention workgroups own one (row, head) each and pull its cached K / V rows into registers before the query exists;
+// Why: a batch-1 decode step of the launch path is 102 dependent launches of ~4.8 us each although a layer's 37.7 MB of fp32 weights stream
+// in ~6 us: every launch pays boundary + ramp + one load round trip + drain.  Here the stack is ONE launch of 256 resident workgroups:
+//   * 192 GEMV workgroups own a fixed slice of every projection of every layer (12 q/k/v rows, 4 o_proj rows, 16 gate|up pairs, 4 down rows = 192 KB of
+//     weights per layer); their 8 compute waves keep the slice in registers and request each array for the NEXT use one wait ahead, paced (SCHED 3: one 1 KB
+//     fragment per wave every ~0.2 us while the edge waves gather), so the weight stream runs AHEAD of the layer's dependency edges
+//     (MI355X_MICROARCH.md price list, row prefetch-credit) and every product is VALU work on registers;
+//   * 64 attention workgroups own one (row, head, key share) each and pull its cached K / V rows into registers before the query exists;
 //   * the activations travel between workgroups as 8-byte {tag, value} granules (one sc1 store each, cdna_hip_programming.md Guideline 16 R2):
-//     the data is the flag, a consumer wave re-reads its granules until every tag equals this launch's epoch -- no fences, no counters,
+//     the data is the flag, a consumer wave re-reads its granules until every tag equals (launch counter, layer) -- no fences, no counters,
 //     placement-independent.  Two "edge" waves per workgroup do all gathering, epilogues and publishing, so the compute waves never poll
 //     (a poll's result would queue behind their in-flight weight loads: vmcnt retires in order);
-//   * the residual stream enters and leaves through plain global memory (the launch boundary orders it), so consecutive layers are
-//     consecutive launches and a layer has four in-launch edges: q|k|v -> attention, attention -> o_proj, o_proj -> gate|up, gate|up -> down.
+//   * five edges per layer: q|k|v -> attention, attention -> o_proj, (x + attention) -> gate|up, silu(gate) * up -> down, layer output -> next layer;
+//     the residual stream enters the launch and leaves it through plain global memory (the sampler wrote it, the heads read it: launch boundaries).
 // Every spin is bounded; a give-up sets a device error word that makes this and every later launch return at once (ctts_gpt_progress
-// reports it).  The epoch is a device counter the launch itself advances (graph replay freezes kernel arguments).
+// reports it).  The tag's launch counter is a device word the launch itself advances (graph replay freezes kernel arguments).
+// Residency: the launch is a plain one and assumes its 256 workgroups are co-resident (one per CU, nothing else running persistent launches on the device):
+// a per-device file lock keeps other processes off the mode, and decode calls of one process that launch persistent kernels take turns (gpt_engine.hip PersistTurn).
 #include "kernels.h"
 #include "persist.h"
 

@@ -140,3 +140,65 @@ def test_a_withheld_hand_off_ends_the_step_with_an_error_instead_of_hanging(gpt)
     g.set_option("persistent_fault", 0)
     ids, _ = _gen(g, 1, 24, 12)
     assert torch.equal(ids[0], ref_ids[0]), "the engine did not recover after the reported give-up"
+
+
+def test_two_engines_of_one_process_take_turns_with_their_persistent_launches():
+    """VERDICT r4 / ADVICE r4: the persistent mode's lock is per process, so two engines of ONE process (a base engine and a second pipeline / a LoRA sibling) both own
+    it; driven from two threads on two streams their launches -- each needs all 256 workgroups resident -- could starve each other until the 0.3 s give-up.  Decode
+    calls that launch persistent kernels now take turns (an event chain between the streams, gpt_engine.hip PersistTurn): both threads finish without a give-up and
+    with the tokens a solo run gives them."""
+    import threading
+    from chatttsplus_amd.hip_models import GPT
+    sd = synth.gpt_state_dict(synth.GPT_REAL, 1234)
+    gs = [GPT(LLAMA, max_batch=2, max_seq_len=400, weight_dtype="fp32") for _ in range(2)]
+    try:
+        for g in gs:
+            g.load_state_dict(sd)
+            assert g.get_option("persistent_rows") == 4
+        solo = [_gen(gs[i], 1 + i, 40, 96, seed=11 + i) for i in range(2)]
+        out, err = [None, None], [None, None]
+
+        def work(i):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    for _ in range(3):
+                        out[i] = _gen(gs[i], 1 + i, 40, 96, seed=11 + i)
+            except BaseException as e:          # noqa: BLE001 (reported below)
+                err[i] = e
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert err == [None, None], err
+        for i in range(2):
+            for r in range(1 + i):
+                assert torch.equal(out[i][0][r], solo[i][0][r]) and torch.equal(out[i][1][r], solo[i][1][r]), f"engine {i} row {r}: concurrent run differs from the solo run"
+    finally:
+        for g in gs:
+            g.close()
+
+
+def test_persistent_weight_images_are_built_on_first_need(gpt):
+    """the persistent launch keeps its own per-workgroup image of the layer weights (755 MB for 20 layers).  It is built by the first decode call of <= 4
+    rows, not at load time: an engine that only serves larger batches never allocates it."""
+    from chatttsplus_amd.hip_models import GPT
+    g = GPT(LLAMA, max_batch=8, max_seq_len=200, weight_dtype="fp32")
+    try:
+        g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+        assert g.get_option("persistent_rows") == 4
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        _gen(g, 8, 24, 8)                                    # the launch chain: no image
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+        ids_a, _ = _gen(g, 1, 24, 8)                         # first <= 4-row decode: 20 x 37.75 MB
+        torch.cuda.synchronize()
+        free2 = torch.cuda.mem_get_info()[0]
+        assert free0 - free1 < 300 * 2 ** 20, "the batch-8 request allocated the persistent weight images"
+        assert free1 - free2 > 600 * 2 ** 20, "the batch-1 request did not build the persistent weight images"
+        ref_ids, _ = _gen(gpt, 1, 24, 8)
+        assert torch.equal(ids_a[0], ref_ids[0])
+    finally:
+        g.close()

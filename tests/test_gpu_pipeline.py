@@ -526,3 +526,41 @@ def test_per_utterance_lora_inside_the_projection_launches_equals_the_separate_l
                 else:
                     assert torch.equal(many[1].ids[u], plain.ids[u]), u
     g.close()
+
+
+def test_row_adapters_survive_a_second_generate_and_compaction():
+    """`set_row_adapters` applies to "the following generate() calls".  ctts_gpt_compact clears the engine's live adapter flag once every adapter-carrying
+    row has left the batch; ctts_gpt_begin restored the per-row slots only while that flag was still set -- so a second generate() after ONE set_row_adapters() call ran
+    without its adapters, silently.  Here the only adapter row finishes first (its limit is short), the batch is compacted, and the same call is repeated: identical
+    tokens and hidden states, and different from the adapter-less run."""
+    from chatttsplus_amd.hip_models import GPT
+    g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=8, max_seq_len=128, weight_dtype="fp32")
+    try:
+        g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+        rl = np.random.Generator(np.random.Philox(key=5))
+        g.load_adapter(0, [(l, t, (rl.standard_normal((8, 768)) * 0.05).astype(np.float32), (rl.standard_normal((768, 8)) * 0.05).astype(np.float32), 2.0)
+                           for l in range(20) for t in ("q_proj", "k_proj", "v_proj", "o_proj")])
+        B, T, N = 8, 12, 64
+        ids, mask = synth.prompt_ids(B, T, 21178, 77)
+        emb = g(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))
+        lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+
+        def run():
+            return list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=N,
+                                   logits_warpers=lw, logits_processors=[], return_hidden=True, noise="device", seed=3, max_new_tokens_per_row=[4] + [N] * 7))[-1]      # (compaction serves batches of >= 8 sequences)
+
+        plain = run()
+        g.set_row_adapters([0] + [-1] * 7)                 # ONE call; the adapter row stops after 4 tokens and is compacted away
+        first = run()
+        assert g.compactions, "the case has no teeth: no row left the batch"
+        second = run()
+        g.set_row_adapters(None)
+        assert float((first.hiddens[0] - plain.hiddens[0]).abs().max()) > 1e-3, "the adapter changes nothing: the case has no teeth"
+        for b in range(B):
+            assert torch.equal(second.ids[b], first.ids[b]) and torch.equal(second.hiddens[b], first.hiddens[b]), f"row {b}: the second generate() lost the adapters"
+        for b in range(1, B):
+            assert torch.equal(first.ids[b], plain.ids[b]), f"adapter-less row {b} differs from the plain run"
+        third = run()                                       # ... and after set_row_adapters(None) the engine is plain again
+        assert torch.equal(third.hiddens[0], plain.hiddens[0])
+    finally:
+        g.close()
