@@ -67,6 +67,23 @@ def cpu_baseline(prompt_len: int, sample_steps: int):
                        f"after a 4-step run is subtracted, same synthetic weights; host has {os.cpu_count()} logical CPUs")
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when it creates a communicator; the contract is ONE JSON line on stdout.  File-descriptor level
+    redirection (the banner comes from C code) around the group's creation and its first collective."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -531,8 +548,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
-        assert dist.get_world_size() == args.gpus
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+            assert dist.get_world_size() == args.gpus
+            dist.barrier()                                                                # the communicator exists (and has said so) before anything is printed
 
     from chatttsplus_amd import synth
     from chatttsplus_amd.hip_models.gpt import GPT

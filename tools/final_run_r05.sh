@@ -1,0 +1,39 @@
+# Round-5 evidence collection on one MI355X box (one gpurun call): GPU suite + smoke, the bench lines (default, the driver's arguments, --force-pg = the N > 1
+# path on a one-rank RCCL group), step time vs batch, the persistent MFMA stack's probe (ids vs the launch chain, step times, phase marks), rocprofv3 kernel
+# stats of batch 1 / batch 32 launch chain / batch 32 persistent MFMA stack, FETCH / WRITE traffic at the timed window's context (prompt 293 -> mean context 309).
+# Small summaries only -> gpurun_out/fin_r05 (tools/collect_profiles_r05.py copies them to profiles/).
+set -x
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/fin_r05
+mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+tail -3 $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+timeout 900 python bench.py > $O/bench_b1_fp32.json 2> $O/bench_b1_fp32.err; cut -c1-200 $O/bench_b1_fp32.json
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_b1_fp32_steps20.json 2>/dev/null; cut -c1-200 $O/bench_b1_fp32_steps20.json
+timeout 600 python bench.py --steps 20 --warmup 5 --force-pg > $O/bench_b1_fp32_steps20_force_pg.json 2>/dev/null; cut -c1-200 $O/bench_b1_fp32_steps20_force_pg.json
+for B in 32; do timeout 300 python bench.py --batch $B --steps 256 --cpu-steps 0 --no-extras > $O/bench_b${B}_fp32.json 2>/dev/null; cut -c1-160 $O/bench_b${B}_fp32.json; done
+timeout 300 python bench.py --batch 32 --steps 256 --cpu-steps 0 --no-extras --option mfma_rows=32 > $O/bench_b32_fp32_persistent_mfma.json 2>/dev/null; cut -c1-160 $O/bench_b32_fp32_persistent_mfma.json
+timeout 300 python tools/tb_curve.py fp32 1 2 3 4 5 6 8 10 12 14 16 17 18 20 22 24 26 28 30 32 > $O/step_time_vs_batch_fp32.jsonl 2>/dev/null
+timeout 400 python tools/pm_probe.py --batches 5,8,12,16,17,24,32 --steps 16 --prompt 293 --marks 32 --time-steps 32 > $O/pm_probe.jsonl 2>/dev/null; cat $O/pm_probe.jsonl | cut -c1-400
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b1 -- python $R/bench.py --steps 128 --warmup 16 --cpu-steps 0 --no-extras > /tmp/prof_b1.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b32 -- python $R/bench.py --batch 32 --steps 64 --warmup 16 --cpu-steps 0 --no-extras > /tmp/prof_b32.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b32pm -- python $R/bench.py --batch 32 --steps 64 --warmup 16 --cpu-steps 0 --no-extras --option mfma_rows=32 > /tmp/prof_b32pm.log 2>&1
+for t in b1 b32 b32pm; do
+  f=$(find /tmp/prof_$t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${t}_fp32_kernel_stats.csv
+  grep '"metric"' /tmp/prof_$t.log | cut -c1-400 > $O/${t}_prof_bench.json
+done
+for t in b1 b32 b32pm; do
+  BA="--batch 1"; [ $t = b32 ] && BA="--batch 32"; [ $t = b32pm ] && BA="--batch 32 --option mfma_rows=32"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_${t}_$c
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${t}_$c -- python $R/bench.py $BA --prompt 293 --steps 16 --warmup 8 --gen-tokens 0 --cpu-steps 0 --no-extras > /tmp/pmc_${t}_$c.log 2>&1
+    db=$(find /tmp/pmc_${t}_$c -name '*.db' | head -1)
+    [ -n "$db" ] && python $R/tools/rocpd_pmc.py $db $c 14 $O/pmc_${t}_$c.json > /dev/null 2>> $O/pmc_errors.log || { echo "no db for $t $c" >> $O/pmc_errors.log; tail -3 /tmp/pmc_${t}_$c.log >> $O/pmc_errors.log; }
+  done
+done
+cd $R
+ls -la $O; cat $O/pmc_errors.log 2>/dev/null | tail -5; head -6 $O/b32pm_fp32_kernel_stats.csv | cut -c1-200
