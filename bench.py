@@ -573,6 +573,8 @@ def main():
         dist.broadcast(spk, src=0)
     use_graph = 0 if args.no_graph else 1
     persist_rows = g.get_option("persistent_rows")             # effective value: 1 on fp32 engines that hold the device's persistent-launch lock
+    mfma_rows, mfma_min = g.get_option("mfma_rows"), g.get_option("mfma_rows_min")      # the opt-in persistent MFMA stack (--option mfma_rows=32)
+    on_mfma = mfma_min <= B <= mfma_rows
     leg = Leg(g, dev, rank, world, grouped)
     XR = max(1, args.extra_reps)
     r = leg.run(B, P, K, W, spk=spk, use_graph=use_graph, keep_hidden=True, gen_tokens=args.gen_tokens)
@@ -713,12 +715,14 @@ def main():
     if rank == 0:
         traffic, traffic_note = None, None
         try:      # HBM bytes/step from the committed rocprofv3 PMC passes (profiles/): same kernels, same batch, same context as the timed window; not live
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
-            ent = tj.get(f"b{B}_{args.dtype}" + ("" if persist_rows >= B else "_launch_chain"))
+            tp = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json")]
+            tp = [q for q in tp if os.path.exists(q)][0]                      # the newest committed PMC passes
+            tj = json.load(open(tp))
+            ent = tj.get(f"b{B}_{args.dtype}" + ("_persistent_mfma" if on_mfma else "" if (persist_rows >= B or B > 4) else "_launch_chain"))
             if ent:
                 traffic = ent.get("hbm_bytes_per_step")
                 traffic_note = (f"PMC FETCH_SIZE (x2, the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per decode step, separate rocprofv3 --pmc passes of "
-                                f"`{ent.get('command')}` (profiles/r04_pmc_*.json): mean context {ent.get('mean_context')} = the timed window's; "
+                                f"`{ent.get('command')}` (profiles/{os.path.basename(tp)[:8]}*.json): mean context {ent.get('mean_context')} = the timed window's; "
                                 f"{ent.get('traffic_over_algorithmic')} x the algorithmic bytes")
         except Exception:
             pass
@@ -736,8 +740,9 @@ def main():
                                    f"random-init weights of the real 20x768 architecture",
                        "batch_per_gpu": B, "prompt_len": P, "untimed_steps_before_window": r["s0"], "weights": args.dtype, "kv_cache": args.dtype,
                        "accumulate": "f32", "hipgraph": bool(use_graph), "parallelism": f"replicas x{world} (utterance sharding)",
-                       "decode_path": ("persistent launch (20 layers = 1 launch, persist_layer.hip)" if persist_rows >= B else "launch chain (5 launches per layer)"),
-                       "persistent_rows": persist_rows},
+                       "decode_path": ("persistent MFMA stack (20 layers = 1 launch, persist_mfma.hip; opt-in)" if on_mfma else
+                                       "persistent launch (20 layers = 1 launch, persist_layer.hip)" if persist_rows >= B else "launch chain (5 launches per layer)"),
+                       "persistent_rows": persist_rows, "mfma_rows": mfma_rows},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": traffic_note,
