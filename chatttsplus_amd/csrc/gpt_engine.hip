@@ -232,7 +232,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
-    h->persist_rows = (c->dtype == CTTS_DTYPE_F32) ? 4 : 0;
+    h->persist_rows = 4;                                         // both dtypes since round 5 (fp16 engines: half weights + half K / V in the image, fp32 activations)
     h->pm_rows_max = 0;                                          // opt-in: ctts_gpt_set_option("mfma_rows", 5..32)
     h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)
@@ -287,8 +287,7 @@ static int ensure_persist(ctts_gpt* h, bool required) {
     CTTS_HIP_CHECK(hipGetDevice(&dev));
     CTTS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const char* why = nullptr;
-    if (h->cfg.dtype != CTTS_DTYPE_F32) why = "fp32 engines only";
-    else if (h->L > 31) why = "at most 31 decoder layers";
+    if (h->L > 31) why = "at most 31 decoder layers";
     else if (cus < PL_BLOCKS) why = "the device has fewer than 256 compute units";
     else if (!persist_device_lock(dev)) why = "another process already runs persistent launches on this device";
     if (why) {
@@ -307,9 +306,10 @@ static int ensure_persist(ctts_gpt* h, bool required) {
 // the weight images, on first need (called outside stream capture: allocates, launches on the null stream, synchronises)
 static int persist_images(ctts_gpt* h) {
     if (h->pimg != nullptr || !h->persist_ok) return 0;
-    if (dev_alloc((void**)&h->pimg, PL_LAYER_BYTES * h->L)) return 1;
+    const size_t layer_bytes = PL_LAYER_BYTES / 4 * h->esz;
+    if (dev_alloc((void**)&h->pimg, layer_bytes * h->L)) return 1;
     for (int l = 0; l < h->L; ++l)
-        if (launch_persist_repack(h->lw[l].qkv, h->lw[l].o, h->lw[l].gu, h->lw[l].d, h->pimg + PL_LAYER_BYTES * l, nullptr)) return 1;
+        if (launch_persist_repack(h->esz == 2, h->lw[l].qkv, h->lw[l].o, h->lw[l].gu, h->lw[l].d, h->pimg + layer_bytes * l, nullptr)) return 1;
     CTTS_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 }
@@ -924,14 +924,14 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // fp32: the RMSNorm factor then multiplies the C tile instead of the operand -- (sum w x) rs instead of sum w (x rs), one rounding
     // apart; token ids stay bit-exact on every golden (tests/test_gpu_gpt.py)
     const bool xhm = (st != nullptr) && h->xh_mode && !splitd;
-    if (st != nullptr && h->cur_persist && h->pimg != nullptr && dt == CTTS_DTYPE_F32 && R <= PL_MAXR && !lora) {
+    if (st != nullptr && h->cur_persist && h->pimg != nullptr && R <= PL_MAXR && !lora) {
         // one persistent launch per layer (persist_layer.hip): the residual stream stays in x, nothing is left in partial or packed form
         if (form) { form->parts = false; form->xh = false; }
         // (persistent_layers_per_launch, default all: the whole stack is ONE launch; 1 = a launch per layer, the first version of the structure)
         const int per = (h->persist_lpl > 0 && h->persist_lpl < h->L) ? h->persist_lpl : h->L;
         for (int l = 0; l < h->L; l += per) {
             PersistArgs pa = {};
-            pa.w = h->pimg + PL_LAYER_BYTES * l; pa.n_layers = (h->L - l < per) ? h->L - l : per;
+            pa.w = h->pimg + PL_LAYER_BYTES / 4 * h->esz * l; pa.half_w = h->esz == 2 ? 1 : 0; pa.n_layers = (h->L - l < per) ? h->L - l : per;
             pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
             pa.kv = kv_layer(h, l, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
             pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1; pa.g_x = pa.g_act + PL_G_ACT; pa.g_part = pa.g_x + PL_G_X; pa.S = h->cur_persist;
@@ -1214,7 +1214,7 @@ static int advance_rows(ctts_gpt* h, int n_steps) {
 // Returns the key splits per (row, head) (0 = launch chain): as many shares as keep every share within what a workgroup prefetches, at most 64 / (12 B) and
 // PL_SMAX; a context beyond twice that many prefetchable keys goes back to the launch chain (its attention spreads the keys over up to 96 workgroups).
 static inline int decode_persist(const ctts_gpt* h, int B, int L) {
-    if (!(h->persist_rows > 0 && h->pimg != nullptr && h->cfg.dtype == CTTS_DTYPE_F32 && B <= h->persist_rows && B <= PL_MAXR && !h->lora_rows)) return 0;
+    if (!(h->persist_rows > 0 && h->pimg != nullptr && B <= h->persist_rows && B <= PL_MAXR && !h->lora_rows)) return 0;
     int cap = PL_ATT_BLOCKS / (PL_NH * B);
     cap = cap > PL_SMAX ? PL_SMAX : (cap < 1 ? 1 : cap);
     if (h->persist_splits > 0) cap = h->persist_splits < cap ? h->persist_splits : cap;
@@ -1232,7 +1232,7 @@ static inline int decode_pm(const ctts_gpt* h, int B) {
 static inline int pick_decode_path(ctts_gpt* h, int longest) {
     h->cur_splits = decode_splits(h, h->B, longest);
     h->cur_pm = decode_pm(h, h->B);
-    if (!h->cur_pm && h->persist_ok && h->pimg == nullptr && h->persist_rows > 0 && h->B <= h->persist_rows && h->cfg.dtype == CTTS_DTYPE_F32 && !h->lora_rows && persist_images(h)) return 1;
+    if (!h->cur_pm && h->persist_ok && h->pimg == nullptr && h->persist_rows > 0 && h->B <= h->persist_rows && !h->lora_rows && persist_images(h)) return 1;
     h->cur_persist = h->cur_pm ? 0 : decode_persist(h, h->B, longest);
     return 0;
 }

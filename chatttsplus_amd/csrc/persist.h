@@ -29,7 +29,8 @@
 #define PL_G_TOTAL (PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT + PL_G_X + PL_G_PART)
 
 struct PersistArgs {
-    const char* w;                  // layer 0's image [192][PL_BLOCK_BYTES]; layer l at + l * PL_LAYER_BYTES
+    const char* w;                  // layer 0's image [192][PL_BLOCK_BYTES]; layer l at + l * PL_LAYER_BYTES (fp16 engines: half of both)
+    int half_w;                     // 1: fp16 engine -- half weights in the image, half K / V cache; activations and granules stay fp32
     int n_layers;                   // decoder layers run by this launch (<= 31: a granule tag is launch counter * 32 + layer)
     float* x;                       // residual stream [R][768], read at entry, rewritten at the end
     const RowMeta* meta;            // decode rows
@@ -59,5 +60,5 @@ struct PersistArgs {
 };
 
 int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s);
-int launch_persist_repack(const void* qkv, const void* o, const void* gu, const void* d, void* dst, hipStream_t s);
+int launch_persist_repack(int half_w, const void* qkv, const void* o, const void* gu, const void* d, void* dst, hipStream_t s);
 int persist_configure();

@@ -81,6 +81,26 @@ __device__ inline void watch_sentinels(const u64* base, OffFn off, int n, unsign
 __device__ inline float dot4(const f32x4 w, const f32x4 x, float acc) {
     return fmaf(w[3], x[3], fmaf(w[2], x[2], fmaf(w[1], x[1], fmaf(w[0], x[0], acc))));
 }
+// fp16 engines (round 5): the same per-workgroup image with half weights -- a lane's fragment is its 4 weights of a row as 8 bytes; activations, granules and
+// accumulation stay fp32 (no activation is rounded to fp16 on this path, unlike the launch chain's fp16 MFMA operands)
+__device__ inline float dot4(const half4 w, const f32x4 x, float acc) {
+    return fmaf((float)w[3], x[3], fmaf((float)w[2], x[2], fmaf((float)w[1], x[1], fmaf((float)w[0], x[0], acc))));
+}
+template <typename WT> struct PlW;
+template <> struct PlW<float> { typedef f32x4 frag; };
+template <> struct PlW<half_t> { typedef half4 frag; };
+// 8 dims of a cached K / V row as a lane holds them
+template <typename WT> struct PlKV;
+template <> struct PlKV<float> {
+    f32x4 a, b;
+    __device__ inline void load(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    __device__ inline float at(int j) const { return j < 4 ? a[j & 3] : b[j & 3]; }
+};
+template <> struct PlKV<half_t> {
+    half8 h;
+    __device__ inline void load(const half_t* p) { h = *(const half8*)p; }
+    __device__ inline float at(int j) const { return (float)h[j]; }
+};
 __device__ inline float pl_exp_diff(float m, float mn) { return (m == -INFINITY) ? 0.f : expf(m - mn); }
 
 // SCHED = when a compute wave requests its weight arrays (each array is needed one phase per layer: q|k|v rows in A, o_proj rows in C, gate|up in D, down in E):
@@ -89,8 +109,10 @@ __device__ inline float pl_exp_diff(float m, float mn) { return (m == -INFINITY)
 //      more than one wait ahead, so at most gate|up + down (18 of the 27 fragments) are live at once: 36 fewer VGPRs (the 2- to 4-row kernels spill under 1).
 // (Re-requesting every array right after its use, a whole layer ahead, put the gate|up burst in front of the act gather's polls and the down burst in
 //  front of the next layer's x gather: +6.7 us per layer, profiles/r04_persist_probe_v2_one_launch.jsonl.)
-template <int R, int SCHED>
+template <int R, int SCHED, typename WT>
 __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const PersistArgs a) {
+    typedef typename PlW<WT>::frag wfrag;
+    constexpr size_t BLOCK_BYTES = (size_t)PL_BLOCK_BYTES / 4 * sizeof(WT), LAYER_BYTES = PL_LAYER_BYTES / 4 * sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const xs = (float*)smem;                       // activations of the current phase [R][768] ([R][3072] for the down projection)
     float* const red = xs + R * PL_I;                     // compute waves' results [8 waves][4 slots][R]
@@ -111,7 +133,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
     if (tid == 0) { abort_s[0] = 0; abort_s[1] = 0; }
 
     if (b < PL_GEMV_BLOCKS) {
-        const char* wb = a.w + (size_t)b * PL_BLOCK_BYTES;
+        const char* wb = a.w + (size_t)b * BLOCK_BYTES;
         if (wave < 8) {
             // ------------------------------------------------ compute wave: weights in registers, products on the VALU.
             // The four weight arrays form a ring over the layers: each is re-requested for layer l + 1 right after its last use in layer l, so the
@@ -120,13 +142,13 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
             const size_t oo = (size_t)PL_QKV_BYTES / 16 + (size_t)wave * (3 * 64) + lane;                          // [j 3][lane]
             const size_t og = (size_t)(PL_QKV_BYTES + PL_O_BYTES) / 16 + (size_t)wave * (4 * 3 * 64) + lane;       // [pair 2][gate|up][j 3][lane]
             const size_t od = (size_t)(PL_QKV_BYTES + PL_O_BYTES + PL_GU_BYTES) / 16 + (size_t)wave * (6 * 64) + lane;   // [j 6][lane]
-            f32x4 q_w[2][3], o_w[3], g_w[4][3], d_w[6];
+            wfrag q_w[2][3], o_w[3], g_w[4][3], d_w[6];
 #define PL_LOAD_Q(base_) do { if (wave < 6) { _Pragma("unroll") for (int row = 0; row < 2; ++row) _Pragma("unroll") for (int j = 0; j < 3; ++j) \
-                q_w[row][j] = __builtin_nontemporal_load((const f32x4*)(base_) + oq + (row * 3 + j) * 64); } } while (0)
-#define PL_LOAD_O(base_) do { if (wave < 4) { _Pragma("unroll") for (int j = 0; j < 3; ++j) o_w[j] = __builtin_nontemporal_load((const f32x4*)(base_) + oo + j * 64); } } while (0)
+                q_w[row][j] = __builtin_nontemporal_load((const wfrag*)(base_) + oq + (row * 3 + j) * 64); } } while (0)
+#define PL_LOAD_O(base_) do { if (wave < 4) { _Pragma("unroll") for (int j = 0; j < 3; ++j) o_w[j] = __builtin_nontemporal_load((const wfrag*)(base_) + oo + j * 64); } } while (0)
 #define PL_LOAD_G(base_) do { _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int j = 0; j < 3; ++j) \
-                g_w[s][j] = __builtin_nontemporal_load((const f32x4*)(base_) + og + (s * 3 + j) * 64); } while (0)
-#define PL_LOAD_D(base_) do { _Pragma("unroll") for (int j = 0; j < 6; ++j) d_w[j] = __builtin_nontemporal_load((const f32x4*)(base_) + od + j * 64); } while (0)
+                g_w[s][j] = __builtin_nontemporal_load((const wfrag*)(base_) + og + (s * 3 + j) * 64); } while (0)
+#define PL_LOAD_D(base_) do { _Pragma("unroll") for (int j = 0; j < 6; ++j) d_w[j] = __builtin_nontemporal_load((const wfrag*)(base_) + od + j * 64); } while (0)
             PL_LOAD_Q(wb);
             if (SCHED == 1) PL_LOAD_O(wb);
             __builtin_amdgcn_sched_barrier(0);
@@ -146,7 +168,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
 #define PL_PIECE(stmt_) do { stmt_; if (!ready_) { for (int z_ = 0; z_ < pace; ++z_) __builtin_amdgcn_s_sleep(2); ready_ = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= tgt_; } } while (0)
 #define PL_PACE_END() do { while (!ready_) { __builtin_amdgcn_s_sleep(1); ready_ = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= tgt_; } asm volatile("" ::: "memory"); } while (0)
                 for (int l = 0; l < NL; ++l) {
-                    const char* const wn = wb + PL_LAYER_BYTES;
+                    const char* const wn = wb + LAYER_BYTES;
                     const bool more = l + 1 < NL;
                     f32x4 xr[R][3];
                     // ---- wait for x, requesting o_proj(l); phase A
@@ -154,7 +176,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                         PL_PACE_BEGIN();
                         if (wave < 4) {
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) PL_PIECE(o_w[j] = __builtin_nontemporal_load((const f32x4*)wb + oo + j * 64));
+                            for (int j = 0; j < 3; ++j) PL_PIECE(o_w[j] = __builtin_nontemporal_load((const wfrag*)wb + oo + j * 64));
                         }
                         PL_PACE_END();
                     }
@@ -181,7 +203,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) PL_PIECE(g_w[s][j] = __builtin_nontemporal_load((const f32x4*)wb + og + (s * 3 + j) * 64));
+                            for (int j = 0; j < 3; ++j) PL_PIECE(g_w[s][j] = __builtin_nontemporal_load((const wfrag*)wb + og + (s * 3 + j) * 64));
                         PL_PACE_END();
                     }
 #pragma unroll
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     {
                         PL_PACE_BEGIN();
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) PL_PIECE(d_w[j] = __builtin_nontemporal_load((const f32x4*)wb + od + j * 64));
+                        for (int j = 0; j < 6; ++j) PL_PIECE(d_w[j] = __builtin_nontemporal_load((const wfrag*)wb + od + j * 64));
                         PL_PACE_END();
                     }
 #pragma unroll
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
 #pragma unroll
                             for (int row = 0; row < 2; ++row)
 #pragma unroll
-                                for (int j = 0; j < 3; ++j) PL_PIECE(q_w[row][j] = __builtin_nontemporal_load((const f32x4*)wn + oq + (row * 3 + j) * 64));
+                                for (int j = 0; j < 3; ++j) PL_PIECE(q_w[row][j] = __builtin_nontemporal_load((const wfrag*)wn + oq + (row * 3 + j) * 64));
                         }
                         PL_PACE_END();
                     }
@@ -247,12 +269,12 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 return;
             }
             for (int l = 0; l < NL; ++l) {
-                const char* const wn = wb + PL_LAYER_BYTES;   // next layer's image
+                const char* const wn = wb + LAYER_BYTES;      // next layer's image
                 const bool more = l + 1 < NL;
                 if (SCHED == 2) {
                     // these three are requested and used inside one layer: say so (the conditional requests otherwise make them loop-carried and all 27
                     // fragments stay allocated through the whole loop)
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const wfrag z = {};
 #pragma unroll
                     for (int j = 0; j < 3; ++j) o_w[j] = z;
 #pragma unroll
@@ -436,8 +458,8 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     store_granule(gq + dA, tag, ya);
                     store_granule(gq + dB, tag, yb);
                     if (which >= 1) {                            // KV append (llama.py:633): later steps read it from the cache
-                        float* c = (float*)a.kv + (size_t)l * 2 * kv_per + (which == 2 ? kv_per : 0) + (((size_t)mA.seq * PL_NH + hh) * a.Lmax + mA.slot) * CTTS_HEAD_DIM;
-                        c[dA] = ya; c[dB] = yb;
+                        WT* c = (WT*)a.kv + (size_t)l * 2 * kv_per + (which == 2 ? kv_per : 0) + (((size_t)mA.seq * PL_NH + hh) * a.Lmax + mA.slot) * CTTS_HEAD_DIM;
+                        c[dA] = (WT)ya; c[dB] = (WT)yb;              // (fp16 engines: plain conversion, like the launch chain's K / V stores)
                     }
                 }
                 if (last) PL_MARK(3);
@@ -550,7 +572,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
         const int grp = lane >> 3, sub = lane & 7;
         const size_t head_off = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
         constexpr int PRE = 6;                                // iterations requested before the query exists: 8 waves x 8 keys x 6 = 384 keys
-        f32x4 kf[PRE][2], vf[PRE][2];
+        PlKV<WT> kf[PRE], vf[PRE];
         bool ok[PRE];
         bool any_ok[PRE];
 #pragma unroll
@@ -559,17 +581,16 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
             ok[u] = p < kv1;
             any_ok[u] = kv0 + 8 * (wave + 8 * u) < kv1;       // wave-uniform: some lane group of this wave has a key in iteration u
         }
-#define PL_LOAD_KV(l_) do { const float* const kb_ = (const float*)a.kv + (size_t)(l_) * 2 * kv_per + head_off; const float* const vb_ = kb_ + kv_per; \
+#define PL_LOAD_KV(l_) do { const WT* const kb_ = (const WT*)a.kv + (size_t)(l_) * 2 * kv_per + head_off; const WT* const vb_ = kb_ + kv_per; \
         _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p_ = kv0 + 8 * (wave + 8 * u) + grp; const int pc_ = ok[u] ? p_ : m.kv_start; \
-            kf[u][0] = *(const f32x4*)(kb_ + (size_t)pc_ * CTTS_HEAD_DIM); kf[u][1] = *(const f32x4*)(kb_ + (size_t)pc_ * CTTS_HEAD_DIM + 4); \
-            vf[u][0] = *(const f32x4*)(vb_ + (size_t)pc_ * CTTS_HEAD_DIM); vf[u][1] = *(const f32x4*)(vb_ + (size_t)pc_ * CTTS_HEAD_DIM + 4); } } while (0)
+            kf[u].load(kb_ + (size_t)pc_ * CTTS_HEAD_DIM); vf[u].load(vb_ + (size_t)pc_ * CTTS_HEAD_DIM); } } while (0)
         PL_LOAD_KV(0);
         __builtin_amdgcn_sched_barrier(0);
         if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
         __syncthreads();                                      // S0
         for (int l = 0; l < NL; ++l) {
-            const float* const kb = (const float*)a.kv + (size_t)l * 2 * kv_per + head_off;
-            const float* const vb = kb + kv_per;
+            const WT* const kb = (const WT*)a.kv + (size_t)l * 2 * kv_per + head_off;
+            const WT* const vb = kb + kv_per;
             __syncthreads();                                  // B1: q (x 1/8), k_new, v_new in LDS
             const f32x4 q0 = *(const f32x4*)(qs + 8 * sub), q1 = *(const f32x4*)(qs + 8 * sub + 4);
             // two passes over the keys held in registers: scores -> the wave's maximum -> ONE exponential per key (no running rescale)
@@ -579,8 +600,8 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
             for (int u = 0; u < PRE; ++u) {
                 sc[u] = -INFINITY;
                 if (any_ok[u]) {
-                    float dot = q0[0] * kf[u][0][0] + q0[1] * kf[u][0][1] + q0[2] * kf[u][0][2] + q0[3] * kf[u][0][3] +
-                                q1[0] * kf[u][1][0] + q1[1] * kf[u][1][1] + q1[2] * kf[u][1][2] + q1[3] * kf[u][1][3];
+                    float dot = q0[0] * kf[u].at(0) + q0[1] * kf[u].at(1) + q0[2] * kf[u].at(2) + q0[3] * kf[u].at(3) +
+                                q1[0] * kf[u].at(4) + q1[1] * kf[u].at(5) + q1[2] * kf[u].at(6) + q1[3] * kf[u].at(7);
                     dot += dpp_f<DPP_XOR1>(dot);
                     dot += dpp_f<DPP_XOR2>(dot);
                     dot += dpp_f<DPP_HALF_MIRROR>(dot);
@@ -597,17 +618,17 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 if (any_ok[u]) {
                     const float pe = (sc[u] == -INFINITY) ? 0.f : expf(sc[u] - mrun);
                     lrun += pe;
-                    o[0] += pe * vf[u][0][0]; o[1] += pe * vf[u][0][1]; o[2] += pe * vf[u][0][2]; o[3] += pe * vf[u][0][3];
-                    o[4] += pe * vf[u][1][0]; o[5] += pe * vf[u][1][1]; o[6] += pe * vf[u][1][2]; o[7] += pe * vf[u][1][3];
+                    o[0] += pe * vf[u].at(0); o[1] += pe * vf[u].at(1); o[2] += pe * vf[u].at(2); o[3] += pe * vf[u].at(3);
+                    o[4] += pe * vf[u].at(4); o[5] += pe * vf[u].at(5); o[6] += pe * vf[u].at(6); o[7] += pe * vf[u].at(7);
                 }
             }
             for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64) {       // contexts beyond 256 keys: the rest streams behind the query (wave-uniform bound)
                 const int p = wb0 + grp;
                 const bool live = p < kv1;
                 const int pc = live ? p : m.kv_start;
-                const f32x4 k0 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM), k1 = *(const f32x4*)(kb + (size_t)pc * CTTS_HEAD_DIM + 4);
-                const f32x4 v0 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM), v1 = *(const f32x4*)(vb + (size_t)pc * CTTS_HEAD_DIM + 4);
-                float dot = q0[0] * k0[0] + q0[1] * k0[1] + q0[2] * k0[2] + q0[3] * k0[3] + q1[0] * k1[0] + q1[1] * k1[1] + q1[2] * k1[2] + q1[3] * k1[3];
+                PlKV<WT> ks_, vs_;
+                ks_.load(kb + (size_t)pc * CTTS_HEAD_DIM); vs_.load(vb + (size_t)pc * CTTS_HEAD_DIM);
+                float dot = q0[0] * ks_.at(0) + q0[1] * ks_.at(1) + q0[2] * ks_.at(2) + q0[3] * ks_.at(3) + q1[0] * ks_.at(4) + q1[1] * ks_.at(5) + q1[2] * ks_.at(6) + q1[3] * ks_.at(7);
                 dot += dpp_f<DPP_XOR1>(dot);
                 dot += dpp_f<DPP_XOR2>(dot);
                 dot += dpp_f<DPP_HALF_MIRROR>(dot);
@@ -615,8 +636,8 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 const float scl = pl_exp_diff(mrun, mn);
                 const float pe = live ? expf(dot - mn) : 0.f;
                 lrun = lrun * scl + pe;
-                o[0] = o[0] * scl + pe * v0[0]; o[1] = o[1] * scl + pe * v0[1]; o[2] = o[2] * scl + pe * v0[2]; o[3] = o[3] * scl + pe * v0[3];
-                o[4] = o[4] * scl + pe * v1[0]; o[5] = o[5] * scl + pe * v1[1]; o[6] = o[6] * scl + pe * v1[2]; o[7] = o[7] * scl + pe * v1[3];
+                o[0] = o[0] * scl + pe * vs_.at(0); o[1] = o[1] * scl + pe * vs_.at(1); o[2] = o[2] * scl + pe * vs_.at(2); o[3] = o[3] * scl + pe * vs_.at(3);
+                o[4] = o[4] * scl + pe * vs_.at(4); o[5] = o[5] * scl + pe * vs_.at(5); o[6] = o[6] * scl + pe * vs_.at(6); o[7] = o[7] * scl + pe * vs_.at(7);
                 mrun = mn;
             }
             // the 8 key groups of the wave share mrun: plain sums over the lanes with equal `sub`
@@ -726,13 +747,16 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
     }
 }
 
-// ---- packed MFMA-A tile images (gpt_engine.hip pack_tiles: [row tile][k tile][lane][4 floats]) -> the per-workgroup register images above
-__global__ __launch_bounds__(256) void persist_repack_kernel(const f32x4* qkv, const f32x4* o, const f32x4* gu, const f32x4* d, f32x4* dst) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;               // destination float4 of this layer: [192 workgroups][12288]
+// ---- packed MFMA-A tile images (gpt_engine.hip pack_tiles: [row tile][k tile][lane][16 B]) -> the per-workgroup register images above.  A destination
+// fragment = 4 consecutive k of one weight row (16 bytes fp32, 8 bytes fp16); in the fp16 tile image a lane's 16 bytes hold 8 consecutive k of a 32-wide k-tile
+template <typename WT>
+__global__ __launch_bounds__(256) void persist_repack_kernel(const typename PlW<WT>::frag* qkv, const typename PlW<WT>::frag* o, const typename PlW<WT>::frag* gu,
+                                                             const typename PlW<WT>::frag* d, typename PlW<WT>::frag* dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;               // destination fragment of this layer: [192 workgroups][12288]
     if (idx >= PL_GEMV_BLOCKS * (PL_BLOCK_BYTES / 16)) return;
     const int g = idx / (PL_BLOCK_BYTES / 16), oo = idx % (PL_BLOCK_BYTES / 16);
-    const f32x4* src;
-    int row_tile, i, k4, ktiles;
+    const typename PlW<WT>::frag* src;
+    int row_tile, i, k4, ktiles;                                   // k4 = index of the 4-wide k group; ktiles = 16-wide k-tiles of the matrix
     if (oo < PL_QKV_BYTES / 16) {
         const int pw = oo / 384, rem = oo % 384, row = rem / 192, j = (rem % 192) / 64, ln = rem % 64;
         const int hh = g >> 4, jj = g & 15;
@@ -756,35 +780,37 @@ __global__ __launch_bounds__(256) void persist_repack_kernel(const f32x4* qkv, c
         const int row = 4 * g + (w >> 1);
         row_tile = row >> 4; i = row & 15; k4 = 384 * (w & 1) + 64 * j + ln; ktiles = 192; src = d;
     }
-    dst[idx] = src[((size_t)row_tile * ktiles + (k4 >> 2)) * 64 + i + 16 * (k4 & 3)];
+    if constexpr (sizeof(WT) == 4) dst[idx] = src[((size_t)row_tile * ktiles + (k4 >> 2)) * 64 + i + 16 * (k4 & 3)];
+    else dst[idx] = src[(((size_t)row_tile * (ktiles / 2) + (k4 >> 3)) * 64 + i + 16 * ((k4 >> 1) & 3)) * 2 + (k4 & 1)];      // 32-wide k-tiles, 8 halfs per lane: two 4-groups each
 }
 
-int launch_persist_repack(const void* qkv, const void* o, const void* gu, const void* d, void* dst, hipStream_t s) {
+int launch_persist_repack(int half_w, const void* qkv, const void* o, const void* gu, const void* d, void* dst, hipStream_t s) {
     const int n = PL_GEMV_BLOCKS * (PL_BLOCK_BYTES / 16);
-    hipLaunchKernelGGL(persist_repack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const f32x4*)qkv, (const f32x4*)o, (const f32x4*)gu, (const f32x4*)d, (f32x4*)dst);
+    if (half_w) hipLaunchKernelGGL(persist_repack_kernel<half_t>, dim3((n + 255) / 256), dim3(256), 0, s, (const half4*)qkv, (const half4*)o, (const half4*)gu, (const half4*)d, (half4*)dst);
+    else hipLaunchKernelGGL(persist_repack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, (const f32x4*)qkv, (const f32x4*)o, (const f32x4*)gu, (const f32x4*)d, (f32x4*)dst);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + 8 * 4 * R + 2 * R + 4 * R) * 4 + 16 + (192 + 8 * 8 * 10) * 4; }
 
-template <int R, int SCHED>
+template <int R, int SCHED, typename WT>
 static int persist_launch_t(const PersistArgs& a, hipStream_t s, bool configure_only) {
-    auto kern = persist_layer_kernel<R, SCHED>;
+    auto kern = persist_layer_kernel<R, SCHED, WT>;
     if (configure_only) { CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(R))); return 0; }
     hipLaunchKernelGGL(kern, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(R), s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
-template <int SCHED>
+template <int SCHED, typename WT>
 static int persist_launch_r(int R, const PersistArgs& a, hipStream_t s, bool cfg) {
     // exact row counts: a spare row would append stale K / V rows to a live cache lane
-    if (cfg) return persist_launch_t<1, SCHED>(a, s, true) | persist_launch_t<2, SCHED>(a, s, true) | persist_launch_t<3, SCHED>(a, s, true) | persist_launch_t<4, SCHED>(a, s, true);
+    if (cfg) return persist_launch_t<1, SCHED, WT>(a, s, true) | persist_launch_t<2, SCHED, WT>(a, s, true) | persist_launch_t<3, SCHED, WT>(a, s, true) | persist_launch_t<4, SCHED, WT>(a, s, true);
     switch (R) {
-        case 1: return persist_launch_t<1, SCHED>(a, s, false);
-        case 2: return persist_launch_t<2, SCHED>(a, s, false);
-        case 3: return persist_launch_t<3, SCHED>(a, s, false);
-        case 4: return persist_launch_t<4, SCHED>(a, s, false);
+        case 1: return persist_launch_t<1, SCHED, WT>(a, s, false);
+        case 2: return persist_launch_t<2, SCHED, WT>(a, s, false);
+        case 3: return persist_launch_t<3, SCHED, WT>(a, s, false);
+        case 4: return persist_launch_t<4, SCHED, WT>(a, s, false);
     }
     ctts_set_error("persistent layer: %d rows (max %d)", R, PL_MAXR);
     return 1;
@@ -792,9 +818,11 @@ static int persist_launch_r(int R, const PersistArgs& a, hipStream_t s, bool cfg
 
 int persist_configure() {
     PersistArgs a = {};
-    return persist_launch_r<1>(1, a, nullptr, true) | persist_launch_r<2>(1, a, nullptr, true) | persist_launch_r<3>(1, a, nullptr, true);
+    return persist_launch_r<1, float>(1, a, nullptr, true) | persist_launch_r<2, float>(1, a, nullptr, true) | persist_launch_r<3, float>(1, a, nullptr, true) |
+           persist_launch_r<3, half_t>(1, a, nullptr, true);
 }
 
 int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s) {
-    return (a.sched == 1) ? persist_launch_r<1>(R, a, s, false) : (a.sched == 2) ? persist_launch_r<2>(R, a, s, false) : persist_launch_r<3>(R, a, s, false);
+    if (a.half_w) return persist_launch_r<3, half_t>(R, a, s, false);          // fp16 engines: the paced schedule only
+    return (a.sched == 1) ? persist_launch_r<1, float>(R, a, s, false) : (a.sched == 2) ? persist_launch_r<2, float>(R, a, s, false) : persist_launch_r<3, float>(R, a, s, false);
 }
