@@ -202,3 +202,35 @@ def test_persistent_weight_images_are_built_on_first_need(gpt):
         assert torch.equal(ids_a[0], ref_ids[0])
     finally:
         g.close()
+
+
+def test_fp16_engines_use_the_persistent_launch_too():
+    """Round 5: the fast mode had stayed on the launch chain, so at batch 1 it was SLOWER than the parity mode (0.373 vs 0.284 ms/step).  The persistent
+    launch now also takes a half-precision weight image and a half K / V cache (activations, granules and accumulation stay fp32): default for <= 3 rows of an fp16
+    engine.  Against the fp16 launch chain (which rounds the MFMA operands to fp16): the same first tokens, hidden states within the fast mode's tolerance while the
+    tokens agree; replays bitwise identical, hipGraph == eager."""
+    from chatttsplus_amd.hip_models import GPT
+    g = GPT(LLAMA, max_batch=4, max_seq_len=300, weight_dtype="fp16")
+    try:
+        g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+        assert g.get_option("persistent_rows") == 3
+        for B in (1, 3):
+            g.set_option("persistent_rows", 0)
+            c_ids, c_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
+            g.set_option("persistent_rows", 3)
+            p_ids, p_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
+            q_ids, q_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
+            g.use_graph = False
+            try:
+                e_ids, e_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
+            finally:
+                g.use_graph = True
+            for b in range(B):
+                assert torch.equal(p_ids[b], q_ids[b]) and torch.equal(p_h[b], q_h[b]), "two replays differ"
+                assert torch.equal(p_ids[b], e_ids[b]) and torch.equal(p_h[b], e_h[b]), "hipGraph replay != eager launches"
+                same = int((p_ids[b] == c_ids[b]).all(-1).to(torch.int32).cumprod(0).sum())
+                assert same >= 3, f"B={B} row {b}: only {same} leading tokens agree with the fp16 launch chain"
+                rel = float((p_h[b][:same] - c_h[b][:same]).pow(2).mean().sqrt() / c_h[b][:same].pow(2).mean().sqrt())
+                assert rel <= 2e-3, f"B={B} row {b}: hidden states {rel} away from the fp16 launch chain over the {same} agreeing steps"
+    finally:
+        g.close()

@@ -30,7 +30,7 @@ def gen(g, B, P, N, forced=None):
     return res.ids, res.hiddens
 
 
-for B in (1, 2, 4):
+for B in (1, 2, 3, 4):
     r_ids, r_h = gen(g32, B, 40, 48)
     out = {"B": B}
     for name, rows in (("fp16_launch_chain", 0), ("fp16_persistent", 4)):
@@ -42,7 +42,7 @@ for B in (1, 2, 4):
     print(json.dumps(out), flush=True)
 spk = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
 leg = bench.Leg(g16, dev, 0, 1)
-for B in (1, 2, 4):
+for B in (1, 2, 3, 4):
     out = {"B": B}
     for name, rows in (("fp16_launch_chain", 0), ("fp16_persistent", 4)):
         g16.set_option("persistent_rows", rows)
