@@ -918,7 +918,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     const bool pfg = prepack && (dt == CTTS_DTYPE_F16) && h->prefill_gemm_rows > 0 && (R >= h->prefill_gemm_rows) && !lora;
     // prompt pass over >= 384 rows, fp32 engine: the same tiling on the fp16 pipes with head / tail operands -- 3 MFMAs per product instead of 16,
     // fp32-level accuracy (prefill_split.hip); the attention stays the fp32 row kernel
-    const bool pfs = prepack && (dt == CTTS_DTYPE_F32) && h->wsplit != nullptr && h->split_rows_min > 0 && (R >= h->split_rows_min) && !lora;
+    // (round 5: also with per-utterance adapters -- their low-rank terms come from the two lora.hip launches per layer and are added in the split GEMMs' epilogues)
+    const bool pfs = prepack && (dt == CTTS_DTYPE_F32) && h->wsplit != nullptr && h->split_rows_min > 0 && (R >= h->split_rows_min);
     const float sp_scale = 1.0f / 64.0f;
     // decode above the split-K batch sizes: the residual stream travels between kernels as a packed B operand in the engine dtype + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself.  (Handing gate|up
@@ -1009,8 +1010,11 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         if (lora && S != 1) { ctts_set_error("per-utterance LoRA needs unsplit attention"); return 1; }
         if (lfold) { g2.lf = g1.lf; g2.lora_w = NB; }
         else if (lora) {
-            if (launch_lora_delta_o(dt, h->attn_packed, nbg, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
-                                    h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_do, R, h->H, s)) return 1;
+            if (pfs && S == 1) {
+                if (launch_lora_delta_o_split(h->sp_x_hi, h->sp_x_lo, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
+                                              h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_do, R, h->H, s)) return 1;
+            } else if (launch_lora_delta_o(dt, h->attn_packed, nbg, meta, h->lora_slot_of_seq, h->lora_A + lora_l, h->lora_B + lora_l,
+                                           h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4, h->lora_do, R, h->H, s)) return 1;
             g2.lora_delta = h->lora_do;
         }
         if (pfs && S == 1) {

@@ -158,6 +158,8 @@ int launch_lora_delta_qkv(const float* x, const float* lnw, float eps, const Row
                           const float* scale_l, float* delta, int rows, int H, hipStream_t s);
 int launch_lora_delta_o(int dtype, const void* attn_packed, int nbg, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
                         const float* scale_l, float* delta, int rows, int H, hipStream_t s);
+int launch_lora_delta_o_split(const void* hi, const void* lo, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
+                              const float* scale_l, float* delta, int rows, int H, hipStream_t s);
 int launch_prefill_gemm(int epi, const GemmArgs& a, hipStream_t s);      // prefill_gemm.hip: fp16 prompt-pass GEMM (QKV / RESID / SWIGLU epilogues)
 int launch_norm_pack_split(const float* x, void* hi, void* lo, int R, float eps, hipStream_t s);                    // prefill_split.hip (fp32 engine, >= 1536 prompt rows)
 int launch_split_pack(const float* src, void* hi, void* lo, int R, hipStream_t s);

@@ -108,6 +108,33 @@ __global__ __launch_bounds__(256) void lora_delta_o_kernel(const void* attn_pack
     lora_low_rank(o, A_l + off, B_l + off, scale_l[slot * 4 + 3], drow, H, u, tid);
 }
 
+// the same for the parity engine's split prompt pass (prefill_split.hip): the attention output rows exist as head / tail fp16 images [16-row group][24 k-tiles][lane][16 B]
+__global__ __launch_bounds__(256) void lora_delta_o_split_kernel(const half_t* hi, const half_t* lo, const RowMeta* meta, const int* slot_of_seq, const float* A_l,
+                                                               const float* B_l, const float* scale_l, float* delta, int H) {
+    __shared__ float o[768];
+    __shared__ float u[LORA_RMAX];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int slot = slot_of_seq[meta[r].seq];
+    float* drow = delta + (size_t)r * H;
+    if (slot < 0) {
+        for (int i = tid; i < H; i += 256) drow[i] = 0.f;
+        return;
+    }
+    const size_t base = (size_t)(r >> 4) * 24 * 64 * 8;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int c = tid + 256 * i; const size_t q = base + xfrag_index<half_t>(r & 15, c, 24); o[c] = (float)hi[q] + (float)lo[q]; }
+    __syncthreads();
+    const size_t off = ((size_t)slot * 4 + 3) * LORA_RMAX * H;
+    lora_low_rank(o, A_l + off, B_l + off, scale_l[slot * 4 + 3], drow, H, u, tid);
+}
+int launch_lora_delta_o_split(const void* hi, const void* lo, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
+                              const float* scale_l, float* delta, int rows, int H, hipStream_t s) {
+    if (H != 768) { ctts_set_error("lora: hidden %d != 768", H); return 1; }
+    hipLaunchKernelGGL(lora_delta_o_split_kernel, dim3(rows), dim3(256), 0, s, (const half_t*)hi, (const half_t*)lo, meta, slot_of_seq, A_l, B_l, scale_l, delta, H);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_lora_delta_qkv(const float* x, const float* lnw, float eps, const RowMeta* meta, const int* slot_of_seq, const float* A_l, const float* B_l,
                           const float* scale_l, float* delta, int rows, int H, hipStream_t s) {
     if (H != 768) { ctts_set_error("lora: hidden %d != 768", H); return 1; }

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
                 if (!rv) continue;
                 float* xo = a.x_out + (size_t)row * N + (rt0 + t) * 16 + 4 * iq;
                 const f32x4 x = *(const f32x4*)xo, c = acc[t][g];
-                *(f32x4*)xo = (f32x4){x[0] + c[0] * sc, x[1] + c[1] * sc, x[2] + c[2] * sc, x[3] + c[3] * sc};      // residual + proj (llama.py:731,739)
+                f32x4 dl = {0.f, 0.f, 0.f, 0.f};             // per-utterance LoRA term of o_proj (lora.hip): part of the projection
+                if (a.lora_delta != nullptr) dl = *(const f32x4*)(a.lora_delta + (size_t)row * N + (rt0 + t) * 16 + 4 * iq);
+                *(f32x4*)xo = (f32x4){x[0] + (c[0] * sc + dl[0]), x[1] + (c[1] * sc + dl[1]), x[2] + (c[2] * sc + dl[2]), x[3] + (c[3] * sc + dl[3])};      // residual + proj (llama.py:731,739)
             }
         } else if (EPI == EPI_SWIGLU) {
             // tile rows [8 gate | 8 up]: lanes iq 0,1 hold gate rows 4 iq + j, lanes iq 2,3 the matching up rows
@@ -214,11 +216,16 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
                 if (!rv) continue;
                 const int d0 = t * 8 + 4 * (iq & 1);         // first of this lane's 4 frequency indices
                 f32x4 y;
+                f32x4 la = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};      // per-utterance LoRA terms of dims d0.. and d0 + 32.. (lora.hip): before RoPE
+                if (a.lora_delta != nullptr) {
+                    const float* dlp = a.lora_delta + ((size_t)row * 3 + which) * H + hh * CTTS_HEAD_DIM + d0;
+                    la = *(const f32x4*)dlp; lb = *(const f32x4*)(dlp + 32);
+                }
                 if (which < 2) {
                     const f32x4 cs = *(const f32x4*)(a.rope_rows + (size_t)row * 64 + d0), sn = *(const f32x4*)(a.rope_rows + (size_t)row * 64 + 32 + d0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float va = (lowh ? c[j] : o[j]) * sc, vb = (lowh ? o[j] : c[j]) * sc;
+                        const float va = (lowh ? c[j] : o[j]) * sc + la[j], vb = (lowh ? o[j] : c[j]) * sc + lb[j];
                         // q*cos + rotate_half(q)*sin (llama.py:180-181), products rounded separately like the reference
                         const float ya = __fadd_rn(__fmul_rn(va, cs[j]), __fmul_rn(-vb, sn[j]));
                         const float yb = __fadd_rn(__fmul_rn(vb, cs[j]), __fmul_rn(va, sn[j]));
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = c[j] * sc;
+                    for (int j = 0; j < 4; ++j) y[j] = c[j] * sc + (lowh ? la[j] : lb[j]);
                 }
                 const int dd = d0 + (lowh ? 0 : 32);
                 if (which == 0) *(f32x4*)(a.q_out + ((size_t)row * NH + hh) * CTTS_HEAD_DIM + dd) = y;
