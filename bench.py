@@ -174,13 +174,14 @@ def sharded_request_leg(pipe, dev, rank, world, n_utt=256, rows=32, reps=2, max_
         walls.append(wall)
         if best is None or wall < best["wall_s"]:
             tok = per[:, 0].cpu().tolist()
-            best = dict(wall_s=wall, per_rank_useful_tokens=[int(x) for x in tok], per_rank_busy_s=[round(x, 4) for x in per[:, 1].cpu().tolist()],
+            best = dict(first_audio_ms=getattr(pipe, "last_first_audio_ms", None), wall_s=wall, per_rank_useful_tokens=[int(x) for x in tok], per_rank_busy_s=[round(x, 4) for x in per[:, 1].cpu().tolist()],
                         ids_digest=_digest(chk.cpu().numpy()))
     total = float(sum(limits))
     audio_s = sum(256 * (2 * n - 1) for n in limits) / 24000.0
     tok = best["per_rank_useful_tokens"]
     return {"utterances": n_utt, "decode_rows_per_gpu": rows, "prompt_lengths": "U{16..96} tokens", "target_lengths": "U{128..512} tokens", "speakers": 4,
             "path": "ChatTTSPlusPipeline.infer_sharded(continuous=True): partition + speaker/seed broadcast + GPT (continuous batching) + DVAE decoder + Vocos + length all-reduce",
+            "first_vocoder_batch_done_ms_rank0": (round(best["first_audio_ms"], 1) if best.get("first_audio_ms") is not None else None),
             "wall_ms": round(best["wall_s"] * 1e3, 2), "wall_ms_reps": [round(w * 1e3, 2) for w in walls], "useful_tokens": int(total), "useful_tokens_per_s": round(total / best["wall_s"], 1),
             "audio_seconds": round(audio_s, 2), "rtf_audio_s_per_wall_s": round(audio_s / best["wall_s"], 2),
             "per_rank_useful_tokens": tok, "per_rank_busy_s": best["per_rank_busy_s"],

@@ -529,12 +529,44 @@ class ChatTTSPlusPipeline:
                 return
             ready, next_i, first = {}, 0, True
             ids_sink = kwargs.get("_ids_sink")
+            # continuous="throughput" (round 5): the vocoder does not wait for the last utterance.  Finished utterances are vocoded in batches of `vocoder_chunk`
+            # on a SIDE stream while the decode rows keep stepping on the caller's stream (the launch chain leaves most of the chip idle; a <= 4-row tail's
+            # persistent launch simply waits the few tens of microseconds a vocoder kernel holds its CUs).  One list at the end, in input order, as before.
+            overlap = (not ordered) and self.device.type == "cuda" and bool(kwargs.get("overlap_vocoder", True))
+            voc_chunk = int(kwargs.get("vocoder_chunk", 32))
+            side = torch.cuda.Stream(device=self.device) if overlap else None
+            t_req = torch.cuda.Event(enable_timing=True) if overlap else None
+            t_first = None
+            if overlap:
+                t_req.record(torch.cuda.current_stream(self.device))
+            done_wavs, pending = {}, []
+
+            def vocode(batch_idx):
+                nonlocal t_first
+                items = [ready.pop(i) for i in batch_idx]
+                go = torch.cuda.Event()
+                go.record(torch.cuda.current_stream(self.device))      # every token of these utterances was written before this point of the caller's stream
+                side.wait_event(go)
+                with torch.cuda.stream(side):
+                    for it in items:
+                        it.record_stream(side)                           # (views of the generate call's buffers: keep the allocator off them until the side stream is done)
+                    wavs = self._decode_to_wavs(items, use_decoder)
+                    if t_first is None:
+                        t_first = torch.cuda.Event(enable_timing=True)
+                        t_first.record(side)
+                for i, w in zip(batch_idx, wavs):
+                    done_wavs[i] = w
+
             for ev in events:
                 for k, ids_k, hid_k in ev:
                     ready[order[k]] = hid_k if use_decoder else ids_k
                     if ids_sink is not None:
                         ids_sink.append((utt_ids[order[k]], ids_k))
+                    pending.append(order[k])
                 if not ordered:
+                    while overlap and len(pending) >= voc_chunk:
+                        vocode(pending[:voc_chunk])
+                        pending = pending[voc_chunk:]
                     continue
                 run = 0
                 while next_i + run in ready:
@@ -543,7 +575,17 @@ class ChatTTSPlusPipeline:
                     yield self._decode_to_wavs([ready.pop(next_i + j) for j in range(run)], use_decoder)
                     next_i += run
                     first = False
-            rest = [i for i in range(next_i, n_all) if i in ready]      # (everything, in throughput mode; nothing unless the run was interrupted, otherwise)
+            if overlap:
+                if pending:
+                    vocode(pending)
+                torch.cuda.current_stream(self.device).wait_stream(side)      # the caller's stream sees the finished waveforms
+                side.synchronize()
+                self.last_first_audio_ms = t_req.elapsed_time(t_first) if t_first is not None else None
+                rest = sorted(done_wavs)
+                if rest:
+                    yield [done_wavs[i] for i in rest]
+                return
+            rest = [i for i in range(next_i, n_all) if i in ready]      # (everything, in throughput mode without overlap; nothing unless the run was interrupted, otherwise)
             if rest:
                 yield self._decode_to_wavs([ready[i] for i in rest], use_decoder)
             return
