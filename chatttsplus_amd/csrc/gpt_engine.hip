@@ -123,6 +123,8 @@ struct ctts_gpt {
     char* pimg = nullptr;                        //   per-workgroup register images of the layer weights [L][192][192 KB], built on the device from the packed tiles -- on the FIRST
                                                  //   decode call of <= persistent_rows rows (persist_images): an engine that only ever decodes larger batches (a LoRA-merged
                                                  //   sibling serving batch 32) never pays the second 755 MB weight copy
+    char* pimg_head = nullptr;                   //   the folded heads as 14 register-fragment rows per GEMV workgroup (persist.h PL_HEAD_FRAGS): the launch that ends the stack also runs
+    int persist_heads = 1;                       //   the final RMSNorm + heads ("persistent_heads"; code mode, paced schedule): one launch fewer per step
     unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
     unsigned* pl_epoch = nullptr;                //   launch counter = granule tag
     int* pl_error = nullptr;                     //   first give-up code (0 = none); reported by ctts_gpt_progress
@@ -312,6 +314,8 @@ static int persist_images(ctts_gpt* h) {
     if (dev_alloc((void**)&h->pimg, layer_bytes * h->L)) return 1;
     for (int l = 0; l < h->L; ++l)
         if (launch_persist_repack(h->esz == 2, h->lw[l].qkv, h->lw[l].o, h->lw[l].gu, h->lw[l].d, h->pimg + layer_bytes * l, nullptr)) return 1;
+    if (dev_alloc((void**)&h->pimg_head, (size_t)PL_GEMV_BLOCKS * PL_HEAD_FRAGS * 4 * h->esz)) return 1;
+    if (launch_persist_repack_heads(h->esz == 2, h->whead, (h->NVQ * h->V + 15) / 16, h->pimg_head, nullptr)) return 1;
     CTTS_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 }
@@ -352,6 +356,7 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     if (n == "persistent_rows") *value = (h->persist_ok || !h->finalized) ? h->persist_rows : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
     else if (n == "mfma_rows") *value = (h->pm_flags != nullptr || !h->finalized) ? h->pm_rows_max : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
     else if (n == "mfma_rows_min") *value = h->pm_rows_min;
+    else if (n == "persistent_heads") *value = h->persist_heads;
     else if (n == "valu_rows") *value = h->valu_rows;
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
     else if (n == "split_rows") *value = h->split_rows;
@@ -390,6 +395,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
     } else if (n == "mfma_timestamps") {         // diagnostics: the poller of every workgroup records wall_clock64 marks of the last layer (ctts_gpt_debug_read "pm_ts")
         if (value && !h->pm_ts && dev_alloc((void**)&h->pm_ts, (size_t)PM_BLOCKS * PM_NTS * 8)) return 1;
         h->pm_ts_on = value ? 1 : 0;
+    } else if (n == "persistent_heads") {        // 1 (default): the persistent launch that ends the stack also runs the final norm + heads; 0 = the separate heads launch
+        h->persist_heads = value ? 1 : 0;
     } else if (n == "persistent_layers_per_launch") {      // 0 = the whole stack in one launch (default); 1 = one launch per layer
         h->persist_lpl = value < 0 ? 0 : value;
     } else if (n == "persistent_schedule") {               // 1 / 2: see persist_layer.hip
@@ -444,7 +451,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
-                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt,
+                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pimg_head, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt,
                     h->pm_flags, h->pm_epoch, h->pm_slab, h->pm_cnt, h->scale_one, h->pm_ts};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
@@ -897,7 +904,7 @@ static inline int decode_splits(const ctts_gpt* h, int B, int L) {
 
 // What run_layers decided about the hand-off of the residual stream to whatever reads it next (the heads): one place computes the
 // predicates, the consumer uses what was actually launched.
-struct StreamForm { bool parts; bool xh; };     // x = x_dec + dpart[0..3] (split-K down projection) / packed fp16 copy + sums of squares exist
+struct StreamForm { bool parts; bool xh; bool logits; };     // x = x_dec + dpart[0..3] (split-K down projection) / packed fp16 copy + sums of squares exist / the logits (and hidden rows) exist already
 
 // 20 decoder layers on R rows of residual stream x (llama.py:719-749 per layer)
 static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* rope_rows, int R, int S, const DevState* st, hipStream_t s, StreamForm* form = nullptr) {
@@ -929,11 +936,16 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     const bool xhm = (st != nullptr) && h->xh_mode && !splitd;
     if (st != nullptr && h->cur_persist && h->pimg != nullptr && R <= PL_MAXR && !lora) {
         // one persistent launch per layer (persist_layer.hip): the residual stream stays in x, nothing is left in partial or packed form
-        if (form) { form->parts = false; form->xh = false; }
+        // the launch that ends the stack also runs the final norm + the 4 code heads (persist_layer.hip phase H): code mode, paced schedule, images built
+        const bool fuse_heads = h->persist_heads && !h->text_mode && h->persist_sched == 3 && h->pimg_head != nullptr && h->dyn != nullptr;
+        if (form) { form->parts = false; form->xh = false; form->logits = fuse_heads; }
         // (persistent_layers_per_launch, default all: the whole stack is ONE launch; 1 = a launch per layer, the first version of the structure)
         const int per = (h->persist_lpl > 0 && h->persist_lpl < h->L) ? h->persist_lpl : h->L;
         for (int l = 0; l < h->L; l += per) {
             PersistArgs pa = {};
+            if (fuse_heads && l + per >= h->L) {
+                pa.heads = 1; pa.hw = h->pimg_head; pa.logits = h->logits; pa.n_valid = h->NVQ * h->V; pa.lnf = h->lnf; pa.dyn = h->dyn; pa.rows = h->finend;
+            }
             pa.w = h->pimg + PL_LAYER_BYTES / 4 * h->esz * l; pa.half_w = h->esz == 2 ? 1 : 0; pa.n_layers = (h->L - l < per) ? h->L - l : per;
             pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
             pa.kv = kv_layer(h, l, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
@@ -945,7 +957,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     }
     if (st != nullptr && h->cur_pm && h->pm_flags != nullptr && dt == CTTS_DTYPE_F32 && R <= PM_MAXR && !lora) {
         // ONE persistent launch with MFMA projections (persist_mfma.hip): leaves x, and the packed copy + sums of squares the heads' PRO_XH kernel reads
-        if (form) { form->parts = false; form->xh = true; }
+        if (form) { form->parts = false; form->xh = true; form->logits = false; }
         PmArgs pa = {};
         pa.wqkv = (const char*)h->lw[0].qkv; pa.wo = (const char*)h->lw[0].o; pa.wgu = (const char*)h->lw[0].gu; pa.wd = (const char*)h->lw[0].d;
         pa.w_stride = h->L > 1 ? (size_t)((const char*)h->lw[1].qkv - (const char*)h->lw[0].qkv) : 0;
@@ -957,7 +969,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         for (int i = 0; i < PM_NPHASE; ++i) pa.delay[i] = h->pm_delay[i];
         return launch_persist_mfma(pa, s);
     }
-    if (form) { form->parts = splitd; form->xh = xhm; }
+    if (form) { form->parts = splitd; form->xh = xhm; form->logits = false; }
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
         a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq; a.sat = h->sat;
@@ -1080,7 +1092,7 @@ static int run_heads(ctts_gpt* h, bool write_hidden, StreamForm form, hipStream_
 }
 
 static int run_sample_phase(ctts_gpt* h, StreamForm form, hipStream_t s) {
-    if (run_heads(h, true, form, s)) return 1;
+    if (!form.logits && run_heads(h, true, form, s)) return 1;      // (the persistent launch that ended the stack wrote the logits and the hidden rows itself)
     SamplerArgs sa = {};
     sa.dyn = h->dyn; sa.logits = h->logits; sa.V = h->text_mode ? h->vocab_text_head : h->V; sa.B = h->B; sa.st = h->st;
     sa.text_mode = h->text_mode;
@@ -1190,7 +1202,7 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* h, const float* emb, void* stream) {
 extern "C" int ctts_gpt_sample(ctts_gpt* h, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("sample: call begin first"); return 1; }
     CTTS_RANGE("ctts_gpt_sample");
-    return run_sample_phase(h, StreamForm{false, false}, (hipStream_t)stream);
+    return run_sample_phase(h, StreamForm{false, false, false}, (hipStream_t)stream);
 }
 
 extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
@@ -1285,7 +1297,7 @@ struct PersistTurnGuard {
 };
 
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
-    StreamForm form = {false, false};
+    StreamForm form = {false, false, false};
     if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s, &form)) return 1;
     return run_sample_phase(h, form, s);            // the heads add dpart[0..3] / read the packed copy; the sampler then re-materialises x_dec
 }

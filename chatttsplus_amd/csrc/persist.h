@@ -26,10 +26,20 @@
 #define PL_G_X (PL_MAXR * PL_H)
 #define PL_SMAX 5                           // key splits per (row, head): 12 rows x heads x splits <= 64 attention workgroups
 #define PL_G_PART (PL_ATT_BLOCKS * 66)
+// final norm + heads inside the launch (round 5): 14 head rows per GEMV workgroup (192 x 14 = 2688 >= 2504 = 4 x 626), 2 per compute wave 0..6
+#define PL_HEAD_ROWS 14
+#define PL_HEAD_FRAGS (7 * 2 * 3 * 64)     // fragments (4 weights each) of a workgroup's head image: [wave 7][row 2][j 3][lane 64]
 #define PL_G_TOTAL (PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT + PL_G_X + PL_G_PART)
 
 struct PersistArgs {
     const char* w;                  // layer 0's image [192][PL_BLOCK_BYTES]; layer l at + l * PL_LAYER_BYTES (fp16 engines: half of both)
+    const char* hw;                 // heads == 1: the folded heads' image [192][PL_HEAD_FRAGS] fragments (rows >= n_valid are zero)
+    int heads;                      // 1: this launch ends the stack and also runs the final RMSNorm + the 4 folded code heads (gpt.py:422-447): logits, hidden row
+    float* logits;                  //   [R][n_valid]
+    int n_valid;                    //   2504
+    const float* lnf;               //   final norm weight [768] (the heads' columns carry it already; the hidden row needs it)
+    const SamplerDyn* dyn;          //   hidden_out / hidden_stride (device memory, constant address space)
+    const RowState* rows;           //   per-row state: a live row's hidden goes to hiddens[out][end]
     int half_w;                     // 1: fp16 engine -- half weights in the image, half K / V cache; activations and granules stay fp32
     int n_layers;                   // decoder layers run by this launch (<= 31: a granule tag is launch counter * 32 + layer)
     float* x;                       // residual stream [R][768], read at entry, rewritten at the end
@@ -60,5 +70,6 @@ struct PersistArgs {
 };
 
 int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s);
+int launch_persist_repack_heads(int half_w, const void* whead, int n_tiles, void* dst, hipStream_t s);
 int launch_persist_repack(int half_w, const void* qkv, const void* o, const void* gu, const void* d, void* dst, hipStream_t s);
 int persist_configure();

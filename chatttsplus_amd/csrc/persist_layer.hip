@@ -251,6 +251,13 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                             for (int row = 0; row < 2; ++row)
 #pragma unroll
                                 for (int j = 0; j < 3; ++j) PL_PIECE(q_w[row][j] = __builtin_nontemporal_load((const wfrag*)wn + oq + (row * 3 + j) * 64));
+                        } else if (!more && a.heads && wave < 7) {
+                            // the stack ends here: the q|k|v registers take this workgroup's 14 head rows (2 per wave) for the phase behind the last layer
+                            const wfrag* const hwb = (const wfrag*)a.hw + (size_t)b * PL_HEAD_FRAGS + oq;
+#pragma unroll
+                            for (int row = 0; row < 2; ++row)
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) PL_PIECE(q_w[row][j] = __builtin_nontemporal_load(hwb + (row * 3 + j) * 64));
                         }
                         PL_PACE_END();
                     }
@@ -265,6 +272,31 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     }
                     __syncthreads();                          // B2(E)
                     wb = wn;
+                }
+                if (a.heads) {
+                    // ---- phase H: final RMSNorm + the 4 folded heads (gpt.py:422-447) on the last layer's output, gathered like a layer input
+                    {
+                        PL_PACE_BEGIN();
+                        PL_PACE_END();
+                    }
+                    f32x4 xr[R][3];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+                    if (wave < 7) {
+#pragma unroll
+                        for (int row = 0; row < 2; ++row)
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                float acc = 0.f;
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) acc = dot4(q_w[row][j], xr[r][j], acc);
+                                acc = wave_sum(acc);
+                                if (lane == 0) red[(wave * 4 + row) * R + r] = acc;
+                            }
+                    }
+                    __syncthreads();                          // B2(H)
                 }
                 return;
             }
@@ -533,10 +565,55 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 if (e < 4 * R) {
                     const int i = e & 3, r = e >> 2;
                     const float x2 = xres[4 * r + i] + (red[((2 * i) * 4) * R + r] + red[((2 * i + 1) * 4) * R + r]);      // llama.py:739
-                    if (last) a.x[(size_t)r * PL_H + 4 * b + i] = x2;          // the heads read it after the launch boundary
+                    if (last && !a.heads) a.x[(size_t)r * PL_H + 4 * b + i] = x2;          // the heads read it after the launch boundary
                     else {
                         xres[4 * r + i] = x2;
                         store_granule(a.g_x + (size_t)r * PL_H + 4 * b + i, tag, x2);
+                    }
+                }
+            }
+            if (a.heads) {
+                // ---- phase H: the stack's output rows, gathered like a layer's input -> final RMSNorm factor, logits of this workgroup's 14 head rows, hidden columns
+                const unsigned tagh = tag0 + (unsigned)(NL - 1);
+                // what the hidden row of this thread's (row, column) needs: requested here, consumed behind the gather (held through the layer loop they cost spills)
+                int4 hst = make_int4(1, 0, 0, 0);
+                int hout = 0;
+                float lnf_v = 0.f;
+                if (e < 4 * R) {
+                    hst = *(const int4*)(a.rows + (e >> 2));         // {fin, end, attempt, limit}
+                    hout = a.rows[e >> 2].out;
+                    lnf_v = a.lnf[4 * b + (e & 3)];
+                }
+                for (int z = 0; z < a.delay_x; ++z) __builtin_amdgcn_s_sleep(2);
+                float v[6 * R];
+                const bool got = sweep<6 * R>(a.g_x, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tagh, v, a.error, 1, abort_s, a.nap);
+                (void)got;
+#pragma unroll
+                for (int r = 0; r < R; ++r) ssp[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6 * R; ++k) {
+                    xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
+                    ssp[k / 6] += v[k] * v[k];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float s = wave_sum(ssp[r]);
+                    if (lane == 0) ssq[ew * R + r] = s;
+                }
+                PL_B1();                                      // B1(H)
+                __syncthreads();                              // B2(H)
+                if (e < PL_HEAD_ROWS * R) {
+                    const int rr = e % PL_HEAD_ROWS, r = e / PL_HEAD_ROWS, col = PL_HEAD_ROWS * b + rr;
+                    const float rs = 1.0f / sqrtf((ssq[r] + ssq[R + r]) / (float)PL_H + a.eps);          // llama.py:1002 (the weight is folded into the heads' columns)
+                    if (col < a.n_valid) a.logits[(size_t)r * a.n_valid + col] = red[((rr >> 1) * 4 + (rr & 1)) * R + r] * rs;
+                }
+                if (e < 4 * R) {
+                    // hidden = weight * (x * rs) (llama.py:87, gpt.py:422-423) -> hiddens[utterance][its own step] while the row is live
+                    float* const hid_out = ((SamplerDynPtr)a.dyn)->hidden_out;
+                    if (hid_out != nullptr && hst.x == 0) {
+                        const int i = e & 3, r = e >> 2;
+                        const float rs = 1.0f / sqrtf((ssq[r] + ssq[R + r]) / (float)PL_H + a.eps);
+                        hid_out[(size_t)hout * ((SamplerDynPtr)a.dyn)->hidden_stride + (size_t)hst.y * PL_H + 4 * b + i] = lnf_v * (xres[4 * r + i] * rs);
                     }
                 }
             }
@@ -782,6 +859,28 @@ __global__ __launch_bounds__(256) void persist_repack_kernel(const typename PlW<
     }
     if constexpr (sizeof(WT) == 4) dst[idx] = src[((size_t)row_tile * ktiles + (k4 >> 2)) * 64 + i + 16 * (k4 & 3)];
     else dst[idx] = src[(((size_t)row_tile * (ktiles / 2) + (k4 >> 3)) * 64 + i + 16 * ((k4 >> 1) & 3)) * 2 + (k4 & 1)];      // 32-wide k-tiles, 8 halfs per lane: two 4-groups each
+}
+
+// the folded heads' MFMA tile image [n_tiles][48 k-tiles][lane][16 B] -> [192 workgroups][7 waves][2 rows][3 j][64 lanes] fragments; head row = 14 g + 2 wave + row
+template <typename WT>
+__global__ __launch_bounds__(256) void persist_repack_heads_kernel(const typename PlW<WT>::frag* whead, int n_tiles, typename PlW<WT>::frag* dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= PL_GEMV_BLOCKS * PL_HEAD_FRAGS) return;
+    const int g = idx / PL_HEAD_FRAGS, o2 = idx % PL_HEAD_FRAGS, w = o2 / 384, rem = o2 % 384, row = rem / 192, j = (rem % 192) / 64, ln = rem % 64;
+    const int hrow = PL_HEAD_ROWS * g + 2 * w + row, row_tile = hrow >> 4, i = hrow & 15, k4 = 64 * j + ln;
+    typename PlW<WT>::frag v = {};
+    if (row_tile < n_tiles) {
+        if constexpr (sizeof(WT) == 4) v = whead[((size_t)row_tile * 48 + (k4 >> 2)) * 64 + i + 16 * (k4 & 3)];
+        else v = whead[(((size_t)row_tile * 24 + (k4 >> 3)) * 64 + i + 16 * ((k4 >> 1) & 3)) * 2 + (k4 & 1)];
+    }
+    dst[idx] = v;
+}
+int launch_persist_repack_heads(int half_w, const void* whead, int n_tiles, void* dst, hipStream_t s) {
+    const int n = PL_GEMV_BLOCKS * PL_HEAD_FRAGS;
+    if (half_w) hipLaunchKernelGGL(persist_repack_heads_kernel<half_t>, dim3((n + 255) / 256), dim3(256), 0, s, (const half4*)whead, n_tiles, (half4*)dst);
+    else hipLaunchKernelGGL(persist_repack_heads_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, (const f32x4*)whead, n_tiles, (f32x4*)dst);
+    CTTS_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_persist_repack(int half_w, const void* qkv, const void* o, const void* gu, const void* d, void* dst, hipStream_t s) {
