@@ -937,7 +937,8 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     if (st != nullptr && h->cur_persist && h->pimg != nullptr && R <= PL_MAXR && !lora) {
         // one persistent launch per layer (persist_layer.hip): the residual stream stays in x, nothing is left in partial or packed form
         // the launch that ends the stack also runs the final norm + the 4 code heads (persist_layer.hip phase H): code mode, paced schedule, images built
-        const bool fuse_heads = h->persist_heads && !h->text_mode && h->persist_sched == 3 && h->pimg_head != nullptr && h->dyn != nullptr;
+        // (ms/step separate heads launch / fused, tools/ab_options.py: fp32 batch 1 0.2798 / 0.2786, 2 0.3396 / 0.3384, 4 0.4711 / 0.4721; fp16 batch 3 0.3793 / 0.3800 -> up to 2 rows)
+        const bool fuse_heads = h->persist_heads && R <= 2 && !h->text_mode && h->persist_sched == 3 && h->pimg_head != nullptr && h->dyn != nullptr;
         if (form) { form->parts = false; form->xh = false; form->logits = fuse_heads; }
         // (persistent_layers_per_launch, default all: the whole stack is ONE launch; 1 = a launch per layer, the first version of the structure)
         const int per = (h->persist_lpl > 0 && h->persist_lpl < h->L) ? h->persist_lpl : h->L;
