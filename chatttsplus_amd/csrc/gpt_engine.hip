@@ -133,6 +133,7 @@ struct ctts_gpt {
     int pl_ts_on = 0;
     int persist_fault = 0;                       //   test hook ("persistent_fault"): see PersistArgs.fault
     int persist_splits = 0;                      //   cap on the attention's key splits per (row, head) (0 = PL_SMAX); "persistent_splits"
+    int persist_max_keys = 0;                    //   contexts beyond this many keys go back to the launch chain (0 = no limit); "persistent_max_keys"
     int persist_lpl = 0;                         //   decoder layers per persistent launch (0 = all of them in one launch)
     int persist_sched = 3;                       //   weight request schedule (PersistArgs.sched): 1 and 2 measure the same (389.3 / 389.5 us at batch 1, 436.0 / 436.4 at 2);
                                                  //   3 = paced requests: batch 1 373.0 -> 337.4, 2 425.7 -> 404.0, 3 490.1 -> 467.6 (profiles/r04_ab_persist_options.jsonl)
@@ -405,6 +406,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->lora_fold = (value < 0 || value > 3) ? 1 : value;
     } else if (n == "persistent_fault") {                  // test hook: a withheld hand-off; every wait is bounded, ctts_gpt_progress reports the edge
         h->persist_fault = value < 0 ? 0 : value;
+    } else if (n == "persistent_max_keys") {
+        h->persist_max_keys = value < 0 ? 0 : value;
     } else if (n == "persistent_splits") {
         h->persist_splits = value < 0 ? 0 : (value > PL_SMAX ? PL_SMAX : value);
     } else if (n == "persistent_pace") {                   // SCHED 3: ~128-cycle units between two paced weight requests of a wave
@@ -1237,7 +1240,9 @@ static inline int decode_persist(const ctts_gpt* h, int B, int L) {
     int cap = PL_ATT_BLOCKS / (PL_NH * B);
     cap = cap > PL_SMAX ? PL_SMAX : (cap < 1 ? 1 : cap);
     if (h->persist_splits > 0) cap = h->persist_splits < cap ? h->persist_splits : cap;
-    if (L > 2 * PL_SHARE_KEYS * cap + 256) return 0;
+    // (until round 5 a context beyond 2 * 384 * cap + 256 keys went back to the launch chain: the share's tail streamed one 64-key step per round trip.  Four steps
+    //  per round trip now; "persistent_max_keys" restores a limit for A/Bs)
+    if (h->persist_max_keys > 0 && L > h->persist_max_keys) return 0;
     if (L <= PL_SHARE_KEYS + 128) return 1;                 // (one streamed iteration costs less than the extra hop)
     const int want = (L + PL_SHARE_KEYS - 1) / PL_SHARE_KEYS;
     return want > cap ? cap : want;

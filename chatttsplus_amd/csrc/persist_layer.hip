@@ -699,23 +699,35 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     o[4] += pe * vf[u].at(4); o[5] += pe * vf[u].at(5); o[6] += pe * vf[u].at(6); o[7] += pe * vf[u].at(7);
                 }
             }
-            for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64) {       // contexts beyond 256 keys: the rest streams behind the query (wave-uniform bound)
-                const int p = wb0 + grp;
-                const bool live = p < kv1;
-                const int pc = live ? p : m.kv_start;
-                PlKV<WT> ks_, vs_;
-                ks_.load(kb + (size_t)pc * CTTS_HEAD_DIM); vs_.load(vb + (size_t)pc * CTTS_HEAD_DIM);
-                float dot = q0[0] * ks_.at(0) + q0[1] * ks_.at(1) + q0[2] * ks_.at(2) + q0[3] * ks_.at(3) + q1[0] * ks_.at(4) + q1[1] * ks_.at(5) + q1[2] * ks_.at(6) + q1[3] * ks_.at(7);
-                dot += dpp_f<DPP_XOR1>(dot);
-                dot += dpp_f<DPP_XOR2>(dot);
-                dot += dpp_f<DPP_HALF_MIRROR>(dot);
-                const float mn = wave_max(fmaxf(mrun, live ? dot : -INFINITY));       // the wave keeps ONE running maximum
-                const float scl = pl_exp_diff(mrun, mn);
-                const float pe = live ? expf(dot - mn) : 0.f;
-                lrun = lrun * scl + pe;
-                o[0] = o[0] * scl + pe * vs_.at(0); o[1] = o[1] * scl + pe * vs_.at(1); o[2] = o[2] * scl + pe * vs_.at(2); o[3] = o[3] * scl + pe * vs_.at(3);
-                o[4] = o[4] * scl + pe * vs_.at(4); o[5] = o[5] * scl + pe * vs_.at(5); o[6] = o[6] * scl + pe * vs_.at(6); o[7] = o[7] * scl + pe * vs_.at(7);
-                mrun = mn;
+            // Shares beyond the PRE * 64 prefetched keys stream behind the query, UNS steps of 64 keys per round trip (round 5: one step per round trip cost 0.6 us per
+            // 64 keys and layer and sent 3-4-row batches beyond 1024 keys back to the launch chain).  The steps themselves, and their order, are unchanged.
+            constexpr int UNS = 4;
+            for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64 * UNS) {       // (wave-uniform bound)
+                PlKV<WT> ks_[UNS], vs_[UNS];
+                bool live_[UNS];
+#pragma unroll
+                for (int u = 0; u < UNS; ++u) {
+                    const int p = wb0 + 64 * u + grp;
+                    live_[u] = p < kv1;
+                    const int pc = live_[u] ? p : m.kv_start;
+                    ks_[u].load(kb + (size_t)pc * CTTS_HEAD_DIM); vs_[u].load(vb + (size_t)pc * CTTS_HEAD_DIM);
+                }
+#pragma unroll
+                for (int u = 0; u < UNS; ++u) {
+                    if (wb0 + 64 * u >= kv1) break;                                          // (wave-uniform: the step does not exist)
+                    const bool live = live_[u];
+                    float dot = q0[0] * ks_[u].at(0) + q0[1] * ks_[u].at(1) + q0[2] * ks_[u].at(2) + q0[3] * ks_[u].at(3) + q1[0] * ks_[u].at(4) + q1[1] * ks_[u].at(5) + q1[2] * ks_[u].at(6) + q1[3] * ks_[u].at(7);
+                    dot += dpp_f<DPP_XOR1>(dot);
+                    dot += dpp_f<DPP_XOR2>(dot);
+                    dot += dpp_f<DPP_HALF_MIRROR>(dot);
+                    const float mn = wave_max(fmaxf(mrun, live ? dot : -INFINITY));       // the wave keeps ONE running maximum
+                    const float scl = pl_exp_diff(mrun, mn);
+                    const float pe = live ? expf(dot - mn) : 0.f;
+                    lrun = lrun * scl + pe;
+                    o[0] = o[0] * scl + pe * vs_[u].at(0); o[1] = o[1] * scl + pe * vs_[u].at(1); o[2] = o[2] * scl + pe * vs_[u].at(2); o[3] = o[3] * scl + pe * vs_[u].at(3);
+                    o[4] = o[4] * scl + pe * vs_[u].at(4); o[5] = o[5] * scl + pe * vs_[u].at(5); o[6] = o[6] * scl + pe * vs_[u].at(6); o[7] = o[7] * scl + pe * vs_[u].at(7);
+                    mrun = mn;
+                }
             }
             // the 8 key groups of the wave share mrun: plain sums over the lanes with equal `sub`
 #pragma unroll
