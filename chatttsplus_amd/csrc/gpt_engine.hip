@@ -1242,7 +1242,10 @@ static inline int decode_persist(const ctts_gpt* h, int B, int L) {
     if (h->persist_splits > 0) cap = h->persist_splits < cap ? h->persist_splits : cap;
     // (until round 5 a context beyond 2 * 384 * cap + 256 keys went back to the launch chain: the share's tail streamed one 64-key step per round trip.  Four steps
     //  per round trip now; "persistent_max_keys" restores a limit for A/Bs)
-    if (h->persist_max_keys > 0 && L > h->persist_max_keys) return 0;
+    // Measured (tools/long_ctx_probe.py, ms/step launch chain / persistent): 3 rows 1200 keys 0.702 / 0.644, 1900 keys 0.733 / 0.808; 4 rows 1200 keys 0.717 / 0.708,
+    // 1900 keys 0.748 / 0.877; 2 rows (2 shares) 1900 keys 0.568 / 0.535; 1 row 1900 keys 0.504 / 0.364: one workgroup streams a share at ~40 GB/s, so a share
+    // beyond ~1400 keys loses to the chain's 144 attention blocks -> the limit is 1400 keys per share
+    if (L > (h->persist_max_keys > 0 ? h->persist_max_keys : 1400 * cap)) return 0;
     if (L <= PL_SHARE_KEYS + 128) return 1;                 // (one streamed iteration costs less than the extra hop)
     const int want = (L + PL_SHARE_KEYS - 1) / PL_SHARE_KEYS;
     return want > cap ? cap : want;

@@ -38,7 +38,8 @@ def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
     g = gpt
     assert g.get_option("persistent_rows") == 4, "fp32 engines serve up to four decode rows through the persistent launch by default"
     # contexts beyond 512 keys split every (row, head) over 2..5 attention workgroups (2 at 600, 3 at 1000, 5 at 1900; two rows: at most 2)
-    cases = [(1, 48, 96, None), (1, 600, 24, None), (1, 1000, 40, None), (1, 1900, 24, None), (2, 700, 16, [0, 150]),
+    # (round 5: a key share's tail streams 4 steps per round trip, so 3-4 rows stay on the persistent launch up to 1400 keys -- (4, 1200) and (3, 1300) below)
+    cases = [(1, 48, 96, None), (1, 600, 24, None), (1, 1000, 40, None), (1, 1900, 24, None), (2, 700, 16, [0, 150]), (4, 1200, 16, [0, 30, 7, 300]), (3, 1300, 16, None),
              (2, 40, 32, [0, 9]), (3, 33, 24, [0, 5, 17]), (4, 48, 24, [3, 0, 11, 20])]
     for (B, P, N, pad) in cases:
         g.set_option("persistent_rows", 0)
