@@ -304,15 +304,17 @@ __global__ __launch_bounds__(256) void attn_prefill_split_kernel(const RowMeta* 
 #pragma unroll
     for (int db = 0; db < 4; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float mrun = -INFINITY, lpart = 0.f;
-    // staging: thread -> key (tid >> 2) of the chunk, dims 16 (tid & 3) .. + 15
-    const int skey = tid >> 2, sdim = 16 * (tid & 3);
+    // staging: thread -> key (tid >> 2) of the chunk, dims 4 (tid & 3) + 16 i .. + 3 for i = 0..3.  (Round 5: the four lanes of a key used to own 16 CONSECUTIVE dims each;
+    // their transposing 2-byte V stores then sat 16 rows = 544 dwords = 0 or 32 banks apart and the 8-byte K stores 8 dwords apart under a 36-dword row pitch:
+    // 2-way / 4-way LDS bank conflicts on every store, 47 % of the kernel's LDS cycles.  4 dims apart they land 8 / 2 banks apart.)
+    const int skey = tid >> 2, sdim = 4 * (tid & 3);
     f32x4 vst[4], kst[4];
     auto vload = [&](int c) {
         const int key = min(c + skey, bhi);                               // clamp: a valid slot of this sequence (masked later)
         const f32x4* vp = (const f32x4*)(vb + (size_t)key * CTTS_HEAD_DIM + sdim);
         const f32x4* kp = (const f32x4*)(kb + (size_t)key * CTTS_HEAD_DIM + sdim);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { vst[i] = vp[i]; kst[i] = kp[i]; }
+        for (int i = 0; i < 4; ++i) { vst[i] = vp[4 * i]; kst[i] = kp[4 * i]; }
     };
     auto vstore = [&](int buf) {
 #pragma unroll
@@ -321,9 +323,9 @@ __global__ __launch_bounds__(256) void attn_prefill_split_kernel(const RowMeta* 
             split_h4(vst[i], vh, vl);
             split_h4(kst[i], kh, kl);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { vth[buf][sdim + 4 * i + e][skey] = vh[e]; vtl[buf][sdim + 4 * i + e][skey] = vl[e]; }
-            *(half4*)&ksh[buf][skey][sdim + 4 * i] = kh;
-            *(half4*)&ksl[buf][skey][sdim + 4 * i] = kl;
+            for (int e = 0; e < 4; ++e) { vth[buf][sdim + 16 * i + e][skey] = vh[e]; vtl[buf][sdim + 16 * i + e][skey] = vl[e]; }
+            *(half4*)&ksh[buf][skey][sdim + 16 * i] = kh;
+            *(half4*)&ksl[buf][skey][sdim + 16 * i] = kl;
         }
     };
     const int c0 = blo & ~63;
