@@ -17,6 +17,11 @@ timeout 600 python bench.py --steps 20 --warmup 5 --force-pg > $O/bench_b1_fp32_
 for B in 32; do timeout 300 python bench.py --batch $B --steps 256 --cpu-steps 0 --no-extras > $O/bench_b${B}_fp32.json 2>/dev/null; cut -c1-160 $O/bench_b${B}_fp32.json; done
 timeout 300 python bench.py --batch 32 --steps 256 --cpu-steps 0 --no-extras --option mfma_rows=32 > $O/bench_b32_fp32_persistent_mfma.json 2>/dev/null; cut -c1-160 $O/bench_b32_fp32_persistent_mfma.json
 timeout 300 python tools/tb_curve.py fp32 1 2 3 4 5 6 8 10 12 14 16 17 18 20 22 24 26 28 30 32 > $O/step_time_vs_batch_fp32.jsonl 2>/dev/null
+timeout 300 python tools/ab_options.py fp32 "persistent_heads=0,1" --batches 1 2 3 4 --rounds 3 --steps 128 > $O/ab_persistent_heads.jsonl 2>/dev/null; cat $O/ab_persistent_heads.jsonl | cut -c1-300
+timeout 300 python tools/fp16_persist_probe.py > $O/fp16_persist_probe.jsonl 2>/dev/null; tail -4 $O/fp16_persist_probe.jsonl | cut -c1-300
+timeout 300 python tools/long_ctx_probe.py > $O/long_ctx_probe.jsonl 2>/dev/null
+timeout 300 python tools/persist_soak.py --mfma --requests 16 --tokens 400 > $O/pm_soak.json 2>/dev/null; cat $O/pm_soak.json
+timeout 300 python tools/prefill_probe.py 32 512 fp32 > $O/prefill_32x512_fp32.log 2>/dev/null; tail -1 $O/prefill_32x512_fp32.log
 timeout 400 python tools/pm_probe.py --batches 5,8,12,16,17,24,32 --steps 16 --prompt 293 --marks 32 --time-steps 32 > $O/pm_probe.jsonl 2>/dev/null; cat $O/pm_probe.jsonl | cut -c1-400
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b1 -- python $R/bench.py --steps 128 --warmup 16 --cpu-steps 0 --no-extras > /tmp/prof_b1.log 2>&1
