@@ -98,3 +98,21 @@ def test_infer_sharded_through_a_one_rank_nccl_group(tmp_path):
     assert p.exitcode == 0, f"the nccl child exited with {p.exitcode}"
     got = torch.load(out, weights_only=True)
     assert got["ok"] and len(got["lens"]) == N_UTT
+
+
+def test_bench_force_pg_runs_the_multi_rank_path_on_rccl():
+    """`bench.py --gpus 1 --force-pg`: the barriers, the MAX all-reduce, the per-rank gather and the speaker broadcast of the N > 1 path on a one-rank RCCL group,
+    ONE JSON line on stdout (RCCL's own banner is kept off it), the CPU baseline after the group is gone."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-extras", "--cpu-steps", "4", "--force-pg"],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["process_group"] == {"backend": "nccl", "world_size": 1, "forced_at_world_1": True}
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["value"] > 0 and d["cpu_baseline"]["value"] > 0 and len(d["per_rank_tokens_per_s"]) == 1
