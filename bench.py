@@ -79,6 +79,10 @@ class _stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)            # the banner sits in the C library's stdio buffer (fully buffered when stdout is a pipe or a file): out with it, to stderr
+        except Exception:
+            pass
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
