@@ -167,7 +167,7 @@ if not args.skip_times:
     # ---- 4. per-edge prices from the phase marks of the LAST layer of one launch (eager launches) -------------------------------------------
     g.set_option("persistent_rows", 4)
     g.set_option("persistent_timestamps", 1)
-    for B in (1, 2):
+    for B in (1, 2, 3, 4):
         for rep in range(4):
             leg.run(B, 48, 4, 4, spk=spk, use_graph=0, gen_tokens=0)
             ts = debug_read(g, "pl_ts", 256 * 10 * 8).view(np.uint64).reshape(256, 10).astype(np.float64) * 0.01        # us
