@@ -5,7 +5,8 @@
 #define PL_GEMV_BLOCKS 192                 // workgroups that own weight slices
 #define PL_ATT_BLOCKS 64                   // workgroups that own one (row, head) of the attention
 #define PL_BLOCKS (PL_GEMV_BLOCKS + PL_ATT_BLOCKS)
-#define PL_THREADS 640                     // 8 compute waves + 2 edge waves
+#define PL_THREADS(R) ((8 + ((R) == 1 ? 2 : 4)) * 64)      // 8 compute waves + 2 edge waves at one row, 4 at 2..4 rows
+#define PL_THREADS_MAX 768
 #define PL_H 768
 #define PL_I 3072
 #define PL_NH 12

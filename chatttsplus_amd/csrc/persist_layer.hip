@@ -110,14 +110,17 @@ __device__ inline float pl_exp_diff(float m, float mn) { return (m == -INFINITY)
 // (Re-requesting every array right after its use, a whole layer ahead, put the gate|up burst in front of the act gather's polls and the down burst in
 //  front of the next layer's x gather: +6.7 us per layer, profiles/r04_persist_probe_v2_one_launch.jsonl.)
 template <int R, int SCHED, typename WT>
-__global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const PersistArgs a) {
+__global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const PersistArgs a) {
     typedef typename PlW<WT>::frag wfrag;
+    // Edge waves per workgroup: 2 at one row, 4 at 2..4 rows (round 5).  A gather is 768 R (3072 R for the act rows) granules over the edge lanes; with two waves the
+    // per-lane share grew with the rows (6 R and 24 R loads per lane, the act rows one sweep after the other) -- +4.3 us of the +9.2 us per layer between 1 and 4 rows.
+    constexpr int EW = (R == 1) ? 2 : 4, NE = 64 * EW, GX = 768 / NE;      // edge lanes; granules per lane and row of a 768-wide gather (6 or 3)
     constexpr size_t BLOCK_BYTES = (size_t)PL_BLOCK_BYTES / 4 * sizeof(WT), LAYER_BYTES = PL_LAYER_BYTES / 4 * sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const xs = (float*)smem;                       // activations of the current phase [R][768] ([R][3072] for the down projection)
     float* const red = xs + R * PL_I;                     // compute waves' results [8 waves][4 slots][R]
-    float* const ssq = red + 8 * 4 * R;                   // sums of squares of the gathered rows [2 edge waves][R]
-    float* const xres = ssq + 2 * R;                      // this workgroup's 4 columns of the residual stream [R][4] (x, later x + attention, then the layer output)
+    float* const ssq = red + 8 * 4 * R;                   // sums of squares of the gathered rows [edge wave <= 4][R]
+    float* const xres = ssq + 4 * R;                      // this workgroup's 4 columns of the residual stream [R][4] (x, later x + attention, then the layer output)
     int* const abort_s = (int*)(xres + 4 * R);            // [4]: [0] give-up flag, [1] SCHED 3: gathers completed by the edge waves (2 per phase)
     float* const att_s = (float*)(abort_s + 4);           // attention workgroups: q[64] | k_new[64] | v_new[64] | merge[8][8][10]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 lds_int* const arrive = (lds_int*)(abort_s + 1);
                 int phase = 0;
                 const int pace = a.pace;                      // x 128 cycles between two requests of a wave
-#define PL_PACE_BEGIN() const int tgt_ = 2 * (++phase); bool ready_ = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= tgt_
+#define PL_PACE_BEGIN() const int tgt_ = EW * (++phase); bool ready_ = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= tgt_
 #define PL_PIECE(stmt_) do { stmt_; if (!ready_) { for (int z_ = 0; z_ < pace; ++z_) __builtin_amdgcn_s_sleep(2); ready_ = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= tgt_; } } while (0)
 #define PL_PACE_END() do { while (!ready_) { __builtin_amdgcn_s_sleep(1); ready_ = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= tgt_; } asm volatile("" ::: "memory"); } while (0)
                 for (int l = 0; l < NL; ++l) {
@@ -416,11 +419,11 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 }
             }
             // the residual stream: [R][768] from global memory (written by the previous launch) -> xs, sums of squares, own 4 columns
-            constexpr int XIT = (R * 192 + 127) / 128;
+            constexpr int XIT = (R * 192 + NE - 1) / NE;
             f32x4 xv[XIT];
 #pragma unroll
             for (int i = 0; i < XIT; ++i) {
-                const int idx = e + 128 * i;
+                const int idx = e + NE * i;
                 xv[i] = (idx < R * 192) ? ((const f32x4*)a.x)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             f32x4 xown = {0.f, 0.f, 0.f, 0.f};
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
             for (int r = 0; r < R; ++r) ssp[r] = 0.f;
 #pragma unroll
             for (int i = 0; i < XIT; ++i) {
-                const int idx = e + 128 * i;
+                const int idx = e + NE * i;
                 if (idx < R * 192) ((f32x4*)xs)[idx] = xv[i];
                 const float d = xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
 #pragma unroll
@@ -454,16 +457,16 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     // ---- edge 1: the previous layer's output, published by the 192 GEMV workgroups -> xs, sums of squares
                     for (int z = 0; z < a.delay_x; ++z) __builtin_amdgcn_s_sleep(2);
                     // (producers of this wave's columns e + 128 k: workgroups 16 (2 m + ew) + t; each stores its 4 columns of every row in one instruction)
-                    if (a.poll & 1) watch_sentinels(a.g_x, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag - 1u, lane, abort_s);
-                    float v[6 * R];
-                    const bool got = sweep<6 * R>(a.g_x, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag - 1u, v, a.error, 1, abort_s, a.nap);
+                    if (EW == 2 && (a.poll & 1)) watch_sentinels(a.g_x, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag - 1u, lane, abort_s);
+                    float v[GX * R];
+                    const bool got = sweep<GX * R>(a.g_x, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tag - 1u, v, a.error, 1, abort_s, a.nap);
                     (void)got;
 #pragma unroll
                     for (int r = 0; r < R; ++r) ssp[r] = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 6 * R; ++k) {
-                        xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
-                        ssp[k / 6] += v[k] * v[k];
+                    for (int k = 0; k < GX * R; ++k) {
+                        xs[(k / GX) * PL_H + NE * (k % GX) + e] = v[k];
+                        ssp[k / GX] += v[k] * v[k];
                     }
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 PL_B1();                                      // B1(A): the gather is in LDS
                 __syncthreads();                              // B2(A)
                 if (doA) {
-                    const float rs = 1.0f / sqrtf((ssq[rA] + ssq[R + rA]) / (float)PL_H + a.eps);          // llama.py:82-87 (the weight is folded into W's columns)
+                    const float rs = 1.0f / sqrtf((EW == 2 ? ssq[rA] + ssq[R + rA] : (ssq[rA] + ssq[R + rA]) + (ssq[2 * R + rA] + ssq[3 * R + rA])) / (float)PL_H + a.eps);          // llama.py:82-87 (the weight is folded into W's columns)
                     const float va = red[(pwA * 4 + 0) * R + rA] * rs, vb = red[(pwA * 4 + 1) * R + rA] * rs;
                     float ya = va, yb = vb;
                     int which, dA, dB;
@@ -499,12 +502,12 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 for (int z = 0; z < a.delay_att; ++z) __builtin_amdgcn_s_sleep(2);      // the attention cannot have published yet: do not poll into the weight stream
                 {
                     // (this wave's columns belong to the heads 2 m + ew: one sentinel per (row, head))
-                    if (a.poll & 1) watch_sentinels(a.g_att, [ew](int i) { return (i / 6) * PL_H + 64 * (2 * (i % 6) + ew) + 63; }, 6 * R, tag, lane, abort_s);
-                    float v[6 * R];
-                    const bool got = sweep<6 * R>(a.g_att, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, v, a.error, 3, abort_s, a.nap);
+                    if (EW == 2 && (a.poll & 1)) watch_sentinels(a.g_att, [ew](int i) { return (i / 6) * PL_H + 64 * (2 * (i % 6) + ew) + 63; }, 6 * R, tag, lane, abort_s);
+                    float v[GX * R];
+                    const bool got = sweep<GX * R>(a.g_att, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tag, v, a.error, 3, abort_s, a.nap);
                     (void)got;
 #pragma unroll
-                    for (int k = 0; k < 6 * R; ++k) xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
+                    for (int k = 0; k < GX * R; ++k) xs[(k / GX) * PL_H + NE * (k % GX) + e] = v[k];
                 }
                 if (last) PL_MARK(4);
                 PL_B1();                                      // B1(C): the gather is in LDS
@@ -520,16 +523,16 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 // ---- phase D: x + attention -> RMSNorm, gate | up, SiLU * up
                 for (int z = 0; z < a.delay; ++z) __builtin_amdgcn_s_sleep(2);
                 {
-                    if (a.poll & 1) watch_sentinels(a.g_x1, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag, lane, abort_s);
-                    float v[6 * R];
-                    const bool got = sweep<6 * R>(a.g_x1, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tag, v, a.error, 4, abort_s, a.nap);
+                    if (EW == 2 && (a.poll & 1)) watch_sentinels(a.g_x1, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag, lane, abort_s);
+                    float v[GX * R];
+                    const bool got = sweep<GX * R>(a.g_x1, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tag, v, a.error, 4, abort_s, a.nap);
                     (void)got;
 #pragma unroll
                     for (int r = 0; r < R; ++r) ssp[r] = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 6 * R; ++k) {
-                        xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
-                        ssp[k / 6] += v[k] * v[k];
+                    for (int k = 0; k < GX * R; ++k) {
+                        xs[(k / GX) * PL_H + NE * (k % GX) + e] = v[k];
+                        ssp[k / GX] += v[k] * v[k];
                     }
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 __syncthreads();                              // B2(D)
                 if (e < 16 * R) {
                     const int pi = e & 15, r = e >> 4, w = pi >> 1, p = pi & 1;
-                    const float rs = 1.0f / sqrtf((ssq[r] + ssq[R + r]) / (float)PL_H + a.eps);
+                    const float rs = 1.0f / sqrtf((EW == 2 ? ssq[r] + ssq[R + r] : (ssq[r] + ssq[R + r]) + (ssq[2 * R + r] + ssq[3 * R + r])) / (float)PL_H + a.eps);
                     const float gv = red[(w * 4 + 2 * p) * R + r] * rs, uv = red[(w * 4 + 2 * p + 1) * R + r] * rs;
                     store_granule(a.g_act + (size_t)r * PL_I + 16 * b + pi, tag, (gv / (1.0f + expf(-gv))) * uv);       // llama.py:214
                 }
@@ -550,14 +553,34 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 // ---- phase E: silu(gate) * up [R][3072] -> down + residual
                 for (int z = 0; z < a.delay_act; ++z) __builtin_amdgcn_s_sleep(2);
                 // (producers of this wave's columns e + 128 k: workgroups 8 k + 4 ew + t, t < 4; each stores its 16 columns of every row in one instruction)
-                if (a.poll & 1) watch_sentinels(a.g_act, [ew](int i) { return (R - 1) * PL_I + 16 * (8 * (i >> 2) + 4 * ew + (i & 3)) + 15; }, 96, tag, lane, abort_s);
+                if (EW == 2 && (a.poll & 1)) watch_sentinels(a.g_act, [ew](int i) { return (R - 1) * PL_I + 16 * (8 * (i >> 2) + 4 * ew + (i & 3)) + 15; }, 96, tag, lane, abort_s);
+                if constexpr (EW == 2) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float v[24];
-                    const bool got = sweep<24>(a.g_act, (unsigned)(r * PL_I + e), [](int k) { return 128 * k; }, tag, v, a.error, 5, abort_s, a.nap);
-                    (void)got;
+                    for (int r = 0; r < R; ++r) {
+                        float v[24];
+                        const bool got = sweep<24>(a.g_act, (unsigned)(r * PL_I + e), [](int k) { return 128 * k; }, tag, v, a.error, 5, abort_s, a.nap);
+                        (void)got;
 #pragma unroll
-                    for (int k = 0; k < 24; ++k) xs[r * PL_I + 128 * k + e] = v[k];
+                        for (int k = 0; k < 24; ++k) xs[r * PL_I + 128 * k + e] = v[k];
+                    }
+                } else {
+                    // four edge waves: 12 granules per lane and row -> two rows per sweep (24 granules in flight per lane, as before), R / 2 round trips instead of R
+#pragma unroll
+                    for (int r = 0; r + 1 < R; r += 2) {
+                        float v[24];
+                        const bool got = sweep<24>(a.g_act, (unsigned)(r * PL_I + e), [](int k) { return (k / 12) * PL_I + 256 * (k % 12); }, tag, v, a.error, 5, abort_s, a.nap);
+                        (void)got;
+#pragma unroll
+                        for (int k = 0; k < 24; ++k) xs[(r + k / 12) * PL_I + 256 * (k % 12) + e] = v[k];
+                    }
+                    if constexpr ((R & 1) != 0) {
+                        constexpr int r = R - 1;
+                        float v[12];
+                        const bool got = sweep<12>(a.g_act, (unsigned)(r * PL_I + e), [](int k) { return 256 * k; }, tag, v, a.error, 5, abort_s, a.nap);
+                        (void)got;
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) xs[r * PL_I + 256 * k + e] = v[k];
+                    }
                 }
                 if (last) PL_MARK(8);
                 PL_B1();                                      // B1(E): the gather is in LDS
@@ -585,15 +608,15 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     lnf_v = a.lnf[4 * b + (e & 3)];
                 }
                 for (int z = 0; z < a.delay_x; ++z) __builtin_amdgcn_s_sleep(2);
-                float v[6 * R];
-                const bool got = sweep<6 * R>(a.g_x, (unsigned)e, [](int k) { return (k / 6) * PL_H + 128 * (k % 6); }, tagh, v, a.error, 1, abort_s, a.nap);
+                float v[GX * R];
+                const bool got = sweep<GX * R>(a.g_x, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tagh, v, a.error, 1, abort_s, a.nap);
                 (void)got;
 #pragma unroll
                 for (int r = 0; r < R; ++r) ssp[r] = 0.f;
 #pragma unroll
-                for (int k = 0; k < 6 * R; ++k) {
-                    xs[(k / 6) * PL_H + 128 * (k % 6) + e] = v[k];
-                    ssp[k / 6] += v[k] * v[k];
+                for (int k = 0; k < GX * R; ++k) {
+                    xs[(k / GX) * PL_H + NE * (k % GX) + e] = v[k];
+                    ssp[k / GX] += v[k] * v[k];
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -604,7 +627,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                 __syncthreads();                              // B2(H)
                 if (e < PL_HEAD_ROWS * R) {
                     const int rr = e % PL_HEAD_ROWS, r = e / PL_HEAD_ROWS, col = PL_HEAD_ROWS * b + rr;
-                    const float rs = 1.0f / sqrtf((ssq[r] + ssq[R + r]) / (float)PL_H + a.eps);          // llama.py:1002 (the weight is folded into the heads' columns)
+                    const float rs = 1.0f / sqrtf((EW == 2 ? ssq[r] + ssq[R + r] : (ssq[r] + ssq[R + r]) + (ssq[2 * R + r] + ssq[3 * R + r])) / (float)PL_H + a.eps);          // llama.py:1002 (the weight is folded into the heads' columns)
                     if (col < a.n_valid) a.logits[(size_t)r * a.n_valid + col] = red[((rr >> 1) * 4 + (rr & 1)) * R + r] * rs;
                 }
                 if (e < 4 * R) {
@@ -612,7 +635,7 @@ __global__ __launch_bounds__(PL_THREADS) void persist_layer_kernel(const Persist
                     float* const hid_out = ((SamplerDynPtr)a.dyn)->hidden_out;
                     if (hid_out != nullptr && hst.x == 0) {
                         const int i = e & 3, r = e >> 2;
-                        const float rs = 1.0f / sqrtf((ssq[r] + ssq[R + r]) / (float)PL_H + a.eps);
+                        const float rs = 1.0f / sqrtf((EW == 2 ? ssq[r] + ssq[R + r] : (ssq[r] + ssq[R + r]) + (ssq[2 * R + r] + ssq[3 * R + r])) / (float)PL_H + a.eps);
                         hid_out[(size_t)hout * ((SamplerDynPtr)a.dyn)->hidden_stride + (size_t)hst.y * PL_H + 4 * b + i] = lnf_v * (xres[4 * r + i] * rs);
                     }
                 }
@@ -903,13 +926,13 @@ int launch_persist_repack(int half_w, const void* qkv, const void* o, const void
     return 0;
 }
 
-static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + 8 * 4 * R + 2 * R + 4 * R) * 4 + 16 + (192 + 8 * 8 * 10) * 4; }
+static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + 8 * 4 * R + 4 * R + 4 * R) * 4 + 16 + (192 + 8 * 8 * 10) * 4; }
 
 template <int R, int SCHED, typename WT>
 static int persist_launch_t(const PersistArgs& a, hipStream_t s, bool configure_only) {
     auto kern = persist_layer_kernel<R, SCHED, WT>;
     if (configure_only) { CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(R))); return 0; }
-    hipLaunchKernelGGL(kern, dim3(PL_BLOCKS), dim3(PL_THREADS), persist_lds_bytes(R), s, a);
+    hipLaunchKernelGGL(kern, dim3(PL_BLOCKS), dim3(PL_THREADS(R)), persist_lds_bytes(R), s, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
