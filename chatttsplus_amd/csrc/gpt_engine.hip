@@ -236,8 +236,8 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
     // both dtypes since round 5 (fp16 engines: half weights + half K / V in the image, fp32 activations).  fp16: up to 3 rows -- ms/step launch chain / persistent
-    // (tools/fp16_persist_probe.py): batch 1 0.370 / 0.256, 2 0.393 / 0.319, 3 0.423 / 0.381, 4 0.427 / 0.442
-    h->persist_rows = (c->dtype == CTTS_DTYPE_F16) ? 3 : 4;
+    // (tools/fp16_persist_probe.py, two edge waves): batch 1 0.370 / 0.256, 2 0.393 / 0.319, 3 0.423 / 0.381, 4 0.427 / 0.442
+    h->persist_rows = 4;                                         // (fp16 batch 4 with four edge waves: launch chain 0.425, persistent 0.404 ms/step)
     h->pm_rows_max = 0;                                          // opt-in: ctts_gpt_set_option("mfma_rows", 5..32)
     h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)

@@ -5,7 +5,11 @@
 #define PL_GEMV_BLOCKS 192                 // workgroups that own weight slices
 #define PL_ATT_BLOCKS 64                   // workgroups that own one (row, head) of the attention
 #define PL_BLOCKS (PL_GEMV_BLOCKS + PL_ATT_BLOCKS)
-#define PL_THREADS(R) ((8 + ((R) == 1 ? 2 : 4)) * 64)      // 8 compute waves + 2 edge waves at one row, 4 at 2..4 rows
+#ifndef PL_EW_ONE_ROW
+#define PL_EW_ONE_ROW 4                    // edge waves per workgroup at ONE row (A/B builds: tools/build_variant.sh ew2 -DPL_EW_ONE_ROW=2).  ms/step at batch 1, same box,
+#endif                                     //   2 / 4 edge waves: 0.2781 / 0.2685, 0.2784 / 0.2705 (round 5); at 2-4 rows four waves also removed every spill
+#define PL_EDGE_WAVES(R) ((R) == 1 ? PL_EW_ONE_ROW : 4)
+#define PL_THREADS(R) ((8 + PL_EDGE_WAVES(R)) * 64)        // 8 compute waves + 4 edge waves (round 4: 2)
 #define PL_THREADS_MAX 768
 #define PL_H 768
 #define PL_I 3072

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
     typedef typename PlW<WT>::frag wfrag;
     // Edge waves per workgroup: 2 at one row, 4 at 2..4 rows (round 5).  A gather is 768 R (3072 R for the act rows) granules over the edge lanes; with two waves the
     // per-lane share grew with the rows (6 R and 24 R loads per lane, the act rows one sweep after the other) -- +4.3 us of the +9.2 us per layer between 1 and 4 rows.
-    constexpr int EW = (R == 1) ? 2 : 4, NE = 64 * EW, GX = 768 / NE;      // edge lanes; granules per lane and row of a 768-wide gather (6 or 3)
+    constexpr int EW = PL_EDGE_WAVES(R), NE = 64 * EW, GX = 768 / NE;      // edge lanes; granules per lane and row of a 768-wide gather (6 or 3)
     constexpr size_t BLOCK_BYTES = (size_t)PL_BLOCK_BYTES / 4 * sizeof(WT), LAYER_BYTES = PL_LAYER_BYTES / 4 * sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const xs = (float*)smem;                       // activations of the current phase [R][768] ([R][3072] for the down projection)

@@ -214,11 +214,11 @@ def test_fp16_engines_use_the_persistent_launch_too():
     g = GPT(LLAMA, max_batch=4, max_seq_len=300, weight_dtype="fp16")
     try:
         g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
-        assert g.get_option("persistent_rows") == 3
+        assert g.get_option("persistent_rows") == 4
         for B in (1, 3):
             g.set_option("persistent_rows", 0)
             c_ids, c_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
-            g.set_option("persistent_rows", 3)
+            g.set_option("persistent_rows", 4)
             p_ids, p_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
             q_ids, q_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
             g.use_graph = False
