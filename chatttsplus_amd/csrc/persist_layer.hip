@@ -13,7 +13,7 @@
 //   * 64 attention workgroups own one (row, head, key share) each and pull its cached K / V rows into registers before the query exists;
 //   * the activations travel between workgroups as 8-byte {tag, value} granules (one sc1 store each, cdna_hip_programming.md Guideline 16 R2):
 //     the data is the flag, a consumer wave re-reads its granules until every tag equals (launch counter, layer) -- no fences, no counters,
-//     placement-independent.  Two "edge" waves per workgroup do all gathering, epilogues and publishing, so the compute waves never poll
+//     placement-independent.  Four "edge" waves per workgroup (two until round 5) do all gathering, epilogues and publishing, so the compute waves never poll
 //     (a poll's result would queue behind their in-flight weight loads: vmcnt retires in order);
 //   * five edges per layer: q|k|v -> attention, attention -> o_proj, (x + attention) -> gate|up, silu(gate) * up -> down, layer output -> next layer;
 //     the residual stream enters the launch and leaves it through plain global memory (the sampler wrote it, the heads read it: launch boundaries).
