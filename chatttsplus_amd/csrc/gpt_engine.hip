@@ -208,6 +208,8 @@ struct ctts_gpt {
     hipGraphExec_t gexec = nullptr;              // entry selected by the last ensure_graph
     int graph_steps = 4;                         // decode steps captured per graph: a replay costs ~8 us of
                                                  // GPU-side gap, amortised over 4 x 102 kernel nodes
+    int graph_steps_persist = 16;                // ... and per graph of the persistent paths (2 nodes per step: 32 nodes): the replay gap is 8.1 us whatever the graph
+                                                 // holds (profiles/r05_trace_gaps_b1.json), 2.0 us per step at 4 steps, 0.5 us at 16
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -362,6 +364,7 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
     else if (n == "split_rows") *value = h->split_rows;
     else if (n == "graph_steps") *value = h->graph_steps;
+    else if (n == "graph_steps_persistent") *value = h->graph_steps_persist;
     else if (n == "decode_splits") *value = h->force_splits;
     else if (n == "lora_fold") *value = h->lora_fold;
     else if (n == "down_splitk_rows") *value = h->down_sk_rows;
@@ -440,6 +443,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->down_sk_rows = value < 0 ? 0 : value;
     } else if (n == "graph_steps") {
         h->graph_steps = value < 1 ? 1 : (value > 64 ? 64 : value);
+    } else if (n == "graph_steps_persistent") {
+        h->graph_steps_persist = value < 1 ? 1 : (value > 64 ? 64 : value);
     } else {
         ctts_set_error("set_option: unknown option '%s'", name);
         return 1;
@@ -1311,9 +1316,14 @@ static int run_decode_step(ctts_gpt* h, hipStream_t s) {
     return run_sample_phase(h, form, s);            // the heads add dpart[0..3] / read the packed copy; the sampler then re-materialises x_dec
 }
 
-static int ensure_graph(ctts_gpt* h) {
+// steps per replay of the current decode path, given `left` steps to launch: the long graph of the persistent paths while it fits, else the short one
+static int graph_span(const ctts_gpt* h, int left) {
+    return ((h->cur_persist || h->cur_pm) && h->graph_steps_persist > h->graph_steps && left >= h->graph_steps_persist) ? h->graph_steps_persist : h->graph_steps;
+}
+
+static int ensure_graph(ctts_gpt* h, int n_steps) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen, h->cur_persist, h->cur_pm);      // (diagnostic switches are fixed at create)
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen, h->cur_persist, h->cur_pm, n_steps);      // (diagnostic switches are fixed at create)
     std::string key(sig);
     if (h->lora_rows) key.append((const char*)h->lora_row_slots, (size_t)h->B);      // the rows' adapter slots are kernel arguments of the folded launches (LoraFold)
     if (h->graph_gen != h->opt_gen || h->graphs.size() >= 96) {
@@ -1331,7 +1341,7 @@ static int ensure_graph(ctts_gpt* h) {
     ctts_gpt::GraphEntry ge = {nullptr, nullptr};
     CTTS_HIP_CHECK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = 0;
-    for (int i = 0; i < h->graph_steps && !rc; ++i) rc = run_decode_step(h, h->cap_stream);
+    for (int i = 0; i < n_steps && !rc; ++i) rc = run_decode_step(h, h->cap_stream);
     hipError_t e = hipStreamEndCapture(h->cap_stream, &ge.graph);
     if (rc) { if (ge.graph) (void)hipGraphDestroy(ge.graph); return 1; }
     if (e != hipSuccess) { ctts_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return 1; }
@@ -1354,9 +1364,12 @@ extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* st
     PersistTurnGuard turn(h->cur_persist != 0 || h->cur_pm != 0, s);
     if (turn.rc) { ctts_set_error("decode: hipStreamWaitEvent failed"); return 1; }
     if (use_graph) {
-        if (ensure_graph(h)) return 1;
         int left = n_steps;
-        for (; left >= h->graph_steps; left -= h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+        while (left >= h->graph_steps) {
+            const int span = graph_span(h, left);
+            if (ensure_graph(h, span)) return 1;
+            for (; left >= span; left -= span) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+        }
         for (; left > 0; --left) if (run_decode_step(h, s)) return 1;
     } else {
         for (int i = 0; i < n_steps; ++i) if (run_decode_step(h, s)) return 1;
@@ -1605,8 +1618,11 @@ extern "C" int ctts_gpt_time_decode(ctts_gpt* h, int n_steps, float* ms_per_step
             for (int r = 0; r < h->B; ++r) { const int c = std::min(h->row_ctx[r] + (launched - h->launched) + n, h->row_cap[r]); if (c > longest) longest = c; }
             if (pick_decode_path(h, longest + 1)) return 1;
             launched += n;
-            if (ensure_graph(h)) return 1;
-            if (pass == 1) for (int j = 0; j < n; j += h->graph_steps) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+            for (int left = n; left > 0;) {              // (n is a multiple of graph_steps)
+                const int span = graph_span(h, left);
+                if (ensure_graph(h, span)) return 1;
+                for (; left >= span; left -= span) if (pass == 1) CTTS_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+            }
         }
         if (pass == 1) { (void)advance_rows(h, launched - h->launched); h->launched = launched; }
     }

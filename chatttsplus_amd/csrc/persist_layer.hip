@@ -663,16 +663,22 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
     float* const qs = att_s;
     float* const ks = att_s + 64;
     float* const vs = att_s + 128;
-    float* const merge = att_s + 192;                         // [8 waves][8 subs][10]
+    float* const mo = att_s + 192;                            // [8 waves][64]: the waves' unnormalised outputs, one dim per lane
+    float* const mm = mo + 512;                               // [8] the waves' maxima
+    float* const ml = mm + 8;                                 // [8] the waves' sums
     const size_t kv_per = a.kv_per;
     if (wave < 8) {
+        // Round 5 layout: the scores come from K rows held 8 dims per lane (key group = lane / 8, a 3-step DPP sum per key), the output from V rows held ONE DIM PER
+        // LANE (8 keys x PRE registers): a key's weight reaches all lanes through v_readlane and the wave's output is one register per lane -- no cross-lane sums of
+        // 9 values over the key groups (27 ds_bpermute round trips: 0.44 us of the 1.9 us phase, profiles/r05_persist_attention_fine_marks.jsonl).
         const RowMeta m = a.meta[r];
         const int kvc = (m.slot - m.kv_start + S - 1) / S;      // cached keys [kv_start, slot) in S shares; this step's key / value arrive with the query
         const int kv0 = m.kv_start + sp * kvc, kv1 = min(kv0 + kvc, m.slot);
         const int grp = lane >> 3, sub = lane & 7;
-        const size_t head_off = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM + 8 * sub;
+        const size_t head_base = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM;
         constexpr int PRE = 6;                                // iterations requested before the query exists: 8 waves x 8 keys x 6 = 384 keys
-        PlKV<WT> kf[PRE], vf[PRE];
+        PlKV<WT> kf[PRE];
+        WT vv[PRE][8];
         bool ok[PRE];
         bool any_ok[PRE];
 #pragma unroll
@@ -681,17 +687,20 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
             ok[u] = p < kv1;
             any_ok[u] = kv0 + 8 * (wave + 8 * u) < kv1;       // wave-uniform: some lane group of this wave has a key in iteration u
         }
-#define PL_LOAD_KV(l_) do { const WT* const kb_ = (const WT*)a.kv + (size_t)(l_) * 2 * kv_per + head_off; const WT* const vb_ = kb_ + kv_per; \
-        _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p_ = kv0 + 8 * (wave + 8 * u) + grp; const int pc_ = ok[u] ? p_ : m.kv_start; \
-            kf[u].load(kb_ + (size_t)pc_ * CTTS_HEAD_DIM); vf[u].load(vb_ + (size_t)pc_ * CTTS_HEAD_DIM); } } while (0)
+#define PL_LOAD_KV(l_) do { const WT* const kb_ = (const WT*)a.kv + (size_t)(l_) * 2 * kv_per + head_base; const WT* const vb_ = kb_ + kv_per + lane; \
+        _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p0_ = kv0 + 8 * (wave + 8 * u); const int pc_ = ok[u] ? p0_ + grp : m.kv_start; \
+            kf[u].load(kb_ + (size_t)pc_ * CTTS_HEAD_DIM + 8 * sub); \
+            _Pragma("unroll") for (int g = 0; g < 8; ++g) vv[u][g] = vb_[(size_t)min(p0_ + g, kv1 - 1) * CTTS_HEAD_DIM]; } } while (0)
         PL_LOAD_KV(0);
         __builtin_amdgcn_sched_barrier(0);
         if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
         __syncthreads();                                      // S0
         for (int l = 0; l < NL; ++l) {
-            const WT* const kb = (const WT*)a.kv + (size_t)l * 2 * kv_per + head_off;
-            const WT* const vb = kb + kv_per;
+            const WT* const kb = (const WT*)a.kv + (size_t)l * 2 * kv_per + head_base + 8 * sub;
+            const WT* const vb = (const WT*)a.kv + (size_t)l * 2 * kv_per + kv_per + head_base + lane;
             __syncthreads();                                  // B1: q (x 1/8), k_new, v_new in LDS
+#define PL_AMARK(i) do { if (a.ts != nullptr && l + 1 == NL && tid == 0) a.ts[(size_t)b * 10 + (i)] = wall_clock64(); } while (0)
+            PL_AMARK(3);
             const f32x4 q0 = *(const f32x4*)(qs + 8 * sub), q1 = *(const f32x4*)(qs + 8 * sub + 4);
             // two passes over the keys held in registers: scores -> the wave's maximum -> ONE exponential per key (no running rescale)
             float sc[PRE];
@@ -710,30 +719,30 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 }
             }
             float mrun = wave_max(mw);                        // the same in every lane (-inf: this wave holds no key)
-            float lrun = 0.f, o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+            PL_AMARK(4);
+            float lrun = 0.f, o = 0.f;                        // lrun: the weights of this lane's key group; o: dim `lane` of the wave's output
 #pragma unroll
             for (int u = 0; u < PRE; ++u) {
                 if (any_ok[u]) {
                     const float pe = (sc[u] == -INFINITY) ? 0.f : expf(sc[u] - mrun);
                     lrun += pe;
-                    o[0] += pe * vf[u].at(0); o[1] += pe * vf[u].at(1); o[2] += pe * vf[u].at(2); o[3] += pe * vf[u].at(3);
-                    o[4] += pe * vf[u].at(4); o[5] += pe * vf[u].at(5); o[6] += pe * vf[u].at(6); o[7] += pe * vf[u].at(7);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) o = fmaf(readlane_f(pe, 8 * g), (float)vv[u][g], o);
                 }
             }
-            // Shares beyond the PRE * 64 prefetched keys stream behind the query, UNS steps of 64 keys per round trip (round 5: one step per round trip cost 0.6 us per
-            // 64 keys and layer and sent 3-4-row batches beyond 1024 keys back to the launch chain).  The steps themselves, and their order, are unchanged.
+            // Shares beyond the PRE * 64 prefetched keys stream behind the query, UNS steps of 64 keys per round trip
             constexpr int UNS = 4;
             for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64 * UNS) {       // (wave-uniform bound)
-                PlKV<WT> ks_[UNS], vs_[UNS];
+                PlKV<WT> ks_[UNS];
+                WT vs_[UNS][8];
                 bool live_[UNS];
 #pragma unroll
                 for (int u = 0; u < UNS; ++u) {
-                    const int p = wb0 + 64 * u + grp;
-                    live_[u] = p < kv1;
-                    const int pc = live_[u] ? p : m.kv_start;
-                    ks_[u].load(kb + (size_t)pc * CTTS_HEAD_DIM); vs_[u].load(vb + (size_t)pc * CTTS_HEAD_DIM);
+                    const int p0 = wb0 + 64 * u;
+                    live_[u] = p0 + grp < kv1;
+                    ks_[u].load(kb + (size_t)(live_[u] ? p0 + grp : m.kv_start) * CTTS_HEAD_DIM);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) vs_[u][g] = vb[(size_t)min(p0 + g, kv1 - 1) * CTTS_HEAD_DIM];      // (a key past the share: weight 0, any valid row will do)
                 }
 #pragma unroll
                 for (int u = 0; u < UNS; ++u) {
@@ -747,27 +756,20 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     const float scl = pl_exp_diff(mrun, mn);
                     const float pe = live ? expf(dot - mn) : 0.f;
                     lrun = lrun * scl + pe;
-                    o[0] = o[0] * scl + pe * vs_[u].at(0); o[1] = o[1] * scl + pe * vs_[u].at(1); o[2] = o[2] * scl + pe * vs_[u].at(2); o[3] = o[3] * scl + pe * vs_[u].at(3);
-                    o[4] = o[4] * scl + pe * vs_[u].at(4); o[5] = o[5] * scl + pe * vs_[u].at(5); o[6] = o[6] * scl + pe * vs_[u].at(6); o[7] = o[7] * scl + pe * vs_[u].at(7);
+                    o *= scl;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) o = fmaf(readlane_f(pe, 8 * g), (float)vs_[u][g], o);
                     mrun = mn;
                 }
             }
-            // the 8 key groups of the wave share mrun: plain sums over the lanes with equal `sub`
-#pragma unroll
-            for (int off = 8; off < 64; off <<= 1) {
-                lrun += __shfl_xor(lrun, off);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
-            }
-            if (grp == 0) {
-                float* mg = merge + (wave * 8 + sub) * 10;
-                mg[0] = mrun; mg[1] = lrun;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) mg[2 + j] = o[j];
-            }
+            PL_AMARK(5);
+            const float lw = wave_sum(lrun) * 0.125f;         // (the 8 lanes of a key group hold the same weights)
+            mo[wave * 64 + lane] = o;
+            if (lane == 0) { mm[wave] = mrun; ml[wave] = lw; }
+            PL_AMARK(6);
+            __syncthreads();                                  // B2
             if (l + 1 < NL) PL_LOAD_KV(l + 1);                // the next layer's cached rows: a whole layer ahead of its query
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                                  // B2
         }
     } else if (wave == 8) {
         if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
@@ -786,19 +788,17 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
             // this step's own key (slot `m.slot`, the causal end of the row: llama.py:1073-1087): its score, on all 64 lanes (split 0 merges it)
             const float dnew = wave_sum(qs[lane] * ks[lane]);
             __syncthreads();                                  // B2
-            // lane = output dim: combine the 8 waves' partials
-            const int sub = lane >> 3, j = lane & 7;
-            float mwv[8], M = (sp == 0) ? dnew : -INFINITY;
+            if (a.ts != nullptr && l + 1 == NL && lane == 0) a.ts[(size_t)b * 10 + 7] = wall_clock64();
+            // lane = output dim: combine the 8 waves' partials.  The 9 rescale factors (8 waves + this step's own key) are computed side by side in lanes 0..8
+            const float mmv = mm[lane & 7], mlv = ml[lane & 7];
+            const float mj = (lane < 8) ? mmv : ((lane == 8 && sp == 0) ? dnew : -INFINITY);
+            const float lj = (lane < 8) ? mlv : ((lane == 8) ? 1.f : 0.f);
+            float M = wave_max(mj);
+            const float sj = pl_exp_diff(mj, M);
+            float L = wave_sum(sj * lj);
+            float O = readlane_f(sj, 8) * vs[lane];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) { mwv[w] = merge[(w * 8 + sub) * 10]; M = fmaxf(M, mwv[w]); }
-            const float pe = (sp == 0) ? expf(dnew - M) : 0.f;
-            float L = pe, O = pe * vs[lane];
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const float sw = pl_exp_diff(mwv[w], M);
-                L += merge[(w * 8 + sub) * 10 + 1] * sw;
-                O += merge[(w * 8 + sub) * 10 + 2 + j] * sw;
-            }
+            for (int w = 0; w < 8; ++w) O = fmaf(readlane_f(sj, w), mo[w * 64 + lane], O);
             if (S > 1 && sp != 0) {
                 // a share's partial: [max, sum, o[64]] (an empty share publishes max = -inf, sum = 0)
                 u64* const gp = a.g_part + (size_t)(rh * S + sp) * 66;

@@ -78,6 +78,7 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 9; 0 = never)
  *   "nbg2_rows"           decode batches of >= this many rows use 32-row blocks instead of 16-row chunks (default 81 fp32 / 57 fp16)
  *   "graph_steps"         decode steps captured per hipGraph (default 4)
+ *   "graph_steps_persistent"  ... per hipGraph of the persistent paths, whose step is 2 launches (default 16; shorter remainders use "graph_steps")
  *   "lora_fold"           per-utterance adapters at decode: 1 (default) = the rows' low-rank terms come from worker workgroups inside the QKV / o_proj launches
  *                         (lora_worker.h), 0 = two more launches per layer (lora.hip; the prompt pass always uses those)
  *   "persistent_fault"    test hook: one workgroup withholds a hand-off in layer value - 1 (the bounded waits must end the step with an error)

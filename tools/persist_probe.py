@@ -27,6 +27,8 @@ from chatttsplus_amd.hip_models.gpt import GPT, rope_table  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--skip-times", action="store_true")
 ap.add_argument("--skip-layer", action="store_true")
+ap.add_argument("--skip-checks", action="store_true")
+ap.add_argument("--marks-prompt", type=int, default=48)
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
@@ -138,7 +140,7 @@ if not args.skip_layer:
 
 # ---- 2. twenty layers, launch path vs persistent layers -----------------------------------------------------------------------------------
 g, _ = make(20, 4, 1400)
-for (B, P, N, pad) in ((1, 48, 64, None), (2, 40, 48, [0, 9]), (3, 33, 40, [0, 5, 17]), (4, 48, 40, [3, 0, 11, 20]), (1, 600, 24, None), (1, 1000, 48, None)):
+for (B, P, N, pad) in (() if args.skip_checks else ((1, 48, 64, None), (2, 40, 48, [0, 9]), (3, 33, 40, [0, 5, 17]), (4, 48, 40, [3, 0, 11, 20]), (1, 600, 24, None), (1, 1000, 48, None))):
     a_ids, a_hid, _ = gen(g, B, P, N, persist=0, pad_left=pad)
     b_ids, b_hid, _ = gen(g, B, P, N, persist=4, pad_left=pad)
     same = all(torch.equal(x, y) for x, y in zip(a_ids, b_ids))
@@ -164,12 +166,15 @@ if not args.skip_times:
         out(check="step_time_ms", B=B, **{k: {"median": round(statistics.median(t), 5), "min": round(min(t), 5)} for k, t in times.items()},
             ratio_one_launch=round(statistics.median(times["persistent_one_launch"]) / statistics.median(times["launches"]), 4))
 
-    # ---- 4. per-edge prices from the phase marks of the LAST layer of one launch (eager launches) -------------------------------------------
+# ---- 4. per-edge prices from the phase marks of the LAST layer of one launch (eager launches) -------------------------------------------
+if True:
+    spk = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
+    leg = bench.Leg(g, dev, 0, 1)
     g.set_option("persistent_rows", 4)
     g.set_option("persistent_timestamps", 1)
     for B in (1, 2, 3, 4):
         for rep in range(4):
-            leg.run(B, 48, 4, 4, spk=spk, use_graph=0, gen_tokens=0)
+            leg.run(B, args.marks_prompt, 4, 4, spk=spk, use_graph=0, gen_tokens=0)
             ts = debug_read(g, "pl_ts", 256 * 10 * 8).view(np.uint64).reshape(256, 10).astype(np.float64) * 0.01        # us
         gem, att = ts[:192], ts[192:192 + 12 * B, :3]
         t0 = min(gem[:, 0].min(), att[:, 0].min())
@@ -177,6 +182,9 @@ if not args.skip_times:
         med = {n: round(float(np.median(gem[:, i] - t0)), 2) for i, n in enumerate(names)}
         mx = {n: round(float((gem[:, i] - t0).max()), 2) for i, n in enumerate(names)}
         amed = {n: round(float(np.median(att[:, i] - t0)), 2) for i, n in enumerate(["start", "qkv_gathered", "attention_published"])}
+        fine = ts[192:192 + 12 * B]
+        out(check="attention_phase_fine_marks_us", B=B, since_qkv_gathered={n: round(float(np.median(fine[:, i] - fine[:, 1])), 2) for n, i in
+            (("b1_passed_wave0", 3), ("scores_and_max", 4), ("exp_pv", 5), ("cross_lane_sums", 6), ("b2_passed_wave8", 7), ("published", 2))})
         out(check="phase_marks_us_last_layer", B=B, layers_in_launch=20, gemv_median=med, gemv_max=mx, attention_median=amed,
             edges_us={"entry_to_first_barrier": med["x_loaded"], "mean_layer": round((med["end"] - med["x_loaded"]) / 20.0, 3),
                       "qkv_phase": round(med["qkv_published"] - med["x_gathered"], 2), "qkv_edge": round(amed["qkv_gathered"] - med["qkv_published"], 2),
