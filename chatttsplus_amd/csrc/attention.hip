@@ -31,8 +31,119 @@ template <> struct KvLoad<float> {
 
 __device__ inline float safe_exp_diff(float m, float mn) { return (m == -INFINITY) ? 0.f : expf(m - mn); }
 
+// Round 5 layout (first used by the persistent launch's attention workgroups, persist_layer.hip): the scores come from K rows held 8 dims per lane (key group = lane / 8,
+// a 3-step DPP sum per key), the output from V rows held ONE DIM PER LANE: a key's weight reaches all lanes through v_readlane, the wave's output is one register per
+// lane, and the wave rescales once per iteration of 8 * UN keys (one wave-wide maximum) instead of once per key and lane.  The former layout kept 8 output dims per lane
+// and key group and merged the 8 groups at the end with 3 rounds of 10 ds_bpermute + 2 exp each, then the waves one after the other on 8 threads.
 template <typename WT, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const int* done_p, const RowMeta* meta_p, const float* q_p, const void* k_p, const void* v_p,
+                                                            const int NHp, const int Sp, const AttnArgs a) {
+    // leading scalars = what the first loads need; preloaded into SGPRs at wave launch (see skinny_gemm.hip)
+    int done_v = 0;                                   // requested with the first operand loads, tested once they are in flight (common.h)
+    if (done_p != nullptr) done_v = vload_flag(done_p);
+    constexpr int UN = 4;                             // keys per lane group and loop iteration (loads in flight: 2 * UN * 16 B per lane; 8 measured slower)
+    __shared__ float mo[NW][64];
+    __shared__ float mm[NW], ml[NW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform on purpose: the V rows' addresses are then scalar base + lane, not 64-bit vector arithmetic per key)
+    const int grp = lane >> 3, sub = lane & 7;
+    const int r = blockIdx.x / NHp, h = blockIdx.x % NHp, s = blockIdx.y;
+    const RowMeta m = meta_p[r];
+    const int kv0 = m.kv_start, kv1 = m.slot + 1;
+    const int nsplit = Sp;
+    const int chunk = (kv1 - kv0 + nsplit - 1) / nsplit;
+    const int p0 = kv0 + s * chunk;
+    const int p1 = min(p0 + chunk, kv1);
+
+    float q[8];
+    {
+        const float* qp = q_p + ((size_t)r * NHp + h) * CTTS_HEAD_DIM + 8 * sub;
+        const f32x4 q0 = *(const f32x4*)qp, q1 = *(const f32x4*)(qp + 4);
+        q[0] = q0[0] * 0.125f; q[1] = q0[1] * 0.125f; q[2] = q0[2] * 0.125f; q[3] = q0[3] * 0.125f;
+        q[4] = q1[0] * 0.125f; q[5] = q1[1] * 0.125f; q[6] = q1[2] * 0.125f; q[7] = q1[3] * 0.125f;
+    }
+    if (__builtin_amdgcn_readfirstlane(done_v)) return;   // every sequence finished: skip on device
+    const size_t head_base = ((size_t)m.seq * NHp + h) * a.Lmax * CTTS_HEAD_DIM;
+    const WT* kb = (const WT*)k_p + head_base + 8 * sub;
+    const WT* vb = (const WT*)v_p + head_base + lane;
+
+    float mrun = -INFINITY, lrun = 0.f;               // the wave's running maximum (the same in every lane); the weights of this lane's key group
+    float oa[4] = {0.f, 0.f, 0.f, 0.f};               // dim `lane` of the output, as four partial sums (keys g, g + 4 of every group of 8: four independent FMA chains)
+
+    // wave w, lane-group g handle keys p0 + 8*(NW*it + w) + g; the loop bound is wave-uniform (cross-lane ops inside)
+    for (int wb = p0 + 8 * wave; wb < p1; wb += 8 * NW * UN) {
+        float kf[UN][8];
+        typename KvElem<WT>::reg vv[UN][8];
+        bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int pb = wb + 8 * NW * u;           // first key of the wave's group of 8
+            ok[u] = pb + grp < p1;
+            KvLoad<WT>::load8(kb + (size_t)(ok[u] ? pb + grp : kv0) * CTTS_HEAD_DIM, kf[u]);       // clamp: always a valid address
+#pragma unroll
+            for (int g = 0; g < 8; ++g) vv[u][g] = KvElem<WT>::load(vb + (size_t)min(pb + g, p1 - 1) * CTTS_HEAD_DIM);     // (a key past the share has weight 0: any valid row will do)
+        }
+        float sc[UN], mloc = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += q[j] * kf[u][j];
+            dot += dpp_f<DPP_XOR1>(dot);                    // 8-lane group sum on DPP (quad xor1, xor2, half-mirror)
+            dot += dpp_f<DPP_XOR2>(dot);
+            dot += dpp_f<DPP_HALF_MIRROR>(dot);
+            sc[u] = ok[u] ? dot : -INFINITY;
+            mloc = fmaxf(mloc, sc[u]);
+        }
+        const float mn = wave_max(fmaxf(mrun, mloc));       // finite: the iteration holds at least one key (wb < p1)
+        const float scl = safe_exp_diff(mrun, mn);
+        lrun *= scl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oa[i] *= scl;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (wb + 8 * NW * u >= p1) break;               // (wave-uniform: no key of the wave in this group)
+            const float pe = (sc[u] == -INFINITY) ? 0.f : expf(sc[u] - mn);
+            lrun += pe;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) oa[g & 3] = fmaf(readlane_f(pe, 8 * g), KvElem<WT>::f(vv[u][g]), oa[g & 3]);
+        }
+        mrun = mn;
+    }
+    const float lw = wave_sum(lrun) * 0.125f;               // (the 8 lanes of a key group hold the same weights)
+    mo[wave][lane] = (oa[0] + oa[1]) + (oa[2] + oa[3]);
+    if (lane == 0) { mm[wave] = mrun; ml[wave] = lw; }
+    __syncthreads();
+    if (tid < 64) {
+        // lane = output dim; the waves' rescale factors side by side in lanes 0..NW-1
+        const float mmv = mm[lane % NW], mlv = ml[lane % NW];
+        const float mj = (lane < NW) ? mmv : -INFINITY, lj = (lane < NW) ? mlv : 0.f;
+        const float M = wave_max(mj);
+        const float sj = safe_exp_diff(mj, M);
+        const float L = wave_sum(sj * lj);
+        float O = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) O = fmaf(readlane_f(sj, w), mo[w][lane], O);
+        if (a.packed_out != nullptr) {
+            // single split: finish the softmax here and hand the o_proj kernel a ready MFMA B operand (no combine prologue)
+            const float inv = 1.0f / L;
+            const int NBr = 16 * a.nbg, K = a.NH * CTTS_HEAD_DIM, kt = K / WTraits<WT>::KT;
+            const int chunk = r / NBr, n = r % NBr, k = h * CTTS_HEAD_DIM + lane;
+            WT* dst = (WT*)a.packed_out + (size_t)chunk * a.nbg * kt * 64 * WTraits<WT>::EPL;
+            dst[xfrag_index<WT>(n, k, kt)] = (WT)(O * inv);
+            return;
+        }
+        const size_t pi = ((size_t)r * a.NH + h) * a.S + s;
+        if (lane == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = L; }
+        a.part_o[pi * CTTS_HEAD_DIM + lane] = O;
+    }
+}
+
+// The former layout (rounds 1-4): 8 output dims per lane and key group, a rescale per key and lane, the 8 groups merged at the end through ds_bpermute.  Kept for fp16
+// engines once there is a block per CU: there a V row is 128 bytes and one-dim-per-lane loads move 2 bytes per lane and instruction (ms/step at batch 32, fp16,
+// this / the layout above: 0.587 / 0.628; below that the layout above wins: batch 5 0.445 / 0.431, 16 0.499 / 0.489).
+template <typename WT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_g8_kernel(const int* done_p, const RowMeta* meta_p, const float* q_p, const void* k_p, const void* v_p,
                                                             const int NHp, const int Sp, const AttnArgs a) {
     // leading scalars = what the first loads need; preloaded into SGPRs at wave launch (see skinny_gemm.hip)
     int done_v = 0;                                   // requested with the first operand loads, tested once they are in flight (common.h)
@@ -314,7 +425,10 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     } else if (wide) {
         if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
         else hipLaunchKernelGGL((attn_decode_kernel<float, 8>), grid, dim3(512), 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
-    } else if (dtype == 1) hipLaunchKernelGGL((attn_decode_kernel<half_t, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+    } else if (dtype == 1) {
+        if (a.S == 1 && a.st != nullptr) hipLaunchKernelGGL((attn_decode_g8_kernel<half_t, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<half_t, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
+    }
     else hipLaunchKernelGGL((attn_decode_kernel<float, 4>), grid, block, 0, s, done_p, a.meta, a.q, a.k_cache, a.v_cache, a.NH, a.S, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;

@@ -87,6 +87,20 @@ template <typename WT> __device__ inline WT sat_store(float v, int* sat);
 template <> __device__ inline half_t sat_store<half_t>(float v, int* sat) { return sat_half(v, sat); }
 template <> __device__ inline float sat_store<float>(float v, int*) { return v; }
 
+// One cache element held in a register of its own (a V row one dim per lane: attention.hip, persist_layer.hip).  A half is loaded as a zero-extended 16-bit word into a
+// full register: a plain `half` load is a d16 load that keeps the register's other half, i.e. depends on whatever wrote that register before.
+template <typename WT> struct KvElem;
+template <> struct KvElem<float> {
+    typedef float reg;
+    __device__ static inline reg load(const float* p) { return *p; }
+    __device__ static inline float f(reg v) { return v; }
+};
+template <> struct KvElem<half_t> {
+    typedef unsigned reg;
+    __device__ static inline reg load(const half_t* p) { return (unsigned)*(const unsigned short*)p; }
+    __device__ static inline float f(reg v) { return (float)__builtin_bit_cast(half_t, (unsigned short)v); }
+};
+
 // ---- wave64 reductions on DPP (no LDS crossbar): 4 intra-row steps (quad xor1, quad xor2, half-mirror, mirror)
 // leave the 16-lane row result in every lane; the 4 rows are combined through v_readlane.  ~10x cheaper than a
 // 6-step ds_bpermute butterfly (the sampler's 20+ dependent arg-max rounds were 30 us with __shfl_xor).

@@ -142,7 +142,10 @@ struct ctts_gpt {
     // stores are visible fails and costs a whole extra pass, and its loads sit in the queues of the very stores it waits for.  us/step at batch 1 with all three at
     // 0 / 6 / 10 / 14 / 18 / 24 / 32: 334.9 / 307.6 / 288.8 / 281.6 / 286.5 / 295.9 / 316.3; batch 2 at 0 / 12: 402.3 / 346.9; batch 4: 521.2 / 467.4.
     // One at a time around 14 each curve is flat from 11 to 17 (profiles/r04_ab_persist_options.jsonl).  The attention edge needs none (its wait is long).
-    int persist_delay_att = 0, persist_delay = 12, persist_delay_act = 16, persist_delay_x = 15, persist_nap = 1, persist_nap_qkv = 1;
+    // Round 5, after the attention workgroups' phase went from 1.9 to 1.25 us (tools/sweep_persist_delays.sh, ms/step at batch 1 | 4): attention edge 0 / 4 / 8:
+    // 0.2457 / 0.2456 / 0.2456 | 0.4088 / 0.4044 / 0.4033; act edge 12 / 14 / 16 / 18 / 20: 0.2409 / 0.2402 / 0.2425 / 0.2430 / 0.2436 | 0.4165 / 0.4136 / 0.4125 /
+    // 0.4117 / 0.4113 -> 14 + 2 per further row; the other two stayed where they were (10-12 and 13-15).
+    int persist_delay_att = 8, persist_delay = 12, persist_delay_act = 14, persist_delay_x = 15, persist_nap = 1, persist_nap_qkv = 1;
     int persist_poll = -1;                       //   PersistArgs.poll; -1 = by row count: the sentinel pass costs one serial poll at 1-2 rows (batch 1 379.2 -> 387.1 us,
                                                  //   batch 2 430.7 -> 437.8) and pays from 3 rows on, where a full sweep re-reads up to 96 granules per lane (batch 4 547.5 -> 537.6)
     // fp32 engines, pm_rows_min..pm_rows_max decode rows: the decoder stack of a step is ONE persistent launch with MFMA projections (persist_mfma.hip), reading
@@ -959,7 +962,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
             pa.kv = kv_layer(h, l, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
             pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1; pa.g_x = pa.g_act + PL_G_ACT; pa.g_part = pa.g_x + PL_G_X; pa.S = h->cur_persist;
-            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched; pa.pace = h->persist_pace; pa.fault = h->persist_fault; pa.delay_att = h->persist_delay_att; pa.delay = h->persist_delay; pa.delay_act = h->persist_delay_act; pa.delay_x = h->persist_delay_x; pa.nap = h->persist_nap; pa.nap_qkv = h->persist_nap_qkv; pa.poll = (h->persist_poll < 0) ? 0 : h->persist_poll;
+            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched; pa.pace = h->persist_pace; pa.fault = h->persist_fault; pa.delay_att = h->persist_delay_att; pa.delay = h->persist_delay; pa.delay_act = h->persist_delay_act + 2 * (R - 1); pa.delay_x = h->persist_delay_x; pa.nap = h->persist_nap; pa.nap_qkv = h->persist_nap_qkv; pa.poll = (h->persist_poll < 0) ? 0 : h->persist_poll;
             if (launch_persist_layer(R, pa, s)) return 1;
         }
         return 0;

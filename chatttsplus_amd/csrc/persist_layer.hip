@@ -678,7 +678,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
         const size_t head_base = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM;
         constexpr int PRE = 6;                                // iterations requested before the query exists: 8 waves x 8 keys x 6 = 384 keys
         PlKV<WT> kf[PRE];
-        WT vv[PRE][8];
+        typename KvElem<WT>::reg vv[PRE][8];
         bool ok[PRE];
         bool any_ok[PRE];
 #pragma unroll
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
 #define PL_LOAD_KV(l_) do { const WT* const kb_ = (const WT*)a.kv + (size_t)(l_) * 2 * kv_per + head_base; const WT* const vb_ = kb_ + kv_per + lane; \
         _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p0_ = kv0 + 8 * (wave + 8 * u); const int pc_ = ok[u] ? p0_ + grp : m.kv_start; \
             kf[u].load(kb_ + (size_t)pc_ * CTTS_HEAD_DIM + 8 * sub); \
-            _Pragma("unroll") for (int g = 0; g < 8; ++g) vv[u][g] = vb_[(size_t)min(p0_ + g, kv1 - 1) * CTTS_HEAD_DIM]; } } while (0)
+            _Pragma("unroll") for (int g = 0; g < 8; ++g) vv[u][g] = KvElem<WT>::load(vb_ + (size_t)min(p0_ + g, kv1 - 1) * CTTS_HEAD_DIM); } } while (0)
         PL_LOAD_KV(0);
         __builtin_amdgcn_sched_barrier(0);
         if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
@@ -720,21 +720,22 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
             }
             float mrun = wave_max(mw);                        // the same in every lane (-inf: this wave holds no key)
             PL_AMARK(4);
-            float lrun = 0.f, o = 0.f;                        // lrun: the weights of this lane's key group; o: dim `lane` of the wave's output
+            float lrun = 0.f;                                 // the weights of this lane's key group
+            float oa[4] = {0.f, 0.f, 0.f, 0.f};               // dim `lane` of the wave's output as four partial sums (four independent FMA chains instead of one of 8 per iteration)
 #pragma unroll
             for (int u = 0; u < PRE; ++u) {
                 if (any_ok[u]) {
                     const float pe = (sc[u] == -INFINITY) ? 0.f : expf(sc[u] - mrun);
                     lrun += pe;
 #pragma unroll
-                    for (int g = 0; g < 8; ++g) o = fmaf(readlane_f(pe, 8 * g), (float)vv[u][g], o);
+                    for (int g = 0; g < 8; ++g) oa[g & 3] = fmaf(readlane_f(pe, 8 * g), KvElem<WT>::f(vv[u][g]), oa[g & 3]);
                 }
             }
             // Shares beyond the PRE * 64 prefetched keys stream behind the query, UNS steps of 64 keys per round trip
             constexpr int UNS = 4;
             for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64 * UNS) {       // (wave-uniform bound)
                 PlKV<WT> ks_[UNS];
-                WT vs_[UNS][8];
+                typename KvElem<WT>::reg vs_[UNS][8];
                 bool live_[UNS];
 #pragma unroll
                 for (int u = 0; u < UNS; ++u) {
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     live_[u] = p0 + grp < kv1;
                     ks_[u].load(kb + (size_t)(live_[u] ? p0 + grp : m.kv_start) * CTTS_HEAD_DIM);
 #pragma unroll
-                    for (int g = 0; g < 8; ++g) vs_[u][g] = vb[(size_t)min(p0 + g, kv1 - 1) * CTTS_HEAD_DIM];      // (a key past the share: weight 0, any valid row will do)
+                    for (int g = 0; g < 8; ++g) vs_[u][g] = KvElem<WT>::load(vb + (size_t)min(p0 + g, kv1 - 1) * CTTS_HEAD_DIM);      // (a key past the share: weight 0, any valid row will do)
                 }
 #pragma unroll
                 for (int u = 0; u < UNS; ++u) {
@@ -756,15 +757,16 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     const float scl = pl_exp_diff(mrun, mn);
                     const float pe = live ? expf(dot - mn) : 0.f;
                     lrun = lrun * scl + pe;
-                    o *= scl;
 #pragma unroll
-                    for (int g = 0; g < 8; ++g) o = fmaf(readlane_f(pe, 8 * g), (float)vs_[u][g], o);
+                    for (int i = 0; i < 4; ++i) oa[i] *= scl;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) oa[g & 3] = fmaf(readlane_f(pe, 8 * g), KvElem<WT>::f(vs_[u][g]), oa[g & 3]);
                     mrun = mn;
                 }
             }
             PL_AMARK(5);
             const float lw = wave_sum(lrun) * 0.125f;         // (the 8 lanes of a key group hold the same weights)
-            mo[wave * 64 + lane] = o;
+            mo[wave * 64 + lane] = (oa[0] + oa[1]) + (oa[2] + oa[3]);
             if (lane == 0) { mm[wave] = mrun; ml[wave] = lw; }
             PL_AMARK(6);
             __syncthreads();                                  // B2

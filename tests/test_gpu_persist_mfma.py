@@ -52,7 +52,8 @@ def test_mfma_stack_is_opt_in_and_matches_the_launch_chain(gpt):
             for b in range(B):
                 assert torch.equal(ids[b], ref_ids[b]), f"B={B} P={P}: row {b} tokens differ from the launch chain"
                 assert float((hid[b] - ref_h[b]).abs().max()) <= 5e-5, (B, P, b)
-            assert all(torch.equal(hid[b][0], ref_h[b][0]) for b in range(B)) or B < 22, "first step: same sums in the same order from 22 rows on (4-wave attention blocks on both paths)"
+            # (until the launch chain's attention kernel changed its summation order in round 5 -- V one dim per lane, one rescale per 32 keys -- the first step was
+            #  bitwise equal from 22 rows on; the engine keeps the former order, the 5e-5 bound above is the contract)
     finally:
         g.set_option("mfma_rows", 0); g.set_option("split_rows", 8); g.set_option("down_splitk_rows", 9)
 
