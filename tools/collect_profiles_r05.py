@@ -12,7 +12,8 @@ pairs = {"bench_b1_fp32.json": "r05_bench_b1_fp32.json", "bench_b1_fp32_steps20.
          "b1_fp32_kernel_stats.csv": "r05_b1_fp32_kernel_stats.csv", "b32_fp32_kernel_stats.csv": "r05_b32_fp32_kernel_stats.csv",
          "b32pm_fp32_kernel_stats.csv": "r05_b32_fp32_persistent_mfma_kernel_stats.csv", "step_time_vs_batch_fp32.jsonl": "r05_step_time_vs_batch_fp32.jsonl",
          "pm_probe.jsonl": "r05_pm_probe_final.jsonl", "ab_persistent_heads.jsonl": "r05_ab_persistent_heads.jsonl", "fp16_persist_probe.jsonl": "r05_fp16_persist_probe.jsonl",
-         "long_ctx_probe.jsonl": "r05_ab_persist_long_context.jsonl", "pm_soak.json": "r05_pm_soak.json", "prefill_32x512_fp32.log": "r05_prefill_32x512_fp32_ms.log"}
+         "long_ctx_probe.jsonl": "r05_ab_persist_long_context.jsonl", "persist_probe.jsonl": "r05_persist_probe.jsonl", "trace_gaps_b1.json": "r05_trace_gaps_b1.json",
+         "persist_attention_fine_marks_ctx300.jsonl": "r05_persist_attention_fine_marks_ctx300.jsonl", "step_time_vs_batch_fp16.jsonl": "r05_step_time_vs_batch_fp16.jsonl", "pm_soak.json": "r05_pm_soak.json", "prefill_32x512_fp32.log": "r05_prefill_32x512_fp32_ms.log"}
 for src, dst in pairs.items():
     sp = os.path.join(F, src)
     if os.path.exists(sp) and os.path.getsize(sp) > 0:

@@ -22,11 +22,15 @@ timeout 300 python tools/fp16_persist_probe.py > $O/fp16_persist_probe.jsonl 2>/
 timeout 300 python tools/long_ctx_probe.py > $O/long_ctx_probe.jsonl 2>/dev/null
 timeout 300 python tools/persist_soak.py --mfma --requests 16 --tokens 400 > $O/pm_soak.json 2>/dev/null; cat $O/pm_soak.json
 timeout 300 python tools/prefill_probe.py 32 512 fp32 > $O/prefill_32x512_fp32.log 2>/dev/null; tail -1 $O/prefill_32x512_fp32.log
+timeout 300 python tools/persist_probe.py --skip-layer > $O/persist_probe.jsonl 2>/dev/null; grep -c ids_identical $O/persist_probe.jsonl
+timeout 300 python tools/persist_probe.py --skip-layer --skip-times --skip-checks --marks-prompt 300 2>/dev/null | grep fine > $O/persist_attention_fine_marks_ctx300.jsonl
+timeout 300 python tools/tb_curve.py fp16 1 2 3 4 5 8 16 24 32 > $O/step_time_vs_batch_fp16.jsonl 2>/dev/null
 timeout 400 python tools/pm_probe.py --batches 5,8,12,16,17,24,32 --steps 16 --prompt 293 --marks 32 --time-steps 32 > $O/pm_probe.jsonl 2>/dev/null; cat $O/pm_probe.jsonl | cut -c1-400
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b1 -- python $R/bench.py --steps 128 --warmup 16 --cpu-steps 0 --no-extras > /tmp/prof_b1.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b32 -- python $R/bench.py --batch 32 --steps 64 --warmup 16 --cpu-steps 0 --no-extras > /tmp/prof_b32.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b32pm -- python $R/bench.py --batch 32 --steps 64 --warmup 16 --cpu-steps 0 --no-extras --option mfma_rows=32 > /tmp/prof_b32pm.log 2>&1
+f=$(find /tmp/prof_b1 -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && python $R/tools/trace_gaps.py $f > $O/trace_gaps_b1.json
 for t in b1 b32 b32pm; do
   f=$(find /tmp/prof_$t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${t}_fp32_kernel_stats.csv
   grep '"metric"' /tmp/prof_$t.log | cut -c1-400 > $O/${t}_prof_bench.json
