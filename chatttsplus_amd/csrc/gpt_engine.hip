@@ -116,7 +116,7 @@ struct ctts_gpt {
                                                  // an exact-f32 MFMA costs 32 cycles whatever the number of live columns, 48 of them per SIMD and launch.
                                                  // Measured (us/step, MFMA -> VALU, profiles/r04_ab_valu_rows.jsonl): batch 1 481.9 -> 450.8, 2 491.7 -> 477.5,
                                                  // 3 532.6 -> 555.9, 4 536.7 -> 560.3 (the 4-row variant re-reads four LDS operand rows per weight fragment)
-    int persist_rows = 0;                        // fp32 engines (default 4, set at create): decode batches of <= this many rows run the decoder stack as ONE persistent
+    int persist_rows = 0;                        // default PL_MAXR = 5, set at create: decode batches of <= this many rows run the decoder stack as ONE persistent
                                                  // launch (persist_layer.hip).  us/step, launch chain -> persistent (profiles/r04_ab_persist_options.jsonl):
                                                  // batch 1 452 -> 285, batch 2 480 -> 347, batch 4 540 -> 467
     bool persist_ok = false;                     //   the mode's preconditions hold and this process holds the device's lock (ensure_persist)
@@ -242,7 +242,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
     // both dtypes since round 5 (fp16 engines: half weights + half K / V in the image, fp32 activations).  fp16: up to 3 rows -- ms/step launch chain / persistent
     // (tools/fp16_persist_probe.py, two edge waves): batch 1 0.370 / 0.256, 2 0.393 / 0.319, 3 0.423 / 0.381, 4 0.427 / 0.442
-    h->persist_rows = 4;                                         // (fp16 batch 4 with four edge waves: launch chain 0.425, persistent 0.404 ms/step)
+    h->persist_rows = PL_MAXR;                                   // 5 (ms/step launch chain / persistent launch at 5 rows, fp32: 0.540 / 0.389; fp16 at 4 rows: 0.425 / 0.345)
     h->pm_rows_max = 0;                                          // opt-in: ctts_gpt_set_option("mfma_rows", 5..32)
     h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)

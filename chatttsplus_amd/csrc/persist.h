@@ -14,7 +14,7 @@
 #define PL_H 768
 #define PL_I 3072
 #define PL_NH 12
-#define PL_MAXR 4
+#define PL_MAXR 5                          // 12 heads x 5 rows = 60 of the 64 attention workgroups
 #define PL_SHARE_KEYS 384                  // cached keys a workgroup requests before the query exists; a longer share streams behind the query
 // per-workgroup weight image of one layer: 12 q|k|v rows, 4 o_proj rows, 16 gate|up pairs, 4 down rows (fp32)
 #define PL_QKV_BYTES (12 * 768 * 4)

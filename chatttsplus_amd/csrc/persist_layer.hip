@@ -103,6 +103,47 @@ template <> struct PlKV<half_t> {
 };
 __device__ inline float pl_exp_diff(float m, float mn) { return (m == -INFINITY) ? 0.f : expf(m - mn); }
 
+// ---- the compute waves' row sums, several at a time (round 5).  A wave finishes up to 16 dot products per phase (weight rows x decode rows); each was reduced by its
+// own wave_sum (4 DPP steps + 4 v_readlane + the lane-0 store: ~45 instructions, one after the other -- 16 of them were 1.4 us of the 2.5 us gate|up phase at 4 rows).
+// Here the P partial sums of a lane are reduced TOGETHER: at each of the 4 DPP steps a lane keeps one half of its values and gives the other half to its partner
+// (who keeps that half), so the work halves every step: P/2 + P/4 + ... exchanges instead of 4 P.  The partners are wave_sum's (quad xor 1, quad xor 2, half-mirror,
+// mirror) and every value is added in wave_sum's order, so the sums are bit-identical; which half a lane keeps at step s is a parity f_s of its lane bits chosen so that
+// the partners of the LATER steps hold the same values: f0 = b0^b2, f1 = b1^b2, f2 = b2^b3, f3 = b3.  After the 4 steps a lane holds the 16-lane row sum of value
+// idx = f0 P/2 + f1 P/4 + ...; the 4 rows go to LDS as red[wave][base + idx][row] and the reader adds them (r0 + r1) + (r2 + r3), again wave_sum's order.
+constexpr int pl_pow2(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 16; }
+template <int CTRL, int C> __device__ inline void pl_rs_step(float* v, bool f) {
+    if constexpr (C > 1) {
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) {
+            const float keep = f ? v[i + C / 2] : v[i];
+            const float give = f ? v[i] : v[i + C / 2];
+            v[i] = keep + dpp_f<CTRL>(give);
+        }
+    } else v[0] += dpp_f<CTRL>(v[0]);
+}
+#define PL_RED_FLOATS (8 * 32 * 4)          // [compute wave][value < 32][16-lane row]: two groups of <= 16 values per wave (gate|up: pair 0 | pair 1)
+template <int P> __device__ inline void pl_reduce_store(float (&v)[P], float* red, int wave, int lane, int base = 0) {
+    static_assert(P == 1 || P == 2 || P == 4 || P == 8 || P == 16, "pad to a power of two");
+    constexpr int C1 = P > 1 ? P / 2 : 1, C2 = P > 2 ? P / 4 : 1, C3 = P > 4 ? P / 8 : 1;
+    const bool f0 = ((lane ^ (lane >> 2)) & 1) != 0, f1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0, f2 = (((lane >> 2) ^ (lane >> 3)) & 1) != 0, f3 = ((lane >> 3) & 1) != 0;
+    pl_rs_step<DPP_XOR1, P>(v, f0);
+    pl_rs_step<DPP_XOR2, C1>(v, f1);
+    pl_rs_step<DPP_HALF_MIRROR, C2>(v, f2);
+    pl_rs_step<DPP_MIRROR, C3>(v, f3);
+    int idx = 0;
+    bool writer = true;                               // one lane per (value, row): the lanes whose unused parities are 0
+    if (P > 1) idx += f0 ? P / 2 : 0; else writer = writer && !f0;
+    if (C1 > 1) idx += f1 ? C1 / 2 : 0; else writer = writer && !f1;
+    if (C2 > 1) idx += f2 ? C2 / 2 : 0; else writer = writer && !f2;
+    if (C3 > 1) idx += f3 ? C3 / 2 : 0; else writer = writer && !f3;
+    if (writer) red[(wave * 32 + base + idx) * 4 + (lane >> 4)] = v[0];
+}
+__device__ inline float pl_red(const float* red, int wave, int n) {
+    const f32x4 p = *(const f32x4*)(red + (wave * 32 + n) * 4);
+    return (p[0] + p[1]) + (p[2] + p[3]);
+}
+#define PL_PV(N_) float pv[pl_pow2(N_)]; _Pragma("unroll") for (int n_ = 0; n_ < pl_pow2(N_); ++n_) pv[n_] = 0.f
+
 // SCHED = when a compute wave requests its weight arrays (each array is needed one phase per layer: q|k|v rows in A, o_proj rows in C, gate|up in D, down in E):
 //   1: gate|up(l) + q|k|v(l+1) when layer l's attention wait begins, down(l) + o_proj(l+1) when its (x + attention) wait begins;
 //   2: o_proj(l) + gate|up(l) at the attention wait, down(l) at the (x + attention) wait, q|k|v(l+1) at the end of the layer -- nothing is requested
@@ -118,8 +159,8 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
     constexpr size_t BLOCK_BYTES = (size_t)PL_BLOCK_BYTES / 4 * sizeof(WT), LAYER_BYTES = PL_LAYER_BYTES / 4 * sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const xs = (float*)smem;                       // activations of the current phase [R][768] ([R][3072] for the down projection)
-    float* const red = xs + R * PL_I;                     // compute waves' results [8 waves][4 slots][R]
-    float* const ssq = red + 8 * 4 * R;                   // sums of squares of the gathered rows [edge wave <= 4][R]
+    float* const red = xs + R * PL_I;                     // compute waves' results [8 waves][16 values][4 rows of 16 lanes] (pl_reduce_store / pl_red)
+    float* const ssq = red + PL_RED_FLOATS;                   // sums of squares of the gathered rows [edge wave <= 4][R]
     float* const xres = ssq + 4 * R;                      // this workgroup's 4 columns of the residual stream [R][4] (x, later x + attention, then the layer output)
     int* const abort_s = (int*)(xres + 4 * R);            // [4]: [0] give-up flag, [1] SCHED 3: gathers completed by the edge waves (2 per phase)
     float* const att_s = (float*)(abort_s + 4);           // attention workgroups: q[64] | k_new[64] | v_new[64] | merge[8][8][10]
@@ -173,7 +214,6 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 for (int l = 0; l < NL; ++l) {
                     const char* const wn = wb + LAYER_BYTES;
                     const bool more = l + 1 < NL;
-                    f32x4 xr[R][3];
                     // ---- wait for x, requesting o_proj(l); phase A
                     {
                         PL_PACE_BEGIN();
@@ -183,21 +223,22 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                         }
                         PL_PACE_END();
                     }
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
                     if (wave < 6) {
+                        PL_PV(2 * R);
 #pragma unroll
-                        for (int row = 0; row < 2; ++row)
+                        for (int r = 0; r < R; ++r) {              // (one decode row's operands at a time: R x 12 registers of activations otherwise)
+                            f32x4 xr[3];
 #pragma unroll
-                            for (int r = 0; r < R; ++r) {
+                            for (int j = 0; j < 3; ++j) xr[j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+#pragma unroll
+                            for (int row = 0; row < 2; ++row) {
                                 float acc = 0.f;
 #pragma unroll
-                                for (int j = 0; j < 3; ++j) acc = dot4(q_w[row][j], xr[r][j], acc);
-                                acc = wave_sum(acc);
-                                if (lane == 0) red[(wave * 4 + row) * R + r] = acc;
+                                for (int j = 0; j < 3; ++j) acc = dot4(q_w[row][j], xr[j], acc);
+                                pv[row * R + r] = acc;
                             }
+                        }
+                        pl_reduce_store<pl_pow2(2 * R)>(pv, red, wave, lane);
                     }
                     __syncthreads();                          // B2(A)
                     // ---- wait for the attention output, requesting gate|up(l); phase C
@@ -209,19 +250,16 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                             for (int j = 0; j < 3; ++j) PL_PIECE(g_w[s][j] = __builtin_nontemporal_load((const wfrag*)wb + og + (s * 3 + j) * 64));
                         PL_PACE_END();
                     }
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
                     if (wave < 4) {
+                        PL_PV(R);
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
                             float acc = 0.f;
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) acc = dot4(o_w[j], xr[r][j], acc);
-                            acc = wave_sum(acc);
-                            if (lane == 0) red[(wave * 4) * R + r] = acc;
+                            for (int j = 0; j < 3; ++j) acc = dot4(o_w[j], ((const f32x4*)(xs + r * PL_H))[64 * j + lane], acc);
+                            pv[r] = acc;
                         }
+                        pl_reduce_store<pl_pow2(R)>(pv, red, wave, lane);
                     }
                     __syncthreads();                          // B2(C)
                     // ---- wait for x + attention, requesting down(l); phase D
@@ -231,20 +269,46 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                         for (int j = 0; j < 6; ++j) PL_PIECE(d_w[j] = __builtin_nontemporal_load((const wfrag*)wb + od + j * 64));
                         PL_PACE_END();
                     }
+                    if constexpr (R >= 5) {
+                        // (register allocation, measured: at 5 rows this form compiles without spills and the one below with 27-55; at 4 rows it is the other way round)
+                        float pv[2][pl_pow2(2 * R)];
 #pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                        for (int n = 0; n < pl_pow2(2 * R); ++n) { pv[0][n] = 0.f; pv[1][n] = 0.f; }
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            float acc = 0.f;
+                            f32x4 xr[3];
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) acc = dot4(g_w[s][j], xr[r][j], acc);
-                            acc = wave_sum(acc);
-                            if (lane == 0) red[(wave * 4 + s) * R + r] = acc;
+                            for (int j = 0; j < 3; ++j) xr[j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                float acc = 0.f;
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) acc = dot4(g_w[s][j], xr[j], acc);
+                                pv[s >> 1][(s & 1) * R + r] = acc;
+                            }
                         }
+                        pl_reduce_store<pl_pow2(2 * R)>(pv[0], red, wave, lane, 0);
+                        pl_reduce_store<pl_pow2(2 * R)>(pv[1], red, wave, lane, 16);
+                    } else
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        // the wave's two (gate, up) pairs, one after the other: a group of 2 R values each (value (s, r) = red[wave][16 (s / 2) + (s % 2) R + r])
+                        PL_PV(2 * R);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            f32x4 xr[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) xr[j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) {
+                                float acc = 0.f;
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) acc = dot4(g_w[2 * g + t][j], xr[j], acc);
+                                pv[t * R + r] = acc;
+                            }
+                        }
+                        pl_reduce_store<pl_pow2(2 * R)>(pv, red, wave, lane, 16 * g);
+                    }
                     __syncthreads();                          // B2(D)
                     // ---- wait for silu(gate) * up, requesting q|k|v(l+1); phase E
                     {
@@ -265,13 +329,16 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                         PL_PACE_END();
                     }
                     const int half = wave & 1;
+                    {
+                        PL_PV(R);
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float acc = 0.f;
+                        for (int r = 0; r < R; ++r) {
+                            float acc = 0.f;
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) acc = dot4(d_w[j], ((const f32x4*)(xs + r * PL_I))[384 * half + 64 * j + lane], acc);
-                        acc = wave_sum(acc);
-                        if (lane == 0) red[(wave * 4) * R + r] = acc;
+                            for (int j = 0; j < 6; ++j) acc = dot4(d_w[j], ((const f32x4*)(xs + r * PL_I))[384 * half + 64 * j + lane], acc);
+                            pv[r] = acc;
+                        }
+                        pl_reduce_store<pl_pow2(R)>(pv, red, wave, lane);
                     }
                     __syncthreads();                          // B2(E)
                     wb = wn;
@@ -288,6 +355,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
 #pragma unroll
                         for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
                     if (wave < 7) {
+                        PL_PV(2 * R);
 #pragma unroll
                         for (int row = 0; row < 2; ++row)
 #pragma unroll
@@ -295,9 +363,9 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                                 float acc = 0.f;
 #pragma unroll
                                 for (int j = 0; j < 3; ++j) acc = dot4(q_w[row][j], xr[r][j], acc);
-                                acc = wave_sum(acc);
-                                if (lane == 0) red[(wave * 4 + row) * R + r] = acc;
+                                pv[row * R + r] = acc;
                             }
+                        pl_reduce_store<pl_pow2(2 * R)>(pv, red, wave, lane);
                     }
                     __syncthreads();                          // B2(H)
                 }
@@ -327,6 +395,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
 #pragma unroll
                     for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
                 if (wave < 6) {
+                    PL_PV(2 * R);
 #pragma unroll
                     for (int row = 0; row < 2; ++row)
 #pragma unroll
@@ -334,9 +403,9 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                             float acc = 0.f;
 #pragma unroll
                             for (int j = 0; j < 3; ++j) acc = dot4(q_w[row][j], xr[r][j], acc);
-                            acc = wave_sum(acc);
-                            if (lane == 0) red[(wave * 4 + row) * R + r] = acc;
+                            pv[row * R + r] = acc;
                         }
+                    pl_reduce_store<pl_pow2(2 * R)>(pv, red, wave, lane);
                 }
                 if (SCHED == 2) PL_LOAD_O(wb);
                 PL_LOAD_G(wb);
@@ -350,14 +419,15 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
 #pragma unroll
                     for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
                 if (wave < 4) {
+                    PL_PV(R);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         float acc = 0.f;
 #pragma unroll
                         for (int j = 0; j < 3; ++j) acc = dot4(o_w[j], xr[r][j], acc);
-                        acc = wave_sum(acc);
-                        if (lane == 0) red[(wave * 4) * R + r] = acc;
+                        pv[r] = acc;
                     }
+                    pl_reduce_store<pl_pow2(R)>(pv, red, wave, lane);
                 }
                 PL_LOAD_D(wb);
                 if (SCHED == 1 && more) PL_LOAD_O(wn);
@@ -369,28 +439,37 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) xr[r][j] = ((const f32x4*)(xs + r * PL_H))[64 * j + lane];
+                {
+                    float pv[2][pl_pow2(2 * R)];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                    for (int n = 0; n < pl_pow2(2 * R); ++n) { pv[0][n] = 0.f; pv[1][n] = 0.f; }
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float acc = 0.f;
+                    for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) acc = dot4(g_w[s][j], xr[r][j], acc);
-                        acc = wave_sum(acc);
-                        if (lane == 0) red[(wave * 4 + s) * R + r] = acc;
-                    }
+                        for (int r = 0; r < R; ++r) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc = dot4(g_w[s][j], xr[r][j], acc);
+                            pv[s >> 1][(s & 1) * R + r] = acc;
+                        }
+                    pl_reduce_store<pl_pow2(2 * R)>(pv[0], red, wave, lane, 0);
+                    pl_reduce_store<pl_pow2(2 * R)>(pv[1], red, wave, lane, 16);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                              // B2(D)
                 // ---- phase E: down rows, two K halves per row
                 __syncthreads();                              // B1(E): xs = silu(gate) * up, [R][3072]
                 const int half = wave & 1;
+                {
+                    PL_PV(R);
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float acc = 0.f;
+                    for (int r = 0; r < R; ++r) {
+                        float acc = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) acc = dot4(d_w[j], ((const f32x4*)(xs + r * PL_I))[384 * half + 64 * j + lane], acc);
-                    acc = wave_sum(acc);
-                    if (lane == 0) red[(wave * 4) * R + r] = acc;
+                        for (int j = 0; j < 6; ++j) acc = dot4(d_w[j], ((const f32x4*)(xs + r * PL_I))[384 * half + 64 * j + lane], acc);
+                        pv[r] = acc;
+                    }
+                    pl_reduce_store<pl_pow2(R)>(pv, red, wave, lane);
                 }
                 if (SCHED == 2 && more) PL_LOAD_Q(wn);
                 __builtin_amdgcn_sched_barrier(0);
@@ -479,7 +558,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 __syncthreads();                              // B2(A)
                 if (doA) {
                     const float rs = 1.0f / sqrtf((EW == 2 ? ssq[rA] + ssq[R + rA] : (ssq[rA] + ssq[R + rA]) + (ssq[2 * R + rA] + ssq[3 * R + rA])) / (float)PL_H + a.eps);          // llama.py:82-87 (the weight is folded into W's columns)
-                    const float va = red[(pwA * 4 + 0) * R + rA] * rs, vb = red[(pwA * 4 + 1) * R + rA] * rs;
+                    const float va = pl_red(red, pwA, rA) * rs, vb = pl_red(red, pwA, R + rA) * rs;
                     float ya = va, yb = vb;
                     int which, dA, dB;
                     if (pwA < 4) {                               // q / k: RoPE pair (d, d + 32), products rounded separately like the reference (llama.py:180-181)
@@ -514,7 +593,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 __syncthreads();                              // B2(C)
                 if (e < 4 * R) {
                     const int i = e & 3, r = e >> 2;
-                    const float x1 = xres[4 * r + i] + red[(i * 4) * R + r];                               // llama.py:731
+                    const float x1 = xres[4 * r + i] + pl_red(red, i, r);                               // llama.py:731
                     xres[4 * r + i] = x1;
                     if (!(a.fault > 0 && b == 5 && l + 1 == a.fault))          // (test hook "persistent_fault": workgroup 5 withholds its columns in layer fault - 1)
                         store_granule(a.g_x1 + (size_t)r * PL_H + 4 * b + i, tag, x1);
@@ -546,7 +625,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 if (e < 16 * R) {
                     const int pi = e & 15, r = e >> 4, w = pi >> 1, p = pi & 1;
                     const float rs = 1.0f / sqrtf((EW == 2 ? ssq[r] + ssq[R + r] : (ssq[r] + ssq[R + r]) + (ssq[2 * R + r] + ssq[3 * R + r])) / (float)PL_H + a.eps);
-                    const float gv = red[(w * 4 + 2 * p) * R + r] * rs, uv = red[(w * 4 + 2 * p + 1) * R + r] * rs;
+                    const float gv = pl_red(red, w, 16 * p + r) * rs, uv = pl_red(red, w, 16 * p + R + r) * rs;
                     store_granule(a.g_act + (size_t)r * PL_I + 16 * b + pi, tag, (gv / (1.0f + expf(-gv))) * uv);       // llama.py:214
                 }
                 if (last) PL_MARK(7);
@@ -587,7 +666,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 __syncthreads();                              // B2(E)
                 if (e < 4 * R) {
                     const int i = e & 3, r = e >> 2;
-                    const float x2 = xres[4 * r + i] + (red[((2 * i) * 4) * R + r] + red[((2 * i + 1) * 4) * R + r]);      // llama.py:739
+                    const float x2 = xres[4 * r + i] + (pl_red(red, 2 * i, r) + pl_red(red, 2 * i + 1, r));      // llama.py:739
                     if (last && !a.heads) a.x[(size_t)r * PL_H + 4 * b + i] = x2;          // the heads read it after the launch boundary
                     else {
                         xres[4 * r + i] = x2;
@@ -628,7 +707,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 if (e < PL_HEAD_ROWS * R) {
                     const int rr = e % PL_HEAD_ROWS, r = e / PL_HEAD_ROWS, col = PL_HEAD_ROWS * b + rr;
                     const float rs = 1.0f / sqrtf((EW == 2 ? ssq[r] + ssq[R + r] : (ssq[r] + ssq[R + r]) + (ssq[2 * R + r] + ssq[3 * R + r])) / (float)PL_H + a.eps);          // llama.py:1002 (the weight is folded into the heads' columns)
-                    if (col < a.n_valid) a.logits[(size_t)r * a.n_valid + col] = red[((rr >> 1) * 4 + (rr & 1)) * R + r] * rs;
+                    if (col < a.n_valid) a.logits[(size_t)r * a.n_valid + col] = pl_red(red, rr >> 1, (rr & 1) * R + r) * rs;
                 }
                 if (e < 4 * R) {
                     // hidden = weight * (x * rs) (llama.py:87, gpt.py:422-423) -> hiddens[utterance][its own step] while the row is live
@@ -928,7 +1007,7 @@ int launch_persist_repack(int half_w, const void* qkv, const void* o, const void
     return 0;
 }
 
-static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + 8 * 4 * R + 4 * R + 4 * R) * 4 + 16 + (192 + 8 * 8 * 10) * 4; }
+static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + PL_RED_FLOATS + 4 * R + 4 * R) * 4 + 16 + (192 + 8 * 8 * 10) * 4; }
 
 template <int R, int SCHED, typename WT>
 static int persist_launch_t(const PersistArgs& a, hipStream_t s, bool configure_only) {
@@ -941,12 +1020,14 @@ static int persist_launch_t(const PersistArgs& a, hipStream_t s, bool configure_
 template <int SCHED, typename WT>
 static int persist_launch_r(int R, const PersistArgs& a, hipStream_t s, bool cfg) {
     // exact row counts: a spare row would append stale K / V rows to a live cache lane
-    if (cfg) return persist_launch_t<1, SCHED, WT>(a, s, true) | persist_launch_t<2, SCHED, WT>(a, s, true) | persist_launch_t<3, SCHED, WT>(a, s, true) | persist_launch_t<4, SCHED, WT>(a, s, true);
+    if (cfg) return persist_launch_t<1, SCHED, WT>(a, s, true) | persist_launch_t<2, SCHED, WT>(a, s, true) | persist_launch_t<3, SCHED, WT>(a, s, true) | persist_launch_t<4, SCHED, WT>(a, s, true) |
+                    persist_launch_t<5, SCHED, WT>(a, s, true);
     switch (R) {
         case 1: return persist_launch_t<1, SCHED, WT>(a, s, false);
         case 2: return persist_launch_t<2, SCHED, WT>(a, s, false);
         case 3: return persist_launch_t<3, SCHED, WT>(a, s, false);
         case 4: return persist_launch_t<4, SCHED, WT>(a, s, false);
+        case 5: return persist_launch_t<5, SCHED, WT>(a, s, false);
     }
     ctts_set_error("persistent layer: %d rows (max %d)", R, PL_MAXR);
     return 1;

@@ -36,16 +36,16 @@ def _gen(g, B, P, N, pad=None, lp=LP, seed=7):
 
 def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
     g = gpt
-    assert g.get_option("persistent_rows") == 4, "fp32 engines serve up to four decode rows through the persistent launch by default"
+    assert g.get_option("persistent_rows") == 5, "fp32 engines serve up to five decode rows (12 heads x 5 = 60 of the 64 attention workgroups) through the persistent launch by default"
     # contexts beyond 512 keys split every (row, head) over 2..5 attention workgroups (2 at 600, 3 at 1000, 5 at 1900; two rows: at most 2)
     # (round 5: a key share's tail streams 4 steps per round trip, so 3-4 rows stay on the persistent launch up to 1400 keys -- (4, 1200) and (3, 1300) below)
     cases = [(1, 48, 96, None), (1, 600, 24, None), (1, 1000, 40, None), (1, 1900, 24, None), (2, 700, 16, [0, 150]), (4, 1200, 16, [0, 30, 7, 300]), (3, 1300, 16, None),
-             (2, 40, 32, [0, 9]), (3, 33, 24, [0, 5, 17]), (4, 48, 24, [3, 0, 11, 20])]
+             (2, 40, 32, [0, 9]), (3, 33, 24, [0, 5, 17]), (4, 48, 24, [3, 0, 11, 20]), (5, 40, 24, [0, 4, 9, 2, 13]), (5, 1300, 12, None)]
     for (B, P, N, pad) in cases:
         g.set_option("persistent_rows", 0)
         ref_ids, ref_h = _gen(g, B, P, N, pad)
-        variants = [dict(persistent_rows=4), dict(persistent_rows=4, persistent_layers_per_launch=1), dict(persistent_rows=4, persistent_schedule=2, persistent_poll=1),
-                    dict(persistent_rows=4, persistent_schedule=1, persistent_poll=0), dict(persistent_rows=4, persistent_schedule=3, persistent_delay=0, persistent_delay_act=0, persistent_delay_x=0)]
+        variants = [dict(persistent_rows=5), dict(persistent_rows=5, persistent_layers_per_launch=1), dict(persistent_rows=5, persistent_schedule=2, persistent_poll=1),
+                    dict(persistent_rows=5, persistent_schedule=1, persistent_poll=0), dict(persistent_rows=5, persistent_schedule=3, persistent_delay=0, persistent_delay_act=0, persistent_delay_x=0)]
         for v in variants:
             for k, val in v.items():
                 g.set_option(k, val)
@@ -56,8 +56,8 @@ def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
             g.set_option("persistent_layers_per_launch", 0)
             g.set_option("persistent_schedule", 3)
             g.set_option("persistent_poll", 0)
-            g.set_option("persistent_delay", 12); g.set_option("persistent_delay_act", 16); g.set_option("persistent_delay_x", 15)
-    g.set_option("persistent_rows", 4)
+            g.set_option("persistent_delay", 12); g.set_option("persistent_delay_act", 14); g.set_option("persistent_delay_x", 15)
+    g.set_option("persistent_rows", 5)
 
 
 def test_persistent_launch_replay_is_bitwise_reproducible_and_graph_equals_eager(gpt):
@@ -72,7 +72,7 @@ def test_persistent_launch_replay_is_bitwise_reproducible_and_graph_equals_eager
         g.use_graph = True
     assert torch.equal(a_ids[0], b_ids[0]) and torch.equal(a_h[0], b_h[0]), "two replays differ (fixed reduction orders, no atomics on the data path)"
     assert torch.equal(a_ids[0], c_ids[0]) and torch.equal(a_h[0], c_h[0]), "hipGraph replay != eager launches"
-    g.set_option("persistent_rows", 4)
+    g.set_option("persistent_rows", 5)
 
 
 def test_repetition_penalty_reaches_every_utterance_of_a_long_queue(gpt):
@@ -131,7 +131,7 @@ def test_a_withheld_hand_off_ends_the_step_with_an_error_instead_of_hanging(gpt)
     import time
     from chatttsplus_amd import _lib
     g = gpt
-    g.set_option("persistent_rows", 4)
+    g.set_option("persistent_rows", 5)
     ref_ids, _ = _gen(g, 1, 24, 12)
     g.set_option("persistent_fault", 8)
     t0 = time.perf_counter()
@@ -155,7 +155,7 @@ def test_two_engines_of_one_process_take_turns_with_their_persistent_launches():
     try:
         for g in gs:
             g.load_state_dict(sd)
-            assert g.get_option("persistent_rows") == 4
+            assert g.get_option("persistent_rows") == 5
         solo = [_gen(gs[i], 1 + i, 40, 96, seed=11 + i) for i in range(2)]
         out, err = [None, None], [None, None]
 
@@ -188,7 +188,7 @@ def test_persistent_weight_images_are_built_on_first_need(gpt):
     g = GPT(LLAMA, max_batch=8, max_seq_len=200, weight_dtype="fp32")
     try:
         g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
-        assert g.get_option("persistent_rows") == 4
+        assert g.get_option("persistent_rows") == 5
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info()[0]
         _gen(g, 8, 24, 8)                                    # the launch chain: no image
@@ -214,11 +214,11 @@ def test_fp16_engines_use_the_persistent_launch_too():
     g = GPT(LLAMA, max_batch=4, max_seq_len=300, weight_dtype="fp16")
     try:
         g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
-        assert g.get_option("persistent_rows") == 4
+        assert g.get_option("persistent_rows") == 5
         for B in (1, 3):
             g.set_option("persistent_rows", 0)
             c_ids, c_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
-            g.set_option("persistent_rows", 4)
+            g.set_option("persistent_rows", 5)
             p_ids, p_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
             q_ids, q_h = _gen(g, B, 40, 32, [0, 5, 9][:B])
             g.use_graph = False

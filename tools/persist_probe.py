@@ -33,7 +33,8 @@ args = ap.parse_args()
 dev = torch.device("cuda", 0)
 LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
 LP = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
-G_QKV, G_ATT, G_X1, G_ACT = 4 * 12 * 192, 4 * 768, 4 * 768, 4 * 3072
+MAXR = 5
+G_QKV, G_ATT, G_X1, G_ACT = MAXR * 12 * 192, MAXR * 768, MAXR * 768, MAXR * 3072
 
 
 def out(**kw):
@@ -139,10 +140,10 @@ if not args.skip_layer:
     g1.close()
 
 # ---- 2. twenty layers, launch path vs persistent layers -----------------------------------------------------------------------------------
-g, _ = make(20, 4, 1400)
-for (B, P, N, pad) in (() if args.skip_checks else ((1, 48, 64, None), (2, 40, 48, [0, 9]), (3, 33, 40, [0, 5, 17]), (4, 48, 40, [3, 0, 11, 20]), (1, 600, 24, None), (1, 1000, 48, None))):
+g, _ = make(20, MAXR, 1400)
+for (B, P, N, pad) in (() if args.skip_checks else ((1, 48, 64, None), (2, 40, 48, [0, 9]), (3, 33, 40, [0, 5, 17]), (4, 48, 40, [3, 0, 11, 20]), (5, 36, 40, [0, 4, 9, 2, 13]), (5, 420, 24, None), (1, 600, 24, None), (1, 1000, 48, None))):
     a_ids, a_hid, _ = gen(g, B, P, N, persist=0, pad_left=pad)
-    b_ids, b_hid, _ = gen(g, B, P, N, persist=4, pad_left=pad)
+    b_ids, b_hid, _ = gen(g, B, P, N, persist=MAXR, pad_left=pad)
     same = all(torch.equal(x, y) for x, y in zip(a_ids, b_ids))
     herr = max(relerr(y.numpy(), x.numpy()) for x, y in zip(a_hid, b_hid))
     st = debug_read(g, "pl_state", 8).view(np.uint32)
@@ -152,8 +153,8 @@ for (B, P, N, pad) in (() if args.skip_checks else ((1, 48, 64, None), (2, 40, 4
 if not args.skip_times:
     spk = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
     leg = bench.Leg(g, dev, 0, 1)
-    for B in (1, 2, 4):
-        arms = {"launches": (0, 0), "persistent_one_launch": (4, 0), "persistent_launch_per_layer": (4, 1)}
+    for B in (1, 2, 4, 5):
+        arms = {"launches": (0, 0), "persistent_one_launch": (MAXR, 0), "persistent_launch_per_layer": (MAXR, 1)}
         times = {k: [] for k in arms}
         for rnd in range(4):
             for k, (pr, lpl) in arms.items():
@@ -170,9 +171,9 @@ if not args.skip_times:
 if True:
     spk = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
     leg = bench.Leg(g, dev, 0, 1)
-    g.set_option("persistent_rows", 4)
+    g.set_option("persistent_rows", MAXR)
     g.set_option("persistent_timestamps", 1)
-    for B in (1, 2, 3, 4):
+    for B in (1, 2, 3, 4, 5):
         for rep in range(4):
             leg.run(B, args.marks_prompt, 4, 4, spk=spk, use_graph=0, gen_tokens=0)
             ts = debug_read(g, "pl_ts", 256 * 10 * 8).view(np.uint64).reshape(256, 10).astype(np.float64) * 0.01        # us

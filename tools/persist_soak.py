@@ -12,7 +12,7 @@ a = ap.parse_args()
 LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20)
 g = GPT(LLAMA, max_batch=32 if a.mfma else 4, max_seq_len=64 + a.tokens + 16, weight_dtype="fp32", options={"mfma_rows": 32} if a.mfma else {})
 g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
-assert g.get_option("persistent_rows") == 4 and (not a.mfma or g.get_option("mfma_rows") == 32)
+assert g.get_option("persistent_rows") == 5 and (not a.mfma or g.get_option("mfma_rows") == 32)
 g.compact = False                                  # every step of a request at the same row count
 LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
 LP = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
