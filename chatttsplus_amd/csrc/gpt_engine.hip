@@ -326,7 +326,7 @@ static int persist_images(ctts_gpt* h) {
     return 0;
 }
 
-// The persistent MFMA stack's device state: flag words, launch counter, split-K slabs.  Same residency precondition as the <= 4-row launch (256 workgroups, one
+// The persistent MFMA stack's device state: flag words, launch counter, split-K slabs.  Same residency precondition as the <= 5-row launch (256 workgroups, one
 // per CU, all resident): the per-device advisory lock keeps the mode to one process.
 static int ensure_persist_mfma(ctts_gpt* h, bool required) {
     if (h->pm_flags != nullptr || !h->finalized) return 0;

@@ -1,4 +1,4 @@
-// The decoder stack of a small decode batch (<= 4 rows, fp32 engine) as ONE persistent launch (gfx950): all 20 layers of a step, or `n_layers` of them per
+// The decoder stack of a small decode batch (<= 5 rows; fp32 or fp16 engine) as ONE persistent launch (gfx950): all 20 layers of a step, or `n_layers` of them per
 // launch (option "persistent_layers_per_launch"; the first version of the structure ran one layer per launch).
 //
 // Reference arithmetic: LlamaDecoderLayer.forward, chattts_plus/models/llama.py:719-749 (RMSNorm :82-87, q/k/v + RoPE + cache append :619-633,

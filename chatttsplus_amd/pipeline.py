@@ -530,7 +530,7 @@ class ChatTTSPlusPipeline:
             ready, next_i, first = {}, 0, True
             ids_sink = kwargs.get("_ids_sink")
             # continuous="throughput" (round 5): the vocoder does not wait for the last utterance.  Finished utterances are vocoded in batches of `vocoder_chunk`
-            # on a SIDE stream while the decode rows keep stepping on the caller's stream (the launch chain leaves most of the chip idle; a <= 4-row tail's
+            # on a SIDE stream while the decode rows keep stepping on the caller's stream (the launch chain leaves most of the chip idle; a <= 5-row tail's
             # persistent launch simply waits the few tens of microseconds a vocoder kernel holds its CUs).  One list at the end, in input order, as before.
             overlap = (not ordered) and self.device.type == "cuda" and bool(kwargs.get("overlap_vocoder", True))
             voc_chunk = int(kwargs.get("vocoder_chunk", 32))

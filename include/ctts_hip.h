@@ -64,7 +64,7 @@ void ctts_gpt_destroy(ctts_gpt* h);
  * the engine is built, trt_models/llama_trt_model.py:25-81).  Explicit calls only: the product library reads no behaviour from the environment.
  *   "prefill_split_rows"  fp32 engines: prompt passes of >= this many rows use the 3-term fp16 split GEMMs (default 384; 0 = never; before finalize)
  *   "valu_rows"           fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (default 2; 0..4)
- *   "persistent_rows"     decode batches of <= this many rows (<= 4; default 4) run the whole decoder stack of a step as ONE persistent
+ *   "persistent_rows"     decode batches of <= this many rows (<= 5; default 5 = 12 heads x 5 rows on 60 of the 64 attention workgroups) run the whole decoder stack of a step as ONE persistent
  *                         launch of 256 resident workgroups (persist_layer.hip; contexts up to 1024 keys, no per-utterance adapters).  0 = off.  The first
  *                         process that loads an fp32 engine on a device holds the mode (advisory lock /tmp/ctts_persist_<pci>.lock); others stay on launches.
  *                         A persistent launch needs all 256 workgroups resident: run ONE decode at a time per device (two engines of one process decoding
