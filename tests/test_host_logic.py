@@ -288,3 +288,65 @@ def test_warper_list_must_be_top_p_then_top_k():
         sampler_cfg_from_objects([0.3] * 4, 625, 8, 0, [P(), K(), K()], [], 4)
     with pytest.raises(_lib.HipBackendError):
         sampler_cfg_from_objects([0.3] * 4, 625, 8, 0, [P(), P()], [], 4)
+
+
+def test_joint_row_sum_exchange_pattern_of_the_persistent_launch():
+    """persist_layer.hip `pl_reduce_store`: a wave reduces P <= 16 partial sums per lane TOGETHER -- at each of wave_sum's four DPP steps (quad xor 1, quad xor 2,
+    half-mirror, mirror) a lane keeps one half of its values and hands the other half to its partner.  A numpy model of the 64 lanes checks what the kernel relies on:
+    (1) the lane that the step pairs me with holds the same values as I do and keeps the other half (the parities f0 = b0^b2, f1 = b1^b2, f2 = b2^b3, f3 = b3);
+    (2) after the four steps a lane holds the 16-lane row sum of value idx = f0 P/2 + f1 P/4 + ..., added in wave_sum's order (bit-identical in fp32);
+    (3) the writer lanes cover every (value, row) exactly once."""
+    rng = np.random.Generator(np.random.Philox(key=3))
+    lanes = np.arange(64)
+    b = [(lanes >> i) & 1 for i in range(4)]
+    f = [b[0] ^ b[2], b[1] ^ b[2], b[2] ^ b[3], b[3]]
+    row, l16 = lanes >> 4, lanes & 15
+    partner = [lanes ^ 1, lanes ^ 2, (lanes & ~7) | (7 - (lanes & 7)), (lanes & ~15) | (15 - l16)]
+
+    def wave_sum_rows(x):                       # common.h wave_sum up to the row sums: v += dpp(v), four times, fp32
+        v = x.astype(np.float32).copy()
+        for p in partner:
+            v = (v + v[p]).astype(np.float32)
+        return v                                # every lane: the sum of its 16-lane row
+
+    for P in (1, 2, 4, 8, 16):
+        vals = rng.standard_normal((64, P)).astype(np.float32)          # [lane][value]
+        cur = [vals[:, i].copy() for i in range(P)]
+        held = [set(range(P)) for _ in range(64)]                        # original indices a lane still holds
+        C = P
+        for s in range(4):
+            if C > 1:
+                for ln in range(64):
+                    assert held[ln] == held[partner[s][ln]], "the partner must hold the same values"
+                    assert f[s][ln] != f[s][partner[s][ln]], "... and keep the other half"
+                nxt = []
+                for i in range(C // 2):
+                    keep = np.where(f[s] == 1, cur[i + C // 2], cur[i])
+                    give = np.where(f[s] == 1, cur[i], cur[i + C // 2])
+                    nxt.append((keep + give[partner[s]]).astype(np.float32))
+                for ln in range(64):
+                    order = sorted(held[ln])
+                    held[ln] = set(order[C // 2:] if f[s][ln] else order[:C // 2])
+                cur, C = nxt, C // 2
+            else:
+                cur = [(cur[0] + cur[0][partner[s]]).astype(np.float32)]
+        # the value a lane ends with, by the kernel's formula
+        idx = np.zeros(64, dtype=np.int64)
+        writer = np.ones(64, dtype=bool)
+        c = P
+        for s in range(4):
+            if c > 1:
+                idx += f[s] * (c // 2)
+                c //= 2
+            else:
+                writer &= f[s] == 0
+        seen = set()
+        for ln in range(64):
+            assert held[ln] == {int(idx[ln])}
+            want = wave_sum_rows(vals[:, idx[ln]])[ln]
+            assert cur[0][ln] == want, "not bit-identical to wave_sum's row sum"
+            if writer[ln]:
+                key = (int(idx[ln]), int(row[ln]))
+                assert key not in seen
+                seen.add(key)
+        assert seen == {(i, r) for i in range(P) for r in range(4)}
