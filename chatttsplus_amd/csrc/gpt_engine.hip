@@ -137,7 +137,8 @@ struct ctts_gpt {
     int persist_lpl = 0;                         //   decoder layers per persistent launch (0 = all of them in one launch)
     int persist_sched = 3;                       //   weight request schedule (PersistArgs.sched): 1 and 2 measure the same (389.3 / 389.5 us at batch 1, 436.0 / 436.4 at 2);
                                                  //   3 = paced requests: batch 1 373.0 -> 337.4, 2 425.7 -> 404.0, 3 490.1 -> 467.6 (profiles/r04_ab_persist_options.jsonl)
-    int persist_pace = 3;                        //   PersistArgs.pace (us/step at batch 1 before the poll delays: 0 -> 356, 2 -> 342, 3 -> 337.5, 4 -> 339, 6 -> 341, 8 -> 354.6; with them 2 / 3 / 4 / 6: 285.0 / 286.6 / 293.0 / 297.7)
+    int persist_pace = -1;                       //   -1 = by row count: 3 at 1-2 rows, 2 from 3 rows on (round 5, after the joint row sums: ms/step at pace 2 / 3, batch 1: 0.2377 / 0.2342,
+                                                 //   2: 0.2747 / 0.2722, 3: 0.3190 / 0.3221, 4: 0.3489 / 0.3574, 5: 0.4066 / 0.4136).  Round 4 on PersistArgs.pace (us/step at batch 1 before the poll delays: 0 -> 356, 2 -> 342, 3 -> 337.5, 4 -> 339, 6 -> 341, 8 -> 354.6; with them 2 / 3 / 4 / 6: 285.0 / 286.6 / 293.0 / 297.7)
     // ~128-cycle units an edge wave sleeps before its first poll of the (x + attention) / act / layer-output edge: a pass that starts before the producers'
     // stores are visible fails and costs a whole extra pass, and its loads sit in the queues of the very stores it waits for.  us/step at batch 1 with all three at
     // 0 / 6 / 10 / 14 / 18 / 24 / 32: 334.9 / 307.6 / 288.8 / 281.6 / 286.5 / 295.9 / 316.3; batch 2 at 0 / 12: 402.3 / 346.9; batch 4: 521.2 / 467.4.
@@ -417,7 +418,7 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
     } else if (n == "persistent_splits") {
         h->persist_splits = value < 0 ? 0 : (value > PL_SMAX ? PL_SMAX : value);
     } else if (n == "persistent_pace") {                   // SCHED 3: ~128-cycle units between two paced weight requests of a wave
-        h->persist_pace = value < 0 ? 0 : (value > 64 ? 64 : value);
+        h->persist_pace = value < 0 ? -1 : (value > 64 ? 64 : value);          // (< 0: by row count)
     } else if (n == "persistent_delay_att") {
         h->persist_delay_att = value < 0 ? 0 : (value > 256 ? 256 : value);
     } else if (n == "persistent_delay") {
@@ -962,7 +963,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
             pa.kv = kv_layer(h, l, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
             pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1; pa.g_x = pa.g_act + PL_G_ACT; pa.g_part = pa.g_x + PL_G_X; pa.S = h->cur_persist;
-            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched; pa.pace = h->persist_pace; pa.fault = h->persist_fault; pa.delay_att = h->persist_delay_att; pa.delay = h->persist_delay; pa.delay_act = h->persist_delay_act + 2 * (R - 1); pa.delay_x = h->persist_delay_x; pa.nap = h->persist_nap; pa.nap_qkv = h->persist_nap_qkv; pa.poll = (h->persist_poll < 0) ? 0 : h->persist_poll;
+            pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched; pa.pace = h->persist_pace < 0 ? (R <= 2 ? 3 : 2) : h->persist_pace; pa.fault = h->persist_fault; pa.delay_att = h->persist_delay_att; pa.delay = h->persist_delay; pa.delay_act = h->persist_delay_act + 2 * (R - 1); pa.delay_x = h->persist_delay_x; pa.nap = h->persist_nap; pa.nap_qkv = h->persist_nap_qkv; pa.poll = (h->persist_poll < 0) ? 0 : h->persist_poll;
             if (launch_persist_layer(R, pa, s)) return 1;
         }
         return 0;

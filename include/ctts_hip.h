@@ -70,7 +70,7 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *                         A persistent launch needs all 256 workgroups resident: run ONE decode at a time per device (two engines of one process decoding
  *                         concurrently on different streams would have to share the CUs; every wait is bounded and ctts_gpt_progress reports a give-up)
  *   "persistent_layers_per_launch"  0 = the whole stack in one launch (default), n = n layers per launch
- *   "persistent_schedule" weight request schedule of the persistent launch (1 / 2 / 3, default 3 = paced requests)    "persistent_pace"  its pacing interval
+ *   "persistent_schedule" weight request schedule of the persistent launch (1 / 2 / 3, default 3 = paced requests)    "persistent_pace"  its pacing interval (-1 = by row count, the default)
  *   "persistent_delay", "persistent_delay_act", "persistent_delay_x", "persistent_delay_att", "persistent_nap", "persistent_nap_qkv"  when and how often the edge waves poll
  *   "persistent_poll"     0 / 1: sentinel granules before the full sweeps (default 0)
  *   "persistent_timestamps" diagnostics: the persistent launches record per-workgroup phase marks
