@@ -578,8 +578,7 @@ def main():
         dist.broadcast(spk, src=0)
     use_graph = 0 if args.no_graph else 1
     persist_rows = g.get_option("persistent_rows")             # effective value: 1 on fp32 engines that hold the device's persistent-launch lock
-    mfma_rows, mfma_min = g.get_option("mfma_rows"), g.get_option("mfma_rows_min")      # the opt-in persistent MFMA stack (--option mfma_rows=32)
-    on_mfma = mfma_min <= B <= mfma_rows
+    split_rows_dec = g.get_option("split_decode_rows") if args.dtype == "fp32" else 0      # fp32 engines: batches of >= this many rows multiply on the fp16 pipes (head / tail operands)
     leg = Leg(g, dev, rank, world, grouped)
     XR = max(1, args.extra_reps)
     r = leg.run(B, P, K, W, spk=spk, use_graph=use_graph, keep_hidden=True, gen_tokens=args.gen_tokens)
@@ -745,9 +744,10 @@ def main():
                                    f"random-init weights of the real 20x768 architecture",
                        "batch_per_gpu": B, "prompt_len": P, "untimed_steps_before_window": r["s0"], "weights": args.dtype, "kv_cache": args.dtype,
                        "accumulate": "f32", "hipgraph": bool(use_graph), "parallelism": f"replicas x{world} (utterance sharding)",
-                       "decode_path": ("persistent MFMA stack (20 layers = 1 launch, persist_mfma.hip; opt-in)" if on_mfma else
-                                       "persistent launch (20 layers = 1 launch, persist_layer.hip)" if persist_rows >= B else "launch chain (5 launches per layer)"),
-                       "persistent_rows": persist_rows, "mfma_rows": mfma_rows},
+                       "decode_path": ("persistent launch (20 layers = 1 launch, persist_layer.hip)" if persist_rows >= B else
+                                       "launch chain (5 launches per layer" + (", projections as 3-term fp16 head / tail products" if 0 < split_rows_dec <= B else "") +
+                                       (", weight prefetch workgroups" if g.get_option("weight_prefetch_kb") > 0 else "") + ")"),
+                       "persistent_rows": persist_rows, "split_decode_rows": split_rows_dec, "weight_prefetch_kb": g.get_option("weight_prefetch_kb")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": traffic_note,

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libctts_hip.so")
-SOURCES = ["gpt_engine.hip", "skinny_gemm.hip", "persist_layer.hip", "persist_mfma.hip", "prefill_gemm.hip", "prefill_split.hip", "lora.hip", "attention.hip", "sampler.hip", "vocoder.hip", "encoder.hip"]
+SOURCES = ["gpt_engine.hip", "skinny_gemm.hip", "persist_layer.hip", "prefill_gemm.hip", "prefill_split.hip", "lora.hip", "attention.hip", "sampler.hip", "vocoder.hip", "encoder.hip"]
 
 
 def _hipcc() -> str:

@@ -129,6 +129,15 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const int* done_p,
             const float inv = 1.0f / L;
             const int NBr = 16 * a.nbg, K = a.NH * CTTS_HEAD_DIM, kt = K / WTraits<WT>::KT;
             const int chunk = r / NBr, n = r % NBr, k = h * CTTS_HEAD_DIM + lane;
+            if (sizeof(WT) == 4 && a.packed_split) {
+                // the split decode kernels' operand: head / tail fp16 images, 24 k-tiles of 2 KiB per 16-row group (a convex combination of V rows: in range)
+                half_t hi, lo;
+                split_half(O * inv, hi, lo, nullptr);
+                char* p = (char*)a.packed_out + (size_t)chunk * a.nbg * (K / 32) * 2048 + xfrag_split_bytes(n, k, K / 32);
+                *(half_t*)p = hi;
+                *(half_t*)(p + 1024) = lo;
+                return;
+            }
             WT* dst = (WT*)a.packed_out + (size_t)chunk * a.nbg * kt * 64 * WTraits<WT>::EPL;
             dst[xfrag_index<WT>(n, k, kt)] = (WT)(O * inv);
             return;

@@ -59,13 +59,31 @@ template <typename WT> struct WTraits;
 template <> struct WTraits<half_t> {
     static constexpr int KT = 32;       // k per 16-row tile (v_mfma_f32_16x16x32_f16)
     static constexpr int EPL = 8;       // elements per lane per tile (16 bytes)
+    static constexpr int TILE_BYTES = 1024;
     typedef half8 frag;
+    typedef half_t cache_t;             // element type of the K / V cache the engine keeps
 };
 template <> struct WTraits<float> {
     static constexpr int KT = 16;       // 4 x v_mfma_f32_16x16x4_f32 per 16-byte fragment
     static constexpr int EPL = 4;
+    static constexpr int TILE_BYTES = 1024;
     typedef float4 frag;
+    typedef float cache_t;
 };
+// Operand format "split" (round 6): the fp32 PARITY engine's decode projections on the fp16 matrix pipes.  Every operand is a head / tail pair of fp16 images,
+// v = hi + lo with hi = fp16(v), lo = fp16(v - hi) (weights pre-scaled by 64 so that their tails stay normal numbers); a product is three
+// v_mfma_f32_16x16x32_f16 (lo.hi, hi.lo, hi.hi: the dropped lo.lo term is 2^-22 of a product) instead of eight exact-f32 v_mfma_f32_16x16x4_f32 -- 1/5 of the
+// matrix-pipe time at fp32-level accuracy, the same bytes from HBM (2 x 2 bytes per weight).  A (tile, k-tile) pair is stored [hi: 64 lanes x 16 B | lo: 64 lanes x 16 B]
+// = 2 KiB, so one base pointer addresses both images; the tile order is the fp16 engine's.  prefill_split.hip reads the same weight images in the prompt pass.
+struct split_t { half_t hi, lo; };
+template <> struct WTraits<split_t> {
+    static constexpr int KT = 32;
+    static constexpr int EPL = 8;
+    static constexpr int TILE_BYTES = 2048;
+    typedef float cache_t;              // the engine itself is an fp32 engine: fp32 K / V
+};
+#define CTTS_SPLIT_WSCALE 64.0f         // weight images hold 64 * W (== SP_WSCALE of prefill_split.hip)
+#define CTTS_SPLIT_ACT_SCALE 16.0f      // SwiGLU outputs are stored divided by 16 (== SP_ACT_SCALE)
 
 template <typename WT>
 __host__ __device__ inline size_t xfrag_index(int n, int k, int ktiles) {
@@ -82,6 +100,17 @@ __device__ inline half_t sat_half(float v, int* sat) {
     const float c = fminf(fmaxf(v, -65504.f), 65504.f);
     if (!(c == v) && sat != nullptr) atomicAdd(sat, 1);
     return (half_t)((v != v) ? v : c);
+}
+// head / tail of one value (clamped to the fp16 range and reported like sat_half)
+__device__ inline void split_half(float v, half_t& hi, half_t& lo, int* sat) {
+    const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+    if (!(c == v) && sat != nullptr) atomicAdd(sat, 1);
+    hi = (half_t)((v != v) ? v : c);
+    lo = (half_t)(c - (float)hi);
+}
+// byte offset of the HEAD element (n, k) in a split fragment image whose 16-row groups hold `ktiles` k-tiles of 32 (the tail sits 1024 bytes behind it)
+__host__ __device__ inline size_t xfrag_split_bytes(int n, int k, int ktiles) {
+    return ((size_t)((n >> 4) * ktiles + (k >> 5)) * 128 + (n & 15) + 16 * ((k >> 3) & 3)) * 16 + (size_t)(k & 7) * 2;
 }
 template <typename WT> __device__ inline WT sat_store(float v, int* sat);
 template <> __device__ inline half_t sat_store<half_t>(float v, int* sat) { return sat_half(v, sat); }

@@ -31,7 +31,6 @@
 #include "../../include/ctts_hip.h"
 #include "kernels.h"
 #include "persist.h"
-#include "persist_mfma.h"
 #include "roctx_range.h"
 
 static thread_local char g_err[512] = "";
@@ -51,8 +50,9 @@ extern "C" int ctts_version(void) { return 1; }
 
 struct LayerW {
     void *qkv, *o, *gu, *d;      // RMSNorm weights are folded into qkv / gu columns
-    // fp32 engines that can see a prompt pass of >= 1536 rows: head / tail fp16 images of 64 * W (prefill_split.hip), same tile order
-    void *qkv_hi = nullptr, *qkv_lo = nullptr, *o_hi = nullptr, *o_lo = nullptr, *gu_hi = nullptr, *gu_lo = nullptr, *d_hi = nullptr, *d_lo = nullptr;
+    // fp32 engines: head / tail fp16 images of 64 * W, [tile][k tile][head | tail][lane][16 B] in the fp16 tile order (common.h split_t): the prompt pass's split
+    // GEMMs (prefill_split.hip) and the decode projections from split_decode_rows rows on (skinny_gemm.hip) read them
+    void *qkv_sp = nullptr, *o_sp = nullptr, *gu_sp = nullptr, *d_sp = nullptr;
 };
 
 struct ctts_gpt {
@@ -64,6 +64,14 @@ struct ctts_gpt {
     // device
     char* wblob = nullptr;
     char* wsplit = nullptr;                      // fp32 engines: the split images of every layer matrix (2 x 2 bytes per weight), or null
+    void* whead_sp = nullptr;                    //   ... and of the folded code heads
+    bool split_ok = false;                       //   every weight x 64 is inside the fp16 range (otherwise the engine stays on the exact fp32 kernels)
+    int prefetch_mask = 15;                      // which launches' weights are prefetched: bit 0 gate|up (carried by o_proj), 1 down (by gate|up), 2 the next q|k|v / the heads (by down), 3 layer 0's q|k|v (by the heads)
+    int split_rt = 1;                            // split decode kernels: weight row tiles per workgroup of the q|k|v / gate|up launches (1 or 2); "split_row_tiles"
+    int prefetch_kb = 192;                       // decode launch chain: every projection launch carries extra workgroups that pull the NEXT launch's weight image into L2 (kernels.h
+                                                 // WPrefetch), one per this many KiB of it (8..128 of them); 0 = off.  "weight_prefetch_kb"
+    int split_dec_rows = 9;                      // fp32 engines: decode batches of >= this many rows (packed-residual path, no per-utterance adapters) run their projections on the
+                                                 // head / tail images: 3 fp16 MFMAs per product instead of 8 exact-f32 ones (skinny_gemm.hip dispatch_split); 0 = never.  "split_decode_rows"
     void *sp_x_hi = nullptr, *sp_x_lo = nullptr, *sp_act_hi = nullptr, *sp_act_lo = nullptr;   //   ... and of the prompt rows' operands
     int split_rows_min = 384;                    //   prompt passes of at least this many rows use them (prompt pass ms old / split: 192 rows 2.0 / 3.0, 384 rows 3.1 / 3.0,
                                                  //   768 rows 5.3 / 3.6, 1152 rows 7.5 / 3.7; diagnostic builds: CTTS_PREFILL_SPLIT, 0 = never)
@@ -149,19 +157,6 @@ struct ctts_gpt {
     int persist_delay_att = 8, persist_delay = 12, persist_delay_act = 14, persist_delay_x = 15, persist_nap = 1, persist_nap_qkv = 1;
     int persist_poll = -1;                       //   PersistArgs.poll; -1 = by row count: the sentinel pass costs one serial poll at 1-2 rows (batch 1 379.2 -> 387.1 us,
                                                  //   batch 2 430.7 -> 437.8) and pays from 3 rows on, where a full sweep re-reads up to 96 granules per lane (batch 4 547.5 -> 537.6)
-    // fp32 engines, pm_rows_min..pm_rows_max decode rows: the decoder stack of a step is ONE persistent launch with MFMA projections (persist_mfma.hip), reading
-    // the SAME packed tile images as the launch chain (no second weight copy).  "mfma_rows" / "mfma_rows_min"; 0 = off = the DEFAULT: measured slower than the
-    // launch chain at every batch size it serves (ms/step chain / this: batch 8 0.600 / 0.798, 32 0.869 / 1.082, profiles/r05_pm_probe_v2_*.jsonl) -- a hand-off
-    // of a 98 KB operand (write-through stores, drain, flag, poll, coherent loads) costs what a launch boundary costs, DESIGN.md section 0
-    int pm_rows_max = 0, pm_rows_min = PM_MINR;
-    unsigned* pm_flags = nullptr;                //   [5][256] flag words
-    unsigned* pm_epoch = nullptr;                //   launch counter
-    float* pm_slab = nullptr; int* pm_cnt = nullptr;      //   split-K slabs + tickets of the down projection
-    float* scale_one = nullptr;                  //   [rows] 1.0f: the heads' PRO_XH kernel divides by the packed rows' scale, which this path does not apply
-    unsigned long long* pm_ts = nullptr; int pm_ts_on = 0;
-    int cur_pm = 0;                              //   the steps being launched use it
-    int pm_nap = 1, pm_fault = 0;
-    int pm_delay[PM_NPHASE] = {8, 8, 8, 8, 8};   //   ~128-cycle units the poller sleeps before its first pass of each wait
     int no_prepack = 0, prefill_gemm_rows = 1536, xh_heads = 1;   // diagnostic builds only: see run_layers / run_decode_step
     RowMeta *meta_pre = nullptr, *meta_dec = nullptr, *meta_dec0 = nullptr;
     DevState* st = nullptr;
@@ -244,7 +239,6 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     // both dtypes since round 5 (fp16 engines: half weights + half K / V in the image, fp32 activations).  fp16: up to 3 rows -- ms/step launch chain / persistent
     // (tools/fp16_persist_probe.py, two edge waves): batch 1 0.370 / 0.256, 2 0.393 / 0.319, 3 0.423 / 0.381, 4 0.427 / 0.442
     h->persist_rows = PL_MAXR;                                   // 5 (ms/step launch chain / persistent launch at 5 rows, fp32: 0.540 / 0.389; fp16 at 4 rows: 0.425 / 0.345)
-    h->pm_rows_max = 0;                                          // opt-in: ctts_gpt_set_option("mfma_rows", 5..32)
     h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
@@ -327,45 +321,17 @@ static int persist_images(ctts_gpt* h) {
     return 0;
 }
 
-// The persistent MFMA stack's device state: flag words, launch counter, split-K slabs.  Same residency precondition as the <= 5-row launch (256 workgroups, one
-// per CU, all resident): the per-device advisory lock keeps the mode to one process.
-static int ensure_persist_mfma(ctts_gpt* h, bool required) {
-    if (h->pm_flags != nullptr || !h->finalized) return 0;
-    int dev = 0, cus = 0;
-    CTTS_HIP_CHECK(hipGetDevice(&dev));
-    CTTS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const char* why = nullptr;
-    const size_t kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM;
-    if (h->cfg.dtype != CTTS_DTYPE_F32) why = "fp32 engines only";
-    else if (h->L > 31) why = "at most 31 decoder layers";
-    else if (cus < PM_BLOCKS) why = "the device has fewer than 256 compute units";
-    else if (kv_per * 4 >= ((size_t)1 << 32)) why = "a layer's K block exceeds 4 GB (32-bit buffer offsets)";
-    else if (!persist_device_lock(dev)) why = "another process already runs persistent launches on this device";
-    if (why) {
-        h->pm_rows_max = 0;
-        if (required) { ctts_set_error("persistent MFMA stack unavailable: %s", why); return 1; }
-        return 0;
-    }
-    if (persist_mfma_configure()) return 1;
-    if (dev_alloc((void**)&h->pm_flags, (size_t)PM_NPHASE * 256 * 4) || dev_alloc((void**)&h->pm_epoch, 4) || dev_alloc((void**)&h->pm_slab, persist_mfma_slab_floats() * 4) ||
-        dev_alloc((void**)&h->pm_cnt, 48 * 4) || dev_alloc((void**)&h->scale_one, (size_t)(CTTS_MAX_B + 32) * 4)) return 1;
-    if (!h->pl_error && dev_alloc((void**)&h->pl_error, 4)) return 1;
-    const unsigned one = 1;
-    CTTS_HIP_CHECK(hipMemcpy(h->pm_epoch, &one, 4, hipMemcpyHostToDevice));
-    std::vector<float> ones(CTTS_MAX_B + 32, 1.0f);
-    CTTS_HIP_CHECK(hipMemcpy(h->scale_one, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
-    return 0;
-}
-
 extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     if (!h || !name || !value) { ctts_set_error("get_option: null argument"); return 1; }
     const std::string n(name);
     if (n == "persistent_rows") *value = (h->persist_ok || !h->finalized) ? h->persist_rows : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
-    else if (n == "mfma_rows") *value = (h->pm_flags != nullptr || !h->finalized) ? h->pm_rows_max : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
-    else if (n == "mfma_rows_min") *value = h->pm_rows_min;
     else if (n == "persistent_heads") *value = h->persist_heads;
     else if (n == "valu_rows") *value = h->valu_rows;
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
+    else if (n == "split_decode_rows") *value = h->split_dec_rows;
+    else if (n == "weight_prefetch_kb") *value = h->prefetch_kb;
+    else if (n == "split_row_tiles") *value = h->split_rt;
+    else if (n == "weight_prefetch_mask") *value = h->prefetch_mask;
     else if (n == "split_rows") *value = h->split_rows;
     else if (n == "graph_steps") *value = h->graph_steps;
     else if (n == "graph_steps_persistent") *value = h->graph_steps_persist;
@@ -384,25 +350,21 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
     if (n == "prefill_split_rows") {             // prompt passes of >= this many rows use the head / tail fp16 split GEMMs (fp32 engines); 0 = never.  Before finalize.
         if (h->finalized) { ctts_set_error("set_option(prefill_split_rows): set it before the weights are loaded"); return 1; }
         h->split_rows_min = value < 0 ? 0 : value;
+    } else if (n == "split_decode_rows") {       // fp32 engines: decode batches of >= this many rows multiply on the fp16 pipes with head / tail operands (0 = never; see split_dec_rows)
+        if (!h->finalized) h->split_dec_rows = value < 0 ? 0 : value;      // before finalize: also decides whether the images are built
+        else if (value > 0 && !(h->split_ok && h->wsplit)) { ctts_set_error("set_option(split_decode_rows): this engine holds no head / tail weight images (fp16 engine, a weight beyond the fp16 range, or the option was 0 at finalize)"); return 1; }
+        else h->split_dec_rows = value < 0 ? 0 : value;
+    } else if (n == "weight_prefetch_mask") {
+        h->prefetch_mask = value & 15;
+    } else if (n == "split_row_tiles") {
+        h->split_rt = value == 2 ? 2 : 1;
+    } else if (n == "weight_prefetch_kb") {      // launch chain: KiB of the next launch's weights per prefetch workgroup (0 = no prefetch workgroups; see prefetch_kb)
+        h->prefetch_kb = value < 0 ? 0 : (value > 4096 ? 4096 : value);
     } else if (n == "valu_rows") {               // fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (0..4)
         h->valu_rows = value < 0 ? 0 : (value > 4 ? 4 : value);
     } else if (n == "persistent_rows") {         // fp32 engines: decode batches of <= this many rows run each layer as ONE persistent launch (0 = off)
         h->persist_rows = value < 0 ? 0 : (value > CTTS_PERSIST_MAX_ROWS ? CTTS_PERSIST_MAX_ROWS : value);
         if (h->persist_rows > 0 && ensure_persist(h, true)) { h->persist_rows = 0; return 1; }
-    } else if (n == "mfma_rows") {               // fp32 engines: decode batches of mfma_rows_min..mfma_rows rows run the decoder stack as ONE persistent MFMA launch (0 = off)
-        h->pm_rows_max = value < 0 ? 0 : (value > PM_MAXR ? PM_MAXR : value);
-        if (h->pm_rows_max > 0 && ensure_persist_mfma(h, true)) { h->pm_rows_max = 0; return 1; }
-    } else if (n == "mfma_rows_min") {           // (below it the VALU persistent launch / the launch chain serve the batch; 1 lets the MFMA stack take every batch up to mfma_rows)
-        h->pm_rows_min = value < 1 ? 1 : value;
-    } else if (n == "mfma_nap") {
-        h->pm_nap = value < 0 ? 0 : (value > 256 ? 256 : value);
-    } else if (n == "mfma_fault") {              // test hook: a withheld flag; every wait is bounded, ctts_gpt_progress reports the edge
-        h->pm_fault = value < 0 ? 0 : value;
-    } else if (n.rfind("mfma_delay_", 0) == 0 && n.size() == 12 && n[11] >= '0' && n[11] < '0' + PM_NPHASE) {      // mfma_delay_0 .. _4
-        h->pm_delay[n[11] - '0'] = value < 0 ? 0 : (value > 1024 ? 1024 : value);
-    } else if (n == "mfma_timestamps") {         // diagnostics: the poller of every workgroup records wall_clock64 marks of the last layer (ctts_gpt_debug_read "pm_ts")
-        if (value && !h->pm_ts && dev_alloc((void**)&h->pm_ts, (size_t)PM_BLOCKS * PM_NTS * 8)) return 1;
-        h->pm_ts_on = value ? 1 : 0;
     } else if (n == "persistent_heads") {        // 1 (default): the persistent launch that ends the stack also runs the final norm + heads; 0 = the separate heads launch
         h->persist_heads = value ? 1 : 0;
     } else if (n == "persistent_layers_per_launch") {      // 0 = the whole stack in one launch (default); 1 = one launch per layer
@@ -460,11 +422,10 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
 extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
-    void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
+    void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->whead_sp, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
-                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pimg_head, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt,
-                    h->pm_flags, h->pm_epoch, h->pm_slab, h->pm_cnt, h->scale_one, h->pm_ts};
+                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pimg_head, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -636,7 +597,7 @@ static void pack_tiles(WT* dst, int n_row_tiles, int K, RowFn rows, const float*
 // Returns false when a (norm-folded) weight times 64 leaves the fp16 range (|w| >= 1023.5): the images would hold inf; the caller then keeps the
 // engine on the exact fp32 prompt kernels.
 template <typename RowFn>
-static bool pack_tiles_split(half_t* hi, half_t* lo, int n_row_tiles, int K, RowFn rows, const float* colscale = nullptr) {
+static bool pack_tiles_split(half_t* dst, int n_row_tiles, int K, RowFn rows, const float* colscale = nullptr) {
     constexpr int KT = 32, EPL = 8;
     const int ktiles = K / KT;
     bool in_range = true;
@@ -645,14 +606,15 @@ static bool pack_tiles_split(half_t* hi, half_t* lo, int n_row_tiles, int K, Row
             const float* src = rows(rt * 16 + i);
             for (int kt = 0; kt < ktiles; ++kt)
                 for (int kq = 0; kq < 4; ++kq) {
-                    const size_t o = (((size_t)rt * ktiles + kt) * 64 + i + 16 * kq) * EPL;
+                    half_t* hi = dst + ((((size_t)rt * ktiles + kt) * 2) * 64 + i + 16 * kq) * EPL;      // head fragment of the (tile, k-tile) pair; the tail 64 lanes behind it
+                    half_t* lo = hi + 64 * EPL;
                     const int k0 = kt * KT + kq * EPL;
                     for (int j = 0; j < EPL; ++j) {
-                        const float v = 64.0f * (colscale ? src[k0 + j] * colscale[k0 + j] : src[k0 + j]);       // == SP_WSCALE; the product rounds exactly like pack_tiles'
+                        const float v = src ? CTTS_SPLIT_WSCALE * (colscale ? src[k0 + j] * colscale[k0 + j] : src[k0 + j]) : 0.f;      // the product rounds exactly like pack_tiles'
                         const half_t h = (half_t)v;
                         if (!(fabsf(v) <= 65504.0f)) in_range = false;
-                        hi[o + j] = h;
-                        lo[o + j] = (half_t)(v - (float)h);
+                        hi[j] = h;
+                        lo[j] = (half_t)(v - (float)h);
                     }
                 }
         }
@@ -677,8 +639,9 @@ static int finalize_t(ctts_gpt* h) {
     std::vector<WT> blob(total);
     h->lw.resize(L);
     if (dev_alloc((void**)&h->wblob, total * sizeof(WT))) return 1;
-    // fp32 engine whose prompt passes can reach the split-GEMM threshold: head / tail fp16 images of the layer matrices too
-    const bool want_split = (sizeof(WT) == 4) && h->split_rows_min > 0 && (long)h->cfg.max_batch * h->cfg.max_seq >= h->split_rows_min;
+    // fp32 engine whose prompt passes can reach the split-GEMM threshold, or whose decode batches can reach split_decode_rows: head / tail fp16 images of the layer matrices too
+    const bool want_split = (sizeof(WT) == 4) && ((h->split_rows_min > 0 && (long)h->cfg.max_batch * h->cfg.max_seq >= h->split_rows_min) ||
+                                                   (h->split_dec_rows > 0 && h->cfg.max_batch >= h->split_dec_rows));
     std::vector<half_t> sblob;
     if (want_split) {
         sblob.resize(per_layer * 2 * L);
@@ -723,11 +686,11 @@ static int finalize_t(ctts_gpt* h) {
         pack_tiles<WT>(base + n_qkv + n_o, 2 * I / 16, H, gu_row, t.l2->data());
         pack_tiles<WT>(base + n_qkv + n_o + n_gu, HT, I, d_row);
         if (want_split) {
-            half_t *shi = sblob.data() + per_layer * 2 * l, *slo = shi + per_layer;
-            bool ok = pack_tiles_split(shi, slo, 3 * HT, H, qkv_row, t.l1->data());
-            ok = pack_tiles_split(shi + n_qkv, slo + n_qkv, HT, H, o_row) && ok;
-            ok = pack_tiles_split(shi + n_qkv + n_o, slo + n_qkv + n_o, 2 * I / 16, H, gu_row, t.l2->data()) && ok;
-            ok = pack_tiles_split(shi + n_qkv + n_o + n_gu, slo + n_qkv + n_o + n_gu, HT, I, d_row) && ok;
+            half_t* sp = sblob.data() + per_layer * 2 * l;
+            bool ok = pack_tiles_split(sp, 3 * HT, H, qkv_row, t.l1->data());
+            ok = pack_tiles_split(sp + 2 * n_qkv, HT, H, o_row) && ok;
+            ok = pack_tiles_split(sp + 2 * (n_qkv + n_o), 2 * I / 16, H, gu_row, t.l2->data()) && ok;
+            ok = pack_tiles_split(sp + 2 * (n_qkv + n_o + n_gu), HT, I, d_row) && ok;
             if (!ok) split_in_range.store(false);
         }
     };
@@ -746,15 +709,15 @@ static int finalize_t(ctts_gpt* h) {
         h->lw[l].d = dv + (n_qkv + n_o + n_gu) * sizeof(WT);
         if (want_split) {
             char* sv = h->wsplit + per_layer * l * 2 * sizeof(half_t);
-            char* lov = sv + per_layer * sizeof(half_t);
-            h->lw[l].qkv_hi = sv; h->lw[l].qkv_lo = lov;
-            h->lw[l].o_hi = sv + n_qkv * 2; h->lw[l].o_lo = lov + n_qkv * 2;
-            h->lw[l].gu_hi = sv + (n_qkv + n_o) * 2; h->lw[l].gu_lo = lov + (n_qkv + n_o) * 2;
-            h->lw[l].d_hi = sv + (n_qkv + n_o + n_gu) * 2; h->lw[l].d_lo = lov + (n_qkv + n_o + n_gu) * 2;
+            h->lw[l].qkv_sp = sv;
+            h->lw[l].o_sp = sv + n_qkv * 4;
+            h->lw[l].gu_sp = sv + (n_qkv + n_o) * 4;
+            h->lw[l].d_sp = sv + (n_qkv + n_o + n_gu) * 4;
         }
     }
     if (want_split) CTTS_HIP_CHECK(hipMemcpy(h->wsplit, sblob.data(), sblob.size() * sizeof(half_t), hipMemcpyHostToDevice));
-    if (want_split && !split_in_range.load()) h->split_rows_min = 0;      // a weight beyond +-1023: the head / tail images would hold inf -- this engine keeps the exact fp32 prompt kernels
+    h->split_ok = want_split && split_in_range.load();
+    if (want_split && !h->split_ok) { h->split_rows_min = 0; h->split_dec_rows = 0; }      // a weight beyond +-1023: the head / tail images would hold inf -- this engine keeps the exact fp32 kernels
     // heads: fold weight norm, W = v * (g / ||v||_row)  (gpt.py:57-77; torch._weight_norm dim=0)
     std::vector<float> folded((size_t)h->NVQ * V * H);
     for (int i = 0; i < h->NVQ; ++i) {
@@ -777,6 +740,14 @@ static int finalize_t(ctts_gpt* h) {
         return pr < nvalid ? folded.data() + (size_t)pr * H : nullptr;
     }, nf->data());
     h->whead = h->wblob + per_layer * L * sizeof(WT);
+    if (h->split_ok && h->split_dec_rows > 0) {      // the code heads' split images (the decode path's last projection)
+        std::vector<half_t> hs((size_t)head_tiles * 16 * H * 2);
+        const bool ok = pack_tiles_split(hs.data(), head_tiles, H, [&](int pr) -> const float* { return pr < nvalid ? folded.data() + (size_t)pr * H : nullptr; }, nf->data());
+        if (ok) {
+            if (dev_alloc(&h->whead_sp, hs.size() * sizeof(half_t))) return 1;
+            CTTS_HIP_CHECK(hipMemcpy(h->whead_sp, hs.data(), hs.size() * sizeof(half_t), hipMemcpyHostToDevice));
+        }
+    }
     {   // refine-text head (gpt.py:57-64): same weight-norm fold + final-norm fold, its own allocation
         auto g0 = h->host.find("head_text.parametrizations.weight.original0");
         auto v1 = h->host.find("head_text.parametrizations.weight.original1");
@@ -864,7 +835,6 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
     h->host.clear();
     h->finalized = true;
     if (h->persist_rows > 0 && ensure_persist(h, false)) return 1;
-    if (h->pm_rows_max > 0 && ensure_persist_mfma(h, false)) return 1;
     return 0;
 }
 
@@ -916,7 +886,7 @@ static inline int decode_splits(const ctts_gpt* h, int B, int L) {
 
 // What run_layers decided about the hand-off of the residual stream to whatever reads it next (the heads): one place computes the
 // predicates, the consumer uses what was actually launched.
-struct StreamForm { bool parts; bool xh; bool logits; };     // x = x_dec + dpart[0..3] (split-K down projection) / packed fp16 copy + sums of squares exist / the logits (and hidden rows) exist already
+struct StreamForm { bool parts; bool xh; bool logits; bool split; };     // x = x_dec + dpart[0..3] (split-K down projection) / packed copy + sums of squares exist / the logits (and hidden rows) exist already / the packed copy is a head / tail fp16 pair (split_t)
 
 // 20 decoder layers on R rows of residual stream x (llama.py:719-749 per layer)
 static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* rope_rows, int R, int S, const DevState* st, hipStream_t s, StreamForm* form = nullptr) {
@@ -946,12 +916,16 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // fp32: the RMSNorm factor then multiplies the C tile instead of the operand -- (sum w x) rs instead of sum w (x rs), one rounding
     // apart; token ids stay bit-exact on every golden (tests/test_gpu_gpt.py)
     const bool xhm = (st != nullptr) && h->xh_mode && !splitd;
+    // ... and from split_decode_rows rows on (fp32 engines) the projections read head / tail fp16 images of weights and operands: 3 fp16 MFMAs per product instead of 8
+    // exact-f32 ones (common.h split_t; the prompt pass's arithmetic, prefill_split.hip).  Layer 0's q|k|v projection normalises the sampler's fp32 rows and stays exact.
+    const bool spd = xhm && dt == CTTS_DTYPE_F32 && h->split_ok && h->wsplit != nullptr && h->split_dec_rows > 0 && R >= h->split_dec_rows && !lora && S == 1;
+    const int dts = spd ? 2 : dt;                              // launch_gemm's operand format
     if (st != nullptr && h->cur_persist && h->pimg != nullptr && R <= PL_MAXR && !lora) {
         // one persistent launch per layer (persist_layer.hip): the residual stream stays in x, nothing is left in partial or packed form
         // the launch that ends the stack also runs the final norm + the 4 code heads (persist_layer.hip phase H): code mode, paced schedule, images built
         // (ms/step separate heads launch / fused, tools/ab_options.py: fp32 batch 1 0.2798 / 0.2786, 2 0.3396 / 0.3384, 4 0.4711 / 0.4721; fp16 batch 3 0.3793 / 0.3800 -> up to 2 rows)
         const bool fuse_heads = h->persist_heads && R <= 2 && !h->text_mode && h->persist_sched == 3 && h->pimg_head != nullptr && h->dyn != nullptr;
-        if (form) { form->parts = false; form->xh = false; form->logits = fuse_heads; }
+        if (form) { form->parts = false; form->xh = false; form->logits = fuse_heads; form->split = false; }
         // (persistent_layers_per_launch, default all: the whole stack is ONE launch; 1 = a launch per layer, the first version of the structure)
         const int per = (h->persist_lpl > 0 && h->persist_lpl < h->L) ? h->persist_lpl : h->L;
         for (int l = 0; l < h->L; l += per) {
@@ -968,21 +942,18 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         }
         return 0;
     }
-    if (st != nullptr && h->cur_pm && h->pm_flags != nullptr && dt == CTTS_DTYPE_F32 && R <= PM_MAXR && !lora) {
-        // ONE persistent launch with MFMA projections (persist_mfma.hip): leaves x, and the packed copy + sums of squares the heads' PRO_XH kernel reads
-        if (form) { form->parts = false; form->xh = true; form->logits = false; }
-        PmArgs pa = {};
-        pa.wqkv = (const char*)h->lw[0].qkv; pa.wo = (const char*)h->lw[0].o; pa.wgu = (const char*)h->lw[0].gu; pa.wd = (const char*)h->lw[0].d;
-        pa.w_stride = h->L > 1 ? (size_t)((const char*)h->lw[1].qkv - (const char*)h->lw[0].qkv) : 0;
-        pa.n_layers = h->L; pa.R = R; pa.x = x; pa.meta = meta; pa.rope_rows = rope_rows;
-        pa.kv = kv_layer(h, 0, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
-        pa.q_buf = h->q_buf; pa.attn_packed = (float*)h->attn_packed; pa.xh = (float*)h->xh; pa.ssq = h->ssq; pa.act = (float*)h->act;
-        pa.slab = h->pm_slab; pa.cnt = h->pm_cnt; pa.flags = h->pm_flags; pa.epoch = h->pm_epoch; pa.error = h->pl_error; pa.done = &st->all_done;
-        pa.ts = h->pm_ts_on ? h->pm_ts : nullptr; pa.eps = 1e-6f; pa.nap = h->pm_nap; pa.fault = h->pm_fault;
-        for (int i = 0; i < PM_NPHASE; ++i) pa.delay[i] = h->pm_delay[i];
-        return launch_persist_mfma(pa, s);
-    }
-    if (form) { form->parts = splitd; form->xh = xhm; form->logits = false; }
+    if (form) { form->parts = splitd; form->xh = xhm; form->logits = false; form->split = spd; }
+    // weight prefetch across the launch boundaries of a decode step (kernels.h WPrefetch): launch k carries workgroups that pull launch k + 1's weight image into L2.
+    // (16-row chunks only: every consumer workgroup column is then one row tile; per-utterance adapters shift the consumers' block indices by their workers: off)
+    const int pf_kb = (st != nullptr && nbg == 1 && !lora) ? h->prefetch_kb : 0;
+    auto set_pf = [&](GemmArgs& g, const void* w, int n_tiles, int K, int fmt, int bit) {          // fmt: 0 fp32 tiles, 1 fp16 tiles, 2 head / tail pairs
+        if (pf_kb <= 0 || w == nullptr || !((h->prefetch_mask >> bit) & 1) || (spd && h->split_rt != 1)) return;
+        const size_t tile = (size_t)16 * K * (fmt == 1 ? 2 : 4);
+        size_t nb = (tile * n_tiles + (size_t)pf_kb * 1024 - 1) / ((size_t)pf_kb * 1024);
+        nb = (nb + 7) & ~(size_t)7;
+        g.pf.ptr = w; g.pf.unit_bytes = (unsigned)tile; g.pf.n_units = (unsigned)n_tiles;
+        g.pf_blocks = (int)(nb < 8 ? 8 : (nb > 128 ? 128 : nb));
+    };
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
         a.st = st; a.R = R; a.eps = 1e-6f; a.meta = meta; a.Lmax = h->cfg.max_seq; a.sat = h->sat;
@@ -1009,7 +980,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         }
         if (pfs) {
             if (launch_norm_pack_split(x, h->sp_x_hi, h->sp_x_lo, R, a.eps, s)) return 1;
-            if (launch_prefill_split_gemm(EPI_QKV, g1, h->lw[l].qkv_hi, h->lw[l].qkv_lo, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_QKV, g1, h->lw[l].qkv_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, s)) return 1;
         } else if (prepack) {
             g1.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
@@ -1017,13 +988,14 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         } else if (xhm) {
             g1.scale_out = h->scale_o;
             if (l > 0) { g1.xh = h->xh; g1.ssq = h->ssq; g1.scale_in = h->scale_d; }
-            if (launch_gemm(dt, nbg, l > 0 ? PRO_XH : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
+            if (spd && l > 0) { g1.W = h->lw[l].qkv_sp; g1.rt = h->split_rt; }
+            if (launch_gemm(l > 0 ? dts : dt, nbg, l > 0 ? PRO_XH : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         } else if (launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
         at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
         if (st == nullptr) { at.T = h->pre_T; at.row0 = (int)(meta - h->meta_pre); }       // prompt pass: position of this pass in the flattened [B][T] prompt
-        at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg;
+        at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg; at.packed_split = spd ? 1 : 0;
         if (pfs && S == 1) { if (launch_attention_split(at, h->sp_x_hi, h->sp_x_lo, s)) return 1; }      // writes o_proj's head / tail operand images directly
         else if (launch_attention(dt, at, s)) return 1;
         // softmax combine + o_proj + residual (S == 1: attention already wrote the normalised, packed B operand)
@@ -1043,28 +1015,42 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g2.lora_delta = h->lora_do;
         }
         if (pfs && S == 1) {
-            if (launch_prefill_split_gemm(EPI_RESID, g2, h->lw[l].o_hi, h->lw[l].o_lo, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_RESID, g2, h->lw[l].o_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, s)) return 1;
         } else if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
-        else if (launch_gemm(dt, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (splitd ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
+        else {
+            if (spd) g2.W = h->lw[l].o_sp;
+            set_pf(g2, spd ? h->lw[l].gu_sp : h->lw[l].gu, 2 * h->I / 16, h->H, dts, 0);
+            if (launch_gemm(dts, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (splitd ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
+        }
         // RMSNorm + gate|up + SiLU*up
         GemmArgs g3 = a;
         g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act;
         if (pfs) {
             if (launch_norm_pack_split(x, h->sp_x_hi, h->sp_x_lo, R, a.eps, s)) return 1;
-            if (launch_prefill_split_gemm(EPI_SWIGLU, g3, h->lw[l].gu_hi, h->lw[l].gu_lo, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, sp_scale, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_SWIGLU, g3, h->lw[l].gu_sp, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, sp_scale, s)) return 1;
         } else if (prepack) {
             g3.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
             if (pfg ? launch_prefill_gemm(EPI_SWIGLU, g3, s) : launch_gemm(dt, nbg, PRO_PACKED, EPI_SWIGLU, g3, chunks, s)) return 1;
         } else if (xhm) {
             g3.xh = h->xh; g3.ssq = h->ssq; g3.scale_in = h->scale_o; g3.scale_out = h->scale_d;
-            if (launch_gemm(dt, nbg, PRO_XH, EPI_SWIGLU, g3, chunks, s)) return 1;
-        } else if (launch_gemm(dt, nbg, PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
+            if (spd) { g3.W = h->lw[l].gu_sp; g3.rt = h->split_rt; }
+            set_pf(g3, spd ? h->lw[l].d_sp : h->lw[l].d, h->H / 16, h->I, dts, 1);
+            if (launch_gemm(dts, nbg, PRO_XH, EPI_SWIGLU, g3, chunks, s)) return 1;
+        } else {
+            set_pf(g3, h->lw[l].d, h->H / 16, h->I, dt, 1);
+            if (launch_gemm(dt, nbg, PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
+        }
         // down + residual
         GemmArgs g4 = a;
         g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x;
+        if (l + 1 < h->L) set_pf(g4, spd ? h->lw[l + 1].qkv_sp : h->lw[l + 1].qkv, 3 * h->H / 16, h->H, dts, 2);
+        else if (!h->text_mode) {                  // the code heads (run_heads picks the same image)
+            const bool hsp = spd && h->whead_sp != nullptr && h->xh_heads;
+            set_pf(g4, hsp ? h->whead_sp : h->whead, (h->NVQ * h->V + 15) / 16, h->H, hsp ? 2 : dt, 2);
+        }
         if (pfs) {      // the SwiGLU images hold silu(g) * u / 16
-            if (launch_prefill_split_gemm(EPI_RESID, g4, h->lw[l].d_hi, h->lw[l].d_lo, h->sp_act_hi, h->sp_act_lo, nullptr, nullptr, sp_scale * 16.0f, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_RESID, g4, h->lw[l].d_sp, h->sp_act_hi, h->sp_act_lo, nullptr, nullptr, sp_scale * 16.0f, s)) return 1;
         } else if (pfg) {
             if (launch_prefill_gemm(EPI_RESID, g4, s)) return 1;
         } else if (splitd) {
@@ -1072,11 +1058,12 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             if (launch_gemm(dt, nbg, PRO_PACKED, EPI_PART, g4, chunks, s)) return 1;
         } else if (xhm) {                          // (the last layer's copy is for the heads: run_heads)
             g4.xh = h->xh; g4.ssq = h->ssq; g4.scale_in = h->scale_d;
-            if (nbg == 1 && R >= h->down_sk_rows && h->down_sk_rows > 0) {
+            if (spd) g4.W = h->lw[l].d_sp;
+            if ((nbg == 1 || spd) && R >= h->down_sk_rows && h->down_sk_rows > 0) {
                 // K sliced 4 ways inside the launch, last arriver combines (EPI_RESID_XH_SK, kernels.h)
-                g4.ktiles_total = h->I / (h->esz == 2 ? 32 : 16); g4.sk_slab = h->sk_slab; g4.sk_cnt = h->sk_cnt;
-                if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH_SK, g4, chunks, s)) return 1;
-            } else if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID_XH, g4, chunks, s)) return 1;
+                g4.ktiles_total = h->I / ((h->esz == 2 || spd) ? 32 : 16); g4.sk_slab = h->sk_slab; g4.sk_cnt = h->sk_cnt;
+                if (launch_gemm(dts, nbg, PRO_PACKED, EPI_RESID_XH_SK, g4, chunks, s)) return 1;
+            } else if (launch_gemm(dts, nbg, PRO_PACKED, EPI_RESID_XH, g4, chunks, s)) return 1;
         } else if (launch_gemm(dt, nbg, PRO_PACKED, EPI_RESID, g4, chunks, s)) return 1;
     }
     return 0;
@@ -1095,11 +1082,18 @@ static int run_heads(ctts_gpt* h, bool write_hidden, StreamForm form, hipStream_
     a.dyn = write_hidden ? h->dyn : nullptr;       // the kernel tests dyn->hidden_out itself
     a.rows = h->finend;
     a.opart = h->dpart; a.np = form.parts ? 4 : 0;
+    if (h->prefetch_kb > 0 && (h->prefetch_mask & 8) && nbg == 1 && !h->lora_rows && !h->text_mode && !h->cur_persist) {      // the next step's first projection (the sampler runs in between and leaves L2 alone)
+        const size_t tile = (size_t)16 * h->H * h->esz, total = tile * (3 * h->H / 16);
+        size_t nb = ((total + (size_t)h->prefetch_kb * 1024 - 1) / ((size_t)h->prefetch_kb * 1024) + 7) & ~(size_t)7;
+        a.pf.ptr = h->lw[0].qkv; a.pf.unit_bytes = (unsigned)tile; a.pf.n_units = (unsigned)(3 * h->H / 16);
+        a.pf_blocks = (int)(nb < 8 ? 8 : (nb > 128 ? 128 : nb));
+    }
     // the last down projection left the rows as packed fp16 + sums of squares (PRO_XH): no fp32 re-normalisation per block.  The text head is a
     // different launch shape (not measured): it keeps the fp32 prologue
-    if (form.xh && !h->text_mode && h->xh_heads) {
-        a.xh = h->xh; a.ssq = h->ssq; a.scale_in = h->cur_pm ? h->scale_one : h->scale_d;      // (the persistent MFMA stack leaves the packed rows unscaled)
-        return launch_gemm(h->cfg.dtype, nbg, PRO_XH, EPI_LOGITS, a, chunks, s);
+    if (form.xh && !h->text_mode && h->xh_heads && (!form.split || h->whead_sp != nullptr)) {
+        a.xh = h->xh; a.ssq = h->ssq; a.scale_in = h->scale_d;
+        if (form.split) a.W = h->whead_sp;
+        return launch_gemm(form.split ? 2 : h->cfg.dtype, nbg, PRO_XH, EPI_LOGITS, a, chunks, s);
     }
     return launch_gemm(h->cfg.dtype, nbg, (nbg == 1) ? PRO_NORM_P : PRO_NORM, EPI_LOGITS, a, chunks, s);
 }
@@ -1215,7 +1209,7 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* h, const float* emb, void* stream) {
 extern "C" int ctts_gpt_sample(ctts_gpt* h, void* stream) {
     if (!h || h->B == 0) { ctts_set_error("sample: call begin first"); return 1; }
     CTTS_RANGE("ctts_gpt_sample");
-    return run_sample_phase(h, StreamForm{false, false, false}, (hipStream_t)stream);
+    return run_sample_phase(h, StreamForm{false, false, false, false}, (hipStream_t)stream);
 }
 
 extern "C" int ctts_gpt_restart(ctts_gpt* h, void* stream) {
@@ -1260,16 +1254,10 @@ static inline int decode_persist(const ctts_gpt* h, int B, int L) {
     return want > cap ? cap : want;
 }
 
-// ... or as ONE persistent launch with MFMA projections (persist_mfma.hip): fp32, mfma_rows_min..mfma_rows rows, no per-utterance adapters.  Takes precedence over the
-// VALU persistent launch where both would serve the batch (mfma_rows_min <= 4).
-static inline int decode_pm(const ctts_gpt* h, int B) {
-    return (h->pm_rows_max > 0 && h->pm_flags != nullptr && h->cfg.dtype == CTTS_DTYPE_F32 && B >= h->pm_rows_min && B <= h->pm_rows_max && B <= PM_MAXR && !h->lora_rows) ? 1 : 0;
-}
 static inline int pick_decode_path(ctts_gpt* h, int longest) {
     h->cur_splits = decode_splits(h, h->B, longest);
-    h->cur_pm = decode_pm(h, h->B);
-    if (!h->cur_pm && h->persist_ok && h->pimg == nullptr && h->persist_rows > 0 && h->B <= h->persist_rows && !h->lora_rows && persist_images(h)) return 1;
-    h->cur_persist = h->cur_pm ? 0 : decode_persist(h, h->B, longest);
+    if (h->persist_ok && h->pimg == nullptr && h->persist_rows > 0 && h->B <= h->persist_rows && !h->lora_rows && persist_images(h)) return 1;
+    h->cur_persist = decode_persist(h, h->B, longest);
     return 0;
 }
 
@@ -1315,19 +1303,19 @@ struct PersistTurnGuard {
 };
 
 static int run_decode_step(ctts_gpt* h, hipStream_t s) {
-    StreamForm form = {false, false, false};
+    StreamForm form = {false, false, false, false};
     if (run_layers(h, h->x_dec, h->meta_dec, h->rope_dec, h->B, h->cur_splits, h->st, s, &form)) return 1;
     return run_sample_phase(h, form, s);            // the heads add dpart[0..3] / read the packed copy; the sampler then re-materialises x_dec
 }
 
 // steps per replay of the current decode path, given `left` steps to launch: the long graph of the persistent paths while it fits, else the short one
 static int graph_span(const ctts_gpt* h, int left) {
-    return ((h->cur_persist || h->cur_pm) && h->graph_steps_persist > h->graph_steps && left >= h->graph_steps_persist) ? h->graph_steps_persist : h->graph_steps;
+    return (h->cur_persist && h->graph_steps_persist > h->graph_steps && left >= h->graph_steps_persist) ? h->graph_steps_persist : h->graph_steps;
 }
 
 static int ensure_graph(ctts_gpt* h, int n_steps) {
     char sig[160];
-    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen, h->cur_persist, h->cur_pm, n_steps);      // (diagnostic switches are fixed at create)
+    snprintf(sig, sizeof(sig), "%d|%d|%p|%d|%d|%d|%d|%d", h->B, h->text_mode, (void*)h->kv, h->cur_splits, h->lora_rows, h->opt_gen, h->cur_persist, n_steps);      // (diagnostic switches are fixed at create)
     std::string key(sig);
     if (h->lora_rows) key.append((const char*)h->lora_row_slots, (size_t)h->B);      // the rows' adapter slots are kernel arguments of the folded launches (LoraFold)
     if (h->graph_gen != h->opt_gen || h->graphs.size() >= 96) {
@@ -1365,7 +1353,7 @@ extern "C" int ctts_gpt_decode(ctts_gpt* h, int n_steps, int use_graph, void* st
         if (pick_decode_path(h, longest)) return 1;
     }
     h->launched += n_steps;
-    PersistTurnGuard turn(h->cur_persist != 0 || h->cur_pm != 0, s);
+    PersistTurnGuard turn(h->cur_persist != 0, s);
     if (turn.rc) { ctts_set_error("decode: hipStreamWaitEvent failed"); return 1; }
     if (use_graph) {
         int left = n_steps;
@@ -1392,11 +1380,6 @@ extern "C" int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_
     if (all_finished) *all_finished = h->host_pin[2];
     if (h->host_pin[12] == 7) {
         ctts_set_error("per-utterance LoRA: a projection tile gave up waiting for its low-rank term (lora_worker.h); use options={'lora_fold': 0}");
-        return 1;
-    }
-    if (h->host_pin[12] >= 8) {
-        ctts_set_error("persistent MFMA decode stack: a workgroup gave up waiting on edge %d (8 = down -> q|k|v, 9 = q|k|v -> attention, 10 = attention -> o_proj, "
-                       "11 = o_proj -> gate|up, 12 = gate|up -> down); is the GPU shared with another process?  Use options={'mfma_rows': 0}", h->host_pin[12]);
         return 1;
     }
     if (h->host_pin[12] != 0) {
@@ -1546,7 +1529,6 @@ extern "C" int ctts_gpt_debug_read(ctts_gpt* h, const char* name, void* out, siz
     else if (n == "logits") { src = h->logits; nb = (size_t)CTTS_MAX_B * h->NVQ * h->V * 4; }
     else if (n == "pl_g" && h->pl_g) { src = h->pl_g; nb = (size_t)PL_G_TOTAL * 8; }
     else if (n == "pl_ts" && h->pl_ts) { src = h->pl_ts; nb = (size_t)PL_BLOCKS * 10 * 8; }
-    else if (n == "pm_ts" && h->pm_ts) { src = h->pm_ts; nb = (size_t)PM_BLOCKS * PM_NTS * 8; }
     else if (n == "xh") { src = h->xh; nb = (size_t)2 * 48 * 1024; }
     else if (n == "ssq") { src = h->ssq; nb = (size_t)32 * 48 * 4; }
     else if (n == "pl_state" && h->pl_epoch) {

@@ -31,6 +31,17 @@ struct LoraFold {
     int diag;                   // timing experiments (option "lora_fold" 2 / 3): 2 = the tiles do not take the terms, 3 = the workers publish zeros at once
 };
 
+// Weight prefetch across a launch boundary (round 6).  A decode step is a chain of dependent launches, each of which requests its whole weight matrix at entry and
+// then waits: HBM idles at every boundary.  The weights do not depend on the activations, so a launch can carry a few extra workgroups ("prefetch blocks", the
+// last ones of its grid) that pull the NEXT launch's weight image into the L2 of the XCD whose workgroups will consume it (block b runs on XCD b % 8: observed
+// dispatch order, used for speed only -- a wrong guess costs an L2 miss, never a wrong result).  They issue LDS-DMA loads (no destination registers, up to 63 in
+// flight per wave) and end; the consumer's non-temporal loads then hit in L2 instead of paying the HBM round trip at the head of its critical path.
+struct WPrefetch {
+    const void* ptr;            // the next launch's packed weight image (null = nothing to prefetch)
+    unsigned unit_bytes;        // contiguous bytes ONE consumer workgroup column reads (its RT row tiles x all k-tiles): unit u is consumed on XCD u % 8
+    unsigned n_units;
+};
+
 // out[R rows][N] = prologue(x)[R][K] . W[N][K]^T  followed by a fused epilogue.
 // W is pre-packed in 16-row x KT-col MFMA-A tiles, [row tile][k tile][lane][16 B] (gpt_engine.cpp).
 struct SamplerDyn;
@@ -77,6 +88,9 @@ struct GemmArgs {
     const RowState* rows;   // heads only: hidden row goes to hiddens[rows[r].out][rows[r].end] while the row is live
     float* sk_slab;         // EPI_RESID_XH_SK: partial tiles [row tile][chunk][slice][256] fp32
     int* sk_cnt;            //                  arrival tickets [row tile][chunk], zero between launches (the last arriver resets its counter)
+    int rt;                 // split operands: weight row tiles per workgroup of the q|k|v / gate|up launches (0 / 1 = one, 2 = two)
+    WPrefetch pf;           // the next launch's weights, pulled into L2 by pf_blocks extra workgroups (a multiple of 8; 0 = none)
+    int pf_blocks;
     int valu;               // fp32 decode, <= 4 rows: products on the VALU instead of exact-f32 MFMA (skinny_gemm.hip, VR; ctts_gpt_set_option "valu_rows")
 };
 
@@ -94,6 +108,7 @@ struct AttnArgs {
     float* part_o;          // [R][NH][S][64]
     void* packed_out;       // S == 1 only: normalised output written straight into the o_proj kernel's fragment-major B operand
     int nbg;                //   rows per chunk = 16*nbg
+    int packed_split;       //   fp32 engine: packed_out is the head / tail fp16 image pair of the split decode kernels (common.h split_t), not fp32 fragments
     int T, row0;            // prompt pass (MFMA flash kernel): prompt length and the flattened index b*T + t of the pass's first row
 };
 
@@ -164,8 +179,8 @@ int launch_prefill_gemm(int epi, const GemmArgs& a, hipStream_t s);      // pref
 int launch_norm_pack_split(const float* x, void* hi, void* lo, int R, float eps, hipStream_t s);                    // prefill_split.hip (fp32 engine, >= 1536 prompt rows)
 int launch_split_pack(const float* src, void* hi, void* lo, int R, hipStream_t s);
 int launch_attention_split(const AttnArgs& a, void* out_hi, void* out_lo, hipStream_t s);
-int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Whi, const void* Wlo, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,
-                              float scale, hipStream_t s);
+int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Wsplit, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,
+                              float scale, hipStream_t s);      // Wsplit: [n tile][k tile][head | tail][lane][16 B] (common.h split_t)
 int launch_norm_pack(int dtype, const float* x, void* out_packed, int R, int nbg, float eps, hipStream_t s);
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s);

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* src, half_
 }
 
 struct SplitGemm {
-    const half_t *Whi, *Wlo, *Xhi, *Xlo;   // fragment images: W [n tile][k tile][lane][8], X [16-row group][k tile][lane][8]
+    const half_t *Whi, *Wlo, *Xhi, *Xlo;   // fragment images: W [n tile][k tile][head | tail][lane][8] (Wlo = Whi + 1 KiB: the tile pairs of common.h split_t), X [16-row group][k tile][lane][8]
     int ktiles, R;
     float scale;                            // applied to the accumulators: 1 / SP_WSCALE (x SP_ACT_SCALE for the down projection)
     half_t *act_hi, *act_lo;                // EPI_SWIGLU: output images [16-row group][96 k-tiles][lane][8] of silu(g) * u / SP_ACT_SCALE
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
     auto src = [&](int f, int kt) -> const char* {
         const half_t* img = (f < 8) ? p.Whi : (f < 16) ? p.Wlo : (f < 24) ? p.Xhi : p.Xlo;
         const int unit = (f < 16) ? nt0 + (f & 7) : g0 + (f & 7);
-        return (const char*)img + ((size_t)unit * ktiles + kt) * 1024 + (unsigned)(lane * 16);
+        return (const char*)img + ((size_t)unit * ktiles + kt) * ((f < 16) ? 2048 : 1024) + (unsigned)(lane * 16);
     };
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -450,10 +450,10 @@ static int sp_launch(const SplitGemm& p, const GemmArgs& a, hipStream_t s) {
 }
 
 // W / X: head and tail images; the operand buffers must cover whole 128-row blocks (gpt_engine.hip allocates PASS_ROWS + 256 rows).
-int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Whi, const void* Wlo, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,
+int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Wsplit, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,
                               float scale, hipStream_t s) {
     SplitGemm p;
-    p.Whi = (const half_t*)Whi; p.Wlo = (const half_t*)Wlo; p.Xhi = (const half_t*)Xhi; p.Xlo = (const half_t*)Xlo;
+    p.Whi = (const half_t*)Wsplit; p.Wlo = (const half_t*)Wsplit + 512; p.Xhi = (const half_t*)Xhi; p.Xlo = (const half_t*)Xlo;
     p.ktiles = a.K / 32; p.R = a.R; p.scale = scale; p.act_hi = (half_t*)act_hi; p.act_lo = (half_t*)act_lo;
     if ((a.n_row_tiles % 8) != 0 || p.ktiles < 2) { ctts_set_error("prefill_split_gemm: %d n tiles / K = %d not supported", a.n_row_tiles, a.K); return 1; }
     if (epi == EPI_QKV) return sp_launch<EPI_QKV>(p, a, s);

@@ -36,9 +36,39 @@ template <> struct Mma<float> {
     }
 };
 
+struct SplitFrag { half8 hi, lo; };
+template <> struct Mma<split_t> {
+    __device__ static inline f32x4 run(const SplitFrag& a, const SplitFrag& b, f32x4 c) {
+        // tails first, head product last (prefill_split.hip): the small terms meet while the accumulator's low bits still see them
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+        return c;
+    }
+};
+
 template <typename WT> struct FragOf;
 template <> struct FragOf<half_t> { typedef half8 type; };
 template <> struct FragOf<float> { typedef f32x4 type; };
+template <> struct FragOf<split_t> { typedef SplitFrag type; };
+
+// fragment `tile` (= 64 lanes x 16 B; split: head | tail) of an operand image, this lane's part.  nt: streamed once (weights)
+template <typename WT> struct FragIO {
+    typedef typename FragOf<WT>::type frag;
+    __device__ static inline frag load(const void* base, size_t tile, int lane) { return ((const frag*)base)[tile * 64 + lane]; }
+    __device__ static inline frag load_nt(const void* base, size_t tile, int lane) { return __builtin_nontemporal_load((const frag*)base + tile * 64 + lane); }
+};
+template <> struct FragIO<split_t> {
+    typedef SplitFrag frag;
+    __device__ static inline frag load(const void* base, size_t tile, int lane) {
+        const half8* p = (const half8*)base + tile * 128 + lane;
+        return SplitFrag{p[0], p[64]};
+    }
+    __device__ static inline frag load_nt(const void* base, size_t tile, int lane) {
+        const half8* p = (const half8*)base + tile * 128 + lane;
+        return SplitFrag{__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 64)};
+    }
+};
 
 // store 4 consecutive-k activations of row n into the fragment-major LDS/global image
 template <typename WT>
@@ -53,6 +83,45 @@ __device__ inline void store_x4<float>(void* base, int n, int k, int ktiles, flo
     f32x4 v = {y0, y1, y2, y3};
     *(f32x4*)((float*)base + xfrag_index<float>(n, k, ktiles)) = v;
 }
+template <>
+__device__ inline void store_x4<split_t>(void* base, int n, int k, int ktiles, float y0, float y1, float y2, float y3) {
+    half_t hh[4], ll[4];
+    split_half(y0, hh[0], ll[0], nullptr); split_half(y1, hh[1], ll[1], nullptr); split_half(y2, hh[2], ll[2], nullptr); split_half(y3, hh[3], ll[3], nullptr);
+    const half4 h = {hh[0], hh[1], hh[2], hh[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    char* p = (char*)base + xfrag_split_bytes(n, k, ktiles);
+    *(half4*)p = h;
+    *(half4*)(p + 1024) = l;
+}
+// one element (n, k) of the fragment-major image whose first tile is `tile0` (epilogues: the packed residual copy, the SwiGLU output)
+template <typename WT> __device__ inline void store_x1(void* base, size_t tile0, int n, int k, int ktiles, float v, int* sat) {
+    WT* dst = (WT*)base + tile0 * 64 * WTraits<WT>::EPL;
+    dst[xfrag_index<WT>(n, k, ktiles)] = sat_store<WT>(v, sat);
+}
+template <> __device__ inline void store_x1<split_t>(void* base, size_t tile0, int n, int k, int ktiles, float v, int* sat) {
+    half_t hi, lo;
+    split_half(v, hi, lo, sat);
+    char* p = (char*)base + tile0 * 2048 + xfrag_split_bytes(n, k, ktiles);
+    *(half_t*)p = hi;
+    *(half_t*)(p + 1024) = lo;
+}
+
+// A prefetch block (kernels.h WPrefetch): block j of npf (a multiple of 8), sitting on XCD `xcd` (its linear block index mod 8), pulls the units u = xcd (mod 8) -- as
+// share j / 8 of the npf / 8 blocks of that XCD.
+// LDS-DMA: no destination registers to protect (cdna_hip_programming.md 5.7 item 1), nothing waits; s_endpgm drains the queue.
+template <int WAVES>
+__device__ inline void weight_prefetch(const WPrefetch pf, const int j, const int npf, const int xcd, char* smem, const int tid) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    if (pf.ptr == nullptr || npf < 8) return;
+    const int sub = j >> 3, nsub = npf >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* dst = smem + wave * 1024;                        // (every DMA of a wave lands on the same 1 KiB: the bytes are not read here)
+    for (unsigned u = xcd + 8 * sub; u < pf.n_units; u += 8 * nsub) {
+        const char* p = (const char*)pf.ptr + (size_t)u * pf.unit_bytes + (unsigned)(tid * 16);
+        for (unsigned off = 0; off < pf.unit_bytes; off += WAVES * 1024)
+            __builtin_amdgcn_global_load_lds((gptr_t)(p + off), (lptr_t)dst, 16, 0, 0);
+    }
+}
 
 // RT = weight row tiles per block: the activation prologue (replicated in every block) is paid once per RT tiles --
 // at 17-32 rows the 384 blocks of gate|up otherwise pull 37 MB of residual stream through L2 per launch.
@@ -64,7 +133,7 @@ __device__ inline void store_x4<float>(void* base, int n, int k, int ktiles, flo
 template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1, int VR = 0, bool LORA = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done_p, const void* Wq, const void* in0, const void* in1,
                                                                   const float* resid_in, const int R, const int misc, const GemmArgs a) {
-    // misc = np | S << 8 | ktiles_total << 16: the three struct fields that address the first loads of some variants (partial
+    // misc = np | S << 3 | ktiles_total << 7 | lora workers << 15 | first prefetch block << 22: the struct fields that address the first loads of some variants (partial
     // sums, attention splits, split-K weight offset) -- kept out of the by-value struct for the same reason as the pointers
     // The six leading scalars are what the first loads of the kernel need (flag, weights, the prologue's operands, the
     // residual rows, the row count).  As plain kernel arguments they are preloaded into SGPRs at wave launch
@@ -74,12 +143,13 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     static_assert(RT == 1 || EPI == EPI_QKV || EPI == EPI_SWIGLU, "multi-tile blocks: QKV / SwiGLU epilogues only");
     static_assert(VR == 0 || (sizeof(WT) == 4 && NBG == 1 && RT == 1 && PRO != PRO_XH && VR <= 4), "VALU products: fp32, one 16-row chunk, <= 4 rows");
     constexpr bool VALU = VR > 0;
+    constexpr bool SPLIT = (WTraits<WT>::TILE_BYTES == 2048);
     typedef typename FragOf<WT>::type frag;
     constexpr int KT = WTraits<WT>::KT;
     constexpr int KTILES = WAVES * KPW;
     constexpr int K = KTILES * KT;
     constexpr int NB = 16 * NBG;
-    constexpr int XS_BYTES = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * 1024;   // LDS image of the B operand
+    constexpr int XS_BYTES = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * WTraits<WT>::TILE_BYTES;   // LDS image of the B operand
     constexpr int PER = K / 256;                      // float4 per lane per row in the prologues
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -89,6 +159,13 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 #define CTTS_EXIT_IF_DONE() if (__builtin_amdgcn_readfirstlane(done_v)) return
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // prefetch blocks (kernels.h WPrefetch): the grid's last x columns
+        const int xreal = (int)((unsigned)misc >> 22);
+        if (xreal != 0 && (int)blockIdx.x >= xreal) {
+            if (blockIdx.y == 0 && blockIdx.z == 0) weight_prefetch<WAVES>(a.pf, (int)blockIdx.x - xreal, (int)gridDim.x - xreal, (int)blockIdx.x & 7, smem, tid);
+            return;
+        }
+    }
     const int chunk = blockIdx.y;
     const int row0 = chunk * NB;
     // per-utterance LoRA (lora_worker.h): the first lw blocks of every chunk evaluate the rows' low-rank terms, the tiles behind them pick the terms up in
@@ -97,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     constexpr bool LORA_QKV = LORA && (EPI == EPI_QKV) && (K == 768) && (VR == 0) && (PRO == PRO_NORM || PRO == PRO_XH);
     constexpr bool LORA_O = LORA && (EPI == EPI_RESID || EPI == EPI_RESID_XH) && (K == 768) && (VR == 0) && (PRO == PRO_PACKED);
     static_assert(!LORA || LORA_QKV || LORA_O, "LoRA workers: the q/k/v and o_proj launches of a decode step");
-    const int lw = (LORA_QKV || LORA_O) ? ((misc >> 24) & 0x7F) : 0;
+    const int lw = (LORA_QKV || LORA_O) ? ((misc >> 15) & 0x7F) : 0;
     int lora_draw = 0;
     // (the layer index is read where the tag is formed: an unconditional read of the argument struct at entry cost the adapter-less launches 0.2 us)
 #define CTTS_LORA_TAG_LO ((unsigned)a.lf.layer * 2u + (LORA_O ? 1u : 0u))
@@ -123,17 +200,17 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     // the whole stream.  Everything the prologue needs is therefore requested first, the (non-temporal) weight
     // fragments last; nothing issued after them is consumed before the MFMAs.
     // split-K launches (EPI_PART): this block owns k-tiles [blockIdx.z*KTILES, +KTILES) of a matrix with ktiles_total k-tiles
-    const int np_ = misc & 0xFF, S_ = (misc >> 8) & 0xFF;
+    const int np_ = misc & 0x7, S_ = (misc >> 3) & 0xF;
     constexpr bool SLICED = (EPI == EPI_PART || EPI == EPI_RESID_XH_SK);
-    const int kt_all = SLICED ? ((misc >> 16) & 0xFF) : KTILES;
+    const int kt_all = SLICED ? ((misc >> 7) & 0xFF) : KTILES;
     const int kt_off = SLICED ? (int)blockIdx.z * KTILES : 0;
-    const frag* Wp = (const frag*)Wq + ((size_t)rt0 * kt_all + kt_off + (size_t)wave * KPW) * 64 + lane;
+    const size_t wt0 = (size_t)rt0 * kt_all + kt_off + (size_t)wave * KPW;       // this wave's first weight fragment
     frag wf[RT][KPW];
     // (sched_barrier: hipcc otherwise hoists the weight loads above the prologue loads again)
 #define CTTS_ISSUE_WEIGHT_LOADS()                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     _Pragma("unroll") for (int t = 0; t < RT; ++t)                                           \
-    _Pragma("unroll") for (int i = 0; i < KPW; ++i) wf[t][i] = __builtin_nontemporal_load(Wp + ((size_t)t * kt_all + i) * 64); \
+    _Pragma("unroll") for (int i = 0; i < KPW; ++i) wf[t][i] = FragIO<WT>::load_nt(Wq, wt0 + (size_t)t * kt_all + i, lane); \
     __builtin_amdgcn_sched_barrier(0)
 
     // 1b. epilogue operands that do not depend on the GEMM are requested now and consumed at the very end, so
@@ -324,7 +401,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     // PRO_PACKED variants with one weight tile per block and <= 12 B fragments per wave: this wave's B fragments are requested in ONE batch ahead of the weights.  Left to
     // the compiler they were loaded two at a time inside the MFMA loop, each pair behind an s_waitcnt: KPW / 2 dependent L2 round trips in a row
     // (6 at the fp32 down projection, the longest GEMM launch of a batch-32 step).
-    constexpr bool PREB = !VALU && (PRO == PRO_PACKED) && ((RT == 1 && NBG * KPW <= 12) || NBG * KPW <= 6);       // <= 48 VGPRs of B fragments (the 1024-thread variants have 128)
+    constexpr bool PREB = !VALU && (PRO == PRO_PACKED) && ((RT == 1 && NBG * KPW * (SPLIT ? 2 : 1) <= 12) || NBG * KPW * (SPLIT ? 2 : 1) <= 6);       // <= 48 VGPRs of B fragments (the 1024-thread variants have 128)
     frag bpre[NBG][KPW];                                                 // PRO_XH / PREB: this wave's B fragments, requested ahead of the weights
     f32x4 bv[(VALU && PRO == PRO_PACKED) ? VR : 1][KPW];                 // VALU: activation row n, this lane's k-group (the 16 lanes of a group read the same 16 bytes)
     if (PRO == PRO_PACKED) {
@@ -336,11 +413,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 for (int i = 0; i < KPW; ++i) bv[n][i] = xq[(size_t)(kt_off + wave * KPW + i) * 64 + n];
         }
         if (PREB) {
-            const frag* xq = (const frag*)in0 + (size_t)chunk * NBG * kt_all * 64 + lane;
 #pragma unroll
             for (int g = 0; g < NBG; ++g)
 #pragma unroll
-                for (int i = 0; i < KPW; ++i) bpre[g][i] = xq[(size_t)(g * kt_all + kt_off + wave * KPW + i) * 64];
+                for (int i = 0; i < KPW; ++i) bpre[g][i] = FragIO<WT>::load(in0, (size_t)chunk * NBG * kt_all + (size_t)(g * kt_all + kt_off + wave * KPW + i), lane);
         }
         CTTS_ISSUE_WEIGHT_LOADS();
         CTTS_EXIT_IF_DONE();
@@ -362,11 +438,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             sc_in = resid_in[row0 + n_f];
         }
         {
-            const frag* xq = (const frag*)in0 + (size_t)chunk * NBG * KTILES * 64 + lane;
 #pragma unroll
             for (int g = 0; g < NBG; ++g)
 #pragma unroll
-                for (int i = 0; i < KPW; ++i) bpre[g][i] = xq[(size_t)(g * KTILES + wave * KPW + i) * 64];
+                for (int i = 0; i < KPW; ++i) bpre[g][i] = FragIO<WT>::load(in0, (size_t)chunk * NBG * KTILES + (size_t)(g * KTILES + wave * KPW + i), lane);
         }
         CTTS_ISSUE_WEIGHT_LOADS();
         CTTS_EXIT_IF_DONE();
@@ -380,7 +455,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             if (LPR == 4) ss += dpp_f<DPP_XOR2>(ss);
             if (frow && part == 0) {
                 const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
-                fac_s[n_f] = rs / sc_in;                            // sc_in is a power of two: exact
+                fac_s[n_f] = SPLIT ? rs / (sc_in * CTTS_SPLIT_WSCALE) : rs / sc_in;      // sc_in (and the split images' weight scale) are powers of two: exact
                 if (EPI == EPI_LOGITS) fac_s[NB + n_f] = rs;        // heads: the hidden rows below need the plain factor
                 if (rt0 == 0 && a.scale_out != nullptr)             // scale of the rows the next EPI_RESID_XH writes
                     a.scale_out[row0 + n_f] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rs) & 0x7F800000u);
@@ -417,8 +492,6 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int g = 0; g < NBG; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const frag* xs = (const frag*)smem;
-    const frag* xg = (const frag*)in0 + (size_t)chunk * NBG * kt_all * 64;
     if constexpr (!VALU)
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
@@ -427,8 +500,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
         for (int g = 0; g < NBG; ++g) {
             frag b;
             if (PRO == PRO_XH || PREB) b = bpre[g][i];
-            else if (PRO == PRO_PACKED) b = xg[(size_t)(g * kt_all + kt_off + kt) * 64 + lane];
-            else b = xs[(g * KTILES + kt) * 64 + lane];
+            else if (PRO == PRO_PACKED) b = FragIO<WT>::load(in0, (size_t)chunk * NBG * kt_all + (size_t)(g * kt_all + kt_off + kt), lane);
+            else b = FragIO<WT>::load(smem, (size_t)(g * KTILES + kt), lane);
 #pragma unroll
             for (int ti = 0; ti < RT; ++ti) acc[ti][g] = Mma<WT>::run(wf[ti][i], b, acc[ti][g]);
         }
@@ -492,6 +565,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sum += q[w * NBG * 256];
         if (PRO == PRO_XH) sum *= fac_s[n];                       // RMSNorm factor (and the xh row scale) applied to the C tile
+        else if (SPLIT) sum *= ((K == 3072 || SLICED) ? CTTS_SPLIT_ACT_SCALE : 1.0f) / CTTS_SPLIT_WSCALE;       // split images: 64 W (and the SwiGLU output / 16 in front of the down projection)
         return sum;
     };
 
@@ -499,17 +573,18 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     //     are read back with sc1 loads (cdna_hip_programming.md Guideline 16 R1).  The sum runs in slice order, so the result does not depend on who is last.
     float sk_v[RITEMS];
     if constexpr (EPI == EPI_RESID_XH_SK) {
-        static_assert(RT == 1 && NBG == 1, "split-K combine: one 16 x 16 tile per block");
+        static_assert(RT == 1, "split-K combine: one weight row tile per block");
+        constexpr int SLAB = 256 * NBG;                              // one (row tile, chunk) partial: 16 columns x 16 NBG rows
         const int nz = gridDim.z, slice = blockIdx.z;
-        float* const slab0 = a.sk_slab + ((size_t)(rt * gridDim.y + chunk) * nz) * 256;
+        float* const slab0 = a.sk_slab + ((size_t)(rt * gridDim.y + chunk) * nz) * SLAB;
         int* const lastp = (int*)(red + WAVES * NBG * 256);          // one LDS word behind the partials (the 16 x 16 x NBG epilogue scratch)
 #pragma unroll
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
             sk_v[u] = 0.f;
-            if (t < 256) {
+            if (t < SLAB) {
                 sk_v[u] = c_elem(t & 15, t >> 4);
-                __hip_atomic_store(slab0 + (size_t)slice * 256 + t, sk_v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slab0 + (size_t)slice * SLAB + t, sk_v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -525,11 +600,11 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 #pragma unroll
         for (int u = 0; u < RITEMS; ++u) {
             const int t = tid + u * WAVES * 64;
-            if (t < 256) {
+            if (t < SLAB) {
                 float pq[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    pq[q] = (q >= nz) ? 0.f : (q == slice) ? sk_v[u] : __hip_atomic_load(slab0 + (size_t)q * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pq[q] = (q >= nz) ? 0.f : (q == slice) ? sk_v[u] : __hip_atomic_load(slab0 + (size_t)q * SLAB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sk_v[u] = ((pq[0] + pq[1]) + pq[2]) + pq[3];
             }
         }
@@ -564,8 +639,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 sq += dpp_f<DPP_XOR1>(sq); sq += dpp_f<DPP_XOR2>(sq); sq += dpp_f<DPP_HALF_MIRROR>(sq); sq += dpp_f<DPP_MIRROR>(sq);
                 if (i == 0) a.ssq[(size_t)r * a.n_row_tiles + rt] = sq;
                 constexpr int KT_OUT = 768 / KT;                  // the stream is H = 768 wide: 24 fp16 / 48 fp32 k-tiles
-                WT* dst = (WT*)a.xh + (size_t)chunk * NBG * KT_OUT * 64 * WTraits<WT>::EPL;
-                dst[xfrag_index<WT>(n, col, KT_OUT)] = sat_store<WT>(xn * xh_scale_pf[u], a.sat);
+                store_x1<WT>(a.xh, (size_t)chunk * NBG * KT_OUT, n, col, KT_OUT, xn * xh_scale_pf[u], a.sat);
             } else if (col < a.n_valid) {
                 a.logits[(size_t)r * a.n_valid + col] = v;
             }
@@ -579,8 +653,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
             float y = 0.f;
             if (r < R) y = (va / (1.0f + expf(-va))) * vb;
             const int ktiles_out = (a.n_row_tiles * 8) / KT;
-            WT* dst = (WT*)a.act_out + (size_t)chunk * NBG * ktiles_out * 64 * WTraits<WT>::EPL;
-                        dst[xfrag_index<WT>(n, rt * 8 + p, ktiles_out)] = sat_store<WT>(y, a.sat);      // silu(g) * u is unbounded: saturate + report (common.h)
+            if (SPLIT) y *= 1.0f / CTTS_SPLIT_ACT_SCALE;
+            store_x1<WT>(a.act_out, (size_t)chunk * NBG * ktiles_out, n, rt * 8 + p, ktiles_out, y, a.sat);      // silu(g) * u is unbounded: saturate + report (common.h)
         } else if (r < R) {  // EPI_QKV: packed rows per tile = dims [8t..8t+7 | 8t+32..8t+39] of one head
             // keep hipcc from scheduling the cache-address arithmetic (and with it a wait on the meta load) at kernel entry
             asm volatile("" : "+v"(meta_pf.seq), "+v"(meta_pf.slot));
@@ -614,11 +688,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
                 float* q = a.q_out + ((size_t)r * NH + h) * CTTS_HEAD_DIM;
                 q[d] = ya; q[d + 32] = yb;
             } else {
-                WT* c = (WT*)(which == 1 ? a.k_cache : a.v_cache) +
+                typedef typename WTraits<WT>::cache_t CT;
+                CT* c = (CT*)(which == 1 ? a.k_cache : a.v_cache) +
                         (((size_t)meta_pf.seq * NH + h) * a.Lmax + meta_pf.slot) * CTTS_HEAD_DIM;
                 // K / V are projections of RMS-normalised rows (|k| <= ||w_row|| * sqrt(768)): plain conversion.  (A saturating store here made
                 // the fp16 prompt pass non-reproducible run to run on gfx950 -- same values, different schedule; profiles/README.md round 3.)
-                c[d] = (WT)ya; c[d + 32] = (WT)yb;
+                c[d] = (CT)ya; c[d + 32] = (CT)yb;
             }
         }
     }
@@ -650,7 +725,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 template <typename WT, int NBG, int WAVES, int KPW, int PRO, int EPI, int RT = 1, int VR = 0, bool LORA = false>
 static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configure_only) {
     constexpr int KTILES = WAVES * KPW;
-    constexpr int XS = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * 1024;
+    constexpr int XS = (PRO == PRO_PACKED || PRO == PRO_XH) ? 0 : NBG * KTILES * WTraits<WT>::TILE_BYTES;
     constexpr bool LORA_OK = LORA && (KTILES * WTraits<WT>::KT == 768) && (VR == 0) &&
                              ((EPI == EPI_QKV && (PRO == PRO_NORM || PRO == PRO_XH)) || ((EPI == EPI_RESID || EPI == EPI_RESID_XH) && PRO == PRO_PACKED));
     constexpr int LDS0 = XS + WAVES * NBG * 1024 + 16 * 16 * NBG * 4 + 16;
@@ -679,8 +754,12 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
         ctts_set_error("skinny_gemm: this launch cannot carry LoRA workers (pro %d epi %d workers %d)", PRO, EPI, a.lora_w);
         return 1;
     }
-    const int misc = (a.np & 0xFF) | ((a.S & 0xFF) << 8) | ((a.ktiles_total & 0xFF) << 16) | (a.lora_w << 24);
-    hipLaunchKernelGGL(kern, dim3(a.n_row_tiles / RT + a.lora_w, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc, a);
+    const int xreal = a.n_row_tiles / RT + a.lora_w;
+    // prefetch blocks: a multiple of 8 (the real blocks keep their XCDs), whole DMA sweeps only, and the first-prefetch-block field of misc has 10 bits
+    const bool pf_on = a.pf_blocks >= 8 && a.pf.ptr != nullptr && (a.pf.unit_bytes % (WAVES * 1024)) == 0 && xreal < 1024;
+    const int npf = pf_on ? (a.pf_blocks & ~7) : 0;
+    const int misc = (a.np & 0x7) | ((a.S & 0xF) << 3) | ((a.ktiles_total & 0xFF) << 7) | ((a.lora_w & 0x7F) << 15) | (int)((unsigned)(npf ? xreal : 0) << 22);
+    hipLaunchKernelGGL(kern, dim3(xreal + npf, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -804,6 +883,39 @@ static int dispatch(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t
     return 1;
 }
 
+// fp32 engines, decode batches of >= split_decode_rows rows on the packed-residual path (gpt_engine.hip run_layers): head / tail fp16 operands, 3 fp16 MFMAs per product
+// (common.h split_t).  K = 768: 24 k-tiles of 2 KiB = 8 waves x 3 (the fp32 tiling's bytes per wave: 6 KiB of weights in flight per lane group);
+// K = 3072: 96 = 16 x 6, or four in-launch K slices of 8 x 3.
+template <int NBG>
+static int dispatch_split(int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s, bool cfg) {
+    constexpr int W768 = 8, P768 = 3, W3072 = 16, P3072 = 6;
+    if (cfg) {
+        int rc = 0;
+        rc |= launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_QKV>(a, chunks, s, true);
+        rc |= launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_SWIGLU>(a, chunks, s, true);
+        rc |= launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_LOGITS>(a, chunks, s, true);
+        rc |= launch_one<split_t, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
+        rc |= launch_one<split_t, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
+        rc |= launch_one<split_t, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH_SK>(a, chunks, s, true);
+        rc |= launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_QKV, 2>(a, chunks, s, true);
+        rc |= launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_SWIGLU, 2>(a, chunks, s, true);
+        return rc;
+    }
+    if (a.lora_w != 0 || a.lora_delta != nullptr) { ctts_set_error("skinny_gemm: the split decode kernels carry no per-utterance adapters"); return 1; }
+    if (a.rt == 2) {         // two weight row tiles per workgroup: the operand fragments are loaded once per two tiles
+        if (pro == PRO_XH && epi == EPI_QKV) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_QKV, 2>(a, chunks, s, false);
+        if (pro == PRO_XH && epi == EPI_SWIGLU) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_SWIGLU, 2>(a, chunks, s, false);
+    }
+    if (pro == PRO_XH && epi == EPI_QKV) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_QKV>(a, chunks, s, false);
+    if (pro == PRO_XH && epi == EPI_SWIGLU) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_SWIGLU>(a, chunks, s, false);
+    if (pro == PRO_XH && epi == EPI_LOGITS) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_LOGITS>(a, chunks, s, false);
+    if (pro == PRO_PACKED && epi == EPI_RESID_XH && a.K == 768) return launch_one<split_t, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, false);
+    if (pro == PRO_PACKED && epi == EPI_RESID_XH) return launch_one<split_t, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, false);
+    if (pro == PRO_PACKED && epi == EPI_RESID_XH_SK) return launch_one<split_t, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH_SK>(a, chunks, s, false);
+    ctts_set_error("skinny_gemm (split operands): unsupported prologue/epilogue %d/%d", pro, epi);
+    return 1;
+}
+
 // Prompt pass: RMSNorm once per row into the fragment-major B-operand image the GEMMs read with PRO_PACKED.  In the decode
 // step every block normalises its <= 32 rows itself (cheaper than a launch); over a whole prompt that replication is
 // tiles x rows x 3 KB of L2 reads per layer (13 GB per pass at 1536 rows), so the prompt pass normalises once instead.
@@ -838,7 +950,10 @@ int launch_norm_pack(int dtype, const float* x, void* out, int R, int nbg, float
 }
 
 int launch_gemm(int dtype, int nbg, int pro, int epi, const GemmArgs& a, int chunks, hipStream_t s) {
-    if (dtype == 1) {
+    if (dtype == 2) {         // fp32 engine, head / tail fp16 operands (split_t)
+        if (nbg == 1) return dispatch_split<1>(pro, epi, a, chunks, s, false);
+        if (nbg == 2) return dispatch_split<2>(pro, epi, a, chunks, s, false);
+    } else if (dtype == 1) {
         if (nbg == 1) return dispatch<half_t, 1>(pro, epi, a, chunks, s, false);
         if (nbg == 2) return dispatch<half_t, 2>(pro, epi, a, chunks, s, false);
     } else {
@@ -856,5 +971,7 @@ int gemm_configure() {
     rc |= dispatch<half_t, 2>(0, 0, a, 1, nullptr, true);
     rc |= dispatch<float, 1>(0, 0, a, 1, nullptr, true);
     rc |= dispatch<float, 2>(0, 0, a, 1, nullptr, true);
+    rc |= dispatch_split<1>(0, 0, a, 1, nullptr, true);
+    rc |= dispatch_split<2>(0, 0, a, 1, nullptr, true);
     return rc;
 }

@@ -405,8 +405,8 @@ class GPT:
             if self.dtype_code == _lib.DTYPE_F16:
                 msg = f"use weight_dtype='fp32' for this checkpoint"
             else:
-                msg = ("the fp32 engine's long-prompt pass keeps silu(gate) * up / 16 as fp16 head / tail images; construct the GPT with "
-                       "prefill_split_rows=0 to keep the exact fp32 prompt kernels for this checkpoint")
+                msg = ("the fp32 engine's long-prompt pass and its decode batches of >= 9 rows keep silu(gate) * up / 16 and the scaled residual rows as fp16 head / tail "
+                       "images; construct the GPT with options={'prefill_split_rows': 0, 'split_decode_rows': 0} to keep the exact fp32 kernels for this checkpoint")
             warnings.warn(f"hip GPT (weight_dtype {'fp16' if self.dtype_code == _lib.DTYPE_F16 else 'fp32'}): {n} fp16 stores saturated or were NaN "
                           f"during this {what}; {msg}", RuntimeWarning)
         return n

@@ -529,11 +529,13 @@ class ChatTTSPlusPipeline:
                 return
             ready, next_i, first = {}, 0, True
             ids_sink = kwargs.get("_ids_sink")
-            # continuous="throughput" (round 5): the vocoder does not wait for the last utterance.  Finished utterances are vocoded in batches of `vocoder_chunk`
-            # on a SIDE stream while the decode rows keep stepping on the caller's stream (the launch chain leaves most of the chip idle; a <= 5-row tail's
-            # persistent launch simply waits the few tens of microseconds a vocoder kernel holds its CUs).  One list at the end, in input order, as before.
-            overlap = (not ordered) and self.device.type == "cuda" and bool(kwargs.get("overlap_vocoder", True))
-            voc_chunk = int(kwargs.get("vocoder_chunk", 32))
+            # continuous="throughput" + overlap_vocoder=True (round 5; OPT-IN since round 6): the vocoder does not wait for the last utterance.  Finished utterances are
+            # vocoded in batches of `vocoder_chunk` on a SIDE stream while the decode rows keep stepping on the caller's stream.  Measured: no gain (256 ragged utterances
+            # 2682 vs 2665-2687 ms: the vocoder's GEMMs fill the chip and the decode chain's small kernels queue behind them), and a <= 5-row tail's persistent launch
+            # -- which needs all 256 workgroups resident -- then shares the chip with vocoder kernels.  Its waits are bounded and the soak test
+            # (tests/test_gpu_pipeline.py::test_vocoder_overlap_soak) drives exactly that overlap, but a default that buys nothing stays off.  One list at the end, in input order.
+            overlap = (not ordered) and self.device.type == "cuda" and bool(kwargs.get("overlap_vocoder", False))
+            voc_chunk = max(1, int(kwargs.get("vocoder_chunk", 32)))
             side = torch.cuda.Stream(device=self.device) if overlap else None
             t_req = torch.cuda.Event(enable_timing=True) if overlap else None
             t_first = None

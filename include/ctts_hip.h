@@ -63,10 +63,14 @@ void ctts_gpt_destroy(ctts_gpt* h);
 /* Named engine options (the YAML's `kwargs.options` of the hip GPT; no counterpart in the reference -- the TensorRT path fixes such choices when
  * the engine is built, trt_models/llama_trt_model.py:25-81).  Explicit calls only: the product library reads no behaviour from the environment.
  *   "prefill_split_rows"  fp32 engines: prompt passes of >= this many rows use the 3-term fp16 split GEMMs (default 384; 0 = never; before finalize)
+ *   "split_decode_rows"   fp32 engines: decode batches of >= this many rows (packed-residual path, >= 9 rows, no per-utterance adapters) run their projections on the fp16 matrix
+ *                         pipes with head / tail fp16 operands -- 3 MFMAs per product at fp32-level accuracy, the prompt pass's arithmetic -- instead of exact-f32 MFMA
+ *                         (default 9; 0 = never.  Set to 0 BEFORE finalize and the engine builds no head / tail weight images unless the prompt pass needs them)
  *   "valu_rows"           fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (default 2; 0..4)
  *   "persistent_rows"     decode batches of <= this many rows (<= 5; default 5 = 12 heads x 5 rows on 60 of the 64 attention workgroups) run the whole decoder stack of a step as ONE persistent
- *                         launch of 256 resident workgroups (persist_layer.hip; contexts up to 1024 keys, no per-utterance adapters).  0 = off.  The first
- *                         process that loads an fp32 engine on a device holds the mode (advisory lock /tmp/ctts_persist_<pci>.lock); others stay on launches.
+ *                         launch of 256 resident workgroups (persist_layer.hip; up to 1400 keys per key share -- longer contexts go back to the launch chain -- no per-utterance adapters; the final
+ *                         norm + code heads run inside the launch at <= 2 rows).  0 = off.  The first
+ *                         process that loads an engine (either dtype) on a device holds the mode (advisory lock /tmp/ctts_persist_<pci>.lock); others stay on launches.
  *                         A persistent launch needs all 256 workgroups resident: run ONE decode at a time per device (two engines of one process decoding
  *                         concurrently on different streams would have to share the CUs; every wait is bounded and ctts_gpt_progress reports a give-up)
  *   "persistent_layers_per_launch"  0 = the whole stack in one launch (default), n = n layers per launch
@@ -82,18 +86,12 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "lora_fold"           per-utterance adapters at decode: 1 (default) = the rows' low-rank terms come from worker workgroups inside the QKV / o_proj launches
  *                         (lora_worker.h), 0 = two more launches per layer (lora.hip; the prompt pass always uses those)
  *   "persistent_fault"    test hook: one workgroup withholds a hand-off in layer value - 1 (the bounded waits must end the step with an error)
- *   "mfma_rows"           fp32 engines, OPT-IN (default 0 = off): decode batches of "mfma_rows_min" (default 5) .. this many rows (<= 32) run the decoder stack of a
- *                         step as ONE persistent launch with MFMA projections (persist_mfma.hip; same packed weight images, same sums as the launch chain).  Measured
- *                         slower than the launch chain on MI355X, hence off; same residency rule and device lock as "persistent_rows"
- *   "mfma_nap", "mfma_delay_0" .. "mfma_delay_4"  how often / how long after a phase starts its poller looks at the producing phase's flag words
- *   "mfma_timestamps"     diagnostics: per-workgroup phase marks of the last layer ("pm_ts" of ctts_gpt_debug_read)      "mfma_fault"  test hook like "persistent_fault"
  * Unknown names are an error. */
 int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value);
 int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value);      /* the EFFECTIVE value ("persistent_rows" reads 0 where the mode is unavailable) */
 
 /* Diagnostics (tools/persist_probe.py): copies a named internal buffer to HOST memory -- "x_dec", "q_buf", "logits", "pl_g" (the persistent
- * layer's granule buffers), "pl_ts" (its per-workgroup phase marks, option "persistent_timestamps"), "pl_state" ({epoch, error}), "pm_ts" (phase marks of the persistent MFMA stack,
- * option "mfma_timestamps"), "xh" / "ssq" (the packed residual copy and its per-tile sums of squares).  Synchronises. */
+ * layer's granule buffers), "pl_ts" (its per-workgroup phase marks, option "persistent_timestamps"), "pl_state" ({epoch, error}), "xh" / "ssq" (the packed residual copy and its per-tile sums of squares).  Synchronises. */
 int ctts_gpt_debug_read(ctts_gpt* h, const char* name, void* out, size_t max_bytes, size_t* bytes, void* stream);
 
 /* replaces GPT.from_pretrained -> load_state_dict (gpt.py:84-85).  `name` is the reference

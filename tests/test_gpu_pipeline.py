@@ -27,10 +27,11 @@ def _tokenizer(tmp_path):
     return Tokenizer(tokenizer=bt)
 
 
-def test_pipeline_infer_matches_oracle_chain(tmp_path):
-    from chatttsplus_amd.pipeline import ChatTTSPlusPipeline, InferCodeParams, load_config
+def _make_pipe(tmp_path, max_batch=8, max_seq_len=256):
+    """ChatTTSPlusPipeline on synthetic checkpoints written to tmp_path (the drop-in path: YAML -> infer_type "hip" -> hip_models)."""
+    from chatttsplus_amd.pipeline import ChatTTSPlusPipeline, load_config
     cfg = load_config(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "infer", "chattts_plus_hip.yaml"))
-    cfg["MODELS"]["gpt"]["kwargs"].update(weight_dtype="fp32", max_batch=8, max_seq_len=256)
+    cfg["MODELS"]["gpt"]["kwargs"].update(weight_dtype="fp32", max_batch=max_batch, max_seq_len=max_seq_len)
     os.makedirs(tmp_path / "asset")
     gsd = synth.gpt_state_dict(synth.GPT_REAL, 1234)
     dsd = synth.dvae_state_dict(synth.DVAE_REAL, 1234)
@@ -41,6 +42,67 @@ def test_pipeline_infer_matches_oracle_chain(tmp_path):
         torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, tmp_path / "asset" / name)
     tok = _tokenizer(tmp_path)
     pipe = ChatTTSPlusPipeline(cfg, device="cuda", tokenizer=tok, checkpoint_dir=str(tmp_path))
+    return pipe, tok, dict(gpt=gsd, dvae=dsd, vocos=vsd, enc=esd)
+
+
+def test_vocoder_overlap_soak(tmp_path):
+    """continuous="throughput" with overlap_vocoder=True (opt-in): finished utterances are vocoded in batches of `vocoder_chunk` on a SIDE stream while the remaining rows keep
+    decoding -- here on 3 / 5 rows, i.e. on PERSISTENT launches that need all 256 workgroups resident while cnx_gemm_kernel batches hold CUs (the serial
+    counterpart is _decode_to_wavs, pipeline:435-457).  14 ragged utterances, vocoder_chunk=2 -> >= 6 vocoder batches start while rows are still stepping.  Every waveform
+    must equal the overlap-free run, no bounded wait may give up (pl_state.error == 0), and the whole request is repeated (soak)."""
+    import ctypes as C
+    import json
+    from chatttsplus_amd.pipeline import InferCodeParams
+    pipe, tok, _ = _make_pipe(tmp_path)
+    spk = torch.load(os.path.join(GOLDEN, "speakers", "2222.pt"), weights_only=True)
+    texts = ["a b c d a b", "c a", "b", "d d c", "a b", "c c c c a", "b a d", "a", "b b a c d", "c d", "a a a b", "d", "c b a", "b d d a c c"]
+    lims = [40, 9, 14, 22, 6, 31, 12, 5, 36, 8, 17, 4, 11, 27]            # ragged per-utterance token limits: rows finish (and are re-used) at different steps
+    pv = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=40, min_new_token=40, show_tqdm=False)
+    gpt = pipe.models_dict["gpt"]
+    assert gpt.get_option("persistent_rows") == 5
+
+    def run(rows, **kw):
+        res = list(pipe.infer(list(texts), skip_refine_text=True, do_text_optimization=False, params_infer_code=pv, noise="device", noise_seed=31, slice_size=rows,
+                              continuous="throughput", max_new_tokens_per_utterance=lims, **kw))
+        assert len(res) == 1 and len(res[0]) == len(texts)
+        return [w.cpu().numpy() for w in res[0]]
+
+    def pl_error():
+        buf = (C.c_uint * 2)()
+        n = C.c_size_t(0)
+        from chatttsplus_amd import _lib
+        _lib.check(gpt._lib.ctts_gpt_debug_read(gpt._h, b"pl_state", buf, 8, C.byref(n), None), "debug_read")
+        return int(buf[1])
+
+    loops, worst, t_overlap = 0, 0.0, []
+    for rows in (3, 5):
+        ref = run(rows)
+        assert [w.shape[0] for w in ref] == [256 * (2 * n - 1) for n in lims]
+        for it in range(26):
+            got = run(rows, overlap_vocoder=True, vocoder_chunk=2)
+            loops += 1
+            assert pl_error() == 0, f"rows={rows} loop {it}: a persistent launch gave up waiting while the vocoder held CUs"
+            for u in range(len(texts)):
+                a, b = ref[u], got[u]
+                assert a.shape == b.shape, (rows, it, u)
+                rel = float(np.sqrt(np.mean((a - b) ** 2))) / float(np.sqrt(np.mean(a ** 2)))
+                worst = max(worst, rel)
+                assert rel <= 1e-4, (rows, it, u, rel)
+            t_overlap.append(getattr(pipe, "last_first_audio_ms", None))
+    # a non-positive chunk must not loop forever (ADVICE r5): clamped to 1
+    one = run(3, overlap_vocoder=True, vocoder_chunk=0)
+    assert all(a.shape == b.shape for a, b in zip(one, ref))
+    out = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r06_overlap_soak.json"), "w") as f:
+            json.dump(dict(loops=loops, utterances=len(texts), rows=[3, 5], vocoder_chunk=2, worst_rel_rms=worst, give_ups=0,
+                           first_vocoder_batch_ms=[t for t in t_overlap if t is not None][:4]), f)
+
+
+def test_pipeline_infer_matches_oracle_chain(tmp_path):
+    from chatttsplus_amd.pipeline import InferCodeParams
+    pipe, tok, sds = _make_pipe(tmp_path)
+    gsd, dsd, vsd, esd = sds["gpt"], sds["dvae"], sds["vocos"], sds["enc"]
     spk = torch.load(os.path.join(GOLDEN, "speakers", "2222.pt"), weights_only=True)       # base16384 string
     params = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=40, min_new_token=2, show_tqdm=False)
     texts = ["a b c d a b", "c a"]

@@ -1,0 +1,112 @@
+"""Decode projections of the fp32 (parity) engine on the fp16 matrix pipes (round 6; skinny_gemm.hip dispatch_split, common.h split_t): from
+`split_decode_rows` rows on, weights and operands are head / tail fp16 image pairs and a product is three v_mfma_f32_16x16x32_f16 instead of eight
+exact-f32 MFMAs -- the prompt pass's arithmetic (prefill_split.hip) applied to the loop of gpt.py:389-546 over llama.py:719-749.
+
+The bit-exact-vs-reference statement rides on the goldens of tests/test_gpu_gpt.py (gpt_real_b32_ragged, the teacher-forced 17 / 32 / 33-row cases run
+through this path by default).  Here: the path against the exact-f32 kernels it replaces, on the same engine."""
+import numpy as np
+import pytest
+import torch
+
+from chatttsplus_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
+LP = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
+LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20)
+
+
+@pytest.fixture(scope="module")
+def gpt():
+    from chatttsplus_amd.hip_models import GPT
+    g = GPT(LLAMA, max_batch=40, max_seq_len=400, weight_dtype="fp32")
+    g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+    yield g
+    g.close()
+
+
+def _gen(g, B, P, N, pad=None, seed=7, graph=True):
+    ids, mask = synth.prompt_ids(B, P, 21178, 4321, pad_left=pad)
+    emb = g(torch.from_numpy(ids), torch.ones(B, P, dtype=torch.bool))
+    g.use_graph = graph
+    try:
+        res = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N, min_new_token=N,
+                              logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="device", seed=seed))[-1]
+    finally:
+        g.use_graph = True
+    return res.ids, res.hiddens
+
+
+@pytest.mark.parametrize("B,P,N,pad", [(9, 40, 24, None), (16, 33, 24, [(5 * i) % 30 for i in range(16)]), (17, 48, 24, None), (24, 40, 16, [(7 * i) % 36 for i in range(24)]),
+                                       (32, 48, 32, [(3 * i) % 40 for i in range(32)]), (40, 30, 8, None)])
+def test_split_decode_matches_the_exact_f32_kernels(gpt, B, P, N, pad):
+    g = gpt
+    assert g.get_option("split_decode_rows") == 9, "fp32 engines run decode batches of >= 9 rows on the head / tail images by default"
+    try:
+        g.set_option("split_decode_rows", 0)
+        ref_ids, ref_h = _gen(g, B, P, N, pad)
+        g.set_option("split_decode_rows", 9)
+        ids, hid = _gen(g, B, P, N, pad)
+    finally:
+        g.set_option("split_decode_rows", 9)
+    worst = 0.0
+    for b in range(B):
+        assert torch.equal(ids[b], ref_ids[b]), f"B={B}: row {b} tokens differ from the exact-f32 kernels"
+        worst = max(worst, float((hid[b] - ref_h[b]).abs().max()))
+    # hidden rows are O(1) (the final RMSNorm's output times its weight); the oracle tolerance of tests/test_gpu_gpt.py is 2e-5 abs
+    assert worst <= 2e-5, (B, worst)
+
+
+@pytest.mark.parametrize("opts", [dict(nbg2_rows=17), dict(split_row_tiles=2), dict(nbg2_rows=17, split_row_tiles=2), dict(weight_prefetch_kb=48), dict(weight_prefetch_kb=0)])
+def test_split_decode_launch_shapes_agree(gpt, opts):
+    """The other launch shapes of the same arithmetic -- 32-row blocks (with the in-launch K-slice combine of the down projection), two weight row tiles per workgroup,
+    prefetch workgroups on / off -- sample the same tokens; a product's terms are added in the same order whatever the shape, so the hidden rows agree to the last bit
+    except where a 32-row block changes nothing but the workgroup a row rides in (still the same sums)."""
+    g = gpt
+    base = {k: g.get_option(k) for k in opts}
+    ref_ids, ref_h = _gen(g, 24, 40, 16, [(7 * i) % 36 for i in range(24)])
+    try:
+        for k, v in opts.items():
+            g.set_option(k, v)
+        ids, hid = _gen(g, 24, 40, 16, [(7 * i) % 36 for i in range(24)])
+    finally:
+        for k, v in base.items():
+            g.set_option(k, v)
+    for b in range(24):
+        assert torch.equal(ids[b], ref_ids[b]), (opts, b)
+        assert float((hid[b] - ref_h[b]).abs().max()) <= 2e-6, (opts, b)
+
+
+def test_split_decode_graph_equals_eager_and_replays_bitwise(gpt):
+    g = gpt
+    a_ids, a_h = _gen(g, 32, 48, 24)
+    b_ids, b_h = _gen(g, 32, 48, 24)
+    c_ids, c_h = _gen(g, 32, 48, 24, graph=False)
+    for b in range(32):
+        assert torch.equal(a_ids[b], b_ids[b]) and torch.equal(a_h[b], b_h[b]), "two replays differ (fixed reduction orders, no atomics on the data path)"
+        assert torch.equal(a_ids[b], c_ids[b]) and torch.equal(a_h[b], c_h[b]), "hipGraph replay != eager launches"
+
+
+def test_split_decode_rows_are_independent_of_the_batch_they_ride_in(gpt):
+    """An utterance's tokens must not depend on its neighbours (the reference decodes rows independently, llama.py:719-749): rows 0..8 of a 32-row batch == the same
+    rows decoded as a 9-row batch (both on the split kernels, different 16-row chunk populations)."""
+    g = gpt
+    ids32, _ = _gen(g, 32, 48, 24)
+    ids9, _ = _gen(g, 9, 48, 24)
+    for b in range(9):
+        assert torch.equal(ids32[b], ids9[b]), b
+
+
+def test_an_engine_without_the_images_refuses_the_option():
+    from chatttsplus_amd.hip_models import GPT
+    g = GPT(LLAMA, max_batch=12, max_seq_len=30, weight_dtype="fp32", options={"split_decode_rows": 0, "prefill_split_rows": 0})
+    g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
+    try:
+        assert g.get_option("split_decode_rows") == 0
+        with pytest.raises(Exception, match="head / tail"):
+            g.set_option("split_decode_rows", 9)
+        ids, _ = _gen(g, 10, 12, 6)          # still decodes, on the exact-f32 kernels
+        assert len(ids) == 10
+    finally:
+        g.close()

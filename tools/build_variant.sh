@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 OUT=chatttsplus_amd/_lib/ab_$NAME
 mkdir -p $OUT
-for f in gpt_engine skinny_gemm prefill_gemm prefill_split lora attention sampler vocoder encoder persist_layer persist_mfma; do
+for f in gpt_engine skinny_gemm prefill_gemm prefill_split lora attention sampler vocoder encoder persist_layer; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=8 "$@" -c chatttsplus_amd/csrc/$f.hip -o $OUT/$f.o &
 done
 wait

@@ -1,4 +1,4 @@
-"""Soak of the persistent decode launch: many long generations at 1..4 rows back to back; every request must end without a give-up (ctts_gpt_progress raises on
+"""Soak of the persistent decode launch: many long generations at 1..max-rows rows back to back; every request must end without a give-up (ctts_gpt_progress raises on
 one) and a repeated request must reproduce its tokens bit for bit.  python tools/persist_soak.py [--requests 24] [--tokens 1500]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,18 +7,18 @@ from chatttsplus_amd import synth
 from chatttsplus_amd.hip_models import GPT
 
 ap = argparse.ArgumentParser(); ap.add_argument("--requests", type=int, default=24); ap.add_argument("--tokens", type=int, default=1500)
-ap.add_argument("--mfma", action="store_true", help="soak the opt-in persistent MFMA stack instead: batches of 5..32 rows (persist_mfma.hip)")
+ap.add_argument("--max-rows", type=int, default=5, help="row counts 1..max-rows take turns (the persistent launch serves up to persistent_rows of them)")
 a = ap.parse_args()
 LLAMA = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20)
-g = GPT(LLAMA, max_batch=32 if a.mfma else 4, max_seq_len=64 + a.tokens + 16, weight_dtype="fp32", options={"mfma_rows": 32} if a.mfma else {})
+g = GPT(LLAMA, max_batch=a.max_rows, max_seq_len=64 + a.tokens + 16, weight_dtype="fp32")
 g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
-assert g.get_option("persistent_rows") == 5 and (not a.mfma or g.get_option("mfma_rows") == 32)
+assert g.get_option("persistent_rows") >= min(5, a.max_rows)
 g.compact = False                                  # every step of a request at the same row count
 LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
 LP = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
 steps, t0, first = 0, time.perf_counter(), {}
 for i in range(a.requests):
-    B = (5, 8, 13, 16, 17, 24, 29, 32)[i % 8] if a.mfma else 1 + i % 4
+    B = 1 + i % a.max_rows
     ids, mask = synth.prompt_ids(B, 48, 21178, 4321 + (i % 8), pad_left=[(3 * b) % 7 for b in range(B)])
     emb = g(torch.from_numpy(ids), torch.ones(B, 48, dtype=torch.bool))
     out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=a.tokens, min_new_token=a.tokens,
@@ -30,6 +30,6 @@ for i in range(a.requests):
         assert first[key] == sig, f"request {i}: tokens differ from the first run of the same request"
     first[key] = sig
 torch.cuda.synchronize()
-print(json.dumps({"engine": "persist_mfma.hip (5..32 rows)" if a.mfma else "persist_layer.hip (1..4 rows)", "requests": a.requests, "decode_steps": steps, "layer_stack_launches": steps, "give_ups": 0, "repeats_identical": True,
+print(json.dumps({"engine": f"persist_layer.hip (1..{a.max_rows} rows)", "requests": a.requests, "decode_steps": steps, "layer_stack_launches": steps, "give_ups": 0, "repeats_identical": True,
                   "seconds": round(time.perf_counter() - t0, 1)}))
 g.close()
