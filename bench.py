@@ -649,6 +649,11 @@ def main():
                 # multi-rank runs stop here: the remaining legs characterise one GPU (measured at N = 1) and every leg is a rendezvous --
                 # a rank failing inside one of them would leave the others waiting at its barrier
                 raise StopIteration
+            # BASELINE configs[1] measured WHOLE: one 512-token generation at batch 1, steps 4..512 timed in one piece (the first sample belongs to the
+            # prompt pass, three more steps capture the graph) -- the headline above is a K-step window around step 256 of the same generation
+            e = run_reps(leg, XR, 1, P, 508, 4, spk=spk, use_graph=use_graph, gen_tokens=0)
+            extra["batch1_full512"] = summarize(e, world)
+            extra["batch1_full512"]["timed_steps"] = "4..512 of a 512-token generation (mean context %.0f)" % e["mean_ctx"]
             # configs[2] as written: mixed-length utterances, left-padded to the longest prompt (P_b ~ U{16..96}), padded KV
             rng = np.random.Generator(np.random.Philox(key=77 + rank))
             plen = rng.integers(16, 97, size=EB)

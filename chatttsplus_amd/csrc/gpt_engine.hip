@@ -66,10 +66,16 @@ struct ctts_gpt {
     char* wsplit = nullptr;                      // fp32 engines: the split images of every layer matrix (2 x 2 bytes per weight), or null
     void* whead_sp = nullptr;                    //   ... and of the folded code heads
     bool split_ok = false;                       //   every weight x 64 is inside the fp16 range (otherwise the engine stays on the exact fp32 kernels)
-    int prefetch_mask = 15;                      // which launches' weights are prefetched: bit 0 gate|up (carried by o_proj), 1 down (by gate|up), 2 the next q|k|v / the heads (by down), 3 layer 0's q|k|v (by the heads)
-    int split_rt = 1;                            // split decode kernels: weight row tiles per workgroup of the q|k|v / gate|up launches (1 or 2); "split_row_tiles"
-    int prefetch_kb = 192;                       // decode launch chain: every projection launch carries extra workgroups that pull the NEXT launch's weight image into L2 (kernels.h
-                                                 // WPrefetch), one per this many KiB of it (8..128 of them); 0 = off.  "weight_prefetch_kb"
+    int split_nbg2_rows = 17;                    // ... and from this many rows on they take 32-row blocks (one workgroup per weight tile streams it once for all 32 rows; the down projection's K is
+                                                 // sliced four ways inside the launch as at 16-row chunks).  ms/step 16-row chunks / 32-row blocks: 17 rows 0.723 / 0.700, 24: 0.822 / 0.800, 32: 0.846 / 0.824
+                                                 // (profiles/r06_ab_split_shapes.jsonl).  "split_nbg2_rows"
+    int prefetch_mask = 1;                      // which launches' weights are prefetched: bit 0 gate|up (carried by o_proj), 1 down (by gate|up), 2 the next q|k|v / the heads (by down), 3 layer 0's q|k|v (by the heads)
+    int prefetch_kb = 96;                        // decode launch chain, packed-residual path (>= 9 rows; fp16 engines: >= 17): the o_proj launch -- 2.4 MB of weights of its own -- carries extra
+                                                 // workgroups that pull the gate|up launch's 18.9 MB weight image into L2 (kernels.h WPrefetch), one per this many KiB of it (8..256 of
+                                                 // them); 0 = off.  "weight_prefetch_kb".  ms/step without / with (profiles/r06_ab_weight_prefetch.jsonl): fp32 batch 9 0.610 / 0.588, 16 0.635 / 0.605,
+                                                 // 32 0.826 / 0.804; fp16 batch 32 0.603 / 0.588.  The other carriers stream large matrices themselves and lose what their consumers gain
+                                                 // ("weight_prefetch_mask": down carried by gate|up +4.8 %, the next q|k|v carried by down +2.7 %), and at 6-8 rows (split-K launch slices) the o_proj
+                                                 // carrier loses too: off there
     int split_dec_rows = 9;                      // fp32 engines: decode batches of >= this many rows (packed-residual path, no per-utterance adapters) run their projections on the
                                                  // head / tail images: 3 fp16 MFMAs per product instead of 8 exact-f32 ones (skinny_gemm.hip dispatch_split); 0 = never.  "split_decode_rows"
     void *sp_x_hi = nullptr, *sp_x_lo = nullptr, *sp_act_hi = nullptr, *sp_act_lo = nullptr;   //   ... and of the prompt rows' operands
@@ -140,6 +146,7 @@ struct ctts_gpt {
     int cur_persist = 0;                         //   the steps being launched use the persistent layer
     int pl_ts_on = 0;
     int persist_fault = 0;                       //   test hook ("persistent_fault"): see PersistArgs.fault
+    int persist_pair_keys = 704;                 //   6..8 rows: contexts beyond this many keys go back to the launch chain; "persistent_pair_keys"
     int persist_splits = 0;                      //   cap on the attention's key splits per (row, head) (0 = PL_SMAX); "persistent_splits"
     int persist_max_keys = 0;                    //   contexts beyond this many keys go back to the launch chain (0 = no limit); "persistent_max_keys"
     int persist_lpl = 0;                         //   decoder layers per persistent launch (0 = all of them in one launch)
@@ -238,7 +245,7 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
     // both dtypes since round 5 (fp16 engines: half weights + half K / V in the image, fp32 activations).  fp16: up to 3 rows -- ms/step launch chain / persistent
     // (tools/fp16_persist_probe.py, two edge waves): batch 1 0.370 / 0.256, 2 0.393 / 0.319, 3 0.423 / 0.381, 4 0.427 / 0.442
-    h->persist_rows = PL_MAXR;                                   // 5 (ms/step launch chain / persistent launch at 5 rows, fp32: 0.540 / 0.389; fp16 at 4 rows: 0.425 / 0.345)
+    h->persist_rows = PL_MAXR_ONE;                               // 5 (ms/step launch chain / persistent launch at 5 rows, fp32: 0.540 / 0.389; fp16 at 4 rows: 0.425 / 0.345)
     h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
@@ -330,7 +337,8 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
     else if (n == "split_decode_rows") *value = h->split_dec_rows;
     else if (n == "weight_prefetch_kb") *value = h->prefetch_kb;
-    else if (n == "split_row_tiles") *value = h->split_rt;
+    else if (n == "nbg2_rows") *value = h->nbg2_rows;
+    else if (n == "split_nbg2_rows") *value = h->split_nbg2_rows;
     else if (n == "weight_prefetch_mask") *value = h->prefetch_mask;
     else if (n == "split_rows") *value = h->split_rows;
     else if (n == "graph_steps") *value = h->graph_steps;
@@ -355,9 +363,9 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         else if (value > 0 && !(h->split_ok && h->wsplit)) { ctts_set_error("set_option(split_decode_rows): this engine holds no head / tail weight images (fp16 engine, a weight beyond the fp16 range, or the option was 0 at finalize)"); return 1; }
         else h->split_dec_rows = value < 0 ? 0 : value;
     } else if (n == "weight_prefetch_mask") {
-        h->prefetch_mask = value & 15;
-    } else if (n == "split_row_tiles") {
-        h->split_rt = value == 2 ? 2 : 1;
+        h->prefetch_mask = value & 31;
+    } else if (n == "split_nbg2_rows") {
+        h->split_nbg2_rows = value < 17 ? 17 : value;
     } else if (n == "weight_prefetch_kb") {      // launch chain: KiB of the next launch's weights per prefetch workgroup (0 = no prefetch workgroups; see prefetch_kb)
         h->prefetch_kb = value < 0 ? 0 : (value > 4096 ? 4096 : value);
     } else if (n == "valu_rows") {               // fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (0..4)
@@ -375,6 +383,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->lora_fold = (value < 0 || value > 3) ? 1 : value;
     } else if (n == "persistent_fault") {                  // test hook: a withheld hand-off; every wait is bounded, ctts_gpt_progress reports the edge
         h->persist_fault = value < 0 ? 0 : value;
+    } else if (n == "persistent_pair_keys") {
+        h->persist_pair_keys = value < 0 ? 0 : value;
     } else if (n == "persistent_max_keys") {
         h->persist_max_keys = value < 0 ? 0 : value;
     } else if (n == "persistent_splits") {
@@ -891,13 +901,15 @@ struct StreamForm { bool parts; bool xh; bool logits; bool split; };     // x = 
 // 20 decoder layers on R rows of residual stream x (llama.py:719-749 per layer)
 static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* rope_rows, int R, int S, const DevState* st, hipStream_t s, StreamForm* form = nullptr) {
     const int dt = h->cfg.dtype;
-    const int nbg = (R <= 16 || (st != nullptr && R < h->nbg2_rows)) ? 1 : 2;     // decode rows: see nbg2_rows
+    const bool lora = h->lora_rows != 0;                   // per-utterance adapters: the residual stream must be materialised in x (no split-K partials)
+    // fp32 engines, decode batches of >= split_decode_rows rows: head / tail fp16 operands (the predicate is completed below; it needs the packed-residual path)
+    const bool spd_ok = st != nullptr && dt == CTTS_DTYPE_F32 && h->xh_mode && h->split_ok && h->wsplit != nullptr && h->split_dec_rows > 0 && R >= h->split_dec_rows && R > h->split_rows && !lora && S == 1;
+    const int nbg = (R <= 16 || (st != nullptr && R < (spd_ok ? h->split_nbg2_rows : h->nbg2_rows))) ? 1 : 2;     // decode rows: see nbg2_rows / split_nbg2_rows
     const int NB = 16 * nbg;
     const int chunks = (R + NB - 1) / NB;
     // small decode batches: the down projection is launched as 4 split-K slices (192 blocks instead of 48 x 1024 threads);
     // its partial sums dp[0..3] are added, in order, by the next consumers of the residual stream (QKV RMSNorm, o_proj
     // residual, final heads) -- deterministic, no atomics.  x itself is re-materialised by every o_proj.
-    const bool lora = h->lora_rows != 0;                   // per-utterance adapters: the residual stream must be materialised in x (no split-K partials)
     const bool splitd = (st != nullptr) && (R <= h->split_rows) && (nbg == 1) && !lora;
     // prompt pass over more than a few chunks: normalise every row once (norm_pack_kernel) instead of in every GEMM block
     const bool prepack = (st == nullptr) && (nbg == 2) && (R > 64) && !h->no_prepack;
@@ -918,7 +930,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     const bool xhm = (st != nullptr) && h->xh_mode && !splitd;
     // ... and from split_decode_rows rows on (fp32 engines) the projections read head / tail fp16 images of weights and operands: 3 fp16 MFMAs per product instead of 8
     // exact-f32 ones (common.h split_t; the prompt pass's arithmetic, prefill_split.hip).  Layer 0's q|k|v projection normalises the sampler's fp32 rows and stays exact.
-    const bool spd = xhm && dt == CTTS_DTYPE_F32 && h->split_ok && h->wsplit != nullptr && h->split_dec_rows > 0 && R >= h->split_dec_rows && !lora && S == 1;
+    const bool spd = xhm && spd_ok;
     const int dts = spd ? 2 : dt;                              // launch_gemm's operand format
     if (st != nullptr && h->cur_persist && h->pimg != nullptr && R <= PL_MAXR && !lora) {
         // one persistent launch per layer (persist_layer.hip): the residual stream stays in x, nothing is left in partial or packed form
@@ -945,14 +957,15 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     if (form) { form->parts = splitd; form->xh = xhm; form->logits = false; form->split = spd; }
     // weight prefetch across the launch boundaries of a decode step (kernels.h WPrefetch): launch k carries workgroups that pull launch k + 1's weight image into L2.
     // (16-row chunks only: every consumer workgroup column is then one row tile; per-utterance adapters shift the consumers' block indices by their workers: off)
-    const int pf_kb = (st != nullptr && nbg == 1 && !lora) ? h->prefetch_kb : 0;
+    const int pf_kb = (st != nullptr && xhm && !lora && (dt == CTTS_DTYPE_F32 || R >= 17)) ? h->prefetch_kb : 0;
     auto set_pf = [&](GemmArgs& g, const void* w, int n_tiles, int K, int fmt, int bit) {          // fmt: 0 fp32 tiles, 1 fp16 tiles, 2 head / tail pairs
-        if (pf_kb <= 0 || w == nullptr || !((h->prefetch_mask >> bit) & 1) || (spd && h->split_rt != 1)) return;
+        if (pf_kb <= 0 || w == nullptr || !((h->prefetch_mask >> bit) & 1)) return;
         const size_t tile = (size_t)16 * K * (fmt == 1 ? 2 : 4);
         size_t nb = (tile * n_tiles + (size_t)pf_kb * 1024 - 1) / ((size_t)pf_kb * 1024);
         nb = (nb + 7) & ~(size_t)7;
-        g.pf.ptr = w; g.pf.unit_bytes = (unsigned)tile; g.pf.n_units = (unsigned)n_tiles;
-        g.pf_blocks = (int)(nb < 8 ? 8 : (nb > 128 ? 128 : nb));
+        nb = nb < 8 ? 8 : (nb > 256 ? 256 : nb);
+        if (g.pf.ptr == nullptr) { g.pf.ptr = w; g.pf.unit_bytes = (unsigned)tile; g.pf.n_units = (unsigned)n_tiles; g.pf_blocks = (int)nb; }
+        else { g.pf2.ptr = w; g.pf2.unit_bytes = (unsigned)tile; g.pf2.n_units = (unsigned)n_tiles; if ((int)nb > g.pf_blocks) g.pf_blocks = (int)nb; }
     };
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
@@ -988,7 +1001,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         } else if (xhm) {
             g1.scale_out = h->scale_o;
             if (l > 0) { g1.xh = h->xh; g1.ssq = h->ssq; g1.scale_in = h->scale_d; }
-            if (spd && l > 0) { g1.W = h->lw[l].qkv_sp; g1.rt = h->split_rt; }
+            if (spd && l > 0) g1.W = h->lw[l].qkv_sp;
             if (launch_gemm(l > 0 ? dts : dt, nbg, l > 0 ? PRO_XH : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         } else if (launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         AttnArgs at = {};
@@ -1020,6 +1033,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         else {
             if (spd) g2.W = h->lw[l].o_sp;
             set_pf(g2, spd ? h->lw[l].gu_sp : h->lw[l].gu, 2 * h->I / 16, h->H, dts, 0);
+            set_pf(g2, spd ? h->lw[l].d_sp : h->lw[l].d, h->H / 16, h->I, dts, 4);          // (bit 4: the down image too, two launches ahead)
             if (launch_gemm(dts, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (splitd ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
         }
         // RMSNorm + gate|up + SiLU*up
@@ -1034,7 +1048,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             if (pfg ? launch_prefill_gemm(EPI_SWIGLU, g3, s) : launch_gemm(dt, nbg, PRO_PACKED, EPI_SWIGLU, g3, chunks, s)) return 1;
         } else if (xhm) {
             g3.xh = h->xh; g3.ssq = h->ssq; g3.scale_in = h->scale_o; g3.scale_out = h->scale_d;
-            if (spd) { g3.W = h->lw[l].gu_sp; g3.rt = h->split_rt; }
+            if (spd) g3.W = h->lw[l].gu_sp;
             set_pf(g3, spd ? h->lw[l].d_sp : h->lw[l].d, h->H / 16, h->I, dts, 1);
             if (launch_gemm(dts, nbg, PRO_XH, EPI_SWIGLU, g3, chunks, s)) return 1;
         } else {
@@ -1071,7 +1085,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
 
 // final RMSNorm + heads on the h->B decode rows; `form` = how the last run_layers left them (all false after a prompt pass / restart)
 static int run_heads(ctts_gpt* h, bool write_hidden, StreamForm form, hipStream_t s) {
-    const int nbg = (h->B <= 16 || h->B < h->nbg2_rows) ? 1 : 2;
+    const int nbg = (h->B <= 16 || h->B < (form.split ? h->split_nbg2_rows : h->nbg2_rows)) ? 1 : 2;      // (the packed rows' layout does not depend on the producer's block height)
     const int chunks = (h->B + 16 * nbg - 1) / (16 * nbg);
     GemmArgs a = {};
     a.st = h->st; a.R = h->B; a.eps = 1e-6f; a.meta = h->meta_dec;
@@ -1248,6 +1262,12 @@ static inline int decode_persist(const ctts_gpt* h, int B, int L) {
     // Measured (tools/long_ctx_probe.py, ms/step launch chain / persistent): 3 rows 1200 keys 0.702 / 0.644, 1900 keys 0.733 / 0.808; 4 rows 1200 keys 0.717 / 0.708,
     // 1900 keys 0.748 / 0.877; 2 rows (2 shares) 1900 keys 0.568 / 0.535; 1 row 1900 keys 0.504 / 0.364: one workgroup streams a share at ~40 GB/s, so a share
     // beyond ~1400 keys loses to the chain's 144 attention blocks -> the limit is 1400 keys per share
+    if (B > PL_MAXR_ONE) {
+        // 6..8 rows: two (row, head) items per attention workgroup, no key splits: 192 keys per item are requested before the query exists, the rest streams behind it
+        // 128 keys per round trip -- the chain's 72..96 attention blocks win beyond a few such trips ("persistent_max_keys")
+        if (h->persist_sched != 3) return 0;
+        return (L > (h->persist_max_keys > 0 ? h->persist_max_keys : h->persist_pair_keys)) ? 0 : 1;
+    }
     if (L > (h->persist_max_keys > 0 ? h->persist_max_keys : 1400 * cap)) return 0;
     if (L <= PL_SHARE_KEYS + 128) return 1;                 // (one streamed iteration costs less than the extra hop)
     const int want = (L + PL_SHARE_KEYS - 1) / PL_SHARE_KEYS;

@@ -14,7 +14,8 @@
 #define PL_H 768
 #define PL_I 3072
 #define PL_NH 12
-#define PL_MAXR 5                          // 12 heads x 5 rows = 60 of the 64 attention workgroups
+#define PL_MAXR_ONE 5                      // 12 heads x 5 rows = 60 of the 64 attention workgroups: up to here one (row, head[, key share]) per attention workgroup
+#define PL_MAXR 8                          // 6..8 rows: two (row, head) items per attention workgroup, 4 compute waves + 1 edge wave each (round 6)
 #define PL_SHARE_KEYS 384                  // cached keys a workgroup requests before the query exists; a longer share streams behind the query
 // per-workgroup weight image of one layer: 12 q|k|v rows, 4 o_proj rows, 16 gate|up pairs, 4 down rows (fp32)
 #define PL_QKV_BYTES (12 * 768 * 4)

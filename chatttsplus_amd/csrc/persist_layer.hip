@@ -26,6 +26,9 @@
 
 typedef unsigned long long u64;
 
+#ifndef PL_LB
+#define PL_LB PL_THREADS_MAX
+#endif
 #define PL_SPIN_LIMIT (1u << 18)      // ~0.3 s of polling before a wave gives up
 
 __device__ inline void store_granule(u64* g, unsigned tag, float v) {
@@ -60,6 +63,43 @@ __device__ inline bool sweep(const u64* base, unsigned lane_elem, OffFn off, uns
     }
 }
 
+// The same sweep through a buffer descriptor (6..8 rows).  The granules of a sweep lie 2 KB (columns) and 6 / 24 KB (rows) apart -- beyond the 4 KB immediate of a global
+// load, so the flat form needs a 64-bit address pair per granule: 24 granules = 48 address registers beside the 48 data registers, and the 8-row kernel wanted 190 VGPRs
+// (it has 168: 20 spills, a scratch reload in front of every publish, 0.70 ms per step instead of ~0.57).  A buffer load takes the lane's byte offset in ONE register and
+// the granule's offset as a scalar: no per-granule address registers at all (cdna_hip_programming.md T8).  aux: sc1 (the relaxed agent-scope load's cache policy) + the
+// intrinsic's volatile bit (the loop re-reads memory another workgroup writes).
+template <int N, typename OffFn>
+__device__ inline bool sweep_buf(const u64* base, unsigned n_granules, unsigned lane_elem, OffFn off, unsigned tag, float (&v)[N], int* err, int code, volatile int* abort_s, int nap = 1) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(n_granules * 8u), 0x00020000);
+    const unsigned voff = lane_elem * 8u;
+#pragma unroll 1
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, off(k) * 8, (int)(16u | 0x80000000u));
+            v[k] = __builtin_bit_cast(float, x[0]);
+            ok = ok && (x[1] == tag);
+        }
+        if (__all(ok)) return true;
+        bool giveup = spins >= PL_SPIN_LIMIT || *abort_s != 0;
+        if (!giveup && (spins & 1023u) == 1023u) giveup = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (giveup) {
+            if ((threadIdx.x & 63) == 0) { atomicCAS(err, 0, code); *abort_s = 1; }
+            return false;
+        }
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
+    }
+}
+// the GEMV edge waves' sweeps: flat loads up to 5 rows (the tuned kernels stay as they are), buffer loads from 6 rows on
+#ifndef PL_BUF_MIN_R
+#define PL_BUF_MIN_R (PL_MAXR_ONE + 1)     // (A/B builds: tools/build_variant.sh bufall -DPL_BUF_MIN_R=1)
+#endif
+#define PL_SWEEP(N_, base_, count_, lane_elem_, off_, tag_, v_, code_) \
+    ((R >= PL_BUF_MIN_R) ? sweep_buf<N_>(base_, (unsigned)(count_), lane_elem_, off_, tag_, v_, a.error, code_, abort_s, a.nap) \
+                       : sweep<N_>(base_, lane_elem_, off_, tag_, v_, a.error, code_, abort_s, a.nap))
+
 // Before a wave sweeps ALL its granules of an edge it watches one "sentinel" granule per producer workgroup that feeds it (the last one that producer
 // stores): 96 eight-byte loads per pass instead of up to 3072.  A hint only -- stores of different lanes land in any order -- the sweep that follows checks
 // every tag; bounded, silent (the sweep reports).
@@ -78,6 +118,13 @@ __device__ inline void watch_sentinels(const u64* base, OffFn off, int n, unsign
     }
 }
 
+// 6..8 rows: the granule store addresses are loop invariants that hipcc hoists out of the layer loop as 64-bit pairs and then SPILLS (a scratch reload in front of every
+// publish: the 7- and 8-row kernels ran 0.63 / 0.70 ms per step).  The element index made opaque at the use site keeps the address formation there: one 32-bit index per
+// store stays live instead of a pointer pair.
+template <bool ON> __device__ inline int pl_opq(int idx) {
+    if constexpr (ON) asm volatile("" : "+v"(idx));
+    return idx;
+}
 __device__ inline float dot4(const f32x4 w, const f32x4 x, float acc) {
     return fmaf(w[3], x[3], fmaf(w[2], x[2], fmaf(w[1], x[1], fmaf(w[0], x[0], acc))));
 }
@@ -151,7 +198,7 @@ __device__ inline float pl_red(const float* red, int wave, int n) {
 // (Re-requesting every array right after its use, a whole layer ahead, put the gate|up burst in front of the act gather's polls and the down burst in
 //  front of the next layer's x gather: +6.7 us per layer, profiles/r04_persist_probe_v2_one_launch.jsonl.)
 template <int R, int SCHED, typename WT>
-__global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const PersistArgs a) {
+__global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs a) {
     typedef typename PlW<WT>::frag wfrag;
     // Edge waves per workgroup: 2 at one row, 4 at 2..4 rows (round 5).  A gather is 768 R (3072 R for the act rows) granules over the edge lanes; with two waves the
     // per-lane share grew with the rows (6 R and 24 R loads per lane, the act rows one sweep after the other) -- +4.3 us of the +9.2 us per layer between 1 and 4 rows.
@@ -163,7 +210,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
     float* const ssq = red + PL_RED_FLOATS;                   // sums of squares of the gathered rows [edge wave <= 4][R]
     float* const xres = ssq + 4 * R;                      // this workgroup's 4 columns of the residual stream [R][4] (x, later x + attention, then the layer output)
     int* const abort_s = (int*)(xres + 4 * R);            // [4]: [0] give-up flag, [1] SCHED 3: gathers completed by the edge waves (2 per phase)
-    float* const att_s = (float*)(abort_s + 4);           // attention workgroups: q[64] | k_new[64] | v_new[64] | merge[8][8][10]
+    float* const att_s = (float*)(abort_s + 4);           // attention workgroups: q[2][64] | k_new[2][64] | v_new[2][64] | the waves' outputs [8][64], maxima [8], sums [8]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
@@ -269,7 +316,11 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                         for (int j = 0; j < 6; ++j) PL_PIECE(d_w[j] = __builtin_nontemporal_load((const wfrag*)wb + od + j * 64));
                         PL_PACE_END();
                     }
+#ifdef PL_EXP_E2
+                    if constexpr (R == 5) {
+#else
                     if constexpr (R >= 5) {
+#endif
                         // (register allocation, measured: at 5 rows this form compiles without spills and the one below with 27-55; at 4 rows it is the other way round)
                         float pv[2][pl_pow2(2 * R)];
 #pragma unroll
@@ -538,7 +589,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     // (producers of this wave's columns e + 128 k: workgroups 16 (2 m + ew) + t; each stores its 4 columns of every row in one instruction)
                     if (EW == 2 && (a.poll & 1)) watch_sentinels(a.g_x, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag - 1u, lane, abort_s);
                     float v[GX * R];
-                    const bool got = sweep<GX * R>(a.g_x, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tag - 1u, v, a.error, 1, abort_s, a.nap);
+                    const bool got = PL_SWEEP(GX * R, a.g_x, PL_G_X, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tag - 1u, v, 1);
                     (void)got;
 #pragma unroll
                     for (int r = 0; r < R; ++r) ssp[r] = 0.f;
@@ -568,7 +619,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     } else {
                         which = 2; dA = 4 * jj + 2 * (pwA - 4); dB = dA + 1;
                     }
-                    u64* const gq = a.g_qkv + ((size_t)(rA * PL_NH + hh) * 192 + which * 64);
+                    u64* const gq = a.g_qkv + (size_t)pl_opq<(R > PL_MAXR_ONE)>((rA * PL_NH + hh) * 192 + which * 64);
                     store_granule(gq + dA, tag, ya);
                     store_granule(gq + dB, tag, yb);
                     if (which >= 1) {                            // KV append (llama.py:633): later steps read it from the cache
@@ -583,7 +634,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     // (this wave's columns belong to the heads 2 m + ew: one sentinel per (row, head))
                     if (EW == 2 && (a.poll & 1)) watch_sentinels(a.g_att, [ew](int i) { return (i / 6) * PL_H + 64 * (2 * (i % 6) + ew) + 63; }, 6 * R, tag, lane, abort_s);
                     float v[GX * R];
-                    const bool got = sweep<GX * R>(a.g_att, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tag, v, a.error, 3, abort_s, a.nap);
+                    const bool got = PL_SWEEP(GX * R, a.g_att, PL_G_ATT, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tag, v, 3);
                     (void)got;
 #pragma unroll
                     for (int k = 0; k < GX * R; ++k) xs[(k / GX) * PL_H + NE * (k % GX) + e] = v[k];
@@ -596,7 +647,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     const float x1 = xres[4 * r + i] + pl_red(red, i, r);                               // llama.py:731
                     xres[4 * r + i] = x1;
                     if (!(a.fault > 0 && b == 5 && l + 1 == a.fault))          // (test hook "persistent_fault": workgroup 5 withholds its columns in layer fault - 1)
-                        store_granule(a.g_x1 + (size_t)r * PL_H + 4 * b + i, tag, x1);
+                        store_granule(a.g_x1 + (size_t)pl_opq<(R > PL_MAXR_ONE)>(r * PL_H + 4 * b + i), tag, x1);
                 }
                 if (last) PL_MARK(5);
                 // ---- phase D: x + attention -> RMSNorm, gate | up, SiLU * up
@@ -604,7 +655,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 {
                     if (EW == 2 && (a.poll & 1)) watch_sentinels(a.g_x1, [ew](int i) { return (R - 1) * PL_H + 4 * (16 * (2 * (i >> 4) + ew) + (i & 15)) + 3; }, 96, tag, lane, abort_s);
                     float v[GX * R];
-                    const bool got = sweep<GX * R>(a.g_x1, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tag, v, a.error, 4, abort_s, a.nap);
+                    const bool got = PL_SWEEP(GX * R, a.g_x1, PL_G_X1, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tag, v, 4);
                     (void)got;
 #pragma unroll
                     for (int r = 0; r < R; ++r) ssp[r] = 0.f;
@@ -626,7 +677,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     const int pi = e & 15, r = e >> 4, w = pi >> 1, p = pi & 1;
                     const float rs = 1.0f / sqrtf((EW == 2 ? ssq[r] + ssq[R + r] : (ssq[r] + ssq[R + r]) + (ssq[2 * R + r] + ssq[3 * R + r])) / (float)PL_H + a.eps);
                     const float gv = pl_red(red, w, 16 * p + r) * rs, uv = pl_red(red, w, 16 * p + R + r) * rs;
-                    store_granule(a.g_act + (size_t)r * PL_I + 16 * b + pi, tag, (gv / (1.0f + expf(-gv))) * uv);       // llama.py:214
+                    store_granule(a.g_act + (size_t)pl_opq<(R > PL_MAXR_ONE)>(r * PL_I + 16 * b + pi), tag, (gv / (1.0f + expf(-gv))) * uv);       // llama.py:214
                 }
                 if (last) PL_MARK(7);
                 // ---- phase E: silu(gate) * up [R][3072] -> down + residual
@@ -644,18 +695,34 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     }
                 } else {
                     // four edge waves: 12 granules per lane and row -> two rows per sweep (24 granules in flight per lane, as before), R / 2 round trips instead of R
+#ifdef PL_EXP_E1
+                    if constexpr (R > PL_MAXR_ONE) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            float v[12];
+                            const bool got = PL_SWEEP(12, a.g_act, PL_G_ACT, (unsigned)(r * PL_I + e), [](int k) { return 256 * k; }, tag, v, 5);
+                            (void)got;
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) xs[r * PL_I + 256 * k + e] = v[k];
+                        }
+                    } else
+#endif
 #pragma unroll
                     for (int r = 0; r + 1 < R; r += 2) {
                         float v[24];
-                        const bool got = sweep<24>(a.g_act, (unsigned)(r * PL_I + e), [](int k) { return (k / 12) * PL_I + 256 * (k % 12); }, tag, v, a.error, 5, abort_s, a.nap);
+                        const bool got = PL_SWEEP(24, a.g_act, PL_G_ACT, (unsigned)(r * PL_I + e), [](int k) { return (k / 12) * PL_I + 256 * (k % 12); }, tag, v, 5);
                         (void)got;
 #pragma unroll
                         for (int k = 0; k < 24; ++k) xs[(r + k / 12) * PL_I + 256 * (k % 12) + e] = v[k];
                     }
+#ifdef PL_EXP_E1
+                    if constexpr ((R & 1) != 0 && R <= PL_MAXR_ONE) {
+#else
                     if constexpr ((R & 1) != 0) {
+#endif
                         constexpr int r = R - 1;
                         float v[12];
-                        const bool got = sweep<12>(a.g_act, (unsigned)(r * PL_I + e), [](int k) { return 256 * k; }, tag, v, a.error, 5, abort_s, a.nap);
+                        const bool got = PL_SWEEP(12, a.g_act, PL_G_ACT, (unsigned)(r * PL_I + e), [](int k) { return 256 * k; }, tag, v, 5);
                         (void)got;
 #pragma unroll
                         for (int k = 0; k < 12; ++k) xs[r * PL_I + 256 * k + e] = v[k];
@@ -670,7 +737,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     if (last && !a.heads) a.x[(size_t)r * PL_H + 4 * b + i] = x2;          // the heads read it after the launch boundary
                     else {
                         xres[4 * r + i] = x2;
-                        store_granule(a.g_x + (size_t)r * PL_H + 4 * b + i, tag, x2);
+                        store_granule(a.g_x + (size_t)pl_opq<(R > PL_MAXR_ONE)>(r * PL_H + 4 * b + i), tag, x2);
                     }
                 }
             }
@@ -688,7 +755,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 }
                 for (int z = 0; z < a.delay_x; ++z) __builtin_amdgcn_s_sleep(2);
                 float v[GX * R];
-                const bool got = sweep<GX * R>(a.g_x, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tagh, v, a.error, 1, abort_s, a.nap);
+                const bool got = PL_SWEEP(GX * R, a.g_x, PL_G_X, (unsigned)e, [](int k) { return (k / GX) * PL_H + NE * (k % GX); }, tagh, v, 1);
                 (void)got;
 #pragma unroll
                 for (int r = 0; r < R; ++r) ssp[r] = 0.f;
@@ -735,14 +802,22 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
     // a.S key splits per (row, head) for long contexts (host: decode_persist): split s owns a contiguous share of the cached keys; the splits s > 0 publish
     // their partial (max, sum, unnormalised output) and split 0 merges them with this step's own key -- one more hop, but every share stays within the
     // 384 keys a workgroup holds in registers before the query exists (a longer share streams behind the query: +0.6 us per 64 keys and layer)
-    const int item = b - PL_GEMV_BLOCKS, S = a.S;
-    if (item >= PL_NH * R * S) return;
+    // Round 6, 6..8 rows (PAIR): 12 R items exceed the 64 attention workgroups, so a workgroup serves TWO items -- compute waves 0..3 and edge wave 8 the first,
+    // waves 4..7 and edge wave 9 the second: 4 x 8 x 6 = 192 keys per item requested before the query exists, the rest of a share streams behind it (no key splits).
+    constexpr bool PAIR = R > PL_MAXR_ONE;
+    constexpr int NWI = PAIR ? 4 : 8;                         // compute waves per item
+    const int S = PAIR ? 1 : a.S;
+    // this wave's item: compute waves by their half, edge waves 8 / 9 one each (waves 10, 11 -- and wave 9 outside PAIR -- only keep the barriers)
+    const int isub = PAIR ? ((wave < 8) ? (wave >> 2) : ((wave - 8) & 1)) : 0;
+    const int iw = PAIR ? (wave & 3) : wave;                  // the wave's index among its item's compute waves
+    const int item = PAIR ? 2 * (b - PL_GEMV_BLOCKS) + isub : b - PL_GEMV_BLOCKS;
+    if ((PAIR ? 2 * (b - PL_GEMV_BLOCKS) : item) >= PL_NH * R * S) return;      // (12 R is even: a workgroup holds two items or none)
     const int rh = item / S, sp = item - rh * S;
     const int r = rh / PL_NH, hh = rh % PL_NH;
-    float* const qs = att_s;
-    float* const ks = att_s + 64;
-    float* const vs = att_s + 128;
-    float* const mo = att_s + 192;                            // [8 waves][64]: the waves' unnormalised outputs, one dim per lane
+    float* const qs = att_s + 64 * isub;                       // [2][64] each: q (x 1/8), this step's k, v of the wave's item
+    float* const ks = att_s + 128 + 64 * isub;
+    float* const vs = att_s + 256 + 64 * isub;
+    float* const mo = att_s + 384;                            // [8 waves][64]: the waves' unnormalised outputs, one dim per lane
     float* const mm = mo + 512;                               // [8] the waves' maxima
     float* const ml = mm + 8;                                 // [8] the waves' sums
     const size_t kv_per = a.kv_per;
@@ -755,19 +830,19 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
         const int kv0 = m.kv_start + sp * kvc, kv1 = min(kv0 + kvc, m.slot);
         const int grp = lane >> 3, sub = lane & 7;
         const size_t head_base = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM;
-        constexpr int PRE = 6;                                // iterations requested before the query exists: 8 waves x 8 keys x 6 = 384 keys
+        constexpr int PRE = 6;                                // iterations requested before the query exists: 8 (PAIR: 4) waves x 8 keys x 6 = 384 (192) keys
         PlKV<WT> kf[PRE];
         typename KvElem<WT>::reg vv[PRE][8];
         bool ok[PRE];
         bool any_ok[PRE];
 #pragma unroll
         for (int u = 0; u < PRE; ++u) {
-            const int p = kv0 + 8 * (wave + 8 * u) + grp;
+            const int p = kv0 + 8 * (iw + NWI * u) + grp;
             ok[u] = p < kv1;
-            any_ok[u] = kv0 + 8 * (wave + 8 * u) < kv1;       // wave-uniform: some lane group of this wave has a key in iteration u
+            any_ok[u] = kv0 + 8 * (iw + NWI * u) < kv1;       // wave-uniform: some lane group of this wave has a key in iteration u
         }
 #define PL_LOAD_KV(l_) do { const WT* const kb_ = (const WT*)a.kv + (size_t)(l_) * 2 * kv_per + head_base; const WT* const vb_ = kb_ + kv_per + lane; \
-        _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p0_ = kv0 + 8 * (wave + 8 * u); const int pc_ = ok[u] ? p0_ + grp : m.kv_start; \
+        _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p0_ = kv0 + 8 * (iw + NWI * u); const int pc_ = ok[u] ? p0_ + grp : m.kv_start; \
             kf[u].load(kb_ + (size_t)pc_ * CTTS_HEAD_DIM + 8 * sub); \
             _Pragma("unroll") for (int g = 0; g < 8; ++g) vv[u][g] = KvElem<WT>::load(vb_ + (size_t)min(p0_ + g, kv1 - 1) * CTTS_HEAD_DIM); } } while (0)
         PL_LOAD_KV(0);
@@ -810,15 +885,15 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                     for (int g = 0; g < 8; ++g) oa[g & 3] = fmaf(readlane_f(pe, 8 * g), KvElem<WT>::f(vv[u][g]), oa[g & 3]);
                 }
             }
-            // Shares beyond the PRE * 64 prefetched keys stream behind the query, UNS steps of 64 keys per round trip
-            constexpr int UNS = 4;
-            for (int wb0 = kv0 + 8 * (wave + 8 * PRE); wb0 < kv1; wb0 += 64 * UNS) {       // (wave-uniform bound)
+            // Shares beyond the PRE * 8 NWI prefetched keys stream behind the query, UNS steps of 8 NWI keys per round trip
+            constexpr int UNS = 4, STEP = 8 * NWI;
+            for (int wb0 = kv0 + 8 * (iw + NWI * PRE); wb0 < kv1; wb0 += STEP * UNS) {       // (wave-uniform bound)
                 PlKV<WT> ks_[UNS];
                 typename KvElem<WT>::reg vs_[UNS][8];
                 bool live_[UNS];
 #pragma unroll
                 for (int u = 0; u < UNS; ++u) {
-                    const int p0 = wb0 + 64 * u;
+                    const int p0 = wb0 + STEP * u;
                     live_[u] = p0 + grp < kv1;
                     ks_[u].load(kb + (size_t)(live_[u] ? p0 + grp : m.kv_start) * CTTS_HEAD_DIM);
 #pragma unroll
@@ -826,7 +901,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 }
 #pragma unroll
                 for (int u = 0; u < UNS; ++u) {
-                    if (wb0 + 64 * u >= kv1) break;                                          // (wave-uniform: the step does not exist)
+                    if (wb0 + STEP * u >= kv1) break;                                        // (wave-uniform: the step does not exist)
                     const bool live = live_[u];
                     float dot = q0[0] * ks_[u].at(0) + q0[1] * ks_[u].at(1) + q0[2] * ks_[u].at(2) + q0[3] * ks_[u].at(3) + q1[0] * ks_[u].at(4) + q1[1] * ks_[u].at(5) + q1[2] * ks_[u].at(6) + q1[3] * ks_[u].at(7);
                     dot += dpp_f<DPP_XOR1>(dot);
@@ -852,7 +927,7 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
             if (l + 1 < NL) PL_LOAD_KV(l + 1);                // the next layer's cached rows: a whole layer ahead of its query
             __builtin_amdgcn_sched_barrier(0);
         }
-    } else if (wave == 8) {
+    } else if (wave == 8 || (PAIR && wave == 9)) {
         if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
         const unsigned tag0 = (unsigned)ep_v * 32u;
         __syncthreads();                                      // S0
@@ -864,22 +939,22 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
             qs[lane] = v[0] * 0.125f;                         // 1 / sqrt(64) (llama.py:653-661)
             ks[lane] = v[1];
             vs[lane] = v[2];
-            if (l + 1 == NL) PL_MARK(1);
+            if (l + 1 == NL && wave == 8) PL_MARK(1);
             __syncthreads();                                  // B1
             // this step's own key (slot `m.slot`, the causal end of the row: llama.py:1073-1087): its score, on all 64 lanes (split 0 merges it)
             const float dnew = wave_sum(qs[lane] * ks[lane]);
             __syncthreads();                                  // B2
-            if (a.ts != nullptr && l + 1 == NL && lane == 0) a.ts[(size_t)b * 10 + 7] = wall_clock64();
-            // lane = output dim: combine the 8 waves' partials.  The 9 rescale factors (8 waves + this step's own key) are computed side by side in lanes 0..8
-            const float mmv = mm[lane & 7], mlv = ml[lane & 7];
-            const float mj = (lane < 8) ? mmv : ((lane == 8 && sp == 0) ? dnew : -INFINITY);
-            const float lj = (lane < 8) ? mlv : ((lane == 8) ? 1.f : 0.f);
+            if (a.ts != nullptr && l + 1 == NL && lane == 0 && wave == 8) a.ts[(size_t)b * 10 + 7] = wall_clock64();
+            // lane = output dim: combine the item's NWI waves' partials.  The NWI + 1 rescale factors (the waves + this step's own key) are computed side by side in lanes 0..NWI
+            const float mmv = mm[NWI * isub + (lane & (NWI - 1))], mlv = ml[NWI * isub + (lane & (NWI - 1))];
+            const float mj = (lane < NWI) ? mmv : ((lane == NWI && sp == 0) ? dnew : -INFINITY);
+            const float lj = (lane < NWI) ? mlv : ((lane == NWI) ? 1.f : 0.f);
             float M = wave_max(mj);
             const float sj = pl_exp_diff(mj, M);
             float L = wave_sum(sj * lj);
-            float O = readlane_f(sj, 8) * vs[lane];
+            float O = readlane_f(sj, NWI) * vs[lane];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) O = fmaf(readlane_f(sj, w), mo[w * 64 + lane], O);
+            for (int w = 0; w < NWI; ++w) O = fmaf(readlane_f(sj, w), mo[(NWI * isub + w) * 64 + lane], O);
             if (S > 1 && sp != 0) {
                 // a share's partial: [max, sum, o[64]] (an empty share publishes max = -inf, sum = 0)
                 u64* const gp = a.g_part + (size_t)(rh * S + sp) * 66;
@@ -925,9 +1000,9 @@ __global__ __launch_bounds__(PL_THREADS_MAX) void persist_layer_kernel(const Per
                 }
                 store_granule(a.g_att + (size_t)r * PL_H + hh * CTTS_HEAD_DIM + lane, tag, O / L);
             }
-            if (l + 1 == NL) PL_MARK(2);
+            if (l + 1 == NL && wave == 8) PL_MARK(2);
         }
-        if (a.ts != nullptr && lane == 0) {
+        if (a.ts != nullptr && lane == 0 && wave == 8) {
             a.ts[(size_t)b * 10 + 0] = t_mark[0]; a.ts[(size_t)b * 10 + 1] = t_mark[1]; a.ts[(size_t)b * 10 + 2] = t_mark[2];
         }
     } else {
@@ -1007,7 +1082,7 @@ int launch_persist_repack(int half_w, const void* qkv, const void* o, const void
     return 0;
 }
 
-static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + PL_RED_FLOATS + 4 * R + 4 * R) * 4 + 16 + (192 + 8 * 8 * 10) * 4; }
+static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + PL_RED_FLOATS + 4 * R + 4 * R) * 4 + 16 + (384 + 512 + 16 + 16) * 4; }
 
 template <int R, int SCHED, typename WT>
 static int persist_launch_t(const PersistArgs& a, hipStream_t s, bool configure_only) {
@@ -1020,8 +1095,12 @@ static int persist_launch_t(const PersistArgs& a, hipStream_t s, bool configure_
 template <int SCHED, typename WT>
 static int persist_launch_r(int R, const PersistArgs& a, hipStream_t s, bool cfg) {
     // exact row counts: a spare row would append stale K / V rows to a live cache lane
-    if (cfg) return persist_launch_t<1, SCHED, WT>(a, s, true) | persist_launch_t<2, SCHED, WT>(a, s, true) | persist_launch_t<3, SCHED, WT>(a, s, true) | persist_launch_t<4, SCHED, WT>(a, s, true) |
-                    persist_launch_t<5, SCHED, WT>(a, s, true);
+    if (cfg) {
+        int rc = persist_launch_t<1, SCHED, WT>(a, s, true) | persist_launch_t<2, SCHED, WT>(a, s, true) | persist_launch_t<3, SCHED, WT>(a, s, true) | persist_launch_t<4, SCHED, WT>(a, s, true) |
+                 persist_launch_t<5, SCHED, WT>(a, s, true);
+        if constexpr (SCHED == 3) rc |= persist_launch_t<6, 3, WT>(a, s, true) | persist_launch_t<7, 3, WT>(a, s, true) | persist_launch_t<8, 3, WT>(a, s, true);
+        return rc;
+    }
     switch (R) {
         case 1: return persist_launch_t<1, SCHED, WT>(a, s, false);
         case 2: return persist_launch_t<2, SCHED, WT>(a, s, false);
@@ -1029,7 +1108,14 @@ static int persist_launch_r(int R, const PersistArgs& a, hipStream_t s, bool cfg
         case 4: return persist_launch_t<4, SCHED, WT>(a, s, false);
         case 5: return persist_launch_t<5, SCHED, WT>(a, s, false);
     }
-    ctts_set_error("persistent layer: %d rows (max %d)", R, PL_MAXR);
+    if constexpr (SCHED == 3) {      // 6..8 rows (two attention items per workgroup): the paced schedule only
+        switch (R) {
+            case 6: return persist_launch_t<6, 3, WT>(a, s, false);
+            case 7: return persist_launch_t<7, 3, WT>(a, s, false);
+            case 8: return persist_launch_t<8, 3, WT>(a, s, false);
+        }
+    }
+    ctts_set_error("persistent layer: %d rows (max %d; 6+ rows need the paced schedule)", R, PL_MAXR);
     return 1;
 }
 

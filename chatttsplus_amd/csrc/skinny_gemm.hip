@@ -162,7 +162,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
     {   // prefetch blocks (kernels.h WPrefetch): the grid's last x columns
         const int xreal = (int)((unsigned)misc >> 22);
         if (xreal != 0 && (int)blockIdx.x >= xreal) {
-            if (blockIdx.y == 0 && blockIdx.z == 0) weight_prefetch<WAVES>(a.pf, (int)blockIdx.x - xreal, (int)gridDim.x - xreal, (int)blockIdx.x & 7, smem, tid);
+            if (blockIdx.y == 0 && blockIdx.z == 0) {
+                weight_prefetch<WAVES>(a.pf, (int)blockIdx.x - xreal, (int)gridDim.x - xreal, (int)blockIdx.x & 7, smem, tid);
+                weight_prefetch<WAVES>(a.pf2, (int)blockIdx.x - xreal, (int)gridDim.x - xreal, (int)blockIdx.x & 7, smem, tid);
+            }
             return;
         }
     }
@@ -756,7 +759,7 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
     }
     const int xreal = a.n_row_tiles / RT + a.lora_w;
     // prefetch blocks: a multiple of 8 (the real blocks keep their XCDs), whole DMA sweeps only, and the first-prefetch-block field of misc has 10 bits
-    const bool pf_on = a.pf_blocks >= 8 && a.pf.ptr != nullptr && (a.pf.unit_bytes % (WAVES * 1024)) == 0 && xreal < 1024;
+    const bool pf_on = a.pf_blocks >= 8 && a.pf.ptr != nullptr && (a.pf.unit_bytes % (WAVES * 1024)) == 0 && (a.pf2.ptr == nullptr || (a.pf2.unit_bytes % (WAVES * 1024)) == 0) && xreal < 1024;
     const int npf = pf_on ? (a.pf_blocks & ~7) : 0;
     const int misc = (a.np & 0x7) | ((a.S & 0xF) << 3) | ((a.ktiles_total & 0xFF) << 7) | ((a.lora_w & 0x7F) << 15) | (int)((unsigned)(npf ? xreal : 0) << 22);
     hipLaunchKernelGGL(kern, dim3(xreal + npf, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc, a);
@@ -897,15 +900,9 @@ static int dispatch_split(int pro, int epi, const GemmArgs& a, int chunks, hipSt
         rc |= launch_one<split_t, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
         rc |= launch_one<split_t, NBG, W3072, P3072, PRO_PACKED, EPI_RESID_XH>(a, chunks, s, true);
         rc |= launch_one<split_t, NBG, W768, P768, PRO_PACKED, EPI_RESID_XH_SK>(a, chunks, s, true);
-        rc |= launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_QKV, 2>(a, chunks, s, true);
-        rc |= launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_SWIGLU, 2>(a, chunks, s, true);
         return rc;
     }
     if (a.lora_w != 0 || a.lora_delta != nullptr) { ctts_set_error("skinny_gemm: the split decode kernels carry no per-utterance adapters"); return 1; }
-    if (a.rt == 2) {         // two weight row tiles per workgroup: the operand fragments are loaded once per two tiles
-        if (pro == PRO_XH && epi == EPI_QKV) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_QKV, 2>(a, chunks, s, false);
-        if (pro == PRO_XH && epi == EPI_SWIGLU) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_SWIGLU, 2>(a, chunks, s, false);
-    }
     if (pro == PRO_XH && epi == EPI_QKV) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_QKV>(a, chunks, s, false);
     if (pro == PRO_XH && epi == EPI_SWIGLU) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_SWIGLU>(a, chunks, s, false);
     if (pro == PRO_XH && epi == EPI_LOGITS) return launch_one<split_t, NBG, W768, P768, PRO_XH, EPI_LOGITS>(a, chunks, s, false);

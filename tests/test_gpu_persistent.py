@@ -60,6 +60,37 @@ def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
     g.set_option("persistent_rows", 5)
 
 
+def test_persistent_launch_serves_six_to_eight_rows_with_two_attention_items_per_workgroup(gpt):
+    """Round 6: 12 R (row, head) items exceed the 64 attention workgroups from 6 rows on; the launch then gives every attention workgroup TWO items (4 compute waves + 1
+    edge wave each, 192 keys per item requested before the query exists, the rest streamed behind it).  Same loop of the reference (gpt.py:389-546 over llama.py:719-749):
+    token ids identical to the launch chain, hidden rows within the persistent launch's tolerance, at contexts inside and beyond the prefetched 192 keys."""
+    g = gpt
+    cases = [(6, 40, 24, [0, 4, 9, 2, 13, 1]), (7, 48, 24, None), (8, 33, 32, [0, 5, 17, 3, 0, 9, 30, 2]), (8, 250, 16, None), (6, 420, 12, [0, 100, 7, 0, 300, 1]), (7, 650, 8, None)]
+    try:
+        for (B, P, N, pad) in cases:
+            g.set_option("persistent_rows", 0)
+            ref_ids, ref_h = _gen(g, B, P, N, pad)
+            g.set_option("persistent_rows", 8)
+            assert g.get_option("persistent_rows") == 8
+            ids, hid = _gen(g, B, P, N, pad)
+            for b in range(B):
+                assert torch.equal(ids[b], ref_ids[b]), f"B={B} P={P}: row {b} tokens differ from the launch path"
+                assert float((hid[b] - ref_h[b]).abs().max()) <= 5e-5, (B, P, b)
+        # bitwise reproducible, graph == eager
+        a_ids, a_h = _gen(g, 8, 48, 40)
+        b_ids, b_h = _gen(g, 8, 48, 40)
+        g.use_graph = False
+        try:
+            c_ids, c_h = _gen(g, 8, 48, 40)
+        finally:
+            g.use_graph = True
+        for b in range(8):
+            assert torch.equal(a_ids[b], b_ids[b]) and torch.equal(a_h[b], b_h[b])
+            assert torch.equal(a_ids[b], c_ids[b]) and torch.equal(a_h[b], c_h[b])
+    finally:
+        g.set_option("persistent_rows", 5)
+
+
 def test_persistent_launch_replay_is_bitwise_reproducible_and_graph_equals_eager(gpt):
     g = gpt
     g.set_option("persistent_rows", 1)

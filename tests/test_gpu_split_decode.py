@@ -58,11 +58,10 @@ def test_split_decode_matches_the_exact_f32_kernels(gpt, B, P, N, pad):
     assert worst <= 2e-5, (B, worst)
 
 
-@pytest.mark.parametrize("opts", [dict(nbg2_rows=17), dict(split_row_tiles=2), dict(nbg2_rows=17, split_row_tiles=2), dict(weight_prefetch_kb=48), dict(weight_prefetch_kb=0)])
+@pytest.mark.parametrize("opts", [dict(split_nbg2_rows=99), dict(weight_prefetch_kb=48), dict(weight_prefetch_kb=0)])
 def test_split_decode_launch_shapes_agree(gpt, opts):
-    """The other launch shapes of the same arithmetic -- 32-row blocks (with the in-launch K-slice combine of the down projection), two weight row tiles per workgroup,
-    prefetch workgroups on / off -- sample the same tokens; a product's terms are added in the same order whatever the shape, so the hidden rows agree to the last bit
-    except where a 32-row block changes nothing but the workgroup a row rides in (still the same sums)."""
+    """The other launch shapes of the same arithmetic -- 16-row chunks instead of 32-row blocks (layer 0's exact-f32 q|k|v kernel then splits K over 8 waves instead of
+    16: another summation order, hence the tolerance), prefetch workgroups on / off (bitwise the same: they only warm L2) -- sample the same tokens."""
     g = gpt
     base = {k: g.get_option(k) for k in opts}
     ref_ids, ref_h = _gen(g, 24, 40, 16, [(7 * i) % 36 for i in range(24)])
@@ -75,7 +74,7 @@ def test_split_decode_launch_shapes_agree(gpt, opts):
             g.set_option(k, v)
     for b in range(24):
         assert torch.equal(ids[b], ref_ids[b]), (opts, b)
-        assert float((hid[b] - ref_h[b]).abs().max()) <= 2e-6, (opts, b)
+        assert float((hid[b] - ref_h[b]).abs().max()) <= (1e-5 if "split_nbg2_rows" in opts else 0.0), (opts, b)
 
 
 def test_split_decode_graph_equals_eager_and_replays_bitwise(gpt):
