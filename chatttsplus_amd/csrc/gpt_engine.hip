@@ -146,7 +146,7 @@ struct ctts_gpt {
     int cur_persist = 0;                         //   the steps being launched use the persistent layer
     int pl_ts_on = 0;
     int persist_fault = 0;                       //   test hook ("persistent_fault"): see PersistArgs.fault
-    int persist_pair_keys = 704;                 //   6..8 rows: contexts beyond this many keys go back to the launch chain; "persistent_pair_keys"
+    int persist_pair_keys = 704;                 //   6..8 rows: contexts beyond this many keys (minus 128 per row above 6) go back to the launch chain; "persistent_pair_keys"
     int persist_splits = 0;                      //   cap on the attention's key splits per (row, head) (0 = PL_SMAX); "persistent_splits"
     int persist_max_keys = 0;                    //   contexts beyond this many keys go back to the launch chain (0 = no limit); "persistent_max_keys"
     int persist_lpl = 0;                         //   decoder layers per persistent launch (0 = all of them in one launch)
@@ -245,7 +245,9 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
     // both dtypes since round 5 (fp16 engines: half weights + half K / V in the image, fp32 activations).  fp16: up to 3 rows -- ms/step launch chain / persistent
     // (tools/fp16_persist_probe.py, two edge waves): batch 1 0.370 / 0.256, 2 0.393 / 0.319, 3 0.423 / 0.381, 4 0.427 / 0.442
-    h->persist_rows = PL_MAXR_ONE;                               // 5 (ms/step launch chain / persistent launch at 5 rows, fp32: 0.540 / 0.389; fp16 at 4 rows: 0.425 / 0.345)
+    // fp32: 8 since round 6 (6..8 rows: two attention items per workgroup; ms/step launch chain / persistent launch at mean context 310: 6 rows 0.586 / 0.484, 7: 0.605 / 0.522,
+    // 8: 0.617 / 0.557; at context 560: 6 rows 0.690 / 0.660, 8: 0.704 / 0.721 -> persist_pair_keys).  fp16 stays at 5: its chain is faster there (6 rows 0.467 / 0.489, 8: 0.472 / 0.550)
+    h->persist_rows = (c->dtype == CTTS_DTYPE_F16) ? PL_MAXR_ONE : PL_MAXR;      // (ms/step launch chain / persistent launch at 5 rows, fp32: 0.540 / 0.389; fp16 at 4 rows: 0.425 / 0.345)
     h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
@@ -957,7 +959,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     if (form) { form->parts = splitd; form->xh = xhm; form->logits = false; form->split = spd; }
     // weight prefetch across the launch boundaries of a decode step (kernels.h WPrefetch): launch k carries workgroups that pull launch k + 1's weight image into L2.
     // (16-row chunks only: every consumer workgroup column is then one row tile; per-utterance adapters shift the consumers' block indices by their workers: off)
-    const int pf_kb = (st != nullptr && xhm && !lora && (dt == CTTS_DTYPE_F32 || R >= 17)) ? h->prefetch_kb : 0;
+    const int pf_kb = (st != nullptr && xhm && !lora && (spd || (dt == CTTS_DTYPE_F16 && R >= 17))) ? h->prefetch_kb : 0;      // (the exact-f32 kernels lose with it: batch 32 0.845 -> 0.897)
     auto set_pf = [&](GemmArgs& g, const void* w, int n_tiles, int K, int fmt, int bit) {          // fmt: 0 fp32 tiles, 1 fp16 tiles, 2 head / tail pairs
         if (pf_kb <= 0 || w == nullptr || !((h->prefetch_mask >> bit) & 1)) return;
         const size_t tile = (size_t)16 * K * (fmt == 1 ? 2 : 4);
@@ -1266,7 +1268,7 @@ static inline int decode_persist(const ctts_gpt* h, int B, int L) {
         // 6..8 rows: two (row, head) items per attention workgroup, no key splits: 192 keys per item are requested before the query exists, the rest streams behind it
         // 128 keys per round trip -- the chain's 72..96 attention blocks win beyond a few such trips ("persistent_max_keys")
         if (h->persist_sched != 3) return 0;
-        return (L > (h->persist_max_keys > 0 ? h->persist_max_keys : h->persist_pair_keys)) ? 0 : 1;
+        return (L > (h->persist_max_keys > 0 ? h->persist_max_keys : h->persist_pair_keys - 128 * (B - PL_MAXR_ONE - 1))) ? 0 : 1;      // (704 / 576 / 448 keys at 6 / 7 / 8 rows)
     }
     if (L > (h->persist_max_keys > 0 ? h->persist_max_keys : 1400 * cap)) return 0;
     if (L <= PL_SHARE_KEYS + 128) return 1;                 // (one streamed iteration costs less than the extra hop)

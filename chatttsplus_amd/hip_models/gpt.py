@@ -406,7 +406,13 @@ class GPT:
                 msg = f"use weight_dtype='fp32' for this checkpoint"
             else:
                 msg = ("the fp32 engine's long-prompt pass and its decode batches of >= 9 rows keep silu(gate) * up / 16 and the scaled residual rows as fp16 head / tail "
-                       "images; construct the GPT with options={'prefill_split_rows': 0, 'split_decode_rows': 0} to keep the exact fp32 kernels for this checkpoint")
+                       "images; THIS call's values were clipped there.  The engine now keeps the exact fp32 decode kernels (split_decode_rows=0) for the following calls; "
+                       "construct the GPT with options={'prefill_split_rows': 0, 'split_decode_rows': 0} to keep them from the first call on for this checkpoint")
+                try:
+                    if self.get_option("split_decode_rows") > 0:
+                        self.set_option("split_decode_rows", 0)
+                except Exception:      # noqa: BLE001 (the warning below still tells the caller)
+                    pass
             warnings.warn(f"hip GPT (weight_dtype {'fp16' if self.dtype_code == _lib.DTYPE_F16 else 'fp32'}): {n} fp16 stores saturated or were NaN "
                           f"during this {what}; {msg}", RuntimeWarning)
         return n

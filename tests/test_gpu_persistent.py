@@ -36,7 +36,7 @@ def _gen(g, B, P, N, pad=None, lp=LP, seed=7):
 
 def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
     g = gpt
-    assert g.get_option("persistent_rows") == 5, "fp32 engines serve up to five decode rows (12 heads x 5 = 60 of the 64 attention workgroups) through the persistent launch by default"
+    assert g.get_option("persistent_rows") == 8, "fp32 engines serve up to eight decode rows through the persistent launch by default (5: one attention item per workgroup; 6..8: two)"
     # contexts beyond 512 keys split every (row, head) over 2..5 attention workgroups (2 at 600, 3 at 1000, 5 at 1900; two rows: at most 2)
     # (round 5: a key share's tail streams 4 steps per round trip, so 3-4 rows stay on the persistent launch up to 1400 keys -- (4, 1200) and (3, 1300) below)
     cases = [(1, 48, 96, None), (1, 600, 24, None), (1, 1000, 40, None), (1, 1900, 24, None), (2, 700, 16, [0, 150]), (4, 1200, 16, [0, 30, 7, 300]), (3, 1300, 16, None),
@@ -57,7 +57,7 @@ def test_persistent_launch_is_the_default_and_matches_the_launch_path(gpt):
             g.set_option("persistent_schedule", 3)
             g.set_option("persistent_poll", 0)
             g.set_option("persistent_delay", 12); g.set_option("persistent_delay_act", 14); g.set_option("persistent_delay_x", 15)
-    g.set_option("persistent_rows", 5)
+    g.set_option("persistent_rows", 8)
 
 
 def test_persistent_launch_serves_six_to_eight_rows_with_two_attention_items_per_workgroup(gpt):
@@ -88,7 +88,7 @@ def test_persistent_launch_serves_six_to_eight_rows_with_two_attention_items_per
             assert torch.equal(a_ids[b], b_ids[b]) and torch.equal(a_h[b], b_h[b])
             assert torch.equal(a_ids[b], c_ids[b]) and torch.equal(a_h[b], c_h[b])
     finally:
-        g.set_option("persistent_rows", 5)
+        g.set_option("persistent_rows", 8)
 
 
 def test_persistent_launch_replay_is_bitwise_reproducible_and_graph_equals_eager(gpt):
@@ -103,7 +103,7 @@ def test_persistent_launch_replay_is_bitwise_reproducible_and_graph_equals_eager
         g.use_graph = True
     assert torch.equal(a_ids[0], b_ids[0]) and torch.equal(a_h[0], b_h[0]), "two replays differ (fixed reduction orders, no atomics on the data path)"
     assert torch.equal(a_ids[0], c_ids[0]) and torch.equal(a_h[0], c_h[0]), "hipGraph replay != eager launches"
-    g.set_option("persistent_rows", 5)
+    g.set_option("persistent_rows", 8)
 
 
 def test_repetition_penalty_reaches_every_utterance_of_a_long_queue(gpt):
@@ -162,7 +162,7 @@ def test_a_withheld_hand_off_ends_the_step_with_an_error_instead_of_hanging(gpt)
     import time
     from chatttsplus_amd import _lib
     g = gpt
-    g.set_option("persistent_rows", 5)
+    g.set_option("persistent_rows", 8)
     ref_ids, _ = _gen(g, 1, 24, 12)
     g.set_option("persistent_fault", 8)
     t0 = time.perf_counter()
@@ -186,7 +186,7 @@ def test_two_engines_of_one_process_take_turns_with_their_persistent_launches():
     try:
         for g in gs:
             g.load_state_dict(sd)
-            assert g.get_option("persistent_rows") == 5
+            assert g.get_option("persistent_rows") == 8
         solo = [_gen(gs[i], 1 + i, 40, 96, seed=11 + i) for i in range(2)]
         out, err = [None, None], [None, None]
 
@@ -216,19 +216,19 @@ def test_persistent_weight_images_are_built_on_first_need(gpt):
     """the persistent launch keeps its own per-workgroup image of the layer weights (755 MB for 20 layers).  It is built by the first decode call of <= 4
     rows, not at load time: an engine that only serves larger batches never allocates it."""
     from chatttsplus_amd.hip_models import GPT
-    g = GPT(LLAMA, max_batch=8, max_seq_len=200, weight_dtype="fp32")
+    g = GPT(LLAMA, max_batch=12, max_seq_len=200, weight_dtype="fp32")
     try:
         g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
-        assert g.get_option("persistent_rows") == 5
+        assert g.get_option("persistent_rows") == 8
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info()[0]
-        _gen(g, 8, 24, 8)                                    # the launch chain: no image
+        _gen(g, 12, 24, 8)                                   # the launch chain: no image
         torch.cuda.synchronize()
         free1 = torch.cuda.mem_get_info()[0]
         ids_a, _ = _gen(g, 1, 24, 8)                         # first <= 4-row decode: 20 x 37.75 MB
         torch.cuda.synchronize()
         free2 = torch.cuda.mem_get_info()[0]
-        assert free0 - free1 < 300 * 2 ** 20, "the batch-8 request allocated the persistent weight images"
+        assert free0 - free1 < 300 * 2 ** 20, "the batch-12 request allocated the persistent weight images"
         assert free1 - free2 > 600 * 2 ** 20, "the batch-1 request did not build the persistent weight images"
         ref_ids, _ = _gen(gpt, 1, 24, 8)
         assert torch.equal(ids_a[0], ref_ids[0])

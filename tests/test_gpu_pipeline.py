@@ -59,7 +59,7 @@ def test_vocoder_overlap_soak(tmp_path):
     lims = [40, 9, 14, 22, 6, 31, 12, 5, 36, 8, 17, 4, 11, 27]            # ragged per-utterance token limits: rows finish (and are re-used) at different steps
     pv = InferCodeParams(prompt="[speed_5]", spk_emb=spk, max_new_token=40, min_new_token=40, show_tqdm=False)
     gpt = pipe.models_dict["gpt"]
-    assert gpt.get_option("persistent_rows") == 5
+    assert gpt.get_option("persistent_rows") == 8
 
     def run(rows, **kw):
         res = list(pipe.infer(list(texts), skip_refine_text=True, do_text_optimization=False, params_infer_code=pv, noise="device", noise_seed=31, slice_size=rows,
