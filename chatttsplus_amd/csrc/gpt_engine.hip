@@ -69,13 +69,12 @@ struct ctts_gpt {
     int split_nbg2_rows = 17;                    // ... and from this many rows on they take 32-row blocks (one workgroup per weight tile streams it once for all 32 rows; the down projection's K is
                                                  // sliced four ways inside the launch as at 16-row chunks).  ms/step 16-row chunks / 32-row blocks: 17 rows 0.723 / 0.700, 24: 0.822 / 0.800, 32: 0.846 / 0.824
                                                  // (profiles/r06_ab_split_shapes.jsonl).  "split_nbg2_rows"
-    int prefetch_mask = 1;                      // which launches' weights are prefetched: bit 0 gate|up (carried by o_proj), 1 down (by gate|up), 2 the next q|k|v / the heads (by down), 3 layer 0's q|k|v (by the heads)
     int prefetch_kb = 96;                        // decode launch chain, packed-residual path (>= 9 rows; fp16 engines: >= 17): the o_proj launch -- 2.4 MB of weights of its own -- carries extra
                                                  // workgroups that pull the gate|up launch's 18.9 MB weight image into L2 (kernels.h WPrefetch), one per this many KiB of it (8..256 of
                                                  // them); 0 = off.  "weight_prefetch_kb".  ms/step without / with (profiles/r06_ab_weight_prefetch.jsonl): fp32 batch 9 0.610 / 0.588, 16 0.635 / 0.605,
                                                  // 32 0.826 / 0.804; fp16 batch 32 0.603 / 0.588.  The other carriers stream large matrices themselves and lose what their consumers gain
-                                                 // ("weight_prefetch_mask": down carried by gate|up +4.8 %, the next q|k|v carried by down +2.7 %), and at 6-8 rows (split-K launch slices) the o_proj
-                                                 // carrier loses too: off there
+                                                 // (down carried by gate|up +4.8 %, the next q|k|v carried by down +2.7 %), and at 6-8 rows (split-K launch slices) the o_proj carrier loses
+                                                 // too: off there.  The role is compiled into that one launch only: present in a kernel it costs 0.3 us per launch even when unused
     int split_dec_rows = 9;                      // fp32 engines: decode batches of >= this many rows (packed-residual path, no per-utterance adapters) run their projections on the
                                                  // head / tail images: 3 fp16 MFMAs per product instead of 8 exact-f32 ones (skinny_gemm.hip dispatch_split); 0 = never.  "split_decode_rows"
     void *sp_x_hi = nullptr, *sp_x_lo = nullptr, *sp_act_hi = nullptr, *sp_act_lo = nullptr;   //   ... and of the prompt rows' operands
@@ -341,7 +340,6 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     else if (n == "weight_prefetch_kb") *value = h->prefetch_kb;
     else if (n == "nbg2_rows") *value = h->nbg2_rows;
     else if (n == "split_nbg2_rows") *value = h->split_nbg2_rows;
-    else if (n == "weight_prefetch_mask") *value = h->prefetch_mask;
     else if (n == "split_rows") *value = h->split_rows;
     else if (n == "graph_steps") *value = h->graph_steps;
     else if (n == "graph_steps_persistent") *value = h->graph_steps_persist;
@@ -364,8 +362,6 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         if (!h->finalized) h->split_dec_rows = value < 0 ? 0 : value;      // before finalize: also decides whether the images are built
         else if (value > 0 && !(h->split_ok && h->wsplit)) { ctts_set_error("set_option(split_decode_rows): this engine holds no head / tail weight images (fp16 engine, a weight beyond the fp16 range, or the option was 0 at finalize)"); return 1; }
         else h->split_dec_rows = value < 0 ? 0 : value;
-    } else if (n == "weight_prefetch_mask") {
-        h->prefetch_mask = value & 31;
     } else if (n == "split_nbg2_rows") {
         h->split_nbg2_rows = value < 17 ? 17 : value;
     } else if (n == "weight_prefetch_kb") {      // launch chain: KiB of the next launch's weights per prefetch workgroup (0 = no prefetch workgroups; see prefetch_kb)
@@ -957,17 +953,16 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         return 0;
     }
     if (form) { form->parts = splitd; form->xh = xhm; form->logits = false; form->split = spd; }
-    // weight prefetch across the launch boundaries of a decode step (kernels.h WPrefetch): launch k carries workgroups that pull launch k + 1's weight image into L2.
-    // (16-row chunks only: every consumer workgroup column is then one row tile; per-utterance adapters shift the consumers' block indices by their workers: off)
+    // weight prefetch across a launch boundary of a decode step (kernels.h WPrefetch): the o_proj launch carries workgroups that pull the gate|up launch's weight image into L2
+    // (packed-residual path: every consumer workgroup column is one row tile; per-utterance adapters shift the consumers' block indices by their workers: off)
     const int pf_kb = (st != nullptr && xhm && !lora && (spd || (dt == CTTS_DTYPE_F16 && R >= 17))) ? h->prefetch_kb : 0;      // (the exact-f32 kernels lose with it: batch 32 0.845 -> 0.897)
-    auto set_pf = [&](GemmArgs& g, const void* w, int n_tiles, int K, int fmt, int bit) {          // fmt: 0 fp32 tiles, 1 fp16 tiles, 2 head / tail pairs
-        if (pf_kb <= 0 || w == nullptr || !((h->prefetch_mask >> bit) & 1)) return;
+    auto set_pf = [&](GemmArgs& g, const void* w, int n_tiles, int K, int fmt) {          // fmt: 0 fp32 tiles, 1 fp16 tiles, 2 head / tail pairs
+        if (pf_kb <= 0 || w == nullptr) return;
         const size_t tile = (size_t)16 * K * (fmt == 1 ? 2 : 4);
         size_t nb = (tile * n_tiles + (size_t)pf_kb * 1024 - 1) / ((size_t)pf_kb * 1024);
         nb = (nb + 7) & ~(size_t)7;
         nb = nb < 8 ? 8 : (nb > 256 ? 256 : nb);
-        if (g.pf.ptr == nullptr) { g.pf.ptr = w; g.pf.unit_bytes = (unsigned)tile; g.pf.n_units = (unsigned)n_tiles; g.pf_blocks = (int)nb; }
-        else { g.pf2.ptr = w; g.pf2.unit_bytes = (unsigned)tile; g.pf2.n_units = (unsigned)n_tiles; if ((int)nb > g.pf_blocks) g.pf_blocks = (int)nb; }
+        g.pf.ptr = w; g.pf.unit_bytes = (unsigned)tile; g.pf.n_units = (unsigned)n_tiles; g.pf_blocks = (int)nb;
     };
     for (int l = 0; l < h->L; ++l) {
         GemmArgs a = {};
@@ -1034,8 +1029,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         } else if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
         else {
             if (spd) g2.W = h->lw[l].o_sp;
-            set_pf(g2, spd ? h->lw[l].gu_sp : h->lw[l].gu, 2 * h->I / 16, h->H, dts, 0);
-            set_pf(g2, spd ? h->lw[l].d_sp : h->lw[l].d, h->H / 16, h->I, dts, 4);          // (bit 4: the down image too, two launches ahead)
+            set_pf(g2, spd ? h->lw[l].gu_sp : h->lw[l].gu, 2 * h->I / 16, h->H, dts);
             if (launch_gemm(dts, nbg, (S == 1) ? PRO_PACKED : PRO_ATTN, xhm ? EPI_RESID_XH : (splitd ? EPI_RESID_P : EPI_RESID), g2, chunks, s)) return 1;
         }
         // RMSNorm + gate|up + SiLU*up
@@ -1051,20 +1045,11 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         } else if (xhm) {
             g3.xh = h->xh; g3.ssq = h->ssq; g3.scale_in = h->scale_o; g3.scale_out = h->scale_d;
             if (spd) g3.W = h->lw[l].gu_sp;
-            set_pf(g3, spd ? h->lw[l].d_sp : h->lw[l].d, h->H / 16, h->I, dts, 1);
             if (launch_gemm(dts, nbg, PRO_XH, EPI_SWIGLU, g3, chunks, s)) return 1;
-        } else {
-            set_pf(g3, h->lw[l].d, h->H / 16, h->I, dt, 1);
-            if (launch_gemm(dt, nbg, PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
-        }
+        } else if (launch_gemm(dt, nbg, PRO_NORM, EPI_SWIGLU, g3, chunks, s)) return 1;
         // down + residual
         GemmArgs g4 = a;
         g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x;
-        if (l + 1 < h->L) set_pf(g4, spd ? h->lw[l + 1].qkv_sp : h->lw[l + 1].qkv, 3 * h->H / 16, h->H, dts, 2);
-        else if (!h->text_mode) {                  // the code heads (run_heads picks the same image)
-            const bool hsp = spd && h->whead_sp != nullptr && h->xh_heads;
-            set_pf(g4, hsp ? h->whead_sp : h->whead, (h->NVQ * h->V + 15) / 16, h->H, hsp ? 2 : dt, 2);
-        }
         if (pfs) {      // the SwiGLU images hold silu(g) * u / 16
             if (launch_prefill_split_gemm(EPI_RESID, g4, h->lw[l].d_sp, h->sp_act_hi, h->sp_act_lo, nullptr, nullptr, sp_scale * 16.0f, s)) return 1;
         } else if (pfg) {
@@ -1098,12 +1083,6 @@ static int run_heads(ctts_gpt* h, bool write_hidden, StreamForm form, hipStream_
     a.dyn = write_hidden ? h->dyn : nullptr;       // the kernel tests dyn->hidden_out itself
     a.rows = h->finend;
     a.opart = h->dpart; a.np = form.parts ? 4 : 0;
-    if (h->prefetch_kb > 0 && (h->prefetch_mask & 8) && nbg == 1 && !h->lora_rows && !h->text_mode && !h->cur_persist) {      // the next step's first projection (the sampler runs in between and leaves L2 alone)
-        const size_t tile = (size_t)16 * h->H * h->esz, total = tile * (3 * h->H / 16);
-        size_t nb = ((total + (size_t)h->prefetch_kb * 1024 - 1) / ((size_t)h->prefetch_kb * 1024) + 7) & ~(size_t)7;
-        a.pf.ptr = h->lw[0].qkv; a.pf.unit_bytes = (unsigned)tile; a.pf.n_units = (unsigned)(3 * h->H / 16);
-        a.pf_blocks = (int)(nb < 8 ? 8 : (nb > 128 ? 128 : nb));
-    }
     // the last down projection left the rows as packed fp16 + sums of squares (PRO_XH): no fp32 re-normalisation per block.  The text head is a
     // different launch shape (not measured): it keeps the fp32 prologue
     if (form.xh && !h->text_mode && h->xh_heads && (!form.split || h->whead_sp != nullptr)) {

@@ -88,7 +88,7 @@ struct GemmArgs {
     const RowState* rows;   // heads only: hidden row goes to hiddens[rows[r].out][rows[r].end] while the row is live
     float* sk_slab;         // EPI_RESID_XH_SK: partial tiles [row tile][chunk][slice][256] fp32
     int* sk_cnt;            //                  arrival tickets [row tile][chunk], zero between launches (the last arriver resets its counter)
-    WPrefetch pf, pf2;      // the next launch's weights (and, optionally, the one after's), pulled into L2 by pf_blocks extra workgroups (a multiple of 8; 0 = none)
+    WPrefetch pf;           // o_proj launches of the packed-residual path: the gate|up launch's weights, pulled into L2 by pf_blocks extra workgroups (a multiple of 8; 0 = none)
     int pf_blocks;
     int valu;               // fp32 decode, <= 4 rows: products on the VALU instead of exact-f32 MFMA (skinny_gemm.hip, VR; ctts_gpt_set_option "valu_rows")
 };

@@ -159,12 +159,16 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const int* done
 #define CTTS_EXIT_IF_DONE() if (__builtin_amdgcn_readfirstlane(done_v)) return
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {   // prefetch blocks (kernels.h WPrefetch): the grid's last x columns
+    // prefetch blocks (kernels.h WPrefetch): the grid's last x columns.  Compiled into the ONE launch that carries them: o_proj on the packed-residual path.  (Compiled into
+    // every instantiation, the role cost each launch that never used it 0.3 us -- the <= 8-row chain 6 %, profiles/r06_ab_chain_vs_r05.jsonl -- and as carriers the launches
+    // that stream large matrices themselves lose more than their consumers gain, profiles/r06_ab_weight_prefetch.jsonl.)
+    constexpr bool PFCAP = (EPI == EPI_RESID_XH) && (PRO == PRO_PACKED) && (K == 768) && VR == 0 && !LORA;
+    if constexpr (PFCAP) {
         const int xreal = (int)((unsigned)misc >> 22);
-        if (xreal != 0 && (int)blockIdx.x >= xreal) {
+        if (__builtin_expect(xreal != 0 && (int)blockIdx.x >= xreal, 0)) {      // (unlikely: the block belongs at the END of the code -- laid out in front of the main path it cost every
+                                                                                 //  launch of the <= 8-row chain 0.3 us: a taken branch over 1 KB of cold code at every wave's start)
             if (blockIdx.y == 0 && blockIdx.z == 0) {
                 weight_prefetch<WAVES>(a.pf, (int)blockIdx.x - xreal, (int)gridDim.x - xreal, (int)blockIdx.x & 7, smem, tid);
-                weight_prefetch<WAVES>(a.pf2, (int)blockIdx.x - xreal, (int)gridDim.x - xreal, (int)blockIdx.x & 7, smem, tid);
             }
             return;
         }
@@ -759,7 +763,8 @@ static int launch_one(const GemmArgs& a, int chunks, hipStream_t s, bool configu
     }
     const int xreal = a.n_row_tiles / RT + a.lora_w;
     // prefetch blocks: a multiple of 8 (the real blocks keep their XCDs), whole DMA sweeps only, and the first-prefetch-block field of misc has 10 bits
-    const bool pf_on = a.pf_blocks >= 8 && a.pf.ptr != nullptr && (a.pf.unit_bytes % (WAVES * 1024)) == 0 && (a.pf2.ptr == nullptr || (a.pf2.unit_bytes % (WAVES * 1024)) == 0) && xreal < 1024;
+    constexpr bool PFCAP = (EPI == EPI_RESID_XH) && (PRO == PRO_PACKED) && (KTILES * WTraits<WT>::KT == 768) && VR == 0 && !LORA;      // == the kernel's
+    const bool pf_on = PFCAP && a.pf_blocks >= 8 && a.pf.ptr != nullptr && (a.pf.unit_bytes % (WAVES * 1024)) == 0 && xreal < 1024;
     const int npf = pf_on ? (a.pf_blocks & ~7) : 0;
     const int misc = (a.np & 0x7) | ((a.S & 0xF) << 3) | ((a.ktiles_total & 0xFF) << 7) | ((a.lora_w & 0x7F) << 15) | (int)((unsigned)(npf ? xreal : 0) << 22);
     hipLaunchKernelGGL(kern, dim3(xreal + npf, chunks, nz), dim3(WAVES * 64), LDS, s, done_p, a.W, in0, in1, resid_arg, a.R, misc, a);

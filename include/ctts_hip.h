@@ -66,8 +66,12 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "split_decode_rows"   fp32 engines: decode batches of >= this many rows (packed-residual path, >= 9 rows, no per-utterance adapters) run their projections on the fp16 matrix
  *                         pipes with head / tail fp16 operands -- 3 MFMAs per product at fp32-level accuracy, the prompt pass's arithmetic -- instead of exact-f32 MFMA
  *                         (default 9; 0 = never.  Set to 0 BEFORE finalize and the engine builds no head / tail weight images unless the prompt pass needs them)
+ *   "split_nbg2_rows"     ... and from this many rows on (default 17) they take 32-row blocks instead of 16-row chunks
+ *   "weight_prefetch_kb"  launch chain from 9 rows on (fp16 engines: 17): the o_proj launch carries extra workgroups that pull the gate|up launch's weights into L2, one per this
+ *                         many KiB (default 96; 0 = none).  The other launches were tried as carriers and lose (profiles/r06_ab_weight_prefetch.jsonl)
  *   "valu_rows"           fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (default 2; 0..4)
- *   "persistent_rows"     decode batches of <= this many rows (<= 5; default 5 = 12 heads x 5 rows on 60 of the 64 attention workgroups) run the whole decoder stack of a step as ONE persistent
+ *   "persistent_rows"     decode batches of <= this many rows (<= 8; default 8 on fp32 engines, 5 on fp16 engines; up to 5 rows one (row, head) per attention workgroup, 6..8 rows
+ *                         two, with contexts up to "persistent_pair_keys" = 704 / 576 / 448 keys at 6 / 7 / 8 rows) run the whole decoder stack of a step as ONE persistent
  *                         launch of 256 resident workgroups (persist_layer.hip; up to 1400 keys per key share -- longer contexts go back to the launch chain -- no per-utterance adapters; the final
  *                         norm + code heads run inside the launch at <= 2 rows).  0 = off.  The first
  *                         process that loads an engine (either dtype) on a device holds the mode (advisory lock /tmp/ctts_persist_<pci>.lock); others stay on launches.
