@@ -31,6 +31,11 @@ typedef unsigned long long u64;
 #endif
 #define PL_SPIN_LIMIT (1u << 18)      // ~0.3 s of polling before a wave gives up
 
+// the workgroup's give-up flag lives in LDS and is read / written as LDS (a `volatile int*` access stays a FLAT access to an address-space-cast constant: slower, and
+// this hipcc emits an illegal V_CMP against src_shared_base for it in some of the 6..8-row kernels)
+typedef __attribute__((address_space(3))) int pl_lds_int;
+#define PL_ABORT_GET(p_) __hip_atomic_load((pl_lds_int*)(p_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define PL_ABORT_SET(p_) __hip_atomic_store((pl_lds_int*)(p_), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 __device__ inline void store_granule(u64* g, unsigned tag, float v) {
     __hip_atomic_store(g, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -40,7 +45,7 @@ __device__ inline void store_granule(u64* g, unsigned tag, float v) {
 // version let hipcc hoist a separate 64-bit address pair per granule of every edge out of the layer loop: ~100 VGPRs alive through the loop, spills).
 // Returns false after PL_SPIN_LIMIT passes or once the workgroup / the engine has given up.
 template <int N, typename OffFn>
-__device__ inline bool sweep(const u64* base, unsigned lane_elem, OffFn off, unsigned tag, float (&v)[N], int* err, int code, volatile int* abort_s, int nap = 1) {
+__device__ inline bool sweep(const u64* base, unsigned lane_elem, OffFn off, unsigned tag, float (&v)[N], int* err, int code, int* abort_s, int nap = 1) {
     const u64* p = base + lane_elem;
     asm volatile("" : "+v"(p));
 #pragma unroll 1
@@ -53,10 +58,10 @@ __device__ inline bool sweep(const u64* base, unsigned lane_elem, OffFn off, uns
             ok = ok && ((unsigned)(x >> 32) == tag);
         }
         if (__all(ok)) return true;
-        bool giveup = spins >= PL_SPIN_LIMIT || *abort_s != 0;
+        bool giveup = spins >= PL_SPIN_LIMIT || PL_ABORT_GET(abort_s) != 0;
         if (!giveup && (spins & 1023u) == 1023u) giveup = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         if (giveup) {
-            if ((threadIdx.x & 63) == 0) { atomicCAS(err, 0, code); *abort_s = 1; }
+            if ((threadIdx.x & 63) == 0) { atomicCAS(err, 0, code); PL_ABORT_SET(abort_s); }
             return false;
         }
         for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
@@ -69,7 +74,7 @@ __device__ inline bool sweep(const u64* base, unsigned lane_elem, OffFn off, uns
 // the granule's offset as a scalar: no per-granule address registers at all (cdna_hip_programming.md T8).  aux: sc1 (the relaxed agent-scope load's cache policy) + the
 // intrinsic's volatile bit (the loop re-reads memory another workgroup writes).
 template <int N, typename OffFn>
-__device__ inline bool sweep_buf(const u64* base, unsigned n_granules, unsigned lane_elem, OffFn off, unsigned tag, float (&v)[N], int* err, int code, volatile int* abort_s, int nap = 1) {
+__device__ inline bool sweep_buf(const u64* base, unsigned n_granules, unsigned lane_elem, OffFn off, unsigned tag, float (&v)[N], int* err, int code, int* abort_s, int nap = 1) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(n_granules * 8u), 0x00020000);
     const unsigned voff = lane_elem * 8u;
@@ -83,10 +88,10 @@ __device__ inline bool sweep_buf(const u64* base, unsigned n_granules, unsigned 
             ok = ok && (x[1] == tag);
         }
         if (__all(ok)) return true;
-        bool giveup = spins >= PL_SPIN_LIMIT || *abort_s != 0;
+        bool giveup = spins >= PL_SPIN_LIMIT || PL_ABORT_GET(abort_s) != 0;
         if (!giveup && (spins & 1023u) == 1023u) giveup = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         if (giveup) {
-            if ((threadIdx.x & 63) == 0) { atomicCAS(err, 0, code); *abort_s = 1; }
+            if ((threadIdx.x & 63) == 0) { atomicCAS(err, 0, code); PL_ABORT_SET(abort_s); }
             return false;
         }
         for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
@@ -100,11 +105,82 @@ __device__ inline bool sweep_buf(const u64* base, unsigned n_granules, unsigned 
     ((R >= PL_BUF_MIN_R) ? sweep_buf<N_>(base_, (unsigned)(count_), lane_elem_, off_, tag_, v_, a.error, code_, abort_s, a.nap) \
                        : sweep<N_>(base_, lane_elem_, off_, tag_, v_, a.error, code_, abort_s, a.nap))
 
+// ---- 16-byte act granules (round 6, PL_ACT16).  The act edge is the fattest gather of a layer: every GEMV workgroup needs all 3072 R SwiGLU outputs, as 8-byte
+// {tag, value} granules that is 12 R loads per edge lane and 24.6 KB R per workgroup and layer (4.7 MB R across the chip per poll pass).  Here a producer workgroup
+// packs its 16 outputs of a row into SIX 16-byte granules {v0, v1, v2, check} (the sixth holds one value and two zeros), check = tag + bits(v0) + bits(v1) + bits(v2):
+// 4.5 R loads per lane, 18.4 KB R per workgroup.  Nothing in the ISA promises that a lane's 16-byte store is seen whole by another CU, so the tag is not a
+// plain word: a reader accepts a granule only if check - bits(v0) - bits(v1) - bits(v2) == tag, which a mix of two generations fails (unless the mixed-in words are
+// equal anyway); tools/mb/tear16.hip measures how often that would matter on this chip.  Layout: g_act16[(row * 192 + producer) * 6 + slot], i.e. granule f of the flat
+// array holds columns 16 (f / 6) + 3 (f % 6) + {0, 1, 2} of the [R][3072] act rows -- edge lane e reads f = e + NE k, consecutive lanes consecutive granules.
+#ifndef PL_ACT16
+#define PL_ACT16 1
+#endif
+#define PL_A16_SLOTS 6
+#ifndef PL_A16_MAXR
+#define PL_A16_MAXR PL_MAXR_ONE
+#endif
+#ifndef PL_A16_CHUNK
+#define PL_A16_CHUNK 12
+#endif
+typedef unsigned pl_u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void store_granule16(void* base, unsigned n_granules, unsigned idx, unsigned tag, float v0, float v1, float v2) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(n_granules * 16u), 0x00020000);
+    const unsigned w0 = __builtin_bit_cast(unsigned, v0), w1 = __builtin_bit_cast(unsigned, v1), w2 = __builtin_bit_cast(unsigned, v2);
+    const pl_u32x4 g = {w0, w1, w2, tag + w0 + w1 + w2};
+    __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (int)(idx * 16u), 0, 16);           // sc1, like the 8-byte granules' agent-scope stores
+}
+// one wave re-reads its N granules f0 + stride k (k < N) until every check word matches; TAIL: the last of them exists only in the lanes with f0 + stride (N - 1) < total
+template <int N, bool TAIL>
+__device__ __forceinline__ bool sweep16(const void* base, unsigned total, unsigned f0, unsigned stride, unsigned tag, pl_u32x4 (&v)[N], int* err, int code, int* abort_s, int nap) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(total * 16u), 0x00020000);
+    const unsigned voff = f0 * 16u;
+#pragma unroll 1
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const pl_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(k * stride * 16u), (int)(16u | 0x80000000u));
+            v[k] = x;
+            if (TAIL && k == N - 1) ok = ok && ((x[3] - x[0] - x[1] - x[2] == tag) || (f0 + k * stride >= total));
+            else ok = ok && (x[3] - x[0] - x[1] - x[2] == tag);
+        }
+        if (__all(ok)) return true;
+        bool giveup = spins >= PL_SPIN_LIMIT || PL_ABORT_GET(abort_s) != 0;
+        if (!giveup && (spins & 1023u) == 1023u) giveup = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (giveup) {
+            if ((threadIdx.x & 63) == 0) { atomicCAS(err, 0, code); PL_ABORT_SET(abort_s); }
+            return false;
+        }
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
+    }
+}
+// granules [K0 NE, (K0 + N) NE) of the act gather -> xs
+template <int K0, int N, int NE, int TOT>
+__device__ __forceinline__ void act16_chunk(const void* g_act, int e, unsigned tag, __attribute__((address_space(3))) float* xs, int* err, int* abort_s, int nap) {
+    pl_u32x4 v[N];
+    constexpr bool TAIL = (NE * (K0 + N) > TOT);
+    const bool got = sweep16<N, TAIL>(g_act, (unsigned)TOT, (unsigned)(e + NE * K0), (unsigned)NE, tag, v, err, 5, abort_s, nap);
+    (void)got;
+    int ee = e;
+    asm volatile("" : "+v"(ee));                 // (the column arithmetic below is redone per layer instead of living in registers through the layer loop)
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int f = ee + NE * (K0 + k);
+        if (!(TAIL && k == N - 1) || f < TOT) {
+            const int P = f / PL_A16_SLOTS, s = f - PL_A16_SLOTS * P;
+            __attribute__((address_space(3))) float* const d = xs + 16 * P + 3 * s;
+            const unsigned w0 = v[k][0], w1 = v[k][1], w2 = v[k][2];      // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0 with this hipcc)
+            d[0] = __builtin_bit_cast(float, w0);
+            if (s < 5) { d[1] = __builtin_bit_cast(float, w1); d[2] = __builtin_bit_cast(float, w2); }
+        }
+    }
+}
+
 // Before a wave sweeps ALL its granules of an edge it watches one "sentinel" granule per producer workgroup that feeds it (the last one that producer
 // stores): 96 eight-byte loads per pass instead of up to 3072.  A hint only -- stores of different lanes land in any order -- the sweep that follows checks
 // every tag; bounded, silent (the sweep reports).
 template <typename OffFn>
-__device__ inline void watch_sentinels(const u64* base, OffFn off, int n, unsigned tag, int lane, volatile int* abort_s) {
+__device__ inline void watch_sentinels(const u64* base, OffFn off, int n, unsigned tag, int lane, int* abort_s) {
     const u64* p0 = base + ((lane < n) ? off(lane) : 0);
     const u64* p1 = base + ((lane + 64 < n) ? off(lane + 64) : 0);
     asm volatile("" : "+v"(p0), "+v"(p1));
@@ -113,7 +189,7 @@ __device__ inline void watch_sentinels(const u64* base, OffFn off, int n, unsign
         bool ok = true;
         if (lane < n) ok = (unsigned)(__hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag;
         if (lane + 64 < n) ok = ok && ((unsigned)(__hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag);
-        if (__all(ok) || *abort_s != 0) return;
+        if (__all(ok) || PL_ABORT_GET(abort_s) != 0) return;
         __builtin_amdgcn_s_sleep(2);
     }
 }
@@ -202,6 +278,7 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
     typedef typename PlW<WT>::frag wfrag;
     // Edge waves per workgroup: 2 at one row, 4 at 2..4 rows (round 5).  A gather is 768 R (3072 R for the act rows) granules over the edge lanes; with two waves the
     // per-lane share grew with the rows (6 R and 24 R loads per lane, the act rows one sweep after the other) -- +4.3 us of the +9.2 us per layer between 1 and 4 rows.
+    constexpr bool A16 = PL_ACT16 != 0 && R <= PL_A16_MAXR;      // 16-byte act granules (measured: -1.5 % per step at 1..5 rows, +1 % / +4.5 % at 6 / 8 rows)
     constexpr int EW = PL_EDGE_WAVES(R), NE = 64 * EW, GX = 768 / NE;      // edge lanes; granules per lane and row of a 768-wide gather (6 or 3)
     constexpr size_t BLOCK_BYTES = (size_t)PL_BLOCK_BYTES / 4 * sizeof(WT), LAYER_BYTES = PL_LAYER_BYTES / 4 * sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -673,7 +750,21 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
                 if (last) PL_MARK(6);
                 PL_B1();                                      // B1(D): the gather is in LDS
                 __syncthreads();                              // B2(D)
-                if (e < 16 * R) {
+                if constexpr (A16) {
+                    float av = 0.f;
+                    const int pi = e & 15, r = e >> 4;
+                    if (e < 16 * R) {
+                        const int w = pi >> 1, p = pi & 1;
+                        const float rs = 1.0f / sqrtf((EW == 2 ? ssq[r] + ssq[R + r] : (ssq[r] + ssq[R + r]) + (ssq[2 * R + r] + ssq[3 * R + r])) / (float)PL_H + a.eps);
+                        const float gv = pl_red(red, w, 16 * p + r) * rs, uv = pl_red(red, w, 16 * p + R + r) * rs;
+                        av = (gv / (1.0f + expf(-gv))) * uv;                                                                    // llama.py:214
+                    }
+                    // the 16 lanes of a decode row: lane pi = 3 s collects (pi, pi + 1, pi + 2) and stores granule s
+                    const float a1 = __shfl_down(av, 1), a2 = __shfl_down(av, 2);
+                    if (e < 16 * R && pi % 3 == 0)
+                        store_granule16(a.g_act, PL_GEMV_BLOCKS * PL_A16_SLOTS * R, (unsigned)pl_opq<(R > PL_MAXR_ONE)>((r * PL_GEMV_BLOCKS + b) * PL_A16_SLOTS + pi / 3), tag,
+                                        av, (pi + 1 < 16) ? a1 : 0.f, (pi + 2 < 16) ? a2 : 0.f);
+                } else if (e < 16 * R) {
                     const int pi = e & 15, r = e >> 4, w = pi >> 1, p = pi & 1;
                     const float rs = 1.0f / sqrtf((EW == 2 ? ssq[r] + ssq[R + r] : (ssq[r] + ssq[R + r]) + (ssq[2 * R + r] + ssq[3 * R + r])) / (float)PL_H + a.eps);
                     const float gv = pl_red(red, w, 16 * p + r) * rs, uv = pl_red(red, w, 16 * p + R + r) * rs;
@@ -683,6 +774,16 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
                 // ---- phase E: silu(gate) * up [R][3072] -> down + residual
                 for (int z = 0; z < a.delay_act; ++z) __builtin_amdgcn_s_sleep(2);
                 // (producers of this wave's columns e + 128 k: workgroups 8 k + 4 ew + t, t < 4; each stores its 16 columns of every row in one instruction)
+                if constexpr (A16) {
+                    constexpr int TOT = PL_GEMV_BLOCKS * PL_A16_SLOTS * R, NK = (TOT + NE - 1) / NE;      // granules; per lane
+                    constexpr int NC = (NK + PL_A16_CHUNK - 1) / PL_A16_CHUNK, CH = (NK + NC - 1) / NC;       // sweeps; granules per lane and sweep (4 registers each)
+                    act16_chunk<0, (NK < CH ? NK : CH), NE, TOT>(a.g_act, e, tag, (__attribute__((address_space(3))) float*)xs, a.error, abort_s, a.nap);
+                    if constexpr (NC > 1) act16_chunk<CH, (NK - CH < CH ? NK - CH : CH), NE, TOT>(a.g_act, e, tag, (__attribute__((address_space(3))) float*)xs, a.error, abort_s, a.nap);
+                    if constexpr (NC > 2) act16_chunk<2 * CH, (NK - 2 * CH < CH ? NK - 2 * CH : CH), NE, TOT>(a.g_act, e, tag, (__attribute__((address_space(3))) float*)xs, a.error, abort_s, a.nap);
+                    if constexpr (NC > 3) act16_chunk<3 * CH, (NK - 3 * CH < CH ? NK - 3 * CH : CH), NE, TOT>(a.g_act, e, tag, (__attribute__((address_space(3))) float*)xs, a.error, abort_s, a.nap);
+                    if constexpr (NC > 4) act16_chunk<4 * CH, NK - 4 * CH, NE, TOT>(a.g_act, e, tag, (__attribute__((address_space(3))) float*)xs, a.error, abort_s, a.nap);
+                    static_assert(NC <= 5, "act gather: more chunks");
+                } else {
                 if (EW == 2 && (a.poll & 1)) watch_sentinels(a.g_act, [ew](int i) { return (R - 1) * PL_I + 16 * (8 * (i >> 2) + 4 * ew + (i & 3)) + 15; }, 96, tag, lane, abort_s);
                 if constexpr (EW == 2) {
 #pragma unroll
@@ -727,6 +828,7 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
 #pragma unroll
                         for (int k = 0; k < 12; ++k) xs[r * PL_I + 256 * k + e] = v[k];
                     }
+                }
                 }
                 if (last) PL_MARK(8);
                 PL_B1();                                      // B1(E): the gather is in LDS

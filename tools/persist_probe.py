@@ -33,8 +33,9 @@ args = ap.parse_args()
 dev = torch.device("cuda", 0)
 LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
 LP = [type("R", (), dict(penalty=1.05, past_window=16, max_input_ids=625))()]
-MAXR = 5
-G_QKV, G_ATT, G_X1, G_ACT = MAXR * 12 * 192, MAXR * 768, MAXR * 768, MAXR * 3072
+MAXR = 5                       # rows this probe drives
+GMAXR = 8                      # PL_MAXR: rows the library sizes its granule buffers for (persist.h)
+G_QKV, G_ATT, G_X1, G_ACT = GMAXR * 12 * 192, GMAXR * 768, GMAXR * 768, GMAXR * 3072
 
 
 def out(**kw):
@@ -52,7 +53,18 @@ def granules(g):
     raw = debug_read(g, "pl_g", (G_QKV + G_ATT + G_X1 + G_ACT) * 8).view(np.uint32).reshape(-1, 2)
     val, tag = raw[:, 0].copy().view(np.float32), raw[:, 1].copy()
     o = [0, G_QKV, G_QKV + G_ATT, G_QKV + G_ATT + G_X1, G_QKV + G_ATT + G_X1 + G_ACT]
-    return [(val[o[i]:o[i + 1]], tag[o[i]:o[i + 1]]) for i in range(4)]
+    gs = [(val[o[i]:o[i + 1]], tag[o[i]:o[i + 1]]) for i in range(4)]
+    # the act rows travel as 16-byte granules {v0, v1, v2, tag + bits(v0) + bits(v1) + bits(v2)}, six per (row, producer workgroup) (persist_layer.hip PL_ACT16):
+    # granule f holds columns 16 (f / 6) + 3 (f % 6) + {0, 1, 2} of the [rows][3072] array; unpack to one (value, tag) per column
+    a16 = raw[o[3]:o[4]].reshape(-1)[:MAXR * 192 * 6 * 4].reshape(-1, 4)
+    tg = (a16[:, 3] - a16[:, 0] - a16[:, 1] - a16[:, 2]).astype(np.uint32)
+    av, at = np.zeros(MAXR * 3072, np.float32), np.zeros(MAXR * 3072, np.uint32)
+    f = np.arange(a16.shape[0]); col = 16 * (f // 6) + 3 * (f % 6)
+    for c in range(3):
+        ok = (f % 6 < 5) | (c == 0)
+        av[col[ok] + c] = a16[ok, c].copy().view(np.float32); at[col[ok] + c] = tg[ok]
+    gs[3] = (av, at)
+    return gs
 
 
 def make(cfg_layers, max_batch, max_seq, options=None):
