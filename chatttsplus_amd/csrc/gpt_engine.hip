@@ -137,6 +137,9 @@ struct ctts_gpt {
                                                  //   decode call of <= persistent_rows rows (persist_images): an engine that only ever decodes larger batches (a LoRA-merged
                                                  //   sibling serving batch 32) never pays the second 755 MB weight copy
     char* pimg_head = nullptr;                   //   the folded heads as 14 register-fragment rows per GEMV workgroup (persist.h PL_HEAD_FRAGS): the launch that ends the stack also runs
+    int persist_delay_u = -1;                    //   "persistent_delay_lora": poll delay of the u granules, -1 = 14 + 2 rows (ms/step with an adapter on every row, delay 0 / 8 / 16 / 24:
+                                                 //   batch 1 0.362 / 0.350 / 0.301 / 0.315, 2: 0.417 / 0.410 / 0.349 / 0.353, 4: 0.486 / 0.513 / 0.441 / 0.430; profiles/r06_ab_lora_persistent.jsonl)
+    int persist_lora = 1;                        //   "persistent_lora": rows with per-utterance adapters stay on the persistent launch (round 6; 0 = they take the launch chain, as until round 5)
     int persist_heads = 1;                       //   the final RMSNorm + heads ("persistent_heads"; code mode, paced schedule): one launch fewer per step
     unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
     unsigned* pl_epoch = nullptr;                //   launch counter = granule tag
@@ -171,6 +174,8 @@ struct ctts_gpt {
     // per-utterance LoRA (lora.hip): resident adapters A [layer][slot][target][16][768] and B^T in the same shape (zero padded to r = 16),
     // per-sequence slot table, low-rank terms of the rows being processed
     float *lora_A = nullptr, *lora_B = nullptr, *lora_scale = nullptr, *ln1 = nullptr;
+    float* lora_Af = nullptr;                    //   A of q | k | v with the input RMSNorm weight folded into the columns [layer][slot][3][16][768]: the persistent launch's waves read it (persist_layer.hip LORA)
+    std::vector<float> ln1_host;                 //   host copy of ln1 (fetched at the first ctts_gpt_set_adapter)
     int* lora_slot_of_seq = nullptr;
     signed char lora_row_slots[CTTS_MAX_B];      //   the same per decode ROW (rows move when finished rows are compacted away): travels in the kernel arguments of the folded launches
     std::vector<signed char> lora_rank;          //   [layer][slot][target] rank as loaded (0 = empty)
@@ -334,6 +339,8 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     const std::string n(name);
     if (n == "persistent_rows") *value = (h->persist_ok || !h->finalized) ? h->persist_rows : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
     else if (n == "persistent_heads") *value = h->persist_heads;
+    else if (n == "persistent_lora") *value = h->persist_lora;
+    else if (n == "persistent_delay_lora") *value = h->persist_delay_u;
     else if (n == "valu_rows") *value = h->valu_rows;
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
     else if (n == "split_decode_rows") *value = h->split_dec_rows;
@@ -371,6 +378,10 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
     } else if (n == "persistent_rows") {         // fp32 engines: decode batches of <= this many rows run each layer as ONE persistent launch (0 = off)
         h->persist_rows = value < 0 ? 0 : (value > CTTS_PERSIST_MAX_ROWS ? CTTS_PERSIST_MAX_ROWS : value);
         if (h->persist_rows > 0 && ensure_persist(h, true)) { h->persist_rows = 0; return 1; }
+    } else if (n == "persistent_delay_lora") {
+        h->persist_delay_u = value < 0 ? -1 : (value > 256 ? 256 : value);
+    } else if (n == "persistent_lora") {         // 1 (default): rows with per-utterance adapters stay on the persistent launch; 0 = they take the launch chain
+        h->persist_lora = value ? 1 : 0;
     } else if (n == "persistent_heads") {        // 1 (default): the persistent launch that ends the stack also runs the final norm + heads; 0 = the separate heads launch
         h->persist_heads = value ? 1 : 0;
     } else if (n == "persistent_layers_per_launch") {      // 0 = the whole stack in one launch (default); 1 = one launch per layer
@@ -433,7 +444,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->whead_sp, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
-                    h->lora_A, h->lora_B, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pimg_head, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
+                    h->lora_A, h->lora_B, h->lora_Af, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pimg_head, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->host_pin) (void)hipHostFree(h->host_pin);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -505,6 +516,8 @@ static int lora_target_index(const char* t) {
 static int lora_ensure_storage(ctts_gpt* h) {
     if (h->lora_A) return 0;
     const size_t per = (size_t)h->L * CTTS_MAX_ADAPTERS * 4 * 16 * h->H;
+    if (dev_alloc((void**)&h->lora_Af, per / 4 * 3 * 4)) return 1;
+    CTTS_HIP_CHECK(hipMemset(h->lora_Af, 0, per / 4 * 3 * 4));
     if (dev_alloc((void**)&h->lora_A, per * 4) || dev_alloc((void**)&h->lora_B, per * 4) ||
         dev_alloc((void**)&h->lora_scale, (size_t)h->L * CTTS_MAX_ADAPTERS * 4 * 4) || dev_alloc((void**)&h->lora_slot_of_seq, CTTS_MAX_B * 4) ||
         dev_alloc((void**)&h->lora_dqkv, (size_t)h->pass_rows * 3 * h->H * 4) || dev_alloc((void**)&h->lora_do, (size_t)h->pass_rows * h->H * 4))
@@ -528,6 +541,13 @@ extern "C" int ctts_gpt_set_adapter(ctts_gpt* h, int slot, int layer, const char
     for (int k = 0; k < r; ++k) memcpy(&a16[(size_t)k * H], A + (size_t)k * H, (size_t)H * 4);
     for (int n = 0; n < H; ++n) for (int k = 0; k < r; ++k) b16[(size_t)k * H + n] = B[(size_t)n * r + k];       // rank-major like A: rank r reads r rows
     const size_t off = (((size_t)layer * CTTS_MAX_ADAPTERS + slot) * 4 + t) * 16 * H;
+    if (t < 3) {                                    // the persistent launch's copy: columns times the layer's input RMSNorm weight (its waves see x * rs, not w * (x * rs))
+        if (h->ln1_host.empty()) { h->ln1_host.resize((size_t)h->L * H); CTTS_HIP_CHECK(hipMemcpy(h->ln1_host.data(), h->ln1, h->ln1_host.size() * 4, hipMemcpyDeviceToHost)); }
+        std::vector<float> af(a16);
+        const float* w = &h->ln1_host[(size_t)layer * H];
+        for (int k = 0; k < r; ++k) for (int c = 0; c < H; ++c) af[(size_t)k * H + c] *= w[c];
+        CTTS_HIP_CHECK(hipMemcpy(h->lora_Af + (((size_t)layer * CTTS_MAX_ADAPTERS + slot) * 3 + t) * 16 * H, af.data(), af.size() * 4, hipMemcpyHostToDevice));
+    }
     CTTS_HIP_CHECK(hipMemcpy(h->lora_A + off, a16.data(), a16.size() * 4, hipMemcpyHostToDevice));
     CTTS_HIP_CHECK(hipMemcpy(h->lora_B + off, b16.data(), b16.size() * 4, hipMemcpyHostToDevice));
     CTTS_HIP_CHECK(hipMemcpy(h->lora_scale + ((size_t)layer * CTTS_MAX_ADAPTERS + slot) * 4 + t, &scale, 4, hipMemcpyHostToDevice));
@@ -542,6 +562,7 @@ extern "C" int ctts_gpt_clear_adapter(ctts_gpt* h, int slot) {
     const size_t per = (size_t)4 * 16 * h->H;
     for (int l = 0; l < h->L; ++l) {
         const size_t off = ((size_t)l * CTTS_MAX_ADAPTERS + slot) * per;
+        CTTS_HIP_CHECK(hipMemset(h->lora_Af + off / 4 * 3, 0, per / 4 * 3 * 4));
         CTTS_HIP_CHECK(hipMemset(h->lora_A + off, 0, per * 4));
         CTTS_HIP_CHECK(hipMemset(h->lora_B + off, 0, per * 4));
         CTTS_HIP_CHECK(hipMemset(h->lora_scale + ((size_t)l * CTTS_MAX_ADAPTERS + slot) * 4, 0, 16));
@@ -930,7 +951,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // exact-f32 ones (common.h split_t; the prompt pass's arithmetic, prefill_split.hip).  Layer 0's q|k|v projection normalises the sampler's fp32 rows and stays exact.
     const bool spd = xhm && spd_ok;
     const int dts = spd ? 2 : dt;                              // launch_gemm's operand format
-    if (st != nullptr && h->cur_persist && h->pimg != nullptr && R <= PL_MAXR && !lora) {
+    if (st != nullptr && h->cur_persist && h->pimg != nullptr && R <= PL_MAXR) {
         // one persistent launch per layer (persist_layer.hip): the residual stream stays in x, nothing is left in partial or packed form
         // the launch that ends the stack also runs the final norm + the 4 code heads (persist_layer.hip phase H): code mode, paced schedule, images built
         // (ms/step separate heads launch / fused, tools/ab_options.py: fp32 batch 1 0.2798 / 0.2786, 2 0.3396 / 0.3384, 4 0.4711 / 0.4721; fp16 batch 3 0.3793 / 0.3800 -> up to 2 rows)
@@ -948,6 +969,14 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             pa.kv = kv_layer(h, l, 0); pa.kv_per = (size_t)h->cfg.max_batch * h->NH * h->cfg.max_seq * CTTS_HEAD_DIM; pa.Lmax = h->cfg.max_seq;
             pa.g_qkv = h->pl_g; pa.g_att = pa.g_qkv + PL_G_QKV; pa.g_x1 = pa.g_att + PL_G_ATT; pa.g_act = pa.g_x1 + PL_G_X1; pa.g_x = pa.g_act + PL_G_ACT; pa.g_part = pa.g_x + PL_G_X; pa.S = h->cur_persist;
             pa.epoch = h->pl_epoch; pa.error = h->pl_error; pa.done = &st->all_done; pa.ts = h->pl_ts_on ? h->pl_ts : nullptr; pa.eps = 1e-6f; pa.sched = h->persist_sched; pa.pace = h->persist_pace < 0 ? (R <= 2 ? 3 : 2) : h->persist_pace; pa.fault = h->persist_fault; pa.delay_att = h->persist_delay_att; pa.delay = h->persist_delay; pa.delay_act = h->persist_delay_act + 2 * (R - 1); pa.delay_x = h->persist_delay_x; pa.nap = h->persist_nap; pa.nap_qkv = h->persist_nap_qkv; pa.poll = (h->persist_poll < 0) ? 0 : h->persist_poll;
+            if (lora) {
+                // per-utterance adapters: the rows' slots travel in the arguments (part of the decode-graph key), the operands are read from the resident tables
+                pa.lora = 1; pa.lslots = 0; pa.delay_u = h->persist_delay_u < 0 ? 14 + 2 * R : h->persist_delay_u;
+                for (int r = 0; r < PL_MAXR; ++r) pa.lslots |= (unsigned long long)(unsigned char)(r < R ? h->lora_row_slots[r] : -1) << (8 * r);
+                pa.la_qkv_stride = (size_t)CTTS_MAX_ADAPTERS * 3 * 16 * h->H; pa.la_stride = (size_t)CTTS_MAX_ADAPTERS * 4 * 16 * h->H;
+                pa.la_qkv = h->lora_Af + pa.la_qkv_stride * l; pa.la = h->lora_A + pa.la_stride * l; pa.lb = h->lora_B + pa.la_stride * l;
+                pa.lscale = h->lora_scale + (size_t)l * CTTS_MAX_ADAPTERS * 4; pa.g_u = pa.g_part + PL_G_PART;
+            }
             if (launch_persist_layer(R, pa, s)) return 1;
         }
         return 0;
@@ -1234,7 +1263,8 @@ static int advance_rows(ctts_gpt* h, int n_steps) {
 // Returns the key splits per (row, head) (0 = launch chain): as many shares as keep every share within what a workgroup prefetches, at most 64 / (12 B) and
 // PL_SMAX; a context beyond twice that many prefetchable keys goes back to the launch chain (its attention spreads the keys over up to 96 workgroups).
 static inline int decode_persist(const ctts_gpt* h, int B, int L) {
-    if (!(h->persist_rows > 0 && h->pimg != nullptr && B <= h->persist_rows && B <= PL_MAXR && !h->lora_rows)) return 0;
+    if (!(h->persist_rows > 0 && h->pimg != nullptr && B <= h->persist_rows && B <= PL_MAXR)) return 0;
+    if (h->lora_rows && !(h->persist_lora && h->persist_sched == 3 && h->lora_Af != nullptr && h->H == PL_H)) return 0;      // per-utterance adapters ride inside the launch (round 6, paced schedule)
     int cap = PL_ATT_BLOCKS / (PL_NH * B);
     cap = cap > PL_SMAX ? PL_SMAX : (cap < 1 ? 1 : cap);
     if (h->persist_splits > 0) cap = h->persist_splits < cap ? h->persist_splits : cap;
@@ -1257,7 +1287,7 @@ static inline int decode_persist(const ctts_gpt* h, int B, int L) {
 
 static inline int pick_decode_path(ctts_gpt* h, int longest) {
     h->cur_splits = decode_splits(h, h->B, longest);
-    if (h->persist_ok && h->pimg == nullptr && h->persist_rows > 0 && h->B <= h->persist_rows && !h->lora_rows && persist_images(h)) return 1;
+    if (h->persist_ok && h->pimg == nullptr && h->persist_rows > 0 && h->B <= h->persist_rows && (!h->lora_rows || h->persist_lora) && persist_images(h)) return 1;
     h->cur_persist = decode_persist(h, h->B, longest);
     return 0;
 }

@@ -35,7 +35,8 @@
 // final norm + heads inside the launch (round 5): 14 head rows per GEMV workgroup (192 x 14 = 2688 >= 2504 = 4 x 626), 2 per compute wave 0..6
 #define PL_HEAD_ROWS 14
 #define PL_HEAD_FRAGS (7 * 2 * 3 * 64)     // fragments (4 weights each) of a workgroup's head image: [wave 7][row 2][j 3][lane 64]
-#define PL_G_TOTAL (PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT + PL_G_X + PL_G_PART)
+#define PL_G_U (PL_MAXR * 64)                // per-utterance adapters: u = A h of a row's q (16) | k (16) | v (16) | o_proj (16) terms
+#define PL_G_TOTAL (PL_G_QKV + PL_G_ATT + PL_G_X1 + PL_G_ACT + PL_G_X + PL_G_PART + PL_G_U)
 
 struct PersistArgs {
     const char* w;                  // layer 0's image [192][PL_BLOCK_BYTES]; layer l at + l * PL_LAYER_BYTES (fp16 engines: half of both)
@@ -73,6 +74,16 @@ struct PersistArgs {
     int nap;                        // ~128-cycle units between two poll passes of a GEMV edge wave
     int fault;                      // test hook: > 0 = one workgroup withholds a hand-off in layer fault - 1 (the give-up path must end the step, not hang it)
     int poll;                       // bit 0: watch one sentinel granule per producer before the full sweep of an edge
+    // per-utterance LoRA adapters inside the launch (round 6; the LORA kernels, paced schedule): row r adds scale * B (A h) of adapter slot lslots[r] to q / k / v / o_proj
+    int lora;                       // 1: some decode row carries an adapter
+    int delay_u;                    //   ~128-cycle units an edge wave sleeps before it polls the u granules (they are published ~0.4 us after the gather completes)
+    unsigned long long lslots;      //   byte r = the adapter slot of decode row r (0xFF: none)
+    const float* la_qkv;            //   layer 0's A of q | k | v with the input RMSNorm weight folded into the columns [slot][3][16][768]; layer l at + l * la_qkv_stride floats
+    const float* la;                //   layer 0's A [slot][4][16][768] (target 3 = o_proj); layer l at + l * la_stride floats
+    const float* lb;                //   B^T, rank-major, same shape and stride as la
+    const float* lscale;            //   [layer][slot][4]
+    size_t la_qkv_stride, la_stride;
+    unsigned long long* g_u;        //   [R][64] granules: u = A h, q 16 | k 16 | v 16 | o_proj 16
 };
 
 int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s);

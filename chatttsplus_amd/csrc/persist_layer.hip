@@ -244,6 +244,10 @@ template <int CTRL, int C> __device__ inline void pl_rs_step(float* v, bool f) {
         }
     } else v[0] += dpp_f<CTRL>(v[0]);
 }
+#define PL_FRONT_BYTES 4096                 // 16 + (384 + 512 + 16 + 16) * 4 = 3728, rounded
+#ifndef PL_TAIL_IT
+#define PL_TAIL_IT 4                        // 6..8 rows: iterations of 8 keys per compute wave that wait in LDS (4 KB each) -- 4 x 8 x 4 = 128 keys per item behind the 192 in registers
+#endif
 #define PL_RED_FLOATS (8 * 32 * 4)          // [compute wave][value < 32][16-lane row]: two groups of <= 16 values per wave (gate|up: pair 0 | pair 1)
 template <int P> __device__ inline void pl_reduce_store(float (&v)[P], float* red, int wave, int lane, int base = 0) {
     static_assert(P == 1 || P == 2 || P == 4 || P == 8 || P == 16, "pad to a power of two");
@@ -267,14 +271,68 @@ __device__ inline float pl_red(const float* red, int wave, int n) {
 }
 #define PL_PV(N_) float pv[pl_pow2(N_)]; _Pragma("unroll") for (int n_ = 0; n_ < pl_pow2(N_); ++n_) pv[n_] = 0.f
 
+// ---- per-utterance LoRA adapters inside the launch (round 6; LORA kernels, paced schedule).  Reference: peft's merge as the pipeline applies it
+// (pipelines/chattts_plus_pipeline.py:420-432), per row instead of per batch: row r adds scale * B (A h) of its adapter to q / k / v (h = the normalised input)
+// and to o_proj (h = the attention output).  A merged weight image per adapter would be 755 MB and a different image per row; the low-rank form is 2 x 16 x 768 MACs
+// per target and row -- work for the two compute waves (6, 7) that own no q|k|v and no o_proj rows:
+//   * wave 2 b + w of the 384 such waves computes ONE u = A[k] . h (16 ranks x 3 targets x R rows <= 384; o_proj: 16 R <= 384), its A row requested a phase ahead
+//     into the registers that hold q|k|v / o_proj rows in the other waves, and publishes it as a granule;
+//   * the same waves request the B entries of their workgroup's OWN 12 q|k|v and 4 o_proj rows a phase ahead and park them in LDS (the scale rides on u);
+//   * the edge lanes that finish a row gather the row's 16 u (one more hop per projection: the u must cross workgroups) and add sum_k B[k][n] u[k].
+// The launch chain computes the same terms in worker workgroups of its q|k|v / o_proj launches (lora_worker.h).
+__device__ inline int pl_slot(unsigned long long slots, int r) { return (int)(signed char)(unsigned char)(slots >> (8 * r)); }
+template <typename WT> struct PlLoraRegs {                // fp16 engines: the adapters are fp32 -- registers of their own (those kernels have room)
+    f32x4 qa_[3], qb_[3], oa_[3], ob_;
+    template <typename Q> __device__ inline f32x4& qa(Q&, int j) { return qa_[j]; }
+    template <typename Q> __device__ inline f32x4& qb(Q&, int j) { return qb_[j]; }
+    template <typename O> __device__ inline f32x4& oa(O&, int j) { return oa_[j]; }
+    template <typename Q> __device__ inline f32x4& ob(Q&) { return ob_; }
+};
+template <> struct PlLoraRegs<float> {                    // fp32 engines: waves 6 and 7 never hold q|k|v or o_proj rows -- their q_w / o_w registers carry the adapter operands
+    __device__ inline f32x4& qa(f32x4 (&q_w)[2][3], int j) { return q_w[0][j]; }
+    __device__ inline f32x4& qb(f32x4 (&q_w)[2][3], int j) { return q_w[1][j]; }
+    __device__ inline f32x4& oa(f32x4 (&o_w)[3], int j) { return o_w[j]; }
+    __device__ inline f32x4& ob(f32x4 (&q_w)[2][3]) { return q_w[0][0]; }      // (requested after phase A, when the q|k|v operands are spent)
+};
+// one wave re-reads N consecutive granules per lane until the tags match; lanes with valid == false pass (every lane of the wave calls this)
+template <int N>
+__device__ inline bool sweep_masked(const u64* base, unsigned lane_elem, bool valid, unsigned tag, float (&v)[N], int* err, int code, int* abort_s, int nap) {
+    const u64* p = base + (valid ? lane_elem : 0u);
+    asm volatile("" : "+v"(p));
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = 0.f;
+    if (!__any(valid)) return true;                       // (a wave without such a lane: no loads at all -- 192 workgroups poll the same few lines)
+#pragma unroll 1
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const u64 x = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[k] = __builtin_bit_cast(float, (unsigned)x);
+                ok = ok && ((unsigned)(x >> 32) == tag);
+            }
+        }
+        if (__all(ok)) return true;
+        bool giveup = spins >= PL_SPIN_LIMIT || PL_ABORT_GET(abort_s) != 0;
+        if (!giveup && (spins & 1023u) == 1023u) giveup = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (giveup) {
+            if ((threadIdx.x & 63) == 0) { atomicCAS(err, 0, code); PL_ABORT_SET(abort_s); }
+            return false;
+        }
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 // SCHED = when a compute wave requests its weight arrays (each array is needed one phase per layer: q|k|v rows in A, o_proj rows in C, gate|up in D, down in E):
 //   1: gate|up(l) + q|k|v(l+1) when layer l's attention wait begins, down(l) + o_proj(l+1) when its (x + attention) wait begins;
 //   2: o_proj(l) + gate|up(l) at the attention wait, down(l) at the (x + attention) wait, q|k|v(l+1) at the end of the layer -- nothing is requested
 //      more than one wait ahead, so at most gate|up + down (18 of the 27 fragments) are live at once: 36 fewer VGPRs (the 2- to 4-row kernels spill under 1).
 // (Re-requesting every array right after its use, a whole layer ahead, put the gate|up burst in front of the act gather's polls and the down burst in
 //  front of the next layer's x gather: +6.7 us per layer, profiles/r04_persist_probe_v2_one_launch.jsonl.)
-template <int R, int SCHED, typename WT>
+template <int R, int SCHED, typename WT, bool LORA = false>
 __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs a) {
+    static_assert(!LORA || SCHED == 3, "per-utterance adapters: the paced schedule only");
     typedef typename PlW<WT>::frag wfrag;
     // Edge waves per workgroup: 2 at one row, 4 at 2..4 rows (round 5).  A gather is 768 R (3072 R for the act rows) granules over the edge lanes; with two waves the
     // per-lane share grew with the rows (6 R and 24 R loads per lane, the act rows one sweep after the other) -- +4.3 us of the +9.2 us per layer between 1 and 4 rows.
@@ -282,12 +340,14 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
     constexpr int EW = PL_EDGE_WAVES(R), NE = 64 * EW, GX = 768 / NE;      // edge lanes; granules per lane and row of a 768-wide gather (6 or 3)
     constexpr size_t BLOCK_BYTES = (size_t)PL_BLOCK_BYTES / 4 * sizeof(WT), LAYER_BYTES = PL_LAYER_BYTES / 4 * sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* const xs = (float*)smem;                       // activations of the current phase [R][768] ([R][3072] for the down projection)
+    // LDS: [front block: give-up flag + the attention workgroups' scratch][GEMV workgroups: xs | red | ssq | xres   /   attention workgroups of the 6..8-row kernels: the K / V tail]
+    int* const abort_s = (int*)smem;                      // [4]: [0] give-up flag, [1] SCHED 3: gathers completed by the edge waves (2 per phase)
+    float* const att_s = (float*)(abort_s + 4);           // attention workgroups: q[2][64] | k_new[2][64] | v_new[2][64] | the waves' outputs [8][64], maxima [8], sums [8]
+    float* const xs = (float*)(smem + PL_FRONT_BYTES);    // activations of the current phase [R][768] ([R][3072] for the down projection)
     float* const red = xs + R * PL_I;                     // compute waves' results [8 waves][16 values][4 rows of 16 lanes] (pl_reduce_store / pl_red)
     float* const ssq = red + PL_RED_FLOATS;                   // sums of squares of the gathered rows [edge wave <= 4][R]
     float* const xres = ssq + 4 * R;                      // this workgroup's 4 columns of the residual stream [R][4] (x, later x + attention, then the layer output)
-    int* const abort_s = (int*)(xres + 4 * R);            // [4]: [0] give-up flag, [1] SCHED 3: gathers completed by the edge waves (2 per phase)
-    float* const att_s = (float*)(abort_s + 4);           // attention workgroups: q[2][64] | k_new[2][64] | v_new[2][64] | the waves' outputs [8][64], maxima [8], sums [8]
+    float* const lbs = xres + 4 * R;                      // LORA: B of this workgroup's own rows [R][12 q|k|v rows][16] | [R][4 o_proj rows][16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
@@ -319,6 +379,38 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
 #define PL_LOAD_D(base_) do { _Pragma("unroll") for (int j = 0; j < 6; ++j) d_w[j] = __builtin_nontemporal_load((const wfrag*)(base_) + od + j * 64); } while (0)
             PL_LOAD_Q(wb);
             if (SCHED == 1) PL_LOAD_O(wb);
+            // ---- LORA (waves 6, 7): this wave's (row, target, rank) of the q|k|v terms, (row, rank) of the o_proj terms; the workgroup's own B entries
+            PlLoraRegs<WT> lr;
+            const unsigned tag0c = (unsigned)ep_v * 32u;
+            const int lw = 2 * b + (wave - 6), ll = (wave - 6) * 64 + lane;             // one of 384 such waves; one of the workgroup's 128 such lanes
+            const int lq_r = lw / 48, lq_tk = lw - 48 * lq_r;                            // q|k|v: row, 16 target + rank
+            const int lq_sl = (LORA && wave >= 6 && lq_r < R) ? pl_slot(a.lslots, lq_r) : -1;
+            const int lo_r = lw >> 4, lo_k = lw & 15;                                    // o_proj: row, rank
+            const int lo_sl = (LORA && wave >= 6 && lo_r < R) ? pl_slot(a.lslots, lo_r) : -1;
+            constexpr int LQM = (192 * R + 127) / 128, LOM = (64 * R + 127) / 128;       // B entries per lane: q|k|v (<= 12), o_proj (<= 4)
+            // element i = ll + 128 m of [R][12 own rows][16 ranks]: own row j = (pw, half) as the edge lanes finish them (pw < 4: q / k dims 2 jj + (pw & 1) (+ 32); else v dims 4 jj + 2 (pw - 4) (+ 1))
+#define PL_LORA_REQ_QKV(l_) do { if (wave >= 6) { \
+                if (lq_sl >= 0) { const f32x4* ap_ = (const f32x4*)(a.la_qkv + (size_t)(l_) * a.la_qkv_stride + (size_t)(lq_sl * 48 + lq_tk) * PL_H); \
+                    _Pragma("unroll") for (int j = 0; j < 3; ++j) lr.qa(q_w, j) = ap_[64 * j + lane]; \
+                    lq_scale = a.lscale[((l_) * 8 + lq_sl) * 4 + (lq_tk >> 4)]; } \
+                int li_ = ll; asm volatile("" : "+v"(li_)); \
+                _Pragma("unroll") for (int m = 0; m < LQM; ++m) { const int i_ = li_ + 128 * m; float v_ = 0.f; \
+                    if (i_ < 192 * R) { const int r_ = i_ / 192, rem_ = i_ - 192 * r_, j_ = rem_ >> 4, k_ = rem_ & 15, sl_ = pl_slot(a.lslots, r_); \
+                        if (sl_ >= 0) { const int pw_ = j_ >> 1, hf_ = j_ & 1, hh_ = b >> 4, jj_ = b & 15; \
+                            const int t_ = pw_ < 4 ? (pw_ >> 1) : 2, d_ = pw_ < 4 ? 2 * jj_ + (pw_ & 1) + 32 * hf_ : 4 * jj_ + 2 * (pw_ - 4) + hf_; \
+                            v_ = a.lb[(size_t)(l_) * a.la_stride + (size_t)((sl_ * 4 + t_) * 16 + k_) * PL_H + hh_ * 64 + d_]; } } \
+                    lr.qb(q_w, m >> 2)[m & 3] = v_; } } } while (0)
+#define PL_LORA_REQ_O(l_) do { if (wave >= 6) { \
+                if (lo_sl >= 0) { const f32x4* ap_ = (const f32x4*)(a.la + (size_t)(l_) * a.la_stride + (size_t)((lo_sl * 4 + 3) * 16 + lo_k) * PL_H); \
+                    _Pragma("unroll") for (int j = 0; j < 3; ++j) lr.oa(o_w, j) = ap_[64 * j + lane]; \
+                    lo_scale = a.lscale[((l_) * 8 + lo_sl) * 4 + 3]; } \
+                int li_ = ll; asm volatile("" : "+v"(li_)); \
+                _Pragma("unroll") for (int m = 0; m < LOM; ++m) { const int i_ = li_ + 128 * m; float v_ = 0.f; \
+                    if (i_ < 64 * R) { const int r_ = i_ >> 6, ii_ = (i_ >> 4) & 3, k_ = i_ & 15, sl_ = pl_slot(a.lslots, r_); \
+                        if (sl_ >= 0) v_ = a.lb[(size_t)(l_) * a.la_stride + (size_t)((sl_ * 4 + 3) * 16 + k_) * PL_H + 4 * b + ii_]; } \
+                    lr.ob(q_w)[m] = v_; } } } while (0)
+            float lq_scale = 0.f, lo_scale = 0.f;          // (the scale rides on u: nothing is computed on a requested value before its use, a request never waits)
+            if constexpr (LORA) PL_LORA_REQ_QKV(0);
             __builtin_amdgcn_sched_barrier(0);
             if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;      // every sequence finished (gpt.py:545) / an earlier launch gave up: the same for every workgroup
             __syncthreads();                                  // S0
@@ -347,6 +439,18 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
                         }
                         PL_PACE_END();
                     }
+                    if constexpr (LORA) if (wave >= 6) {
+                        if (lq_sl >= 0) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc = dot4(lr.qa(q_w, j), ((const f32x4*)(xs + lq_r * PL_H))[64 * j + lane], acc);
+                            acc = wave_sum(acc);
+                            const float rs = 1.0f / sqrtf((EW == 2 ? ssq[lq_r] + ssq[R + lq_r] : (ssq[lq_r] + ssq[R + lq_r]) + (ssq[2 * R + lq_r] + ssq[3 * R + lq_r])) / (float)PL_H + a.eps);
+                            if (lane == 0) store_granule(a.g_u + lq_r * 64 + lq_tk, tag0c + (unsigned)l, (acc * rs) * lq_scale);
+                        }
+#pragma unroll
+                        for (int m = 0; m < LQM; ++m) if (ll + 128 * m < 192 * R) lbs[ll + 128 * m] = lr.qb(q_w, m >> 2)[m & 3];
+                    }
                     if (wave < 6) {
                         PL_PV(2 * R);
 #pragma unroll
@@ -365,6 +469,7 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
                         pl_reduce_store<pl_pow2(2 * R)>(pv, red, wave, lane);
                     }
                     __syncthreads();                          // B2(A)
+                    if constexpr (LORA) PL_LORA_REQ_O(l);     // (the q|k|v operands are spent; the attention takes > 2 us)
                     // ---- wait for the attention output, requesting gate|up(l); phase C
                     {
                         PL_PACE_BEGIN();
@@ -373,6 +478,17 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
 #pragma unroll
                             for (int j = 0; j < 3; ++j) PL_PIECE(g_w[s][j] = __builtin_nontemporal_load((const wfrag*)wb + og + (s * 3 + j) * 64));
                         PL_PACE_END();
+                    }
+                    if constexpr (LORA) if (wave >= 6) {
+                        if (lo_sl >= 0) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) acc = dot4(lr.oa(o_w, j), ((const f32x4*)(xs + lo_r * PL_H))[64 * j + lane], acc);
+                            acc = wave_sum(acc);
+                            if (lane == 0) store_granule(a.g_u + lo_r * 64 + 48 + lo_k, tag0c + (unsigned)l, acc * lo_scale);
+                        }
+#pragma unroll
+                        for (int m = 0; m < LOM; ++m) if (ll + 128 * m < 64 * R) lbs[192 * R + ll + 128 * m] = lr.ob(q_w)[m];
                     }
                     if (wave < 4) {
                         PL_PV(R);
@@ -439,6 +555,7 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
                     }
                     __syncthreads();                          // B2(D)
                     // ---- wait for silu(gate) * up, requesting q|k|v(l+1); phase E
+                    if constexpr (LORA) if (more) PL_LORA_REQ_QKV(l + 1);
                     {
                         PL_PACE_BEGIN();
                         if (more && wave < 6) {
@@ -683,10 +800,25 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
                 }
                 if (last) PL_MARK(2);
                 PL_B1();                                      // B1(A): the gather is in LDS
+                float lda = 0.f, ldb = 0.f;                   // LORA: this lane's two rows' scale * B (A h) (pipeline:420-432, per row)
+                float uq[LORA ? 16 : 1];
+                const int slA = (LORA && doA) ? pl_slot(a.lslots, rA) : -1;
+                if constexpr (LORA) {                         // (polled while the compute waves work on phase A: the u cross workgroups)
+                    for (int z = 0; z < a.delay_u; ++z) __builtin_amdgcn_s_sleep(2);
+                    const bool got = sweep_masked<16>(a.g_u, (unsigned)(rA * 64 + (pwA < 4 ? (pwA >> 1) : 2) * 16), slA >= 0, tag, uq, a.error, 9, abort_s, a.nap);
+                    (void)got;
+                }
                 __syncthreads();                              // B2(A)
+                if constexpr (LORA) {
+                    if (slA >= 0) {
+                        const float* const bq = lbs + rA * 192 + 2 * pwA * 16;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { lda = fmaf(bq[k], uq[k], lda); ldb = fmaf(bq[16 + k], uq[k], ldb); }
+                    }
+                }
                 if (doA) {
                     const float rs = 1.0f / sqrtf((EW == 2 ? ssq[rA] + ssq[R + rA] : (ssq[rA] + ssq[R + rA]) + (ssq[2 * R + rA] + ssq[3 * R + rA])) / (float)PL_H + a.eps);          // llama.py:82-87 (the weight is folded into W's columns)
-                    const float va = pl_red(red, pwA, rA) * rs, vb = pl_red(red, pwA, R + rA) * rs;
+                    const float va = pl_red(red, pwA, rA) * rs + lda, vb = pl_red(red, pwA, R + rA) * rs + ldb;
                     float ya = va, yb = vb;
                     int which, dA, dB;
                     if (pwA < 4) {                               // q / k: RoPE pair (d, d + 32), products rounded separately like the reference (llama.py:180-181)
@@ -718,10 +850,25 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
                 }
                 if (last) PL_MARK(4);
                 PL_B1();                                      // B1(C): the gather is in LDS
+                float ldo = 0.f;
+                float uo[LORA ? 16 : 1];
+                const int slO = (LORA && e < 4 * R) ? pl_slot(a.lslots, e >> 2) : -1;
+                if constexpr (LORA) {
+                    for (int z = 0; z < a.delay_u; ++z) __builtin_amdgcn_s_sleep(2);
+                    const bool got = sweep_masked<16>(a.g_u, (unsigned)((e >> 2) * 64 + 48), slO >= 0, tag, uo, a.error, 10, abort_s, a.nap);
+                    (void)got;
+                }
                 __syncthreads();                              // B2(C)
+                if constexpr (LORA) {
+                    if (slO >= 0) {
+                        const float* const bo = lbs + 192 * R + (e >> 2) * 64 + (e & 3) * 16;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) ldo = fmaf(bo[k], uo[k], ldo);
+                    }
+                }
                 if (e < 4 * R) {
                     const int i = e & 3, r = e >> 2;
-                    const float x1 = xres[4 * r + i] + pl_red(red, i, r);                               // llama.py:731
+                    const float x1 = xres[4 * r + i] + (pl_red(red, i, r) + ldo);                       // llama.py:731
                     xres[4 * r + i] = x1;
                     if (!(a.fault > 0 && b == 5 && l + 1 == a.fault))          // (test hook "persistent_fault": workgroup 5 withholds its columns in layer fault - 1)
                         store_granule(a.g_x1 + (size_t)pl_opq<(R > PL_MAXR_ONE)>(r * PL_H + 4 * b + i), tag, x1);
@@ -933,12 +1080,22 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
         const int grp = lane >> 3, sub = lane & 7;
         const size_t head_base = ((size_t)m.seq * PL_NH + hh) * a.Lmax * CTTS_HEAD_DIM;
         constexpr int PRE = 6;                                // iterations requested before the query exists: 8 (PAIR: 4) waves x 8 keys x 6 = 384 (192) keys
+        // Round 6, PAIR: NT more iterations per wave wait in LDS.  With two items per workgroup the registers hold 192 keys of an item; at the bench window's context
+        // (~310) the other ~120 streamed BEHIND the query, one dependent HBM round trip per layer (+2.5 us: the 5 -> 6 row step was +24 %).  LDS-DMA (global_load_lds_dwordx4)
+        // needs no registers: a lane fetches exactly the 16-byte pieces it will read back itself (K: its 8 dims of its key group; V: rows of 64 floats, read one dim per
+        // lane), so the image is lane-linear and every read is conflict-free -- LDS as an asynchronously filled extension of the register file.  The GEMV workgroups' xs
+        // block is idle in an attention workgroup: 8 waves x NT x 4 KB.
+        constexpr int NT = PAIR ? PL_TAIL_IT : 0, PT = PRE + NT;
+        constexpr int TB = sizeof(WT) == 4 ? 4096 : 2048;     // bytes of one LDS iteration: K 8 keys x 64 dims | V 8 keys x 64 dims
+        typedef __attribute__((address_space(3))) char lds_c;
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        lds_c* const tl = (lds_c*)smem + PL_FRONT_BYTES + wave * (NT * TB);
         PlKV<WT> kf[PRE];
         typename KvElem<WT>::reg vv[PRE][8];
-        bool ok[PRE];
-        bool any_ok[PRE];
+        bool ok[PT];
+        bool any_ok[PT];
 #pragma unroll
-        for (int u = 0; u < PRE; ++u) {
+        for (int u = 0; u < PT; ++u) {
             const int p = kv0 + 8 * (iw + NWI * u) + grp;
             ok[u] = p < kv1;
             any_ok[u] = kv0 + 8 * (iw + NWI * u) < kv1;       // wave-uniform: some lane group of this wave has a key in iteration u
@@ -947,6 +1104,25 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
         _Pragma("unroll") for (int u = 0; u < PRE; ++u) if (any_ok[u]) { const int p0_ = kv0 + 8 * (iw + NWI * u); const int pc_ = ok[u] ? p0_ + grp : m.kv_start; \
             kf[u].load(kb_ + (size_t)pc_ * CTTS_HEAD_DIM + 8 * sub); \
             _Pragma("unroll") for (int g = 0; g < 8; ++g) vv[u][g] = KvElem<WT>::load(vb_ + (size_t)min(p0_ + g, kv1 - 1) * CTTS_HEAD_DIM); } } while (0)
+        // the LDS iterations of layer l_: fp32: K dims 8 sub .. + 3 | K dims 8 sub + 4 .. + 7 | V keys 0..3 | V keys 4..7 (1 KB per instruction); fp16: K | V
+#define PL_DMA_KV(l_) do { if constexpr (NT > 0) { const WT* const kb_ = (const WT*)a.kv + (size_t)(l_) * 2 * kv_per + head_base; const WT* const vb_ = kb_ + kv_per; \
+        int ln_ = lane; asm volatile("" : "+v"(ln_));      /* (the lane's source offsets are re-derived per layer: hoisted out of the layer loop they are 11 spilled address pairs) */ \
+        const int grp = ln_ >> 3, sub = ln_ & 7, lane = ln_; \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) if (any_ok[PRE + t]) { const int p0_ = kv0 + 8 * (iw + NWI * (PRE + t)); \
+            const WT* const ks_ = kb_ + (size_t)min(p0_ + grp, kv1 - 1) * CTTS_HEAD_DIM + 8 * sub; \
+            if constexpr (sizeof(WT) == 4) { \
+                __builtin_amdgcn_global_load_lds((gptr_t)ks_, (__attribute__((address_space(3))) void*)(tl + t * TB), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((gptr_t)(ks_ + 4), (__attribute__((address_space(3))) void*)(tl + t * TB + 1024), 16, 0, 0); \
+                const WT* const v0_ = vb_ + (size_t)min(p0_ + (lane >> 4), kv1 - 1) * CTTS_HEAD_DIM + 4 * (lane & 15); \
+                const WT* const v1_ = vb_ + (size_t)min(p0_ + 4 + (lane >> 4), kv1 - 1) * CTTS_HEAD_DIM + 4 * (lane & 15); \
+                __builtin_amdgcn_global_load_lds((gptr_t)v0_, (__attribute__((address_space(3))) void*)(tl + t * TB + 2048), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((gptr_t)v1_, (__attribute__((address_space(3))) void*)(tl + t * TB + 3072), 16, 0, 0); \
+            } else { \
+                __builtin_amdgcn_global_load_lds((gptr_t)ks_, (__attribute__((address_space(3))) void*)(tl + t * TB), 16, 0, 0); \
+                const WT* const v0_ = vb_ + (size_t)min(p0_ + grp, kv1 - 1) * CTTS_HEAD_DIM + 8 * sub; \
+                __builtin_amdgcn_global_load_lds((gptr_t)v0_, (__attribute__((address_space(3))) void*)(tl + t * TB + 1024), 16, 0, 0); \
+            } } } } while (0)
+        PL_DMA_KV(0);
         PL_LOAD_KV(0);
         __builtin_amdgcn_sched_barrier(0);
         if (__builtin_amdgcn_readfirstlane(done_v | err_v)) return;
@@ -959,7 +1135,7 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
             PL_AMARK(3);
             const f32x4 q0 = *(const f32x4*)(qs + 8 * sub), q1 = *(const f32x4*)(qs + 8 * sub + 4);
             // two passes over the keys held in registers: scores -> the wave's maximum -> ONE exponential per key (no running rescale)
-            float sc[PRE];
+            float sc[PT];
             float mw = -INFINITY;
 #pragma unroll
             for (int u = 0; u < PRE; ++u) {
@@ -972,6 +1148,25 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
                     dot += dpp_f<DPP_HALF_MIRROR>(dot);
                     sc[u] = ok[u] ? dot : -INFINITY;
                     mw = fmaxf(mw, sc[u]);
+                }
+            }
+            if constexpr (NT > 0) {
+                // the iterations that waited in LDS: requested a layer ago, long complete (the wait costs nothing; the compiler does not know that LDS depends on vmcnt)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    sc[PRE + t] = -INFINITY;
+                    if (any_ok[PRE + t]) {
+                        PlKV<WT> kt;
+                        if constexpr (sizeof(WT) == 4) { kt.a = *(const __attribute__((address_space(3))) f32x4*)(tl + t * TB + lane * 16); kt.b = *(const __attribute__((address_space(3))) f32x4*)(tl + t * TB + 1024 + lane * 16); }
+                        else kt.h = *(const __attribute__((address_space(3))) half8*)(tl + t * TB + lane * 16);
+                        float dot = q0[0] * kt.at(0) + q0[1] * kt.at(1) + q0[2] * kt.at(2) + q0[3] * kt.at(3) + q1[0] * kt.at(4) + q1[1] * kt.at(5) + q1[2] * kt.at(6) + q1[3] * kt.at(7);
+                        dot += dpp_f<DPP_XOR1>(dot);
+                        dot += dpp_f<DPP_XOR2>(dot);
+                        dot += dpp_f<DPP_HALF_MIRROR>(dot);
+                        sc[PRE + t] = ok[PRE + t] ? dot : -INFINITY;
+                        mw = fmaxf(mw, sc[PRE + t]);
+                    }
                 }
             }
             float mrun = wave_max(mw);                        // the same in every lane (-inf: this wave holds no key)
@@ -987,9 +1182,25 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
                     for (int g = 0; g < 8; ++g) oa[g & 3] = fmaf(readlane_f(pe, 8 * g), KvElem<WT>::f(vv[u][g]), oa[g & 3]);
                 }
             }
-            // Shares beyond the PRE * 8 NWI prefetched keys stream behind the query, UNS steps of 8 NWI keys per round trip
+            if constexpr (NT > 0) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (any_ok[PRE + t]) {
+                        const float pe = (sc[PRE + t] == -INFINITY) ? 0.f : expf(sc[PRE + t] - mrun);
+                        lrun += pe;
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            float vt;
+                            if constexpr (sizeof(WT) == 4) vt = *(const __attribute__((address_space(3))) float*)(tl + t * TB + 2048 + g * 256 + lane * 4);
+                            else vt = (float)*(const __attribute__((address_space(3))) half_t*)(tl + t * TB + 1024 + g * 128 + lane * 2);
+                            oa[g & 3] = fmaf(readlane_f(pe, 8 * g), vt, oa[g & 3]);
+                        }
+                    }
+                }
+            }
+            // Shares beyond the PT * 8 NWI prefetched keys stream behind the query, UNS steps of 8 NWI keys per round trip
             constexpr int UNS = 4, STEP = 8 * NWI;
-            for (int wb0 = kv0 + 8 * (iw + NWI * PRE); wb0 < kv1; wb0 += STEP * UNS) {       // (wave-uniform bound)
+            for (int wb0 = kv0 + 8 * (iw + NWI * PT); wb0 < kv1; wb0 += STEP * UNS) {       // (wave-uniform bound)
                 PlKV<WT> ks_[UNS];
                 typename KvElem<WT>::reg vs_[UNS][8];
                 bool live_[UNS];
@@ -1026,7 +1237,7 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
             if (lane == 0) { mm[wave] = mrun; ml[wave] = lw; }
             PL_AMARK(6);
             __syncthreads();                                  // B2
-            if (l + 1 < NL) PL_LOAD_KV(l + 1);                // the next layer's cached rows: a whole layer ahead of its query
+            if (l + 1 < NL) { PL_DMA_KV(l + 1); PL_LOAD_KV(l + 1); }      // the next layer's cached rows: a whole layer ahead of its query (B2: every LDS read of this layer is done)
             __builtin_amdgcn_sched_barrier(0);
         }
     } else if (wave == 8 || (PAIR && wave == 9)) {
@@ -1184,11 +1395,14 @@ int launch_persist_repack(int half_w, const void* qkv, const void* o, const void
     return 0;
 }
 
-static size_t persist_lds_bytes(int R) { return (size_t)(R * PL_I + PL_RED_FLOATS + 4 * R + 4 * R) * 4 + 16 + (384 + 512 + 16 + 16) * 4; }
+static size_t persist_lds_bytes(int R) {
+    const size_t gemv = (size_t)(R * PL_I + PL_RED_FLOATS + 4 * R + 4 * R + 256 * R) * 4, tail = R > PL_MAXR_ONE ? (size_t)8 * PL_TAIL_IT * 4096 : 0;
+    return PL_FRONT_BYTES + (gemv > tail ? gemv : tail);
+}
 
-template <int R, int SCHED, typename WT>
+template <int R, int SCHED, typename WT, bool LORA = false>
 static int persist_launch_t(const PersistArgs& a, hipStream_t s, bool configure_only) {
-    auto kern = persist_layer_kernel<R, SCHED, WT>;
+    auto kern = persist_layer_kernel<R, SCHED, WT, LORA>;
     if (configure_only) { CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds_bytes(R))); return 0; }
     hipLaunchKernelGGL(kern, dim3(PL_BLOCKS), dim3(PL_THREADS(R)), persist_lds_bytes(R), s, a);
     CTTS_HIP_CHECK(hipGetLastError());
@@ -1197,7 +1411,24 @@ static int persist_launch_t(const PersistArgs& a, hipStream_t s, bool configure_
 template <int SCHED, typename WT>
 static int persist_launch_r(int R, const PersistArgs& a, hipStream_t s, bool cfg) {
     // exact row counts: a spare row would append stale K / V rows to a live cache lane
+    if constexpr (SCHED == 3) if (!cfg && a.lora) {      // per-utterance adapters: the LORA kernels
+        switch (R) {
+            case 1: return persist_launch_t<1, 3, WT, true>(a, s, false);
+            case 2: return persist_launch_t<2, 3, WT, true>(a, s, false);
+            case 3: return persist_launch_t<3, 3, WT, true>(a, s, false);
+            case 4: return persist_launch_t<4, 3, WT, true>(a, s, false);
+            case 5: return persist_launch_t<5, 3, WT, true>(a, s, false);
+            case 6: return persist_launch_t<6, 3, WT, true>(a, s, false);
+            case 7: return persist_launch_t<7, 3, WT, true>(a, s, false);
+            case 8: return persist_launch_t<8, 3, WT, true>(a, s, false);
+        }
+    }
     if (cfg) {
+        if constexpr (SCHED == 3) {
+            const int rl = persist_launch_t<1, 3, WT, true>(a, s, true) | persist_launch_t<2, 3, WT, true>(a, s, true) | persist_launch_t<3, 3, WT, true>(a, s, true) | persist_launch_t<4, 3, WT, true>(a, s, true) |
+                           persist_launch_t<5, 3, WT, true>(a, s, true) | persist_launch_t<6, 3, WT, true>(a, s, true) | persist_launch_t<7, 3, WT, true>(a, s, true) | persist_launch_t<8, 3, WT, true>(a, s, true);
+            if (rl) return rl;
+        }
         int rc = persist_launch_t<1, SCHED, WT>(a, s, true) | persist_launch_t<2, SCHED, WT>(a, s, true) | persist_launch_t<3, SCHED, WT>(a, s, true) | persist_launch_t<4, SCHED, WT>(a, s, true) |
                  persist_launch_t<5, SCHED, WT>(a, s, true);
         if constexpr (SCHED == 3) rc |= persist_launch_t<6, 3, WT>(a, s, true) | persist_launch_t<7, 3, WT>(a, s, true) | persist_launch_t<8, 3, WT>(a, s, true);
@@ -1228,6 +1459,7 @@ int persist_configure() {
 }
 
 int launch_persist_layer(int R, const PersistArgs& a, hipStream_t s) {
+    if (a.lora && a.sched != 3) { ctts_set_error("persistent layer: per-utterance adapters need the paced schedule"); return 1; }
     if (a.half_w) return persist_launch_r<3, half_t>(R, a, s, false);          // fp16 engines: the paced schedule only
     return (a.sched == 1) ? persist_launch_r<1, float>(R, a, s, false) : (a.sched == 2) ? persist_launch_r<2, float>(R, a, s, false) : persist_launch_r<3, float>(R, a, s, false);
 }

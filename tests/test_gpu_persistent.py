@@ -266,3 +266,63 @@ def test_fp16_engines_use_the_persistent_launch_too():
                 assert rel <= 2e-3, f"B={B} row {b}: hidden states {rel} away from the fp16 launch chain over the {same} agreeing steps"
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("wd", ["fp32", "fp16"])
+def test_per_utterance_adapters_ride_inside_the_persistent_launch(wd):
+    """Round 6: rows that carry a LoRA adapter (pipeline:420-432 per row instead of per batch) stay on the persistent launch -- waves 6 / 7 of
+    the GEMV workgroups compute u = A h, the edge lanes add scale * B u to their q / k / v / o_proj rows (persist_layer.hip LORA).  Against the launch chain's worker
+    workgroups (lora_worker.h; itself held to the per-row merged-weights oracle by tests/test_gpu_pipeline.py): fp32 token ids identical, hiddens <= 5e-5;
+    fp16: first hidden states within 2e-3.  1..8 rows, rows with different adapters / ranks / none, with and without graphs."""
+    import ctypes as C
+    from chatttsplus_amd import _lib
+    from chatttsplus_amd.hip_models import GPT
+    cfg = dict(synth.GPT_REAL); cfg["num_hidden_layers"] = 6
+    llama = dict(LLAMA, num_hidden_layers=6)
+    sd = synth.gpt_state_dict(cfg, 1234)
+    rng = np.random.Generator(np.random.Philox(key=79))
+    g = GPT(llama, max_batch=8, max_seq_len=96, weight_dtype=wd)
+    g.load_state_dict(sd)
+    for ai, r in enumerate((8, 16, 3)):
+        ad = []
+        for l in range(6):
+            for t in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                ad.append((l, t, (rng.standard_normal((r, 768)) * 0.05).astype(np.float32), (rng.standard_normal((768, r)) * 0.05).astype(np.float32), 2.0 - 0.5 * ai))
+        g.load_adapter(ai, ad)
+    assert g.get_option("persistent_lora") == 1
+    g.set_option("persistent_rows", 8)
+
+    def epoch():
+        buf = np.zeros(8, dtype=np.uint8); got = C.c_size_t(0)
+        _lib.check(g._lib.ctts_gpt_debug_read(g._h, b"pl_state", buf.ctypes.data_as(C.c_void_p), 8, C.byref(got), g._stream()), "debug_read")
+        return int(buf.view(np.uint32)[0]), int(buf.view(np.uint32)[1])
+
+    def run(B, slots, on, graphs):
+        g.set_option("persistent_lora", on)
+        g.use_graph = graphs
+        g.set_row_adapters(slots)
+        ids, mask = synth.prompt_ids(B, 18, cfg["num_text_tokens"], 23, pad_left=[(3 * b) % 5 for b in range(B)])
+        emb = g(torch.from_numpy(ids), torch.ones(B, 18, dtype=torch.bool))
+        out = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=12, min_new_token=12,
+                              logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="device", seed=5))[-1]
+        g.set_row_adapters(None)
+        return out
+
+    for B, slots in ((1, [1]), (2, [0, -1]), (3, [2, 1, 0]), (5, [0, 1, -1, 2, 1]), (6, [1, -1, 0, 0, 2, -1]), (8, [0, 1, 2, -1, 1, 0, -1, 2])):
+        ref = run(B, slots, 0, True)
+        e0, _ = epoch()
+        for graphs in (True, False):
+            out = run(B, slots, 1, graphs)
+            e1, err = epoch()
+            assert err == 0 and e1 > e0, f"B={B}: the persistent launch did not run (launch counter {e0} -> {e1}, error word {err})"
+            e0 = e1
+            for b in range(B):
+                if wd == "fp32":
+                    assert torch.equal(out.ids[b], ref.ids[b]), f"B={B} row {b} (slot {slots[b]}, graphs {graphs}): token ids differ from the launch chain"
+                    assert float((out.hiddens[b] - ref.hiddens[b]).abs().max()) <= 5e-5, f"B={B} row {b}"
+                else:
+                    h0, r0 = out.hiddens[b][0], ref.hiddens[b][0]
+                    assert float((h0 - r0).pow(2).mean().sqrt() / r0.pow(2).mean().sqrt()) <= 2e-3, f"B={B} row {b}"
+        base = run(B, None, 1, True)
+        assert any(slots[b] >= 0 and not torch.equal(base.hiddens[b], ref.hiddens[b]) for b in range(B)), "the adapters change nothing"
+    g.close()

@@ -25,6 +25,7 @@ ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--fixed", default="", help="other options held fixed: a=1,b=2")
 ap.add_argument("--prompt", type=int, default=48)
 ap.add_argument("--gen-tokens", type=int, default=512)
+ap.add_argument("--adapters", action="store_true", help="every row carries one of two rank-8 LoRA adapters")
 a = ap.parse_args()
 name, vals = a.sweep.split("=")
 vals = [int(v) for v in vals.split(",")]
@@ -34,10 +35,17 @@ g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
 for kv in [x for x in a.fixed.split(",") if x]:
     k, v = kv.split("=")
     g.set_option(k, int(v))
+if a.adapters:
+    rl = np.random.Generator(np.random.Philox(key=31))
+    for slot in range(2):
+        g.load_adapter(slot, [(l, t, (rl.standard_normal((8, 768)) * 0.02).astype(np.float32), (rl.standard_normal((768, 8)) * 0.02).astype(np.float32), 2.0)
+                              for l in range(20) for t in ("q_proj", "k_proj", "v_proj", "o_proj")])
 spk = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
 leg = bench.Leg(g, dev, 0, 1)
 for B in a.batches:
     times = {v: [] for v in vals}
+    if a.adapters:
+        g.set_row_adapters([b % 2 for b in range(B)])
     for rnd in range(a.rounds + 1):
         for v in vals:
             g.set_option(name, v)

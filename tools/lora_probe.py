@@ -1,5 +1,5 @@
 """Per-utterance LoRA at batch 32: decode step time with the low-rank terms inside the QKV / o_proj launches (lora_fold 1), as two more launches per layer
-(0), and without adapters.  python tools/lora_probe.py [--rows 32] [--tokens 384] [--dtype fp32]"""
+(0), inside the persistent launch (mode "persist", <= 8 rows), and without adapters.  python tools/lora_probe.py [--rows 32] [--tokens 384] [--dtype fp32] [--modes none,fold,launch,persist]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -33,6 +33,7 @@ def run(n):
 for mode in a.modes.split(","):
     g.set_row_adapters(None if mode == "none" else [(b % 5) - 1 for b in range(B)])
     g.set_option("lora_fold", {"launch": 0, "fold": 1, "notake": 2, "zeros": 3}.get(mode, 1))
+    g.set_option("persistent_lora", 1 if mode in ("persist", "none") else 0)      # "persist": rows with adapters stay on the persistent launch (<= 8 rows, round 6)
     run(32)
     best = min((run(a.tokens) - run(a.tokens // 4)) / (a.tokens - a.tokens // 4) for _ in range(a.reps))
     print(json.dumps({"mode": mode, "rows": B, "dtype": a.dtype, "ms_per_step": round(best * 1e3, 5)}), flush=True)

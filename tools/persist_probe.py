@@ -29,6 +29,7 @@ ap.add_argument("--skip-times", action="store_true")
 ap.add_argument("--skip-layer", action="store_true")
 ap.add_argument("--skip-checks", action="store_true")
 ap.add_argument("--marks-prompt", type=int, default=48)
+ap.add_argument("--adapters", action="store_true", help="phase marks with a per-utterance LoRA adapter on every row (round 6: the LORA kernels)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 LW = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
@@ -185,7 +186,14 @@ if True:
     leg = bench.Leg(g, dev, 0, 1)
     g.set_option("persistent_rows", MAXR)
     g.set_option("persistent_timestamps", 1)
+    if args.adapters:
+        rl = np.random.Generator(np.random.Philox(key=31))
+        for slot in range(2):
+            g.load_adapter(slot, [(l, t, (rl.standard_normal((8, 768)) * 0.02).astype(np.float32), (rl.standard_normal((768, 8)) * 0.02).astype(np.float32), 2.0)
+                                  for l in range(20) for t in ("q_proj", "k_proj", "v_proj", "o_proj")])
     for B in (1, 2, 3, 4, 5):
+        if args.adapters:
+            g.set_row_adapters([b % 2 for b in range(B)])
         for rep in range(4):
             leg.run(B, args.marks_prompt, 4, 4, spk=spk, use_graph=0, gen_tokens=0)
             ts = debug_read(g, "pl_ts", 256 * 10 * 8).view(np.uint64).reshape(256, 10).astype(np.float64) * 0.01        # us
@@ -198,7 +206,7 @@ if True:
         fine = ts[192:192 + 12 * B]
         out(check="attention_phase_fine_marks_us", B=B, since_qkv_gathered={n: round(float(np.median(fine[:, i] - fine[:, 1])), 2) for n, i in
             (("b1_passed_wave0", 3), ("scores_and_max", 4), ("exp_pv", 5), ("cross_lane_sums", 6), ("b2_passed_wave8", 7), ("published", 2))})
-        out(check="phase_marks_us_last_layer", B=B, layers_in_launch=20, gemv_median=med, gemv_max=mx, attention_median=amed,
+        out(check="phase_marks_us_last_layer", B=B, adapters=bool(args.adapters), layers_in_launch=20, gemv_median=med, gemv_max=mx, attention_median=amed,
             edges_us={"entry_to_first_barrier": med["x_loaded"], "mean_layer": round((med["end"] - med["x_loaded"]) / 20.0, 3),
                       "qkv_phase": round(med["qkv_published"] - med["x_gathered"], 2), "qkv_edge": round(amed["qkv_gathered"] - med["qkv_published"], 2),
                       "attention_phase": round(amed["attention_published"] - amed["qkv_gathered"], 2),
