@@ -734,7 +734,15 @@ class GPT:
 
         with torch.cuda.device(dev):
             st = self._stream()
-            first = list(range(R))
+            # Order of service: longest expected utterance first (LPT list scheduling) -- the request ends when its LAST row does, and a long utterance admitted late
+            # decodes alone on a 32-row engine (the 256-utterance request: 2905 steps launched for 2518 ideal ones in arrival order).  The expectation is the row's own
+            # token limit where the caller gave one, else the prompt length (longer text, longer audio).  Results do not depend on the order: every output is indexed
+            # by utterance and the device noise is keyed by the utterance id.  Default: arrival order ("fifo"): a streaming caller wants its first utterance first.
+            if getattr(self, "schedule", "fifo") == "longest_first":      # (ChatTTSPlusPipeline's throughput mode orders the request itself; direct callers opt in)
+                order = sorted(range(N), key=(lambda u: (-lims[u], u)) if row_limits is not None else (lambda u: (-lens[u], u)))
+            else:
+                order = list(range(N))
+            first = order[:R]
             Ta, emb_a, mask_a = prompts_of(first)
             uid_arr = np.ascontiguousarray([uids[u] for u in first], dtype=np.uint64)
             lim_arr = np.ascontiguousarray([lims[u] for u in first], dtype=np.int32)
@@ -746,10 +754,10 @@ class GPT:
             _lib.check(lib.ctts_gpt_begin(h, R, Ta, mask_a.data_ptr(), C.byref(sc), C.byref(io), st), "begin")
             _lib.check(lib.ctts_gpt_prefill(h, emb_a.data_ptr(), st), "prefill")
             _lib.check(lib.ctts_gpt_sample(h, st), "sample")
-            queue = [(u, 0) for u in range(R, N)]                  # (utterance, regenerate attempt)
+            queue = [(u, 0) for u in order[R:]]                    # (utterance, regenerate attempt)
             book = RowBook()
             for r in range(R):
-                book.seat(r, r)
+                book.seat(r, first[r])
             n_done, since_free = 0, 0
             pins = [torch.zeros(2 * R, dtype=torch.int32).pin_memory() for _ in range(2)]
             evs = [torch.cuda.Event() for _ in range(2)]

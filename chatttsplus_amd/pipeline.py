@@ -491,7 +491,14 @@ class ChatTTSPlusPipeline:
             # utterances), one list at the end.  An utterance's result does not depend on the order -- its noise is keyed by its id.
             ordered = kwargs.get("continuous") != "throughput"
             n_all = len(texts_all)
-            order = list(range(n_all)) if ordered else sorted(range(n_all), key=lambda i: -len(texts_all[i]))
+            # (round 6: by the utterance's own token limit where the caller gave one -- the 256-utterance request of bench.py: 2625 decode steps instead of 2905 for
+            #  2518 ideal ones, 30.9 k -> 35.8 k useful tokens/s; `throughput_order = "input"` keeps arrival order)
+            if ordered or getattr(self, "throughput_order", "longest_first") != "longest_first":
+                order = list(range(n_all))
+            elif utt_limits is not None:
+                order = sorted(range(n_all), key=lambda i: (-int(utt_limits[i]), -len(texts_all[i]), i))
+            else:
+                order = sorted(range(n_all), key=lambda i: (-len(texts_all[i]), i))
             pic = params_infer_code
             if torch.is_tensor(pic.spk_emb) and pic.spk_emb.dim() == 2 and pic.spk_emb.shape[0] == n_all:      # one speaker row per utterance
                 pic = dataclasses.replace(pic, spk_emb=pic.spk_emb[torch.as_tensor(order, device=pic.spk_emb.device)])

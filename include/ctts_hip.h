@@ -72,11 +72,15 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "valu_rows"           fp32 engines: decode batches of <= this many rows run their projections on the VALU instead of exact-f32 MFMA (default 2; 0..4)
  *   "persistent_rows"     decode batches of <= this many rows (<= 8; default 8 on fp32 engines, 5 on fp16 engines; up to 5 rows one (row, head) per attention workgroup, 6..8 rows
  *                         two, with contexts up to "persistent_pair_keys" = 704 / 576 / 448 keys at 6 / 7 / 8 rows) run the whole decoder stack of a step as ONE persistent
- *                         launch of 256 resident workgroups (persist_layer.hip; up to 1400 keys per key share -- longer contexts go back to the launch chain -- no per-utterance adapters; the final
- *                         norm + code heads run inside the launch at <= 2 rows).  0 = off.  The first
+ *                         launch of 256 resident workgroups (persist_layer.hip; up to 1400 keys per key share -- longer contexts go back to the launch chain; the final
+ *                         norm + code heads run inside the launch at <= 2 rows; the two-item workgroups of 6..8 rows keep 192 keys of an item in registers and 128 more in LDS).
+ *                         0 = off.  The first
  *                         process that loads an engine (either dtype) on a device holds the mode (advisory lock /tmp/ctts_persist_<pci>.lock); others stay on launches.
  *                         A persistent launch needs all 256 workgroups resident: run ONE decode at a time per device (two engines of one process decoding
  *                         concurrently on different streams would have to share the CUs; every wait is bounded and ctts_gpt_progress reports a give-up)
+ *   "persistent_lora"     1 (default): rows that carry a per-utterance adapter stay on the persistent launch -- its otherwise idle compute waves evaluate A h, the edge lanes add
+ *                         B (A h) to their q / k / v / o_proj rows (paced schedule; 0 = such batches take the launch chain's worker workgroups, "lora_fold")
+ *   "persistent_delay_lora"  poll delay of that hand-off (-1 = 14 + 2 rows, the default)
  *   "persistent_layers_per_launch"  0 = the whole stack in one launch (default), n = n layers per launch
  *   "persistent_schedule" weight request schedule of the persistent launch (1 / 2 / 3, default 3 = paced requests)    "persistent_pace"  its pacing interval (-1 = by row count, the default)
  *   "persistent_delay", "persistent_delay_act", "persistent_delay_x", "persistent_delay_att", "persistent_nap", "persistent_nap_qkv"  when and how often the edge waves poll

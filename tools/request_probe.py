@@ -16,6 +16,7 @@ g = GPT(bench.LLAMA, max_batch=rows, max_seq_len=48 + 96 + 512 + 32, weight_dtyp
 g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
 if len(sys.argv) > 3:
     g.compact_chunk = int(sys.argv[3])
+FIFO = os.environ.get("CTTS_SCHEDULE") == "fifo"           # arrival order instead of longest-first
 syn = Synth(dict(synth.DVAE_REAL), dict(synth.VOCOS_REAL), max_frames=2 * 512 + 64, device=str(dev), max_batch=32)
 syn.load("dvae.", synth.dvae_state_dict(synth.DVAE_REAL, 1234)); syn.load("vocos.", synth.vocos_state_dict(synth.VOCOS_REAL, 1234))
 texts, limits, spk_index = bench._request_256(NU)
@@ -26,6 +27,8 @@ if len(sys.argv) > 4:
     kw["admit_min"] = int(sys.argv[4])
 with tempfile.TemporaryDirectory() as td:
     pipe = ChatTTSPlusPipeline.from_components(g, syn, synth.toy_tokenizer(td), dev)
+    if FIFO:
+        pipe.throughput_order = "input"
     shares = {"vocoder_s": 0.0}
     orig = pipe._decode_to_wavs
     def timed(*a, **k):
