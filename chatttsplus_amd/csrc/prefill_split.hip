@@ -254,18 +254,21 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
 #define FS_PITCH 68        // halfs per V^T row in LDS (64 keys + pad; rows stay 8-byte aligned)
 #define FS_KPITCH 72       // halfs per K row in LDS (64 dims + pad; rows stay 16-byte aligned)
 #define FS_LDS (2 * (2 * 64 * FS_PITCH + 2 * 64 * FS_KPITCH) * 2)
-__global__ __launch_bounds__(256) void attn_prefill_split_kernel(const RowMeta* meta_p, const float* q_p, const float* k_p, const float* v_p, const int NHp, const int R,
+#ifndef FS_WAVES
+#define FS_WAVES 8          // waves (16 queries each) per block: 8 since round 6 (4 before)
+#endif
+__global__ __launch_bounds__(64 * FS_WAVES) void attn_prefill_split_kernel(const RowMeta* meta_p, const float* q_p, const float* k_p, const float* v_p, const int NHp, const int R,
                                                                const AttnArgs a, half_t* out_hi, half_t* out_lo) {
     extern __shared__ __attribute__((aligned(16))) char fs_lds[];
     typedef half_t (*vt_t)[64][FS_PITCH];
     typedef half_t (*ks_t)[64][FS_KPITCH];
     vt_t vth = (vt_t)fs_lds, vtl = (vt_t)(fs_lds + 2 * 64 * FS_PITCH * 2);
     ks_t ksh = (ks_t)(fs_lds + 4 * 64 * FS_PITCH * 2), ksl = (ks_t)(fs_lds + 4 * 64 * FS_PITCH * 2 + 2 * 64 * FS_KPITCH * 2);
-    __shared__ int range_s[4][3];
+    __shared__ int range_s[FS_WAVES][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qn = lane & 15, iq = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y, T = a.T;
-    const int t = blockIdx.x * 64 + wave * 16 + qn;                       // this lane's query (prompt position)
+    const int t = blockIdx.x * (16 * FS_WAVES) + wave * 16 + qn;         // this lane's query (prompt position)
     const int r = b * T + t - a.row0;                                     // its row in the current pass
     const bool live = (t < T) && (r >= 0) && (r < R);
     RowMeta m = {0, 0, -1, 0};
@@ -277,10 +280,10 @@ __global__ __launch_bounds__(256) void attn_prefill_split_kernel(const RowMeta* 
     for (int off = 1; off < 16; off <<= 1) { wlo = min(wlo, __shfl_xor(wlo, off)); whi = max(whi, __shfl_xor(whi, off)); wsq = max(wsq, __shfl_xor(wsq, off)); }
     if (lane == 0) { range_s[wave][0] = wlo; range_s[wave][1] = whi; range_s[wave][2] = wsq; }
     __syncthreads();
-    const int blo = min(min(range_s[0][0], range_s[1][0]), min(range_s[2][0], range_s[3][0]));
-    const int bhi = max(max(range_s[0][1], range_s[1][1]), max(range_s[2][1], range_s[3][1]));
+    int blo = range_s[0][0], bhi = range_s[0][1], cseq = range_s[0][2];
+#pragma unroll
+    for (int w = 1; w < FS_WAVES; ++w) { blo = min(blo, range_s[w][0]); bhi = max(bhi, range_s[w][1]); cseq = max(cseq, range_s[w][2]); }
     if (bhi < 0) return;                                                  // no live query in this block (uniform)
-    const int cseq = max(max(range_s[0][2], range_s[1][2]), max(range_s[2][2], range_s[3][2]));
     wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
     const size_t head_off = ((size_t)cseq * NHp + h) * a.Lmax * CTTS_HEAD_DIM;
     const float* kb = k_p + head_off;
@@ -304,28 +307,30 @@ __global__ __launch_bounds__(256) void attn_prefill_split_kernel(const RowMeta* 
 #pragma unroll
     for (int db = 0; db < 4; ++db) oacc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float mrun = -INFINITY, lpart = 0.f;
-    // staging: thread -> key (tid >> 2) of the chunk, dims 4 (tid & 3) + 16 i .. + 3 for i = 0..3.  (Round 5: the four lanes of a key used to own 16 CONSECUTIVE dims each;
-    // their transposing 2-byte V stores then sat 16 rows = 544 dwords = 0 or 32 banks apart and the 8-byte K stores 8 dwords apart under a 36-dword row pitch:
-    // 2-way / 4-way LDS bank conflicts on every store, 47 % of the kernel's LDS cycles.  4 dims apart they land 8 / 2 banks apart.)
-    const int skey = tid >> 2, sdim = 4 * (tid & 3);
-    f32x4 vst[4], kst[4];
+    // staging: thread -> key (tid / SPK) of the chunk, SPK threads per key, dims 4 (tid % SPK) + 4 SPK i .. + 3 for i < 16 / SPK.  (Round 5: the lanes of a key used to own
+    // CONSECUTIVE dims; their transposing 2-byte V stores then sat 16 rows = 544 dwords = 0 or 32 banks apart and the 8-byte K stores 8 dwords apart under a 36-dword row
+    // pitch: 2-way / 4-way LDS bank conflicts on every store, 47 % of the kernel's LDS cycles.  4 dims apart they land 8 / 2 banks apart.)
+    // Round 6: 8 waves = 128 queries per block share a staged chunk (4 waves = 64 queries before): half the loads, splits and transposing stores per query.
+    constexpr int SPK = FS_WAVES, SNI = 16 / SPK;                         // threads per key; 16-byte pieces per thread and array
+    const int skey = tid / SPK, sdim = 4 * (tid % SPK);
+    f32x4 vst[SNI], kst[SNI];
     auto vload = [&](int c) {
         const int key = min(c + skey, bhi);                               // clamp: a valid slot of this sequence (masked later)
         const f32x4* vp = (const f32x4*)(vb + (size_t)key * CTTS_HEAD_DIM + sdim);
         const f32x4* kp = (const f32x4*)(kb + (size_t)key * CTTS_HEAD_DIM + sdim);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { vst[i] = vp[4 * i]; kst[i] = kp[4 * i]; }
+        for (int i = 0; i < SNI; ++i) { vst[i] = vp[SPK * i]; kst[i] = kp[SPK * i]; }
     };
     auto vstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < SNI; ++i) {
             half4 vh, vl, kh, kl;
             split_h4(vst[i], vh, vl);
             split_h4(kst[i], kh, kl);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { vth[buf][sdim + 16 * i + e][skey] = vh[e]; vtl[buf][sdim + 16 * i + e][skey] = vl[e]; }
-            *(half4*)&ksh[buf][skey][sdim + 16 * i] = kh;
-            *(half4*)&ksl[buf][skey][sdim + 16 * i] = kl;
+            for (int e = 0; e < 4; ++e) { vth[buf][sdim + 4 * SPK * i + e][skey] = vh[e]; vtl[buf][sdim + 4 * SPK * i + e][skey] = vl[e]; }
+            *(half4*)&ksh[buf][skey][sdim + 4 * SPK * i] = kh;
+            *(half4*)&ksl[buf][skey][sdim + 4 * SPK * i] = kl;
         }
     };
     const int c0 = blo & ~63;
@@ -379,16 +384,23 @@ __global__ __launch_bounds__(256) void attn_prefill_split_kernel(const RowMeta* 
             mrun = mn;
 #pragma unroll
             for (int db = 0; db < 4; ++db) { oacc[db][0] *= sc; oacc[db][1] *= sc; oacc[db][2] *= sc; oacc[db][3] *= sc; }
+            // P.V on the double-rate v_mfma_f32_16x16x32_f16 (round 6; 16x16x16 before: twice the instructions): a 32-key operand = two 16-key tiles, the lane's k-slots
+            // 8 iq + e <-> keys 16 tl + 4 iq + e of tile tl = 2 pr (e < 4) and of tile 2 pr + 1 (e >= 4) -- the same assignment in A (V^T, two 8-byte reads) and B (P^T)
 #pragma unroll
-            for (int tl = 0; tl < 4; ++tl)
+            for (int pr = 0; pr < 2; ++pr) {
+                const half8 ph = {pTh[2 * pr][0], pTh[2 * pr][1], pTh[2 * pr][2], pTh[2 * pr][3], pTh[2 * pr + 1][0], pTh[2 * pr + 1][1], pTh[2 * pr + 1][2], pTh[2 * pr + 1][3]};
+                const half8 pl = {pTl[2 * pr][0], pTl[2 * pr][1], pTl[2 * pr][2], pTl[2 * pr][3], pTl[2 * pr + 1][0], pTl[2 * pr + 1][1], pTl[2 * pr + 1][2], pTl[2 * pr + 1][3]};
 #pragma unroll
                 for (int db = 0; db < 4; ++db) {
-                    const half4 vh = *(const half4*)&vth[buf][16 * db + qn][16 * tl + 4 * iq];      // A = V^T: row = dim (lane & 15), keys 4 iq ..
-                    const half4 vl = *(const half4*)&vtl[buf][16 * db + qn][16 * tl + 4 * iq];
-                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vl, pTh[tl], oacc[db], 0, 0, 0);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, pTl[tl], oacc[db], 0, 0, 0);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, pTh[tl], oacc[db], 0, 0, 0);
+                    const half4 vha = *(const half4*)&vth[buf][16 * db + qn][32 * pr + 4 * iq], vhb = *(const half4*)&vth[buf][16 * db + qn][32 * pr + 16 + 4 * iq];      // A = V^T: row = dim (lane & 15)
+                    const half4 vla = *(const half4*)&vtl[buf][16 * db + qn][32 * pr + 4 * iq], vlb = *(const half4*)&vtl[buf][16 * db + qn][32 * pr + 16 + 4 * iq];
+                    const half8 vh = {vha[0], vha[1], vha[2], vha[3], vhb[0], vhb[1], vhb[2], vhb[3]};
+                    const half8 vl = {vla[0], vla[1], vla[2], vla[3], vlb[0], vlb[1], vlb[2], vlb[3]};
+                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, oacc[db], 0, 0, 0);
                 }
+            }
         }
         if (more) vstore(buf ^ 1);
         __syncthreads();
@@ -419,8 +431,8 @@ int launch_attention_split(const AttnArgs& a, void* out_hi, void* out_lo, hipStr
     }
     if (a.T <= 0 || a.S != 1) { ctts_set_error("attention_split: prompt pass only"); return 1; }
     const int B = (a.row0 + a.R + a.T - 1) / a.T;                         // sequences 0 .. B-1 may have rows in this pass
-    dim3 g3((a.T + 63) / 64, a.NH, B);
-    hipLaunchKernelGGL(attn_prefill_split_kernel, g3, dim3(256), FS_LDS, s, a.meta, a.q, (const float*)a.k_cache, (const float*)a.v_cache, a.NH, a.R, a, (half_t*)out_hi, (half_t*)out_lo);
+    dim3 g3((a.T + 16 * FS_WAVES - 1) / (16 * FS_WAVES), a.NH, B);
+    hipLaunchKernelGGL(attn_prefill_split_kernel, g3, dim3(64 * FS_WAVES), FS_LDS, s, a.meta, a.q, (const float*)a.k_cache, (const float*)a.v_cache, a.NH, a.R, a, (half_t*)out_hi, (half_t*)out_lo);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
