@@ -724,7 +724,7 @@ def main():
     if rank == 0:
         traffic, traffic_note = None, None
         try:      # HBM bytes/step from the committed rocprofv3 PMC passes (profiles/): same kernels, same batch, same context as the timed window; not live
-            tp = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json")]
+            tp = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")]
             tp = [q for q in tp if os.path.exists(q)][0]                      # the newest committed PMC passes
             tj = json.load(open(tp))
             ent = tj.get(f"b{B}_{args.dtype}" + ("_persistent_mfma" if on_mfma else "" if (persist_rows >= B or B > 4) else "_launch_chain"))

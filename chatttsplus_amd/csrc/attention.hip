@@ -424,7 +424,7 @@ int launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     // unsplit rows: 8 waves per (row, head) keep twice the K/V bytes in flight per CU while there are fewer blocks than CUs; from one
     // block per CU on, 4-wave blocks balance better (us/step at mean context 312: batch 8 471 vs 479, 16 512 vs 521 | 32 613 vs 598, 64 800 vs 774)
     static const int wide_env = diag_env("CTTS_ATTN_WIDE") ? atoi(diag_env("CTTS_ATTN_WIDE")) : -1;     // diagnostic builds: force 8-wave (1) / 4-wave (0) blocks
-    const bool wide = (a.S == 1) && (a.st != nullptr) && (wide_env < 0 ? (a.R * a.NH < 256) : wide_env != 0);
+    const bool wide = (a.S == 1) && (a.st != nullptr) && (wide_env < 0 ? (a.R * a.NH < (a.wide_blocks > 0 ? a.wide_blocks : 256)) : wide_env != 0);
     static const int tiled_env = diag_env("CTTS_PREFILL_ATTN") ? atoi(diag_env("CTTS_PREFILL_ATTN")) : 1;    // diagnostic builds: 0 = prompt attention row by row
     if (a.st == nullptr && a.S == 1 && a.packed_out != nullptr && a.R >= 64 && dtype == 1 && a.T > 0 && tiled_env >= 1) {
         // prompt pass, fp16: MFMA flash attention, block = (64 queries, head, sequence)

@@ -129,7 +129,7 @@ struct ctts_gpt {
                                                  // an exact-f32 MFMA costs 32 cycles whatever the number of live columns, 48 of them per SIMD and launch.
                                                  // Measured (us/step, MFMA -> VALU, profiles/r04_ab_valu_rows.jsonl): batch 1 481.9 -> 450.8, 2 491.7 -> 477.5,
                                                  // 3 532.6 -> 555.9, 4 536.7 -> 560.3 (the 4-row variant re-reads four LDS operand rows per weight fragment)
-    int persist_rows = 0;                        // default PL_MAXR = 5, set at create: decode batches of <= this many rows run the decoder stack as ONE persistent
+    int persist_rows = 0;                        // default 8 (fp32) / 5 (fp16), set at create: decode batches of <= this many rows run the decoder stack as ONE persistent
                                                  // launch (persist_layer.hip).  us/step, launch chain -> persistent (profiles/r04_ab_persist_options.jsonl):
                                                  // batch 1 452 -> 285, batch 2 480 -> 347, batch 4 540 -> 467
     bool persist_ok = false;                     //   the mode's preconditions hold and this process holds the device's lock (ensure_persist)
@@ -139,6 +139,11 @@ struct ctts_gpt {
     char* pimg_head = nullptr;                   //   the folded heads as 14 register-fragment rows per GEMV workgroup (persist.h PL_HEAD_FRAGS): the launch that ends the stack also runs
     int persist_delay_u = -1;                    //   "persistent_delay_lora": poll delay of the u granules, -1 = 14 + 2 rows (ms/step with an adapter on every row, delay 0 / 8 / 16 / 24:
                                                  //   batch 1 0.362 / 0.350 / 0.301 / 0.315, 2: 0.417 / 0.410 / 0.349 / 0.353, 4: 0.486 / 0.513 / 0.441 / 0.430; profiles/r06_ab_lora_persistent.jsonl)
+    int attn_wide_blocks = 0;                    // "attn_wide_blocks": decode attention takes 8-wave blocks while rows x heads < this (0 = 256).  Set at create: 512 (fp32) / 4096 (fp16).
+                                                 //   Until round 6 the limit was one block per CU (256), tuned on the round-4 attention layout; on the V-one-dim-per-lane layout
+                                                 //   8-wave blocks win further up (ms/step 4-wave / 8-wave, fp32: 22 rows 0.749 / 0.724, 28: 0.773 / 0.749, 32: 0.785 / 0.768, 40: 0.946 / 0.939,
+                                                 //   48: 1.010 / 1.032; fp16: 32 rows 0.574 / 0.567, 48: 0.683 / 0.668, 64: 0.740 / 0.713; profiles/r06_ab_attn_wide_blocks.jsonl) --
+                                                 //   this was round 5's unexplained 20 -> 22-row step (+10 %)
     int persist_lora = 1;                        //   "persistent_lora": rows with per-utterance adapters stay on the persistent launch (round 6; 0 = they take the launch chain, as until round 5)
     int persist_heads = 1;                       //   the final RMSNorm + heads ("persistent_heads"; code mode, paced schedule): one launch fewer per step
     unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
@@ -247,11 +252,13 @@ extern "C" int ctts_gpt_create(const ctts_gpt_cfg* c, ctts_gpt** out) {
     h->H = c->hidden; h->I = c->inter; h->NH = c->heads; h->L = c->layers; h->V = c->vocab_code; h->NVQ = c->num_vq;
     h->esz = (c->dtype == CTTS_DTYPE_F16) ? 2 : 4;
     h->split_rows = 8;                                           // both dtypes (the comment at split_rows)
-    // both dtypes since round 5 (fp16 engines: half weights + half K / V in the image, fp32 activations).  fp16: up to 3 rows -- ms/step launch chain / persistent
-    // (tools/fp16_persist_probe.py, two edge waves): batch 1 0.370 / 0.256, 2 0.393 / 0.319, 3 0.423 / 0.381, 4 0.427 / 0.442
+    // both dtypes since round 5 (fp16 engines: half weights + half K / V in the image, fp32 activations).  fp16: up to 5 rows -- ms/step launch chain / persistent launch on the
+    // final round-5 kernel (four edge waves, joint row sums; profiles/r05_step_time_vs_batch_fp16.jsonl): batch 1 0.370 / 0.235, 2: 0.393 / 0.276, 3: 0.423 / 0.312, 4: 0.425 / 0.346,
+    // 5: 0.431 / 0.389 (round 6 with the 16-byte act granules: 0.229 / 0.268 / - / 0.342 / 0.380; the first version, two edge waves, had lost at 4 rows: 0.427 / 0.442)
     // fp32: 8 since round 6 (6..8 rows: two attention items per workgroup; ms/step launch chain / persistent launch at mean context 310: 6 rows 0.586 / 0.484, 7: 0.605 / 0.522,
     // 8: 0.617 / 0.557; at context 560: 6 rows 0.690 / 0.660, 8: 0.704 / 0.721 -> persist_pair_keys).  fp16 stays at 5: its chain is faster there (6 rows 0.467 / 0.489, 8: 0.472 / 0.550)
     h->persist_rows = (c->dtype == CTTS_DTYPE_F16) ? PL_MAXR_ONE : PL_MAXR;      // (ms/step launch chain / persistent launch at 5 rows, fp32: 0.540 / 0.389; fp16 at 4 rows: 0.425 / 0.345)
+    h->attn_wide_blocks = (c->dtype == CTTS_DTYPE_F16) ? 4096 : 512;
     h->nbg2_rows = (c->dtype == CTTS_DTYPE_F16) ? 57 : 81;
     h->down_sk_rows = 9;                                         // = the first batch size of the packed-residual path (split_rows + 1)
     // Diagnostic switches exist only in builds with -DCTTS_DIAG (python -m chatttsplus_amd.build --diag) and are read HERE, once: the
@@ -325,12 +332,23 @@ static int ensure_persist(ctts_gpt* h, bool required) {
 static int persist_images(ctts_gpt* h) {
     if (h->pimg != nullptr || !h->persist_ok) return 0;
     const size_t layer_bytes = PL_LAYER_BYTES / 4 * h->esz;
-    if (dev_alloc((void**)&h->pimg, layer_bytes * h->L)) return 1;
-    for (int l = 0; l < h->L; ++l)
-        if (launch_persist_repack(h->esz == 2, h->lw[l].qkv, h->lw[l].o, h->lw[l].gu, h->lw[l].d, h->pimg + layer_bytes * l, nullptr)) return 1;
-    if (dev_alloc((void**)&h->pimg_head, (size_t)PL_GEMV_BLOCKS * PL_HEAD_FRAGS * 4 * h->esz)) return 1;
-    if (launch_persist_repack_heads(h->esz == 2, h->whead, (h->NVQ * h->V + 15) / 16, h->pimg_head, nullptr)) return 1;
-    CTTS_HIP_CHECK(hipDeviceSynchronize());
+    // built into locals and published only when complete: a failed allocation or repack (an engine beside others on a full device) leaves the engine on the launch
+    // chain -- the mode is an optimisation -- instead of failing the decode call that happened to need the images first, or leaving half-built ones behind
+    char* img = nullptr; char* img_head = nullptr;
+    bool ok = dev_alloc((void**)&img, layer_bytes * h->L) == 0;
+    for (int l = 0; ok && l < h->L; ++l)
+        ok = launch_persist_repack(h->esz == 2, h->lw[l].qkv, h->lw[l].o, h->lw[l].gu, h->lw[l].d, img + layer_bytes * l, nullptr) == 0;
+    ok = ok && dev_alloc((void**)&img_head, (size_t)PL_GEMV_BLOCKS * PL_HEAD_FRAGS * 4 * h->esz) == 0;
+    ok = ok && launch_persist_repack_heads(h->esz == 2, h->whead, (h->NVQ * h->V + 15) / 16, img_head, nullptr) == 0;
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (img) (void)hipFree(img);
+        if (img_head) (void)hipFree(img_head);
+        h->persist_rows = 0;                                     // (ctts_gpt_get_option reports it; "persistent_rows" can be set again)
+        return 0;
+    }
+    h->pimg = img; h->pimg_head = img_head;
     return 0;
 }
 
@@ -340,6 +358,7 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     if (n == "persistent_rows") *value = (h->persist_ok || !h->finalized) ? h->persist_rows : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
     else if (n == "persistent_heads") *value = h->persist_heads;
     else if (n == "persistent_lora") *value = h->persist_lora;
+    else if (n == "attn_wide_blocks") *value = h->attn_wide_blocks;
     else if (n == "persistent_delay_lora") *value = h->persist_delay_u;
     else if (n == "valu_rows") *value = h->valu_rows;
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
@@ -380,6 +399,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         if (h->persist_rows > 0 && ensure_persist(h, true)) { h->persist_rows = 0; return 1; }
     } else if (n == "persistent_delay_lora") {
         h->persist_delay_u = value < 0 ? -1 : (value > 256 ? 256 : value);
+    } else if (n == "attn_wide_blocks") {
+        h->attn_wide_blocks = value < 0 ? 0 : value;
     } else if (n == "persistent_lora") {         // 1 (default): rows with per-utterance adapters stay on the persistent launch; 0 = they take the launch chain
         h->persist_lora = value ? 1 : 0;
     } else if (n == "persistent_heads") {        // 1 (default): the persistent launch that ends the stack also runs the final norm + heads; 0 = the separate heads launch
@@ -1032,7 +1053,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         } else if (launch_gemm(dt, nbg, splitd ? PRO_NORM_P : PRO_NORM, EPI_QKV, g1, chunks, s)) return 1;
         AttnArgs at = {};
         at.q = h->q_buf; at.k_cache = g1.k_cache; at.v_cache = g1.v_cache; at.Lmax = h->cfg.max_seq; at.NH = h->NH; at.R = R; at.S = S;
-        at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o;
+        at.meta = meta; at.st = st; at.part_ml = h->part_ml; at.part_o = h->part_o; at.wide_blocks = h->attn_wide_blocks;
         if (st == nullptr) { at.T = h->pre_T; at.row0 = (int)(meta - h->meta_pre); }       // prompt pass: position of this pass in the flattened [B][T] prompt
         at.packed_out = (S == 1) ? h->attn_packed : nullptr; at.nbg = nbg; at.packed_split = spd ? 1 : 0;
         if (pfs && S == 1) { if (launch_attention_split(at, h->sp_x_hi, h->sp_x_lo, s)) return 1; }      // writes o_proj's head / tail operand images directly

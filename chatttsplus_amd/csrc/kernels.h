@@ -109,6 +109,7 @@ struct AttnArgs {
     int nbg;                //   rows per chunk = 16*nbg
     int packed_split;       //   fp32 engine: packed_out is the head / tail fp16 image pair of the split decode kernels (common.h split_t), not fp32 fragments
     int T, row0;            // prompt pass (MFMA flash kernel): prompt length and the flattened index b*T + t of the pass's first row
+    int wide_blocks;        // decode, unsplit: 8-wave blocks while rows x heads < this (0 = 256: fewer blocks than CUs; option "attn_wide_blocks")
 };
 
 struct SamplerCfgDev {      // mirrors ctts_sampler_cfg

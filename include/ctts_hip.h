@@ -86,6 +86,7 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "persistent_delay", "persistent_delay_act", "persistent_delay_x", "persistent_delay_att", "persistent_nap", "persistent_nap_qkv"  when and how often the edge waves poll
  *   "persistent_poll"     0 / 1: sentinel granules before the full sweeps (default 0)
  *   "persistent_timestamps" diagnostics: the persistent launches record per-workgroup phase marks
+ *   "attn_wide_blocks"    unsplit decode attention takes 8-wave blocks while rows x heads < this (default 512 on fp32 engines, 4096 on fp16 engines; 0 = 256, the limit until round 6)
  *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection as launch slices up to this batch size (default 8)
  *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 9; 0 = never)
  *   "nbg2_rows"           decode batches of >= this many rows use 32-row blocks instead of 16-row chunks (default 81 fp32 / 57 fp16)

@@ -313,6 +313,18 @@ def test_pipeline_continuous_yields_in_input_order(tmp_path):
     lists = list(pipe._infer(list(TEXTS), False, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, noise_seed=9,
                              continuous="throughput", max_new_tokens_per_utterance=lim))
     assert [(int(w.shape[0]) // 256 + 1) // 2 for w in lists[0]] == [min(a, b) for a, b in zip(want, lim)]
+    # round 6: where the caller gives token limits, throughput mode serves the LONGEST LIMIT first (the request ends with its last row: a long utterance admitted late decodes
+    # alone), ties by text length; `throughput_order = "input"` keeps arrival order
+    gpt.noise_keys = []
+    list(pipe._infer(list(TEXTS), False, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, noise_seed=9, utt_ids=list(range(100, 110)),
+                     continuous="throughput", max_new_tokens_per_utterance=lim))
+    assert [u for _, u in gpt.noise_keys] == [100 + i for i in sorted(range(10), key=lambda i: (-lim[i], -len(TEXTS[i] + " [uv_break]"), i))]
+    pipe.throughput_order = "input"
+    gpt.noise_keys = []
+    list(pipe._infer(list(TEXTS), False, None, True, False, True, True, False, True, params_infer_code=p, slice_size=3, noise_seed=9, utt_ids=list(range(100, 110)),
+                     continuous="throughput", max_new_tokens_per_utterance=lim))
+    assert [u for _, u in gpt.noise_keys] == [100 + i for i in range(10)]
+    del pipe.throughput_order
     # fits the decode rows -> ordinary path (generate), and the combinations that cannot work are refused
     gpt.calls, gpt.many_calls = [], []
     list(pipe._infer(list(TEXTS[:3]), False, None, True, False, True, True, False, True, params_infer_code=InferCodeParams(show_tqdm=False, spk_emb=rows[:3]),

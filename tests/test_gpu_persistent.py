@@ -238,8 +238,8 @@ def test_persistent_weight_images_are_built_on_first_need(gpt):
 
 def test_fp16_engines_use_the_persistent_launch_too():
     """Round 5: the fast mode had stayed on the launch chain, so at batch 1 it was SLOWER than the parity mode (0.373 vs 0.284 ms/step).  The persistent
-    launch now also takes a half-precision weight image and a half K / V cache (activations, granules and accumulation stay fp32): default for <= 3 rows of an fp16
-    engine.  Against the fp16 launch chain (which rounds the MFMA operands to fp16): the same first tokens, hidden states within the fast mode's tolerance while the
+    launch now also takes a half-precision weight image and a half K / V cache (activations, granules and accumulation stay fp32): default for <= 5 rows of an fp16
+    engine (6..8 rows stay on its launch chain, which is faster there).  Against the fp16 launch chain (which rounds the MFMA operands to fp16): the same first tokens, hidden states within the fast mode's tolerance while the
     tokens agree; replays bitwise identical, hipGraph == eager."""
     from chatttsplus_amd.hip_models import GPT
     g = GPT(LLAMA, max_batch=4, max_seq_len=300, weight_dtype="fp16")
