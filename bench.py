@@ -727,14 +727,14 @@ def main():
             tp = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")]
             tp = [q for q in tp if os.path.exists(q)][0]                      # the newest committed PMC passes
             tj = json.load(open(tp))
-            ent = tj.get(f"b{B}_{args.dtype}" + ("_persistent_mfma" if on_mfma else "" if (persist_rows >= B or B > 4) else "_launch_chain"))
+            ent = tj.get(f"b{B}_{args.dtype}" + ("" if (persist_rows >= B or B > 8) else "_launch_chain"))
             if ent:
                 traffic = ent.get("hbm_bytes_per_step")
                 traffic_note = (f"PMC FETCH_SIZE (x2, the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per decode step, separate rocprofv3 --pmc passes of "
                                 f"`{ent.get('command')}` (profiles/{os.path.basename(tp)[:8]}*.json): mean context {ent.get('mean_context')} = the timed window's; "
                                 f"{ent.get('traffic_over_algorithmic')} x the algorithmic bytes")
-        except Exception:
-            pass
+        except (OSError, ValueError, KeyError, IndexError):
+            pass                                       # (no committed PMC passes for this configuration: traffic stays null)
         step_bytes = r["step_bytes"]
         step_ms = r["ev_ms"] / K
         achieved = step_bytes / (step_ms * 1e-3) / 1e9
@@ -756,7 +756,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": traffic_note,
-                         "per": "decode step (one hipGraph replay = 4 steps); the persistent path is one layer-stack launch + heads + sampler per step",
+                         "per": "decode step (one hipGraph replay = 4 steps on the launch chain, 16 on the persistent path, whose step is the layer-stack launch incl. the heads at <= 2 rows + the sampler)",
                          "algorithmic_bytes_per_step": int(step_bytes), "step_ms_hip_events": round(step_ms, 5)},
             "rtf_decode_only": round(B * K * world * (512 / 24000.0) / dt, 2),
             "rtf_end_to_end": (round(B * 256 * (2 * expect - 1) / 24000.0 / ((r["prefill_ms"] + (dt / K) * 1e3 * (expect - 1) + voc_ms) / 1e3), 2)

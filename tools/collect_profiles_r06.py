@@ -3,9 +3,10 @@ profiles/r06_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes (taken at 
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(ROOT, "gpurun_out", "fin_r06")
+F = os.path.join(ROOT, "gpurun_out", "fin_r06b" if "b" in sys.argv[1:] else "fin_r06")      # `b`: the second collection (tools/final_run_r06b.sh) over the first
 P = os.path.join(ROOT, "profiles")
 pairs = {"bench_b1_fp32.json": "r06_bench_b1_fp32.json", "bench_b1_fp32_steps20.json": "r06_bench_b1_fp32_steps20.json", "bench_b32_fp32.json": "r06_bench_b32_fp32.json",
          "b1_fp32_kernel_stats.csv": "r06_b1_fp32_kernel_stats.csv", "b32_fp32_kernel_stats.csv": "r06_b32_fp32_kernel_stats.csv", "b8_fp32_kernel_stats.csv": "r06_b8_fp32_kernel_stats.csv",
@@ -17,7 +18,7 @@ for src, dst in pairs.items():
     if os.path.exists(sp) and os.path.getsize(sp) > 0:
         shutil.copy(sp, os.path.join(P, dst))
     else:
-        print("missing", src)
+        print("missing", src) if "b" not in sys.argv[1:] else None
 fp = os.path.join(F, "bench_b1_fp32_steps20_force_pg.json")
 if os.path.exists(fp):          # (RCCL's banner lines, if any, are not part of the evidence)
     lines = [l for l in open(fp) if l.startswith("{")]
@@ -47,5 +48,10 @@ for t, key, B, cmd in (("b1", "b1_fp32", 1, "bench.py --batch 1 --prompt 293 --s
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         shutil.copy(os.path.join(F, f"pmc_{t}_{c}.json"), os.path.join(P, f"r06_pmc_{key}_{c}.json"))
 if out:
+    try:                                             # (the second collection re-takes batch 32 only)
+        old = json.load(open(os.path.join(P, "r06_pmc_traffic.json")))
+        out = dict(old, **out)
+    except Exception:
+        pass
     json.dump(out, open(os.path.join(P, "r06_pmc_traffic.json"), "w"), indent=1)
     print({k: (v["hbm_bytes_per_step"], v["traffic_over_algorithmic"]) for k, v in out.items()})
