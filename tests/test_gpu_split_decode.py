@@ -110,3 +110,22 @@ def test_an_engine_without_the_images_refuses_the_option():
         assert len(ids) == 10
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("B", [22, 32, 40])
+def test_decode_attention_block_shapes_agree(gpt, B):
+    """Round 6: the decode attention keeps 8-wave blocks up to 42 rows on fp32 engines ("attn_wide_blocks" = 512; until then 4-wave blocks from one block per CU on:
+    round 5's 20 -> 22-row step).  Both shapes evaluate llama.py:653-661 with different splits of the key range over the waves: same tokens, hidden rows within the
+    oracle tolerance."""
+    g = gpt
+    assert g.get_option("attn_wide_blocks") == 512
+    pad = [(5 * i) % 28 for i in range(B)]
+    ref_ids, ref_h = _gen(g, B, 40, 16, pad)
+    try:
+        g.set_option("attn_wide_blocks", 0)                 # 0 = 256: 4-wave blocks at these row counts
+        ids, hid = _gen(g, B, 40, 16, pad)
+    finally:
+        g.set_option("attn_wide_blocks", 512)
+    for b in range(B):
+        assert torch.equal(ids[b], ref_ids[b]), (B, b)
+        assert float((hid[b] - ref_h[b]).abs().max()) <= 2e-5, (B, b)
