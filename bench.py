@@ -646,6 +646,28 @@ def main():
             with tempfile.TemporaryDirectory() as td:
                 pipe = ChatTTSPlusPipeline.from_components(g, syn_r, synth.toy_tokenizer(td), dev)
                 extra["sharded_request"] = sharded_request_leg(pipe, dev, rank, world, n_utt=args.request_utterances, rows=EB)
+                if world == 1:
+                    # the same request in the LATENCY order (`infer(continuous=True)`: arrival order, waveform lists yielded in input order as soon as a prefix of the request is
+                    # complete): what a streaming client sees -- time to the first audio, against the throughput mode above whose one list comes at the end
+                    try:
+                        texts_l, limits_l, spk_l = _request_256(args.request_utterances)
+                        table_l = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
+                        from chatttsplus_amd.pipeline import InferCodeParams
+                        p_l = InferCodeParams(prompt="[speed_5]", max_new_token=512, min_new_token=512, show_tqdm=False, spk_emb=table_l[torch.tensor(spk_l)])
+                        torch.cuda.synchronize(dev)
+                        t_l, first_l, n_l = time.perf_counter(), None, 0
+                        for lst in pipe.infer(list(texts_l), skip_refine_text=True, do_text_optimization=False, params_infer_code=p_l, slice_size=EB, noise="device", noise_seed=4242,
+                                              continuous=True, max_new_tokens_per_utterance=limits_l):
+                            if first_l is None:
+                                torch.cuda.synchronize(dev)
+                                first_l = (time.perf_counter() - t_l) * 1e3
+                            n_l += len(lst)
+                        torch.cuda.synchronize(dev)
+                        w_l = time.perf_counter() - t_l
+                        extra["sharded_request"]["latency_order"] = {"first_audio_ms": round(first_l, 1), "wall_ms": round(w_l * 1e3, 2), "utterances": n_l,
+                                                                     "useful_tokens_per_s": round(sum(limits_l) / w_l, 1)}
+                    except Exception as exl:
+                        extra["sharded_request"]["latency_order"] = f"failed: {type(exl).__name__}: {exl}"
                 del pipe, syn_r
             # north_star: "decode tokens/s on synthetic 512-token prompts ... at 1/2/4/8 GPUs", batch 1 per GPU
             e = run_reps(leg, XR, 1, 512, EK, W, spk=spk, use_graph=use_graph)
