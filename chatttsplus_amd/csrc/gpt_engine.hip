@@ -144,6 +144,9 @@ struct ctts_gpt {
                                                  //   8-wave blocks win further up (ms/step 4-wave / 8-wave, fp32: 22 rows 0.749 / 0.724, 28: 0.773 / 0.749, 32: 0.785 / 0.768, 40: 0.946 / 0.939,
                                                  //   48: 1.010 / 1.032; fp16: 32 rows 0.574 / 0.567, 48: 0.683 / 0.668, 64: 0.740 / 0.713; profiles/r06_ab_attn_wide_blocks.jsonl) --
                                                  //   this was round 5's unexplained 20 -> 22-row step (+10 %)
+    int persist_share_keys = 384;                //   "persistent_share_keys": keys per key share at 1..5 rows before another share is opened.  A share holds 384 keys in registers and (round 6) up to 256
+                                                 //   more in LDS; a second share still opens beyond 384 + 128 keys: ms/step one share of 640 vs shares of 384, batch 1: context 480 0.252 (0.259 with the
+                                                 //   128 keys streamed, round 5), 630: 0.279 vs 0.263 (two shares), 1030: 0.283 vs 0.280 (profiles/r06_ab_pair_lds_tail.jsonl)
     int persist_lora = 1;                        //   "persistent_lora": rows with per-utterance adapters stay on the persistent launch (round 6; 0 = they take the launch chain, as until round 5)
     int persist_heads = 1;                       //   the final RMSNorm + heads ("persistent_heads"; code mode, paced schedule): one launch fewer per step
     unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
@@ -358,6 +361,7 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     if (n == "persistent_rows") *value = (h->persist_ok || !h->finalized) ? h->persist_rows : 0;      // the EFFECTIVE value (0 when the mode is unavailable)
     else if (n == "persistent_heads") *value = h->persist_heads;
     else if (n == "persistent_lora") *value = h->persist_lora;
+    else if (n == "persistent_share_keys") *value = h->persist_share_keys;
     else if (n == "attn_wide_blocks") *value = h->attn_wide_blocks;
     else if (n == "persistent_delay_lora") *value = h->persist_delay_u;
     else if (n == "valu_rows") *value = h->valu_rows;
@@ -401,6 +405,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         h->persist_delay_u = value < 0 ? -1 : (value > 256 ? 256 : value);
     } else if (n == "attn_wide_blocks") {
         h->attn_wide_blocks = value < 0 ? 0 : value;
+    } else if (n == "persistent_share_keys") {
+        h->persist_share_keys = value < 64 ? 384 : value;
     } else if (n == "persistent_lora") {         // 1 (default): rows with per-utterance adapters stay on the persistent launch; 0 = they take the launch chain
         h->persist_lora = value ? 1 : 0;
     } else if (n == "persistent_heads") {        // 1 (default): the persistent launch that ends the stack also runs the final norm + heads; 0 = the separate heads launch
@@ -1301,8 +1307,9 @@ static inline int decode_persist(const ctts_gpt* h, int B, int L) {
         return (L > (h->persist_max_keys > 0 ? h->persist_max_keys : h->persist_pair_keys - 128 * (B - PL_MAXR_ONE - 1))) ? 0 : 1;      // (704 / 576 / 448 keys at 6 / 7 / 8 rows)
     }
     if (L > (h->persist_max_keys > 0 ? h->persist_max_keys : 1400 * cap)) return 0;
-    if (L <= PL_SHARE_KEYS + 128) return 1;                 // (one streamed iteration costs less than the extra hop)
-    const int want = (L + PL_SHARE_KEYS - 1) / PL_SHARE_KEYS;
+    const int share = h->persist_share_keys > 0 ? h->persist_share_keys : PL_SHARE_KEYS;
+    if (L <= share + 128) return 1;                         // (the 128 keys beyond the registers wait in LDS since round 6: cheaper than the extra hop)
+    const int want = (L + share - 1) / share;
     return want > cap ? cap : want;
 }
 

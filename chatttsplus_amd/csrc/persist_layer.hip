@@ -245,6 +245,9 @@ template <int CTRL, int C> __device__ inline void pl_rs_step(float* v, bool f) {
     } else v[0] += dpp_f<CTRL>(v[0]);
 }
 #define PL_FRONT_BYTES 4096                 // 16 + (384 + 512 + 16 + 16) * 4 = 3728, rounded
+#ifndef PL_TAIL_ALL
+#define PL_TAIL_ALL 1
+#endif
 #ifndef PL_TAIL_IT
 #define PL_TAIL_IT 4                        // 6..8 rows: iterations of 8 keys per compute wave that wait in LDS (4 KB each) -- 4 x 8 x 4 = 128 keys per item behind the 192 in registers
 #endif
@@ -1085,7 +1088,7 @@ __global__ __launch_bounds__(PL_LB) void persist_layer_kernel(const PersistArgs 
         // needs no registers: a lane fetches exactly the 16-byte pieces it will read back itself (K: its 8 dims of its key group; V: rows of 64 floats, read one dim per
         // lane), so the image is lane-linear and every read is conflict-free -- LDS as an asynchronously filled extension of the register file.  The GEMV workgroups' xs
         // block is idle in an attention workgroup: 8 waves x NT x 4 KB.
-        constexpr int NT = PAIR ? PL_TAIL_IT : 0, PT = PRE + NT;
+        constexpr int NT = (PAIR || PL_TAIL_ALL) ? PL_TAIL_IT : 0, PT = PRE + NT;      // (PL_TAIL_ALL: also the one-item workgroups of 1..5 rows: 8 waves x 4 x 8 = 256 more keys)
         constexpr int TB = sizeof(WT) == 4 ? 4096 : 2048;     // bytes of one LDS iteration: K 8 keys x 64 dims | V 8 keys x 64 dims
         typedef __attribute__((address_space(3))) char lds_c;
         typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -1396,7 +1399,7 @@ int launch_persist_repack(int half_w, const void* qkv, const void* o, const void
 }
 
 static size_t persist_lds_bytes(int R) {
-    const size_t gemv = (size_t)(R * PL_I + PL_RED_FLOATS + 4 * R + 4 * R + 256 * R) * 4, tail = R > PL_MAXR_ONE ? (size_t)8 * PL_TAIL_IT * 4096 : 0;
+    const size_t gemv = (size_t)(R * PL_I + PL_RED_FLOATS + 4 * R + 4 * R + 256 * R) * 4, tail = (R > PL_MAXR_ONE || PL_TAIL_ALL) ? (size_t)8 * PL_TAIL_IT * 4096 : 0;
     return PL_FRONT_BYTES + (gemv > tail ? gemv : tail);
 }
 
