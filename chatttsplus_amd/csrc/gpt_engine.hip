@@ -144,9 +144,9 @@ struct ctts_gpt {
                                                  //   8-wave blocks win further up (ms/step 4-wave / 8-wave, fp32: 22 rows 0.749 / 0.724, 28: 0.773 / 0.749, 32: 0.785 / 0.768, 40: 0.946 / 0.939,
                                                  //   48: 1.010 / 1.032; fp16: 32 rows 0.574 / 0.567, 48: 0.683 / 0.668, 64: 0.740 / 0.713; profiles/r06_ab_attn_wide_blocks.jsonl) --
                                                  //   this was round 5's unexplained 20 -> 22-row step (+10 %)
-    int persist_share_keys = 384;                //   "persistent_share_keys": keys per key share at 1..5 rows before another share is opened.  A share holds 384 keys in registers and (round 6) up to 256
-                                                 //   more in LDS; a second share still opens beyond 384 + 128 keys: ms/step one share of 640 vs shares of 384, batch 1: context 480 0.252 (0.259 with the
-                                                 //   128 keys streamed, round 5), 630: 0.279 vs 0.263 (two shares), 1030: 0.283 vs 0.280 (profiles/r06_ab_pair_lds_tail.jsonl)
+    int persist_share_keys = 384;                //   "persistent_share_keys": keys per key share at 1..5 rows; one share serves up to this + 128 keys (384 in registers, the rest -- up to 256 -- waits in LDS
+                                                 //   since round 6 instead of streaming behind the query), more keys open a second share.  Re-swept with the LDS tail: 384 stays the best or ties
+                                                 //   from 400 to 1000 keys (one share of 640: context 630 0.279 vs 0.263 ms/step with two shares; profiles/r06_ab_pair_lds_tail.jsonl)
     int persist_lora = 1;                        //   "persistent_lora": rows with per-utterance adapters stay on the persistent launch (round 6; 0 = they take the launch chain, as until round 5)
     int persist_heads = 1;                       //   the final RMSNorm + heads ("persistent_heads"; code mode, paced schedule): one launch fewer per step
     unsigned long long* pl_g = nullptr;          //   granule buffers g_qkv | g_att | g_x1 | g_act
