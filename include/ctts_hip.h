@@ -78,6 +78,7 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *                         process that loads an engine (either dtype) on a device holds the mode (advisory lock /tmp/ctts_persist_<pci>.lock); others stay on launches.
  *                         A persistent launch needs all 256 workgroups resident: run ONE decode at a time per device (two engines of one process decoding
  *                         concurrently on different streams would have to share the CUs; every wait is bounded and ctts_gpt_progress reports a give-up)
+ *   "persistent_share_keys"  1..5 rows: one key share per (row, head) serves up to this + 128 cached keys (384 in registers, the rest in LDS), longer contexts open more shares (default 384)
  *   "persistent_lora"     1 (default): rows that carry a per-utterance adapter stay on the persistent launch -- its otherwise idle compute waves evaluate A h, the edge lanes add
  *                         B (A h) to their q / k / v / o_proj rows (paced schedule; 0 = such batches take the launch chain's worker workgroups, "lora_fold")
  *   "persistent_delay_lora"  poll delay of that hand-off (-1 = 14 + 2 rows, the default)
