@@ -29,6 +29,7 @@ ap.add_argument("--skip-times", action="store_true")
 ap.add_argument("--skip-layer", action="store_true")
 ap.add_argument("--skip-checks", action="store_true")
 ap.add_argument("--marks-prompt", type=int, default=48)
+ap.add_argument("--marks-rows", default="1,2,3,4,5", help="row counts of the phase marks (6..8: the two-item attention workgroups)")
 ap.add_argument("--adapters", action="store_true", help="phase marks with a per-utterance LoRA adapter on every row (round 6: the LORA kernels)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -153,7 +154,8 @@ if not args.skip_layer:
     g1.close()
 
 # ---- 2. twenty layers, launch path vs persistent layers -----------------------------------------------------------------------------------
-g, _ = make(20, MAXR, 1400)
+MARK_ROWS = [int(x) for x in args.marks_rows.split(",")]
+g, _ = make(20, max(MAXR, max(MARK_ROWS)), 1400)
 for (B, P, N, pad) in (() if args.skip_checks else ((1, 48, 64, None), (2, 40, 48, [0, 9]), (3, 33, 40, [0, 5, 17]), (4, 48, 40, [3, 0, 11, 20]), (5, 36, 40, [0, 4, 9, 2, 13]), (5, 420, 24, None), (1, 600, 24, None), (1, 1000, 48, None))):
     a_ids, a_hid, _ = gen(g, B, P, N, persist=0, pad_left=pad)
     b_ids, b_hid, _ = gen(g, B, P, N, persist=MAXR, pad_left=pad)
@@ -184,26 +186,27 @@ if not args.skip_times:
 if True:
     spk = torch.from_numpy(np.stack([synth.speaker_vector(1234 + i) for i in range(4)])).to(dev)
     leg = bench.Leg(g, dev, 0, 1)
-    g.set_option("persistent_rows", MAXR)
+    g.set_option("persistent_rows", max(MAXR, max(MARK_ROWS)))
     g.set_option("persistent_timestamps", 1)
     if args.adapters:
         rl = np.random.Generator(np.random.Philox(key=31))
         for slot in range(2):
             g.load_adapter(slot, [(l, t, (rl.standard_normal((8, 768)) * 0.02).astype(np.float32), (rl.standard_normal((768, 8)) * 0.02).astype(np.float32), 2.0)
                                   for l in range(20) for t in ("q_proj", "k_proj", "v_proj", "o_proj")])
-    for B in (1, 2, 3, 4, 5):
+    for B in MARK_ROWS:
         if args.adapters:
             g.set_row_adapters([b % 2 for b in range(B)])
         for rep in range(4):
             leg.run(B, args.marks_prompt, 4, 4, spk=spk, use_graph=0, gen_tokens=0)
             ts = debug_read(g, "pl_ts", 256 * 10 * 8).view(np.uint64).reshape(256, 10).astype(np.float64) * 0.01        # us
-        gem, att = ts[:192], ts[192:192 + 12 * B, :3]
+        natt = 12 * B if B <= 5 else 6 * B             # (6..8 rows: two items per attention workgroup, the first item's edge wave writes the marks)
+        gem, att = ts[:192], ts[192:192 + natt, :3]
         t0 = min(gem[:, 0].min(), att[:, 0].min())
         names = ["start", "x_loaded", "x_gathered", "qkv_published", "attention_gathered", "x1_published", "x1_gathered", "act_published", "act_gathered", "end"]
         med = {n: round(float(np.median(gem[:, i] - t0)), 2) for i, n in enumerate(names)}
         mx = {n: round(float((gem[:, i] - t0).max()), 2) for i, n in enumerate(names)}
         amed = {n: round(float(np.median(att[:, i] - t0)), 2) for i, n in enumerate(["start", "qkv_gathered", "attention_published"])}
-        fine = ts[192:192 + 12 * B]
+        fine = ts[192:192 + natt]
         out(check="attention_phase_fine_marks_us", B=B, since_qkv_gathered={n: round(float(np.median(fine[:, i] - fine[:, 1])), 2) for n, i in
             (("b1_passed_wave0", 3), ("scores_and_max", 4), ("exp_pv", 5), ("cross_lane_sums", 6), ("b2_passed_wave8", 7), ("published", 2))})
         out(check="phase_marks_us_last_layer", B=B, adapters=bool(args.adapters), layers_in_launch=20, gemv_median=med, gemv_max=mx, attention_median=amed,
