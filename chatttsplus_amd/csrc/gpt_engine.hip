@@ -139,6 +139,8 @@ struct ctts_gpt {
     char* pimg_head = nullptr;                   //   the folded heads as 14 register-fragment rows per GEMV workgroup (persist.h PL_HEAD_FRAGS): the launch that ends the stack also runs
     int persist_delay_u = -1;                    //   "persistent_delay_lora": poll delay of the u granules, -1 = 14 + 2 rows (ms/step with an adapter on every row, delay 0 / 8 / 16 / 24:
                                                  //   batch 1 0.362 / 0.350 / 0.301 / 0.315, 2: 0.417 / 0.410 / 0.349 / 0.353, 4: 0.486 / 0.513 / 0.441 / 0.430; profiles/r06_ab_lora_persistent.jsonl)
+    int prefill_pp_blocks = 1;                   // "prefill_pp_blocks": a split GEMM of the prompt pass may run on prefill_split_gemm_pp_kernel (256-row blocks, counter-phased wave groups) when it has
+                                                 //   at least this many such blocks and the round count favours it (prefill_split.hip sp_launch); 0 = never
     int attn_wide_blocks = 0;                    // "attn_wide_blocks": decode attention takes 8-wave blocks while rows x heads < this (0 = 256).  Set at create: 512 (fp32) / 4096 (fp16).
                                                  //   Until round 6 the limit was one block per CU (256), tuned on the round-4 attention layout; on the V-one-dim-per-lane layout
                                                  //   8-wave blocks win further up (ms/step 4-wave / 8-wave, fp32: 22 rows 0.749 / 0.724, 28: 0.773 / 0.749, 32: 0.785 / 0.768, 40: 0.946 / 0.939,
@@ -363,6 +365,7 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     else if (n == "persistent_lora") *value = h->persist_lora;
     else if (n == "persistent_share_keys") *value = h->persist_share_keys;
     else if (n == "attn_wide_blocks") *value = h->attn_wide_blocks;
+    else if (n == "prefill_pp_blocks") *value = h->prefill_pp_blocks;
     else if (n == "persistent_delay_lora") *value = h->persist_delay_u;
     else if (n == "valu_rows") *value = h->valu_rows;
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
@@ -403,6 +406,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         if (h->persist_rows > 0 && ensure_persist(h, true)) { h->persist_rows = 0; return 1; }
     } else if (n == "persistent_delay_lora") {
         h->persist_delay_u = value < 0 ? -1 : (value > 256 ? 256 : value);
+    } else if (n == "prefill_pp_blocks") {
+        h->prefill_pp_blocks = value < -4 ? 0 : value;      // -3 / -4: always the counter-phased kernel with that many n tiles per wave (tests, A/B)
     } else if (n == "attn_wide_blocks") {
         h->attn_wide_blocks = value < 0 ? 0 : value;
     } else if (n == "persistent_share_keys") {
@@ -1046,7 +1051,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         }
         if (pfs) {
             if (launch_norm_pack_split(x, h->sp_x_hi, h->sp_x_lo, R, a.eps, s)) return 1;
-            if (launch_prefill_split_gemm(EPI_QKV, g1, h->lw[l].qkv_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_QKV, g1, h->lw[l].qkv_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, h->prefill_pp_blocks, s)) return 1;
         } else if (prepack) {
             g1.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
@@ -1081,7 +1086,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g2.lora_delta = h->lora_do;
         }
         if (pfs && S == 1) {
-            if (launch_prefill_split_gemm(EPI_RESID, g2, h->lw[l].o_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_RESID, g2, h->lw[l].o_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, h->prefill_pp_blocks, s)) return 1;
         } else if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
         else {
             if (spd) g2.W = h->lw[l].o_sp;
@@ -1093,7 +1098,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act;
         if (pfs) {
             if (launch_norm_pack_split(x, h->sp_x_hi, h->sp_x_lo, R, a.eps, s)) return 1;
-            if (launch_prefill_split_gemm(EPI_SWIGLU, g3, h->lw[l].gu_sp, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, sp_scale, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_SWIGLU, g3, h->lw[l].gu_sp, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, sp_scale, h->prefill_pp_blocks, s)) return 1;
         } else if (prepack) {
             g3.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
@@ -1107,7 +1112,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         GemmArgs g4 = a;
         g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x;
         if (pfs) {      // the SwiGLU images hold silu(g) * u / 16
-            if (launch_prefill_split_gemm(EPI_RESID, g4, h->lw[l].d_sp, h->sp_act_hi, h->sp_act_lo, nullptr, nullptr, sp_scale * 16.0f, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_RESID, g4, h->lw[l].d_sp, h->sp_act_hi, h->sp_act_lo, nullptr, nullptr, sp_scale * 16.0f, h->prefill_pp_blocks, s)) return 1;
         } else if (pfg) {
             if (launch_prefill_gemm(EPI_RESID, g4, s)) return 1;
         } else if (splitd) {

@@ -180,7 +180,7 @@ int launch_norm_pack_split(const float* x, void* hi, void* lo, int R, float eps,
 int launch_split_pack(const float* src, void* hi, void* lo, int R, hipStream_t s);
 int launch_attention_split(const AttnArgs& a, void* out_hi, void* out_lo, hipStream_t s);
 int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Wsplit, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,
-                              float scale, hipStream_t s);      // Wsplit: [n tile][k tile][head | tail][lane][16 B] (common.h split_t)
+                              float scale, int pp_min_blocks, hipStream_t s);      // Wsplit: [n tile][k tile][head | tail][lane][16 B] (common.h split_t)
 int launch_norm_pack(int dtype, const float* x, void* out_packed, int R, int nbg, float eps, hipStream_t s);
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s);

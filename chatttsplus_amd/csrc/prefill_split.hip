@@ -16,6 +16,8 @@
 // (8 Whi, 8 Wlo, 8 Xhi, 8 Xlo) copied by LDS-DMA into a ring of SP_RING stages (2 x 32 KB: two blocks per CU; 48 MFMAs per wave and stage).
 #include "kernels.h"
 
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
 #define SP_WSCALE 64.0f
 #define SP_ACT_SCALE 16.0f
 // LDS ring of k-tile stages: 2 x 32 KB = two blocks per CU (see cnx_gemm.h): 32 x 512-token prompt pass 26.6 -> 22.8 ms against a ring of 3 (one block per CU)
@@ -82,6 +84,102 @@ struct SplitGemm {
     float scale;                            // applied to the accumulators: 1 / SP_WSCALE (x SP_ACT_SCALE for the down projection)
     half_t *act_hi, *act_lo;                // EPI_SWIGLU: output images [16-row group][96 k-tiles][lane][8] of silu(g) * u / SP_ACT_SCALE
 };
+
+// Epilogue of a wave tile of NT n tiles x NG 16-row groups (both split GEMM kernels).  C tile layout: lane = (iq = lane >> 4, n = lane & 15): activation row n of
+// the group, weight rows 4 * iq + j (j = register).  rt0 = the wave's first n tile (q / k / v: 4 consecutive tiles = one head, tile t of it = dims 8t.. | 8t + 32..;
+// gate|up: a tile = 8 outputs), G0 = its first row group.
+template <int EPI, int NG, int NT>
+__device__ __forceinline__ void sp_epilogue(f32x4 (&acc)[NT][NG], const SplitGemm& p, const GemmArgs& a, const int lane, const int rt0, const int G0) {
+    int nsat = 0;                                          // EPI_SWIGLU: this lane's clamped outputs (one atomic per wave at the end)
+    const int iq = lane >> 4, nn = lane & 15;
+    constexpr int H = 768, NH = H / CTTS_HEAD_DIM, HT = H / 16;
+    const bool lowh = iq < 2;
+    const float sc = p.scale;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int G = G0 + g;                              // 16-row group
+        const int row = G * 16 + nn;
+        const bool rv = row < p.R;
+        if (EPI == EPI_RESID) {
+            const int N = a.n_row_tiles * 16;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (!rv) continue;
+                float* xo = a.x_out + (size_t)row * N + (rt0 + t) * 16 + 4 * iq;
+                const f32x4 x = *(const f32x4*)xo, c = acc[t][g];
+                f32x4 dl = {0.f, 0.f, 0.f, 0.f};             // per-utterance LoRA term of o_proj (lora.hip): part of the projection
+                if (a.lora_delta != nullptr) dl = *(const f32x4*)(a.lora_delta + (size_t)row * N + (rt0 + t) * 16 + 4 * iq);
+                *(f32x4*)xo = (f32x4){x[0] + (c[0] * sc + dl[0]), x[1] + (c[1] * sc + dl[1]), x[2] + (c[2] * sc + dl[2]), x[3] + (c[3] * sc + dl[3])};      // residual + proj (llama.py:731,739)
+            }
+        } else if (EPI == EPI_SWIGLU) {
+            // tile rows [8 gate | 8 up]: lanes iq 0,1 hold gate rows 4 iq + j, lanes iq 2,3 the matching up rows.  Every lane finishes TWO outputs (round 6; the gate
+            // lanes used to finish all four while the up lanes idled through the expf + division: half the epilogue's VALU time): a gate lane keeps j = 0, 1 and
+            // receives the up values, its partner (lane ^ 32) keeps j = 2, 3 and receives the gate values -- two exchanges instead of four, the same arithmetic per output.
+            const int ktiles_out = (a.n_row_tiles * 8) / 32;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 c = acc[t][g];
+                float gv[2], uv[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float got = __shfl_xor(lowh ? c[2 + jj] : c[jj], 32);
+                    gv[jj] = (lowh ? c[jj] : got) * sc;
+                    uv[jj] = (lowh ? got : c[2 + jj]) * sc;
+                }
+                if (rv) {
+                    half2v h, l;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const float y = (gv[jj] / (1.0f + expf(-gv[jj]))) * uv[jj] * (1.0f / SP_ACT_SCALE);
+                        const float cl = fminf(fmaxf(y, -65504.f), 65504.f);       // silu(g) * u / 16 is unbounded: clamp + report (split_h4), also in the fp32 engine's prompt pass
+                        nsat += !(cl == y);
+                        h[jj] = (half_t)cl;
+                        l[jj] = (half_t)(cl - (float)h[jj]);
+                    }
+                    const size_t off = (size_t)G * ktiles_out * 64 * 8 + xfrag_index<half_t>(nn, (rt0 + t) * 8 + 4 * (iq & 1) + (lowh ? 0 : 2), ktiles_out);
+                    *(half2v*)(p.act_hi + off) = h;
+                    *(half2v*)(p.act_lo + off) = l;
+                }
+            }
+        } else {                                           // EPI_QKV
+            RowMeta m = {0, 0, 0, 0};
+            if (rv && rt0 >= HT) m = a.meta[row];           // (a wave's tiles never straddle q | k | v: 48 tiles each, rt0 a multiple of NT = 3 or 4)
+            const int which = rt0 / HT;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int T = rt0 + t, hh = (T % HT) >> 2;   // head of this tile
+                const f32x4 c = acc[t][g];
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(c[j], 32);
+                if (!rv) continue;
+                const int d0 = (T & 3) * 8 + 4 * (iq & 1);   // first of this lane's 4 frequency indices
+                f32x4 y;
+                f32x4 la = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};      // per-utterance LoRA terms of dims d0.. and d0 + 32.. (lora.hip): before RoPE
+                if (a.lora_delta != nullptr) {
+                    const float* dlp = a.lora_delta + ((size_t)row * 3 + which) * H + hh * CTTS_HEAD_DIM + d0;
+                    la = *(const f32x4*)dlp; lb = *(const f32x4*)(dlp + 32);
+                }
+                if (which < 2) {
+                    const f32x4 cs = *(const f32x4*)(a.rope_rows + (size_t)row * 64 + d0), sn = *(const f32x4*)(a.rope_rows + (size_t)row * 64 + 32 + d0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float va = (lowh ? c[j] : o[j]) * sc + la[j], vb = (lowh ? o[j] : c[j]) * sc + lb[j];
+                        // q*cos + rotate_half(q)*sin (llama.py:180-181), products rounded separately like the reference: dims < 32 take a cos - b sin, dims >= 32 b cos + a sin
+                        y[j] = __fadd_rn(__fmul_rn(lowh ? va : vb, cs[j]), __fmul_rn(lowh ? -vb : va, sn[j]));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = c[j] * sc + (lowh ? la[j] : lb[j]);
+                }
+                const int dd = d0 + (lowh ? 0 : 32);
+                if (which == 0) *(f32x4*)(a.q_out + ((size_t)row * NH + hh) * CTTS_HEAD_DIM + dd) = y;
+                else *(f32x4*)((float*)(which == 1 ? a.k_cache : a.v_cache) + (((size_t)m.seq * NH + hh) * a.Lmax + m.slot) * CTTS_HEAD_DIM + dd) = y;
+            }
+        }
+    }
+    if (EPI == EPI_SWIGLU && a.sat != nullptr && nsat != 0) atomicAdd(a.sat, nsat);
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_kernel(const SplitGemm p, const GemmArgs a) {
@@ -158,89 +256,128 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
     }
 #undef SP_DMA
 #undef SP_WAIT_BAR
-    // ---- epilogue.  C tile layout: lane = (iq = lane >> 4, n = lane & 15): activation row n of the group, weight rows 4 * iq + j (j = register)
-    const int iq = lane >> 4, nn = lane & 15;
-    constexpr int H = 768, NH = H / CTTS_HEAD_DIM, HT = H / 16;
-    const int rt0 = nt0 + wn * 4;                          // the wave's 4 n tiles: one head of q / k / v (tile t = dims 8t.. | 8t + 32..), or 32 outputs of gate|up
-    const bool lowh = iq < 2;
-    const float sc = p.scale;
+    sp_epilogue<EPI, 4, 4>(acc, p, a, lane, nt0 + wn * 4, g0 + wr * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same product on 256-row blocks with two wave groups in counter-phase (round 6; long prompt passes: sp_launch decides by a round count).
+//
+// Why: the 128 x 128 kernel above measured 0.38-0.40 MFMA-busy (profiles/r06_pmc_mfma_split.json).  A 3-term product needs FOUR fragments per 16 x 16 x 32 tile
+// pair, so the operand traffic a plain fp16 GEMM has with 64 x 64 wave tiles needs 128 x 64 here: a wave holds NT = 4 n tiles x 8 row groups (24 fragments for 96
+// MFMAs: 0.25 instead of 0.33 fragments per MFMA; 128 accumulator registers), 8 waves = 2 row halves x 4 feature quarters = 256 rows x 256 features per block, ONE
+// block per CU (ring of 2 x 64 KB stages): half the L2 -> LDS bytes per MFMA.  With one block per CU the waves of a SIMD would read and multiply in lock step (the
+// 128 x 128 kernel overlaps through its second block), so the two row halves (waves 0-3 / 4-7: one of each per SIMD) run half an iteration apart: while a group
+// multiplies k-tile kt out of registers the other reads its fragments and issues its LDS-DMA copies.
+//   phase p (between two block barriers):   even: group 0 reads stage p / 2, group 1 multiplies stage p / 2 - 1;   odd: group 0 multiplies, group 1 reads stage (p - 1) / 2
+//   stage s lives in buffer s & 1: read by group 0 in phase 2 s, by group 1 in phase 2 s + 1; the copies of stage s + 2 are issued by group 0's waves in phase 2 s + 2
+//   and by group 1's in phase 2 s + 3 (their READ phases) and waited for (vmcnt 0, every wave its own) at the end of phase 2 s + 3, before group 0 reads it.
+// Accumulation order per output element = the 128 x 128 kernel's (k-tiles ascending; tail.head, head.tail, head.head): the kernels agree bit for bit
+// (tests/test_gpu_split_decode.py::test_prompt_pass_block_shapes_agree_bitwise).
+// Measured at 32 x 512 prompt rows (profiles/r06_ab_prefill_pp_gemm.jsonl): gate|up 429 -> 368 us, q|k|v 183 -> 170 (NT = 3), o_proj + down 287 -> 238 (NT = 3: 256
+// blocks = one per CU instead of 768 on 512 slots); prompt pass 21.6 -> 19.1 ms.  Where a gate|up launch's time goes (experiment builds of the first version, 461 us):
+// MFMAs alone 250 us (1.86 PFLOP/s: the chip clocks ~1.8 GHz under this load), + copies, reads and barriers 298, + epilogue 383 (after the epilogue below took all
+// lanes; 461 before) -- the first version issued group 1's copies in front of its MFMAs (60-180 issue cycles per copy): 74 us; fragment reads cost nothing.
+#define SPB_STAGE (64 * 1024)
+// NT = n tiles per wave: 4 (256-feature blocks) or 3 (192-feature blocks: N = 768 becomes 4 x 64 = 256 blocks for 16384 rows -- one per CU -- instead of 192, and
+// q|k|v 768 blocks = 3 full rounds instead of 576 = 2.25).  launch_prefill_split_gemm takes the cheaper of the shapes.
+template <int EPI, int NT>
+__global__ __launch_bounds__(512, 1) void prefill_split_gemm_pp_kernel(const SplitGemm p, const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wn = wave & 3;               // wr = row half = phase group
+    int bx = blockIdx.x, by = blockIdx.y;                  // XCD-aware tile order as above
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, seq = lin >> 3, rpx = gridDim.y >> 3;
+        bx = seq / rpx;
+        by = (seq % rpx) * 8 + xcd;
+    }
+    constexpr int NW = 4 * NT;                             // n tiles per block
+    constexpr int NP = 2 * NW + 32;                        // 1 KiB fragments per stage: NW Whi tiles, NW Wlo tiles, 16 Xhi groups, 16 Xlo groups
+    const int nt0 = bx * NW, g0 = by * 16;
+    const int ktiles = p.ktiles;
+    auto src = [&](int f, int kt) -> const char* {          // (f is wave-uniform: the selects are scalar)
+        const half_t* img = (f < NW) ? p.Whi : (f < 2 * NW) ? p.Wlo : (f < 2 * NW + 16) ? p.Xhi : p.Xlo;
+        const int unit = (f < NW) ? nt0 + f : (f < 2 * NW) ? nt0 + f - NW : g0 + ((f - 2 * NW) & 15);
+        return (const char*)img + ((size_t)unit * ktiles + kt) * ((f < 2 * NW) ? 2048 : 1024) + (unsigned)(lane * 16);
+    };
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // a wave's copies of a stage: fragments wave + 8 i, i < NP / 8 (8 or 7 per wave)
+#define SPB_DMA(kt_, buf_)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NP / 8; ++i) {                                                                  \
+        const int f = wave + 8 * i;                                                                                        \
+        __builtin_amdgcn_global_load_lds((gptr_t)src(f, (kt_)), (lptr_t)(lds + (buf_) * SPB_STAGE + f * 1024), 16, 0, 0); \
+    }
+    // s_waitcnt immediates (gfx9): vmcnt[3:0] | [15:14], expcnt[6:4] = 7 (none), lgkmcnt[11:8]
+#define SPB_BAR_VM0_LGKM0 { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#define SPB_BAR_LGKM0 { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    f32x4 acc[NT][8];                                      // [n tile][row group]
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int G = g0 + wr * 4 + g;                     // 16-row group
-        const int row = G * 16 + nn;
-        const bool rv = row < p.R;
-        if (EPI == EPI_RESID) {
-            const int N = a.n_row_tiles * 16;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (!rv) continue;
-                float* xo = a.x_out + (size_t)row * N + (rt0 + t) * 16 + 4 * iq;
-                const f32x4 x = *(const f32x4*)xo, c = acc[t][g];
-                f32x4 dl = {0.f, 0.f, 0.f, 0.f};             // per-utterance LoRA term of o_proj (lora.hip): part of the projection
-                if (a.lora_delta != nullptr) dl = *(const f32x4*)(a.lora_delta + (size_t)row * N + (rt0 + t) * 16 + 4 * iq);
-                *(f32x4*)xo = (f32x4){x[0] + (c[0] * sc + dl[0]), x[1] + (c[1] * sc + dl[1]), x[2] + (c[2] * sc + dl[2]), x[3] + (c[3] * sc + dl[3])};      // residual + proj (llama.py:731,739)
-            }
-        } else if (EPI == EPI_SWIGLU) {
-            // tile rows [8 gate | 8 up]: lanes iq 0,1 hold gate rows 4 iq + j, lanes iq 2,3 the matching up rows
-            const int ktiles_out = (a.n_row_tiles * 8) / 32;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 c = acc[t][g];
-                f32x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(c[j], 32);
-                if (lowh && rv) {
-                    f32x4 y;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float gv = c[j] * sc, uv = o[j] * sc;
-                        y[j] = (gv / (1.0f + expf(-gv))) * uv * (1.0f / SP_ACT_SCALE);
-                    }
-                    half4 h, l;
-                    split_h4(y, h, l, a.sat);              // silu(g) * u / 16 is unbounded: clamp + report, also in the fp32 engine's prompt pass
-                    const size_t off = (size_t)G * ktiles_out * 64 * 8 + xfrag_index<half_t>(nn, (rt0 + t) * 8 + 4 * iq, ktiles_out);
-                    *(half4*)(p.act_hi + off) = h;
-                    *(half4*)(p.act_lo + off) = l;
-                }
-            }
-        } else {                                           // EPI_QKV
-            const int which = rt0 / HT, hh = (rt0 % HT) >> 2;
-            RowMeta m = {0, 0, 0, 0};
-            if (rv && which != 0) m = a.meta[row];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 c = acc[t][g];
-                f32x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(c[j], 32);
-                if (!rv) continue;
-                const int d0 = t * 8 + 4 * (iq & 1);         // first of this lane's 4 frequency indices
-                f32x4 y;
-                f32x4 la = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};      // per-utterance LoRA terms of dims d0.. and d0 + 32.. (lora.hip): before RoPE
-                if (a.lora_delta != nullptr) {
-                    const float* dlp = a.lora_delta + ((size_t)row * 3 + which) * H + hh * CTTS_HEAD_DIM + d0;
-                    la = *(const f32x4*)dlp; lb = *(const f32x4*)(dlp + 32);
-                }
-                if (which < 2) {
-                    const f32x4 cs = *(const f32x4*)(a.rope_rows + (size_t)row * 64 + d0), sn = *(const f32x4*)(a.rope_rows + (size_t)row * 64 + 32 + d0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float va = (lowh ? c[j] : o[j]) * sc + la[j], vb = (lowh ? o[j] : c[j]) * sc + lb[j];
-                        // q*cos + rotate_half(q)*sin (llama.py:180-181), products rounded separately like the reference
-                        const float ya = __fadd_rn(__fmul_rn(va, cs[j]), __fmul_rn(-vb, sn[j]));
-                        const float yb = __fadd_rn(__fmul_rn(vb, cs[j]), __fmul_rn(va, sn[j]));
-                        y[j] = lowh ? ya : yb;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = c[j] * sc + (lowh ? la[j] : lb[j]);
-                }
-                const int dd = d0 + (lowh ? 0 : 32);
-                if (which == 0) *(f32x4*)(a.q_out + ((size_t)row * NH + hh) * CTTS_HEAD_DIM + dd) = y;
-                else *(f32x4*)((float*)(which == 1 ? a.k_cache : a.v_cache) + (((size_t)m.seq * NH + hh) * a.Lmax + m.slot) * CTTS_HEAD_DIM + dd) = y;
-            }
+        for (int g = 0; g < 8; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    half8 wh[NT], wl[NT], xh[8], xl[8];
+#define SPB_READ(buf_)                                                                                 \
+    {                                                                                                   \
+        const char* cur = lds + (buf_) * SPB_STAGE + lane * 16;                                          \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                 \
+            wh[t] = *(const half8*)(cur + (wn * NT + t) * 1024);                                          \
+            wl[t] = *(const half8*)(cur + (NW + wn * NT + t) * 1024);                                     \
+        }                                                                                                \
+        _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                  \
+            xh[g] = *(const half8*)(cur + (2 * NW + wr * 8 + g) * 1024);                                  \
+            xl[g] = *(const half8*)(cur + (2 * NW + 16 + wr * 8 + g) * 1024);                             \
+        }                                                                                                \
+    }
+    // tails first, head product last: the small terms meet while the accumulator's low bits still see them (as in the 128 x 128 kernel)
+#define SPB_MFMA                                                                                         \
+    {                                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                   \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                   \
+            _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                              \
+                acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], xh[g], acc[t][g], 0, 0, 0);     \
+                acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xl[g], acc[t][g], 0, 0, 0);     \
+                acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xh[g], acc[t][g], 0, 0, 0);     \
+            }                                                                                            \
+        __builtin_amdgcn_s_setprio(0);                                                                   \
+    }
+    // Every copy is issued in a READ phase (a copy costs its wave 60-180 issue cycles: in front of group 1's MFMAs it cost the kernel 16 % of its time) and is waited
+    // for at the end of the phase before the stage's first read: group 0's copies have two phases to land, group 1's one.
+    SPB_DMA(0, 0)
+    SPB_DMA(1, 1)                                          // ktiles >= 2 (checked by the launcher)
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NP / 8));         // vmcnt(NP / 8): stage 0 has landed (a wave's copies retire in order)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 0) {
+        for (int kt = 0; kt < ktiles; ++kt) {
+            // phase 2 kt: group 0 reads stage kt.  Buffer (kt + 1) & 1 (stage kt - 1) was last read by group 1 in phase 2 kt - 1: stage kt + 1 may come
+            if (kt >= 1 && kt + 1 < ktiles) SPB_DMA(kt + 1, (kt + 1) & 1)
+            SPB_READ(kt & 1)
+            SPB_BAR_LGKM0
+            // phase 2 kt + 1: group 0 multiplies
+            SPB_MFMA
+            SPB_BAR_VM0_LGKM0                              // own copies of stage kt + 1 landed before anyone reads it in phase 2 kt + 2
+        }
+    } else {
+        __builtin_amdgcn_s_barrier();                      // phase 0: group 1 has nothing to multiply yet
+        __builtin_amdgcn_sched_barrier(0);
+        for (int kt = 0; kt < ktiles; ++kt) {
+            // phase 2 kt + 1: group 1 reads stage kt; its copies of stage kt + 1 go into the other buffer (free since the end of phase 2 kt - 1) and land within this phase
+            if (kt >= 1 && kt + 1 < ktiles) SPB_DMA(kt + 1, (kt + 1) & 1)
+            SPB_READ(kt & 1)
+            SPB_BAR_VM0_LGKM0                              // fragments in registers; own copies of stage kt + 1 landed
+            // phase 2 kt + 2: group 1 multiplies
+            SPB_MFMA
+            if (kt + 1 < ktiles) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }      // (group 0 left after phase 2 ktiles - 1)
         }
     }
+#undef SPB_DMA
+#undef SPB_READ
+#undef SPB_MFMA
+#undef SPB_BAR_VM0_LGKM0
+#undef SPB_BAR_LGKM0
+    sp_epilogue<EPI, 8, NT>(acc, p, a, lane, nt0 + wn * NT, g0 + wr * 8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,28 +586,46 @@ int launch_split_pack(const float* src, void* hi, void* lo, int R, hipStream_t s
 }
 
 template <int EPI>
-static int sp_launch(const SplitGemm& p, const GemmArgs& a, hipStream_t s) {
+static int sp_launch(const SplitGemm& p, const GemmArgs& a, int pp_min_blocks, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_RING * SP_STAGE));
+        CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_pp_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SPB_STAGE));
+        CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_pp_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SPB_STAGE));
         configured = true;
     }
-    dim3 grid(a.n_row_tiles / 8, (p.R + 127) / 128);
-    hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI>), grid, dim3(256), SP_RING * SP_STAGE, s, p, a);
+    // Block shape by a round count (256 CUs; measured per-round times at K = 768, 32 x 512 prompt rows: 128 x 128 blocks, 512 at a time: 36 us; 256 x 256 blocks,
+    // one per CU: 60 us; 256 x 192: 45 us): the 128 x 128 kernel for short passes, the counter-phased kernel once its blocks fill the chip.  pp_min_blocks < 0 forces
+    // the counter-phased kernel with NT = -pp_min_blocks (tests, A/B).
+    const int rb = (p.R + 255) / 256, nt = a.n_row_tiles;
+    const int b_old = (nt / 8) * ((p.R + 127) / 128);
+    const long c_old = (long)((b_old + 511) / 512) * 36;
+    const int b4 = (nt % 16 == 0) ? (nt / 16) * rb : 0, b3 = (nt % 12 == 0) ? (nt / 12) * rb : 0;
+    const long c4 = b4 ? (long)((b4 + 255) / 256) * 60 : (1L << 40), c3 = b3 ? (long)((b3 + 255) / 256) * 45 : (1L << 40);
+    int shape = 0;                                          // 0: 128 x 128; 3 / 4: counter-phased, NT
+    if (pp_min_blocks < 0) shape = (-pp_min_blocks == 3 && b3) ? 3 : (b4 ? 4 : (b3 ? 3 : 0));
+    else if (pp_min_blocks > 0) {
+        if (b4 >= pp_min_blocks && c4 < c_old && c4 <= c3) shape = 4;
+        else if (b3 >= pp_min_blocks && c3 < c_old) shape = 3;
+    }
+    if (shape == 4) hipLaunchKernelGGL((prefill_split_gemm_pp_kernel<EPI, 4>), dim3(nt / 16, rb), dim3(512), 2 * SPB_STAGE, s, p, a);
+    else if (shape == 3) hipLaunchKernelGGL((prefill_split_gemm_pp_kernel<EPI, 3>), dim3(nt / 12, rb), dim3(512), 2 * SPB_STAGE, s, p, a);
+    else hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI>), dim3(nt / 8, (p.R + 127) / 128), dim3(256), SP_RING * SP_STAGE, s, p, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// W / X: head and tail images; the operand buffers must cover whole 128-row blocks (gpt_engine.hip allocates PASS_ROWS + 256 rows).
+// W / X: head and tail images; the operand buffers must cover whole 256-row blocks (gpt_engine.hip allocates PASS_ROWS + 256 rows, PASS_ROWS a multiple of 256).
+// pp_min_blocks (option "prefill_pp_blocks"): the counter-phased kernel may serve a product that has at least this many of its blocks (0 = never; see sp_launch).
 int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Wsplit, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,
-                              float scale, hipStream_t s) {
+                              float scale, int pp_min_blocks, hipStream_t s) {
     SplitGemm p;
     p.Whi = (const half_t*)Wsplit; p.Wlo = (const half_t*)Wsplit + 512; p.Xhi = (const half_t*)Xhi; p.Xlo = (const half_t*)Xlo;
     p.ktiles = a.K / 32; p.R = a.R; p.scale = scale; p.act_hi = (half_t*)act_hi; p.act_lo = (half_t*)act_lo;
     if ((a.n_row_tiles % 8) != 0 || p.ktiles < 2) { ctts_set_error("prefill_split_gemm: %d n tiles / K = %d not supported", a.n_row_tiles, a.K); return 1; }
-    if (epi == EPI_QKV) return sp_launch<EPI_QKV>(p, a, s);
-    if (epi == EPI_SWIGLU) return sp_launch<EPI_SWIGLU>(p, a, s);
-    if (epi == EPI_RESID) return sp_launch<EPI_RESID>(p, a, s);
+    if (epi == EPI_QKV) return sp_launch<EPI_QKV>(p, a, pp_min_blocks, s);
+    if (epi == EPI_SWIGLU) return sp_launch<EPI_SWIGLU>(p, a, pp_min_blocks, s);
+    if (epi == EPI_RESID) return sp_launch<EPI_RESID>(p, a, pp_min_blocks, s);
     ctts_set_error("prefill_split_gemm: unsupported epilogue %d", epi);
     return 1;
 }

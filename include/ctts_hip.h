@@ -87,6 +87,9 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "persistent_delay", "persistent_delay_act", "persistent_delay_x", "persistent_delay_att", "persistent_nap", "persistent_nap_qkv"  when and how often the edge waves poll
  *   "persistent_poll"     0 / 1: sentinel granules before the full sweeps (default 0)
  *   "persistent_timestamps" diagnostics: the persistent launches record per-workgroup phase marks
+ *   "prefill_pp_blocks"   fp32 engines, prompt pass: a split GEMM may run on 256-row blocks with two counter-phased wave groups (prefill_split.hip) when it has at
+ *                         least this many such blocks and the round count on 256 CUs favours it (default 1; 0 = 128 x 128 blocks only; -4 / -3 = always, with
+ *                         that many n tiles per wave: tests).  All shapes give bit-identical results
  *   "attn_wide_blocks"    unsplit decode attention takes 8-wave blocks while rows x heads < this (default 512 on fp32 engines, 4096 on fp16 engines; 0 = 256, the limit until round 6)
  *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection as launch slices up to this batch size (default 8)
  *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 9; 0 = never)

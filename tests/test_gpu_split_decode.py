@@ -98,6 +98,30 @@ def test_split_decode_rows_are_independent_of_the_batch_they_ride_in(gpt):
         assert torch.equal(ids32[b], ids9[b]), b
 
 
+@pytest.mark.parametrize("B,P,pad", [(24, 40, [(7 * i) % 36 for i in range(24)]), (7, 300, [(41 * i) % 200 for i in range(7)]), (40, 390, None)])
+def test_prompt_pass_block_shapes_agree_bitwise(gpt, B, P, pad):
+    """The prompt pass's split GEMMs (llama.py:619-621,666,737-739 over all prompt rows) have three block shapes: 128 x 128 (two blocks per CU) and, for long passes,
+    256 rows x 256 or 192 features with two counter-phased wave groups (prefill_split_gemm_pp_kernel<EPI, 4 | 3>; option `prefill_pp_blocks`: 0 = never, -4 / -3 =
+    always that shape, > 0 = by round count).  Every output element accumulates its k-tiles in the same order in all of them, so tokens AND hidden states must agree
+    bit for bit -- at row counts that are no multiple of 256 (960, 2100: partial last blocks) and at the largest pass this engine holds (15600 rows)."""
+    g = gpt
+    base = g.get_option("prefill_pp_blocks")
+    assert base > 0, "long prompt passes may take the counter-phased kernel by default"
+    try:
+        g.set_option("prefill_pp_blocks", 0)
+        ref_ids, ref_h = _gen(g, B, P, 3, pad)
+        outs = {}
+        for shape in (-4, -3, base):
+            g.set_option("prefill_pp_blocks", shape)
+            outs[shape] = _gen(g, B, P, 3, pad)
+    finally:
+        g.set_option("prefill_pp_blocks", base)
+    for shape, (ids, hid) in outs.items():
+        for b in range(B):
+            assert torch.equal(ids[b], ref_ids[b]), (shape, B, P, b)
+            assert torch.equal(hid[b], ref_h[b]), (shape, B, P, b, float((hid[b] - ref_h[b]).abs().max()))
+
+
 def test_an_engine_without_the_images_refuses_the_option():
     from chatttsplus_amd.hip_models import GPT
     g = GPT(LLAMA, max_batch=12, max_seq_len=30, weight_dtype="fp32", options={"split_decode_rows": 0, "prefill_split_rows": 0})
