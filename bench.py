@@ -383,6 +383,9 @@ def run_reps(leg, reps, *a, **kw):
     r = rs[order[len(order) // 2]]
     ms = sorted(x["dt"] / x["K"] * 1e3 for x in rs)
     r["spread_ms_per_step"] = {"reps": len(rs), "min": round(ms[0], 5), "median": round(ms[len(ms) // 2], 5), "max": round(ms[-1], 5)}
+    pf = sorted(x["prefill_ms"] for x in rs)                 # the prompt pass likewise: the median rep's (the first pass of a shape pays first-touch costs), spread attached
+    r["prefill_ms"] = pf[len(pf) // 2]
+    r["spread_prefill_ms"] = {"reps": len(rs), "min": round(pf[0], 3), "median": round(pf[len(pf) // 2], 3), "max": round(pf[-1], 3)}
     return r
 
 
@@ -509,6 +512,8 @@ def summarize(r, world):
     out = _summary(r, world, step_ms, ach)
     if "spread_ms_per_step" in r:
         out["spread_ms_per_step"] = r["spread_ms_per_step"]
+    if "spread_prefill_ms" in r:
+        out["spread_prefill_plus_first_sample_ms"] = r["spread_prefill_ms"]
     return out
 
 

@@ -394,6 +394,13 @@ __global__ __launch_bounds__(512, 1) void prefill_split_gemm_pp_kernel(const Spl
 #ifndef FS_WAVES
 #define FS_WAVES 8          // waves (16 queries each) per block: 8 since round 6 (4 before)
 #endif
+// FS_EXP: the softmax exponential.  The parity engine keeps the correctly rounded expf (13 VALU instructions; half of the loop's 444 per 64-key chunk against 48 MFMAs:
+// the kernel is VALU-bound on it).  -DFS_FAST_EXP (A/B builds only, never shipped: profiles/r06_ab_prefill_pp_gemm.jsonl) takes v_exp_f32 (2 instructions, ~1 ulp).
+#ifdef FS_FAST_EXP
+#define FS_EXP(x_) __builtin_amdgcn_exp2f((x_) * 1.44269504088896341f)
+#else
+#define FS_EXP(x_) expf(x_)
+#endif
 __global__ __launch_bounds__(64 * FS_WAVES) void attn_prefill_split_kernel(const RowMeta* meta_p, const float* q_p, const float* k_p, const float* v_p, const int NHp, const int R,
                                                                const AttnArgs a, half_t* out_hi, half_t* out_lo) {
     extern __shared__ __attribute__((aligned(16))) char fs_lds[];
@@ -507,14 +514,14 @@ __global__ __launch_bounds__(64 * FS_WAVES) void attn_prefill_split_kernel(const
             mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
             const float mn = fmaxf(mrun, mloc);
-            const float sc = (mrun == -INFINITY) ? 0.f : expf(mrun - mn);
+            const float sc = (mrun == -INFINITY) ? 0.f : FS_EXP(mrun - mn);
             float ps = 0.f;
             half4 pTh[4], pTl[4];
 #pragma unroll
             for (int tl = 0; tl < 4; ++tl) {
                 f32x4 pv;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { pv[j] = (sT[tl][j] == -INFINITY) ? 0.f : expf(sT[tl][j] - mn); ps += pv[j]; }
+                for (int j = 0; j < 4; ++j) { pv[j] = (sT[tl][j] == -INFINITY) ? 0.f : FS_EXP(sT[tl][j] - mn); ps += pv[j]; }
                 split_h4(pv, pTh[tl], pTl[tl]);
             }
             lpart = lpart * sc + ps;

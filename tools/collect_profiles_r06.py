@@ -6,7 +6,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(ROOT, "gpurun_out", "fin_r06b" if "b" in sys.argv[1:] else "fin_r06")      # `b`: the second collection (tools/final_run_r06b.sh) over the first
+F = os.path.join(ROOT, "gpurun_out", "fin_r06c" if "c" in sys.argv[1:] else "fin_r06b" if "b" in sys.argv[1:] else "fin_r06")      # `b` / `c`: the later collections (tools/final_run_r06b.sh, r06c.sh) over the first
 P = os.path.join(ROOT, "profiles")
 pairs = {"bench_b1_fp32.json": "r06_bench_b1_fp32.json", "bench_b1_fp32_steps20.json": "r06_bench_b1_fp32_steps20.json", "bench_b32_fp32.json": "r06_bench_b32_fp32.json",
          "b1_fp32_kernel_stats.csv": "r06_b1_fp32_kernel_stats.csv", "b32_fp32_kernel_stats.csv": "r06_b32_fp32_kernel_stats.csv", "b8_fp32_kernel_stats.csv": "r06_b8_fp32_kernel_stats.csv",
@@ -18,7 +18,24 @@ for src, dst in pairs.items():
     if os.path.exists(sp) and os.path.getsize(sp) > 0:
         shutil.copy(sp, os.path.join(P, dst))
     else:
-        print("missing", src) if "b" not in sys.argv[1:] else None
+        print("missing", src) if not ({"b", "c"} & set(sys.argv[1:])) else None
+if "c" in sys.argv[1:]:          # third collection: the prompt pass per block shape of its split GEMMs
+    for src, dst in (("stats_32x512_pp_0.csv", "r06_prefill_pp_kernel_stats_128x128.csv"), ("stats_32x512_pp_1.csv", "r06_prefill_pp_kernel_stats_policy.csv"),
+                     ("prefill_shapes_e2e.log", "r06_prefill_shapes_e2e.log")):
+        if os.path.exists(os.path.join(F, src)):
+            shutil.copy(os.path.join(F, src), os.path.join(P, dst))
+    try:
+        mf = json.load(open(os.path.join(F, "pmc_mfma_split.json")))["kernels"]
+        ld = json.load(open(os.path.join(F, "pmc_lds_split.json")))
+        old = json.load(open(os.path.join(P, "r06_pmc_mfma_split.json")))
+        old["prompt_pass_32x512_fp32_counter_phased_gemms"] = {k: {"calls": v["calls"], "avg_us": round(v["avg_us"], 2), "mfma_busy_share_of_simd_cycles_at_2p4GHz": round(v["mfma_busy_share_of_simd_cycles_at_2p4GHz"], 4)}
+                                                                for k, v in mf.items() if "prefill" in k or "skinny" in k}
+        old["prompt_pass_32x512_fp32_counter_phased_gemms"]["lds_pass"] = ld
+        old["note_counter_phased"] = ("third collection (tools/final_run_r06c.sh): the same two counter passes with the split GEMMs on 256-row counter-phased blocks "
+                                      "(prefill_split_gemm_pp_kernel<EPI, NT>; default policy)")
+        json.dump(old, open(os.path.join(P, "r06_pmc_mfma_split.json"), "w"), indent=1)
+    except Exception as e:
+        print("no MFMA-busy pass:", e)
 fp = os.path.join(F, "bench_b1_fp32_steps20_force_pg.json")
 if os.path.exists(fp):          # (RCCL's banner lines, if any, are not part of the evidence)
     lines = [l for l in open(fp) if l.startswith("{")]
