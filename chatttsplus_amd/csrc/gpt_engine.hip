@@ -94,6 +94,7 @@ struct ctts_gpt {
     int rope_n = 0;
     char* kv = nullptr;
     size_t kv_bytes = 0;
+    float* sk_scratch = nullptr; size_t sk_cap_floats = 0;      // split-K partial outputs of short prompt passes (finalize)
     float *x_dec = nullptr, *x_last = nullptr, *x_pre = nullptr, *q_buf = nullptr, *part_ml = nullptr, *part_o = nullptr, *logits = nullptr;
     void* act = nullptr;
     void* attn_packed = nullptr;
@@ -141,6 +142,7 @@ struct ctts_gpt {
                                                  //   batch 1 0.362 / 0.350 / 0.301 / 0.315, 2: 0.417 / 0.410 / 0.349 / 0.353, 4: 0.486 / 0.513 / 0.441 / 0.430; profiles/r06_ab_lora_persistent.jsonl)
     int prefill_pp_blocks = 1;                   // "prefill_pp_blocks": a split GEMM of the prompt pass may run on prefill_split_gemm_pp_kernel (256-row blocks, counter-phased wave groups) when it has
                                                  //   at least this many such blocks and the round count favours it (prefill_split.hip sp_launch); 0 = never
+    int prefill_sk_rows = 2048;                  // "prefill_splitk_rows": prompt passes of <= this many rows slice the down projection's K four ways (prefill_split.hip sp_launch; 0 = never)
     int attn_wide_blocks = 0;                    // "attn_wide_blocks": decode attention takes 8-wave blocks while rows x heads < this (0 = 256).  Set at create: 512 (fp32) / 4096 (fp16).
                                                  //   Until round 6 the limit was one block per CU (256), tuned on the round-4 attention layout; on the V-one-dim-per-lane layout
                                                  //   8-wave blocks win further up (ms/step 4-wave / 8-wave, fp32: 22 rows 0.749 / 0.724, 28: 0.773 / 0.749, 32: 0.785 / 0.768, 40: 0.946 / 0.939,
@@ -366,6 +368,7 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     else if (n == "persistent_share_keys") *value = h->persist_share_keys;
     else if (n == "attn_wide_blocks") *value = h->attn_wide_blocks;
     else if (n == "prefill_pp_blocks") *value = h->prefill_pp_blocks;
+    else if (n == "prefill_splitk_rows") *value = h->prefill_sk_rows;
     else if (n == "persistent_delay_lora") *value = h->persist_delay_u;
     else if (n == "valu_rows") *value = h->valu_rows;
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
@@ -406,6 +409,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         if (h->persist_rows > 0 && ensure_persist(h, true)) { h->persist_rows = 0; return 1; }
     } else if (n == "persistent_delay_lora") {
         h->persist_delay_u = value < 0 ? -1 : (value > 256 ? 256 : value);
+    } else if (n == "prefill_splitk_rows") {
+        h->prefill_sk_rows = value < 0 ? 0 : value;
     } else if (n == "prefill_pp_blocks") {
         h->prefill_pp_blocks = value < -4 ? 0 : value;      // -3 / -4: always the counter-phased kernel with that many n tiles per wave (tests, A/B)
     } else if (n == "attn_wide_blocks") {
@@ -473,7 +478,7 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
 extern "C" void ctts_gpt_destroy(ctts_gpt* h) {
     if (!h) return;
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
-    void* bufs[] = {h->dyn, h->wblob, h->wsplit, h->whead_sp, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
+    void* bufs[] = {h->sk_scratch, h->dyn, h->wblob, h->wsplit, h->whead_sp, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, h->whead_text, h->lnf, h->emb_code, h->emb_text, h->rope, h->x_dec, h->x_last, h->x_pre, h->q_buf, h->part_ml, h->part_o, h->logits,
                     h->act, h->attn_packed, h->norm_packed, h->dpart, h->rope_pre, h->rope_dec, h->meta_pre, h->meta_dec, h->meta_dec0, h->st, h->last_rows,
                     h->hist_ring, h->sat, h->finend, h->xh, h->ssq, h->scale_o, h->scale_d, h->cx, h->crope, h->cmeta, h->cring, h->cfin, h->keep_dev,
                     h->lora_A, h->lora_B, h->lora_Af, h->lora_scale, h->ln1, h->lora_slot_of_seq, h->lora_dqkv, h->lora_do, h->lora_g, h->pimg, h->pimg_head, h->pl_g, h->pl_epoch, h->pl_error, h->pl_ts, h->sk_slab, h->sk_cnt};
@@ -878,6 +883,9 @@ extern "C" int ctts_gpt_finalize(ctts_gpt* h) {
     if (h->wsplit) {     // operand images of the prompt rows for the split GEMMs: heads / tails of the normalised rows | attention outputs (K = 768) and of the SwiGLU outputs (K = 3072)
         const size_t rows = (size_t)PASS_ROWS + PASS_PAD;
         if (dev_alloc(&h->sp_x_hi, rows * H * 2) || dev_alloc(&h->sp_x_lo, rows * H * 2) || dev_alloc(&h->sp_act_hi, rows * h->I * 2) || dev_alloc(&h->sp_act_lo, rows * h->I * 2)) return 1;
+        // short passes slice the down projection's K four ways (prefill_split.hip sp_launch): the slices' partial outputs [4][rows <= 2048, padded to 128][H] fp32 (<= 25 MB)
+        h->sk_cap_floats = (size_t)4 * (size_t)(((PASS_ROWS < 2048 ? PASS_ROWS : 2048) + 127) / 128 * 128) * H;
+        if (dev_alloc((void**)&h->sk_scratch, h->sk_cap_floats * 4)) return 1;
     }
     CTTS_HIP_CHECK(hipHostMalloc((void**)&h->host_pin, 64));
     {
@@ -973,6 +981,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // (round 5: also with per-utterance adapters -- their low-rank terms come from the two lora.hip launches per layer and are added in the split GEMMs' epilogues)
     const bool pfs = prepack && (dt == CTTS_DTYPE_F32) && h->wsplit != nullptr && h->split_rows_min > 0 && (R >= h->split_rows_min);
     const float sp_scale = 1.0f / 64.0f;
+    const SplitGemmPolicy sp_pol = {h->prefill_pp_blocks, h->prefill_sk_rows, h->sk_scratch, h->sk_cap_floats};
     // decode above the split-K batch sizes: the residual stream travels between kernels as a packed B operand in the engine dtype + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself.  (Handing gate|up
     // the packed copy at batches <= 4 too was measured slower in fp16: batch 1 393 vs 381 us/step, 2 415 vs 403, 4 450 vs 443.)
@@ -1051,7 +1060,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         }
         if (pfs) {
             if (launch_norm_pack_split(x, h->sp_x_hi, h->sp_x_lo, R, a.eps, s)) return 1;
-            if (launch_prefill_split_gemm(EPI_QKV, g1, h->lw[l].qkv_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, h->prefill_pp_blocks, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_QKV, g1, h->lw[l].qkv_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, sp_pol, s)) return 1;
         } else if (prepack) {
             g1.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
@@ -1086,7 +1095,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
             g2.lora_delta = h->lora_do;
         }
         if (pfs && S == 1) {
-            if (launch_prefill_split_gemm(EPI_RESID, g2, h->lw[l].o_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, h->prefill_pp_blocks, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_RESID, g2, h->lw[l].o_sp, h->sp_x_hi, h->sp_x_lo, nullptr, nullptr, sp_scale, sp_pol, s)) return 1;
         } else if (pfg && S == 1) { if (launch_prefill_gemm(EPI_RESID, g2, s)) return 1; }
         else {
             if (spd) g2.W = h->lw[l].o_sp;
@@ -1098,7 +1107,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         g3.W = h->lw[l].gu; g3.n_row_tiles = 2 * h->I / 16; g3.K = h->H; g3.x = x; g3.act_out = h->act;
         if (pfs) {
             if (launch_norm_pack_split(x, h->sp_x_hi, h->sp_x_lo, R, a.eps, s)) return 1;
-            if (launch_prefill_split_gemm(EPI_SWIGLU, g3, h->lw[l].gu_sp, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, sp_scale, h->prefill_pp_blocks, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_SWIGLU, g3, h->lw[l].gu_sp, h->sp_x_hi, h->sp_x_lo, h->sp_act_hi, h->sp_act_lo, sp_scale, sp_pol, s)) return 1;
         } else if (prepack) {
             g3.xpacked = h->norm_packed;
             if (launch_norm_pack(dt, x, h->norm_packed, R, nbg, a.eps, s)) return 1;
@@ -1112,7 +1121,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
         GemmArgs g4 = a;
         g4.W = h->lw[l].d; g4.n_row_tiles = h->H / 16; g4.K = h->I; g4.xpacked = h->act; g4.x_out = x;
         if (pfs) {      // the SwiGLU images hold silu(g) * u / 16
-            if (launch_prefill_split_gemm(EPI_RESID, g4, h->lw[l].d_sp, h->sp_act_hi, h->sp_act_lo, nullptr, nullptr, sp_scale * 16.0f, h->prefill_pp_blocks, s)) return 1;
+            if (launch_prefill_split_gemm(EPI_RESID, g4, h->lw[l].d_sp, h->sp_act_hi, h->sp_act_lo, nullptr, nullptr, sp_scale * 16.0f, sp_pol, s)) return 1;
         } else if (pfg) {
             if (launch_prefill_gemm(EPI_RESID, g4, s)) return 1;
         } else if (splitd) {

@@ -179,8 +179,15 @@ int launch_prefill_gemm(int epi, const GemmArgs& a, hipStream_t s);      // pref
 int launch_norm_pack_split(const float* x, void* hi, void* lo, int R, float eps, hipStream_t s);                    // prefill_split.hip (fp32 engine, >= 1536 prompt rows)
 int launch_split_pack(const float* src, void* hi, void* lo, int R, hipStream_t s);
 int launch_attention_split(const AttnArgs& a, void* out_hi, void* out_lo, hipStream_t s);
+// how a split GEMM of the prompt pass is laid on the chip (prefill_split.hip sp_launch)
+struct SplitGemmPolicy {
+    int pp_min_blocks;          // "prefill_pp_blocks": 256-row counter-phased blocks when there are at least this many and the round count favours them (0 = never, -4 / -3 = always)
+    int sk_rows;                // "prefill_splitk_rows": passes of <= this many rows slice the down projection's K four ways (0 = never)
+    float* sk_scratch;          //   the slices' partial outputs [4][rows padded to 128][N] (an engine buffer for <= 2048 rows)
+    size_t sk_cap_floats;
+};
 int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Wsplit, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,
-                              float scale, int pp_min_blocks, hipStream_t s);      // Wsplit: [n tile][k tile][head | tail][lane][16 B] (common.h split_t)
+                              float scale, const SplitGemmPolicy& pol, hipStream_t s);      // Wsplit: [n tile][k tile][head | tail][lane][16 B] (common.h split_t)
 int launch_norm_pack(int dtype, const float* x, void* out_packed, int R, int nbg, float eps, hipStream_t s);
 int launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 int launch_sampler(const SamplerArgs& a, int blocks, hipStream_t s);

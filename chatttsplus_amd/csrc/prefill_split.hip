@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* src, half_
 struct SplitGemm {
     const half_t *Whi, *Wlo, *Xhi, *Xlo;   // fragment images: W [n tile][k tile][head | tail][lane][8] (Wlo = Whi + 1 KiB: the tile pairs of common.h split_t), X [16-row group][k tile][lane][8]
     int ktiles, R;
+    int kt_per;                             // k-tiles one block multiplies: ktiles, or ktiles / 4 when grid.z slices K (EPI_PART: short passes of the down projection, sp_launch)
+    size_t part_stride;                     // EPI_PART: floats between two slices' partial outputs [slice][row][N] (GemmArgs.part_out)
     float scale;                            // applied to the accumulators: 1 / SP_WSCALE (x SP_ACT_SCALE for the down projection)
     half_t *act_hi, *act_lo;                // EPI_SWIGLU: output images [16-row group][96 k-tiles][lane][8] of silu(g) * u / SP_ACT_SCALE
 };
@@ -110,6 +112,14 @@ __device__ __forceinline__ void sp_epilogue(f32x4 (&acc)[NT][NG], const SplitGem
                 f32x4 dl = {0.f, 0.f, 0.f, 0.f};             // per-utterance LoRA term of o_proj (lora.hip): part of the projection
                 if (a.lora_delta != nullptr) dl = *(const f32x4*)(a.lora_delta + (size_t)row * N + (rt0 + t) * 16 + 4 * iq);
                 *(f32x4*)xo = (f32x4){x[0] + (c[0] * sc + dl[0]), x[1] + (c[1] * sc + dl[1]), x[2] + (c[2] * sc + dl[2]), x[3] + (c[3] * sc + dl[3])};      // residual + proj (llama.py:731,739)
+            }
+        } else if (EPI == EPI_PART) {                      // a K slice's share of the product, scaled; resid_combine_kernel adds the slices in order and the residual
+            const int N = a.n_row_tiles * 16;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (!rv) continue;
+                const f32x4 c = acc[t][g];
+                *(f32x4*)(a.part_out + (size_t)blockIdx.z * p.part_stride + (size_t)row * N + (rt0 + t) * 16 + 4 * iq) = (f32x4){c[0] * sc, c[1] * sc, c[2] * sc, c[3] * sc};
             }
         } else if (EPI == EPI_SWIGLU) {
             // tile rows [8 gate | 8 up]: lanes iq 0,1 hold gate rows 4 iq + j, lanes iq 2,3 the matching up rows.  Every lane finishes TWO outputs (round 6; the gate
@@ -195,12 +205,13 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
         by = (seq % rpx) * 8 + xcd;
     }
     const int nt0 = bx * 8, g0 = by * 8;                   // first n tile / first 16-row group of the block
-    const int ktiles = p.ktiles;
+    const int ktiles = p.kt_per;                           // this block's k-tiles: all of them, or slice blockIdx.z (EPI_PART)
+    const int kt_all = p.ktiles, kt0 = blockIdx.z * p.kt_per;
     // fragment f of a stage: 0..7 Whi tiles, 8..15 Wlo tiles, 16..23 Xhi groups, 24..31 Xlo groups
     auto src = [&](int f, int kt) -> const char* {
         const half_t* img = (f < 8) ? p.Whi : (f < 16) ? p.Wlo : (f < 24) ? p.Xhi : p.Xlo;
         const int unit = (f < 16) ? nt0 + (f & 7) : g0 + (f & 7);
-        return (const char*)img + ((size_t)unit * ktiles + kt) * ((f < 16) ? 2048 : 1024) + (unsigned)(lane * 16);
+        return (const char*)img + ((size_t)unit * kt_all + kt0 + kt) * ((f < 16) ? 2048 : 1024) + (unsigned)(lane * 16);
     };
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -592,18 +603,32 @@ int launch_split_pack(const float* src, void* hi, void* lo, int R, hipStream_t s
     return 0;
 }
 
+// x[row][n] += ((p0 + p1) + p2) + p3: the K slices of a short pass's down projection in slice order, then the residual (llama.py:739) -- fixed order, no atomics
+__global__ __launch_bounds__(256) void resid_combine_kernel(const float* part, const size_t part_stride, float* x, const int n4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // one f32x4 of [R][N]
+    if (i >= n4) return;
+    const f32x4 p0 = ((const f32x4*)part)[i], p1 = ((const f32x4*)(part + part_stride))[i], p2 = ((const f32x4*)(part + 2 * part_stride))[i], p3 = ((const f32x4*)(part + 3 * part_stride))[i];
+    const f32x4 xv = ((const f32x4*)x)[i];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = xv[j] + (((p0[j] + p1[j]) + p2[j]) + p3[j]);
+    ((f32x4*)x)[i] = o;
+}
+
 template <int EPI>
-static int sp_launch(const SplitGemm& p, const GemmArgs& a, int pp_min_blocks, hipStream_t s) {
+static int sp_launch(SplitGemm& p, const GemmArgs& a, const SplitGemmPolicy& pol, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_RING * SP_STAGE));
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_pp_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SPB_STAGE));
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_pp_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SPB_STAGE));
+        if (EPI == EPI_RESID) CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI_PART>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_RING * SP_STAGE));
         configured = true;
     }
     // Block shape by a round count (256 CUs; measured per-round times at K = 768, 32 x 512 prompt rows: 128 x 128 blocks, 512 at a time: 36 us; 256 x 256 blocks,
     // one per CU: 60 us; 256 x 192: 45 us): the 128 x 128 kernel for short passes, the counter-phased kernel once its blocks fill the chip.  pp_min_blocks < 0 forces
     // the counter-phased kernel with NT = -pp_min_blocks (tests, A/B).
+    const int pp_min_blocks = pol.pp_min_blocks;
     const int rb = (p.R + 255) / 256, nt = a.n_row_tiles;
     const int b_old = (nt / 8) * ((p.R + 127) / 128);
     const long c_old = (long)((b_old + 511) / 512) * 36;
@@ -615,6 +640,22 @@ static int sp_launch(const SplitGemm& p, const GemmArgs& a, int pp_min_blocks, h
         if (b4 >= pp_min_blocks && c4 < c_old && c4 <= c3) shape = 4;
         else if (b3 >= pp_min_blocks && c3 < c_old) shape = 3;
     }
+    // Short passes of the down projection (K = 3072: 96 k-tiles in a row, 6 blocks per 128 rows -- 24 blocks on 256 CUs at 448 rows, 75 of the layer's 170 us): K sliced
+    // four ways over grid.z, the slices' shares parked in `pol.sk_scratch`, resid_combine_kernel adds them in slice order and the residual.  Another summation order
+    // than the unsliced kernel's (the usual 1e-7); a.lora_delta never rides here (the o_proj products have K = 768).
+    const size_t rows_pad = (size_t)((p.R + 127) / 128) * 128;
+    if (EPI == EPI_RESID && shape == 0 && pol.sk_rows > 0 && p.R <= pol.sk_rows && p.ktiles >= 64 && (p.ktiles & 3) == 0 && a.lora_delta == nullptr &&
+        pol.sk_scratch != nullptr && 4 * rows_pad * (size_t)(nt * 16) <= pol.sk_cap_floats) {
+        GemmArgs ap = a;
+        ap.part_out = pol.sk_scratch;
+        p.kt_per = p.ktiles / 4; p.part_stride = rows_pad * (size_t)(nt * 16);
+        hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI_PART>), dim3(nt / 8, (p.R + 127) / 128, 4), dim3(256), SP_RING * SP_STAGE, s, p, ap);
+        CTTS_HIP_CHECK(hipGetLastError());
+        const int n4 = p.R * nt * 4;                        // f32x4 elements of [R][N]
+        hipLaunchKernelGGL(resid_combine_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, (const float*)pol.sk_scratch, p.part_stride, a.x_out, n4);
+        CTTS_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (shape == 4) hipLaunchKernelGGL((prefill_split_gemm_pp_kernel<EPI, 4>), dim3(nt / 16, rb), dim3(512), 2 * SPB_STAGE, s, p, a);
     else if (shape == 3) hipLaunchKernelGGL((prefill_split_gemm_pp_kernel<EPI, 3>), dim3(nt / 12, rb), dim3(512), 2 * SPB_STAGE, s, p, a);
     else hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI>), dim3(nt / 8, (p.R + 127) / 128), dim3(256), SP_RING * SP_STAGE, s, p, a);
@@ -623,16 +664,16 @@ static int sp_launch(const SplitGemm& p, const GemmArgs& a, int pp_min_blocks, h
 }
 
 // W / X: head and tail images; the operand buffers must cover whole 256-row blocks (gpt_engine.hip allocates PASS_ROWS + 256 rows, PASS_ROWS a multiple of 256).
-// pp_min_blocks (option "prefill_pp_blocks"): the counter-phased kernel may serve a product that has at least this many of its blocks (0 = never; see sp_launch).
+// pol: block shape / K slicing policy (kernels.h SplitGemmPolicy; options "prefill_pp_blocks", "prefill_splitk_rows").
 int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Wsplit, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,
-                              float scale, int pp_min_blocks, hipStream_t s) {
+                              float scale, const SplitGemmPolicy& pol, hipStream_t s) {
     SplitGemm p;
     p.Whi = (const half_t*)Wsplit; p.Wlo = (const half_t*)Wsplit + 512; p.Xhi = (const half_t*)Xhi; p.Xlo = (const half_t*)Xlo;
-    p.ktiles = a.K / 32; p.R = a.R; p.scale = scale; p.act_hi = (half_t*)act_hi; p.act_lo = (half_t*)act_lo;
+    p.ktiles = a.K / 32; p.kt_per = p.ktiles; p.part_stride = 0; p.R = a.R; p.scale = scale; p.act_hi = (half_t*)act_hi; p.act_lo = (half_t*)act_lo;
     if ((a.n_row_tiles % 8) != 0 || p.ktiles < 2) { ctts_set_error("prefill_split_gemm: %d n tiles / K = %d not supported", a.n_row_tiles, a.K); return 1; }
-    if (epi == EPI_QKV) return sp_launch<EPI_QKV>(p, a, pp_min_blocks, s);
-    if (epi == EPI_SWIGLU) return sp_launch<EPI_SWIGLU>(p, a, pp_min_blocks, s);
-    if (epi == EPI_RESID) return sp_launch<EPI_RESID>(p, a, pp_min_blocks, s);
+    if (epi == EPI_QKV) return sp_launch<EPI_QKV>(p, a, pol, s);
+    if (epi == EPI_SWIGLU) return sp_launch<EPI_SWIGLU>(p, a, pol, s);
+    if (epi == EPI_RESID) return sp_launch<EPI_RESID>(p, a, pol, s);
     ctts_set_error("prefill_split_gemm: unsupported epilogue %d", epi);
     return 1;
 }

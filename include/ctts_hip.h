@@ -90,6 +90,9 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "prefill_pp_blocks"   fp32 engines, prompt pass: a split GEMM may run on 256-row blocks with two counter-phased wave groups (prefill_split.hip) when it has at
  *                         least this many such blocks and the round count on 256 CUs favours it (default 1; 0 = 128 x 128 blocks only; -4 / -3 = always, with
  *                         that many n tiles per wave: tests).  All shapes give bit-identical results
+ *   "prefill_splitk_rows" fp32 engines, prompt pass: passes of <= this many rows slice the down projection's K = 3072 four ways and add the slices in order (default
+ *                         2048; 0 = never): 6 blocks per 128 rows otherwise walk 96 k-tiles each -- an 8 x 56-token pass 3.4 -> 2.4 ms.  Another summation order
+ *                         than the unsliced kernel's (hidden rows move by ~1e-6; token ids unchanged on every golden)
  *   "attn_wide_blocks"    unsplit decode attention takes 8-wave blocks while rows x heads < this (default 512 on fp32 engines, 4096 on fp16 engines; 0 = 256, the limit until round 6)
  *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection as launch slices up to this batch size (default 8)
  *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 9; 0 = never)

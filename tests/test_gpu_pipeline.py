@@ -659,14 +659,21 @@ def test_per_utterance_lora_through_the_split_prompt_pass():
                                                     min_new_token=N, logits_warpers=lw, logits_processors=[], return_hidden=True, noise="device", seed=3))[-1]
                 g.set_row_adapters(None)
             if name == "split":      # round 6: the same pass with its split GEMMs forced onto the 256-row counter-phased blocks (480 rows would take the 128 x 128 ones): the adapter terms
-                for shape in (-3, -4):      # ride in the shared epilogue, every element accumulates in the same order -> the same bits
+                base = None          # ride in the shared epilogue, every element accumulates in the same order -> the same bits (K slicing of the down projection off: another order)
+                g.set_option("prefill_splitk_rows", 0)
+                for shape in (0, -3, -4):
                     g.set_option("prefill_pp_blocks", shape)
                     g.set_row_adapters(slots)
                     pp = list(g.generate(emb, torch.from_numpy(ids), torch.tensor([0.3] * 4), 625, attention_mask=torch.from_numpy(mask), max_new_token=N,
                                          min_new_token=N, logits_warpers=lw, logits_processors=[], return_hidden=True, noise="device", seed=3))[-1]
                     g.set_row_adapters(None)
+                    if base is None:
+                        base = pp
+                        for b in range(B):      # ... and against the default (K sliced four ways at 480 rows): the same tokens, hidden rows one summation order apart
+                            assert torch.equal(base.ids[b], outs[("split", "lora")].ids[b]), b
+                            assert float((base.hiddens[b] - outs[("split", "lora")].hiddens[b]).abs().max()) <= 2e-5, b
                     for b in range(B):
-                        assert torch.equal(pp.ids[b], outs[("split", "lora")].ids[b]) and torch.equal(pp.hiddens[b], outs[("split", "lora")].hiddens[b]), (shape, b)
+                        assert torch.equal(pp.ids[b], base.ids[b]) and torch.equal(pp.hiddens[b], base.hiddens[b]), (shape, b)
         finally:
             g.close()
     for b in range(B):

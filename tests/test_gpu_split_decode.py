@@ -105,9 +105,10 @@ def test_prompt_pass_block_shapes_agree_bitwise(gpt, B, P, pad):
     always that shape, > 0 = by round count).  Every output element accumulates its k-tiles in the same order in all of them, so tokens AND hidden states must agree
     bit for bit -- at row counts that are no multiple of 256 (960, 2100: partial last blocks) and at the largest pass this engine holds (15600 rows)."""
     g = gpt
-    base = g.get_option("prefill_pp_blocks")
+    base, sk = g.get_option("prefill_pp_blocks"), g.get_option("prefill_splitk_rows")
     assert base > 0, "long prompt passes may take the counter-phased kernel by default"
     try:
+        g.set_option("prefill_splitk_rows", 0)                  # (short passes slice the down projection's K: another summation order, its own test below)
         g.set_option("prefill_pp_blocks", 0)
         ref_ids, ref_h = _gen(g, B, P, 3, pad)
         outs = {}
@@ -116,10 +117,35 @@ def test_prompt_pass_block_shapes_agree_bitwise(gpt, B, P, pad):
             outs[shape] = _gen(g, B, P, 3, pad)
     finally:
         g.set_option("prefill_pp_blocks", base)
+        g.set_option("prefill_splitk_rows", sk)
     for shape, (ids, hid) in outs.items():
         for b in range(B):
             assert torch.equal(ids[b], ref_ids[b]), (shape, B, P, b)
             assert torch.equal(hid[b], ref_h[b]), (shape, B, P, b, float((hid[b] - ref_h[b]).abs().max()))
+
+
+@pytest.mark.parametrize("B,P,pad", [(10, 48, [(5 * b) % 11 for b in range(10)]), (24, 40, [(7 * i) % 36 for i in range(24)]), (32, 64, None)])
+def test_short_prompt_passes_slice_the_down_projection(gpt, B, P, pad):
+    """Prompt passes of <= `prefill_splitk_rows` rows (default 2048) slice the down projection's K = 3072 four ways over grid.z and add the slices in order
+    (prefill_split.hip sp_launch, resid_combine_kernel; llama.py:739): 6 blocks per 128 rows otherwise walk 96 k-tiles each on a chip of 256 CUs.  Another summation
+    order than the unsliced kernel's: the same tokens, hidden rows within the oracle tolerance of tests/test_gpu_gpt.py; twice the same bits (no atomics)."""
+    g = gpt
+    sk = g.get_option("prefill_splitk_rows")
+    assert sk == 2048
+    try:
+        g.set_option("prefill_splitk_rows", 0)
+        ref_ids, ref_h = _gen(g, B, P, 4, pad)
+        g.set_option("prefill_splitk_rows", sk)
+        ids, hid = _gen(g, B, P, 4, pad)
+        ids2, hid2 = _gen(g, B, P, 4, pad)
+    finally:
+        g.set_option("prefill_splitk_rows", sk)
+    worst = 0.0
+    for b in range(B):
+        assert torch.equal(ids[b], ref_ids[b]), (B, P, b)
+        assert torch.equal(ids[b], ids2[b]) and torch.equal(hid[b], hid2[b]), (B, P, b)
+        worst = max(worst, float((hid[b] - ref_h[b]).abs().max()))
+    assert 0.0 < worst <= 2e-5, (B, P, worst)                    # (> 0: the sliced path did run)
 
 
 def test_an_engine_without_the_images_refuses_the_option():
