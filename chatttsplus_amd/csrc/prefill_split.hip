@@ -191,8 +191,11 @@ __device__ __forceinline__ void sp_epilogue(f32x4 (&acc)[NT][NG], const SplitGem
     if (EPI == EPI_SWIGLU && a.sat != nullptr && nsat != 0) atomicAdd(a.sat, nsat);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_kernel(const SplitGemm p, const GemmArgs a) {
+// RING = LDS stages of 32 KB.  2: two blocks per CU, the second block's MFMAs fill the first one's barrier / landing bubbles (long passes).  4: one block per CU with three
+// stages in flight, one barrier per k-tile -- for grids of at most one block per CU (short passes), where a k-tile took ~1 us of which 0.4 are MFMAs: with a ring of two the
+// copy of stage kt + 2 is issued only after stage kt is read and has one iteration to land.
+template <int EPI, int RING = SP_RING>
+__global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void prefill_split_gemm_kernel(const SplitGemm p, const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,11 +232,12 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
         for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     SP_DMA(0, 0)
     SP_DMA(1, 1)                                           // ktiles >= 2 (checked by the launcher)
+    if (RING > 2 && ktiles > 2) SP_DMA(2, 2)
     int cb = 0;
     for (int kt = 0; kt < ktiles; ++kt) {
-        // stage kt has landed for every wave (its 8 loads per wave retire before the 8 of stage kt + 1), and every wave is done with the
-        // slot stage kt + 2 is about to overwrite (it held stage kt - 1, whose fragments were consumed before this barrier)
-        if (kt + 1 < ktiles) SP_WAIT_BAR(8) else SP_WAIT_BAR(0)
+        // stage kt has landed for every wave (a wave's 8 loads per stage retire in order: the later stages' may stay in flight), and every wave is done with the
+        // slot the next copy overwrites (RING > 2: it held stage kt - 1, whose fragments were consumed before this barrier)
+        if (RING > 2 && kt + 2 < ktiles) SP_WAIT_BAR(16) else if (kt + 1 < ktiles) SP_WAIT_BAR(8) else SP_WAIT_BAR(0)
         const char* cur = lds + cb * SP_STAGE;
         half8 wh[4], wl[4], xh[4], xl[4];
 #pragma unroll
@@ -246,13 +250,14 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
             xh[g] = *(const half8*)(cur + (16 + wr * 4 + g) * 1024 + lane * 16);
             xl[g] = *(const half8*)(cur + (24 + wr * 4 + g) * 1024 + lane * 16);
         }
-        if (SP_RING == 2) {                                // two stages (64 KB: two blocks per CU): the stage just read is the one the next copy overwrites
+        if (RING == 2) {                                   // two stages (64 KB: two blocks per CU): the stage just read is the one the next copy overwrites
             __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): this wave's fragments are in registers
             __builtin_amdgcn_s_barrier();
         }
-        if (kt + 2 < ktiles) {
-            const int nb = (cb + 2 >= SP_RING) ? cb + 2 - SP_RING : cb + 2;
-            SP_DMA(kt + 2, nb)
+        constexpr int AHEAD = RING == 2 ? 2 : 3;           // stages in flight
+        if (kt + AHEAD < ktiles) {
+            const int nb = (cb + AHEAD >= RING) ? cb + AHEAD - RING : cb + AHEAD;
+            SP_DMA(kt + AHEAD, nb)
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(256, SP_RING == 2 ? 2 : 1) void prefill_split_gemm_
                 acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xl[g], acc[t][g], 0, 0, 0);
                 acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xh[g], acc[t][g], 0, 0, 0);
             }
-        cb = (cb + 1 == SP_RING) ? 0 : cb + 1;
+        cb = (cb + 1 == RING) ? 0 : cb + 1;
     }
 #undef SP_DMA
 #undef SP_WAIT_BAR
@@ -622,7 +627,11 @@ static int sp_launch(SplitGemm& p, const GemmArgs& a, const SplitGemmPolicy& pol
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_RING * SP_STAGE));
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_pp_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SPB_STAGE));
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_pp_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SPB_STAGE));
-        if (EPI == EPI_RESID) CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI_PART>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_RING * SP_STAGE));
+        CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SP_STAGE));
+        if (EPI == EPI_RESID) {
+            CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI_PART>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_RING * SP_STAGE));
+            CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI_PART, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SP_STAGE));
+        }
         configured = true;
     }
     // Block shape by a round count (256 CUs; measured per-round times at K = 768, 32 x 512 prompt rows: 128 x 128 blocks, 512 at a time: 36 us; 256 x 256 blocks,
@@ -649,7 +658,8 @@ static int sp_launch(SplitGemm& p, const GemmArgs& a, const SplitGemmPolicy& pol
         GemmArgs ap = a;
         ap.part_out = pol.sk_scratch;
         p.kt_per = p.ktiles / 4; p.part_stride = rows_pad * (size_t)(nt * 16);
-        hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI_PART>), dim3(nt / 8, (p.R + 127) / 128, 4), dim3(256), SP_RING * SP_STAGE, s, p, ap);
+        if (4 * b_old <= pol.ring4_blocks) hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI_PART, 4>), dim3(nt / 8, (p.R + 127) / 128, 4), dim3(256), 4 * SP_STAGE, s, p, ap);
+        else hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI_PART>), dim3(nt / 8, (p.R + 127) / 128, 4), dim3(256), SP_RING * SP_STAGE, s, p, ap);
         CTTS_HIP_CHECK(hipGetLastError());
         const int n4 = p.R * nt * 4;                        // f32x4 elements of [R][N]
         hipLaunchKernelGGL(resid_combine_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, (const float*)pol.sk_scratch, p.part_stride, a.x_out, n4);
@@ -658,6 +668,7 @@ static int sp_launch(SplitGemm& p, const GemmArgs& a, const SplitGemmPolicy& pol
     }
     if (shape == 4) hipLaunchKernelGGL((prefill_split_gemm_pp_kernel<EPI, 4>), dim3(nt / 16, rb), dim3(512), 2 * SPB_STAGE, s, p, a);
     else if (shape == 3) hipLaunchKernelGGL((prefill_split_gemm_pp_kernel<EPI, 3>), dim3(nt / 12, rb), dim3(512), 2 * SPB_STAGE, s, p, a);
+    else if (b_old <= pol.ring4_blocks) hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI, 4>), dim3(nt / 8, (p.R + 127) / 128), dim3(256), 4 * SP_STAGE, s, p, a);      // at most one block per CU anyway
     else hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI>), dim3(nt / 8, (p.R + 127) / 128), dim3(256), SP_RING * SP_STAGE, s, p, a);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
