@@ -142,6 +142,7 @@ struct ctts_gpt {
                                                  //   batch 1 0.362 / 0.350 / 0.301 / 0.315, 2: 0.417 / 0.410 / 0.349 / 0.353, 4: 0.486 / 0.513 / 0.441 / 0.430; profiles/r06_ab_lora_persistent.jsonl)
     int prefill_pp_blocks = 1;                   // "prefill_pp_blocks": a split GEMM of the prompt pass may run on prefill_split_gemm_pp_kernel (256-row blocks, counter-phased wave groups) when it has
                                                  //   at least this many such blocks and the round count favours it (prefill_split.hip sp_launch); 0 = never
+    int prefill_small_blocks = 192;              // "prefill_small_blocks": prompt-pass split GEMMs of at most this many 128 x 128 blocks (K slices counted) run on 64 x 64 blocks (0 = never)
     int prefill_ring4_blocks = 256;              // "prefill_ring4_blocks": prompt-pass split GEMMs of at most this many 128 x 128 blocks run with a 4-stage LDS ring, one block per CU (0 = never)
     int prefill_sk_rows = 2048;                  // "prefill_splitk_rows": prompt passes of <= this many rows slice the down projection's K four ways (prefill_split.hip sp_launch; 0 = never)
     int attn_wide_blocks = 0;                    // "attn_wide_blocks": decode attention takes 8-wave blocks while rows x heads < this (0 = 256).  Set at create: 512 (fp32) / 4096 (fp16).
@@ -371,6 +372,7 @@ extern "C" int ctts_gpt_get_option(ctts_gpt* h, const char* name, int* value) {
     else if (n == "prefill_pp_blocks") *value = h->prefill_pp_blocks;
     else if (n == "prefill_splitk_rows") *value = h->prefill_sk_rows;
     else if (n == "prefill_ring4_blocks") *value = h->prefill_ring4_blocks;
+    else if (n == "prefill_small_blocks") *value = h->prefill_small_blocks;
     else if (n == "persistent_delay_lora") *value = h->persist_delay_u;
     else if (n == "valu_rows") *value = h->valu_rows;
     else if (n == "prefill_split_rows") *value = h->split_rows_min;
@@ -411,6 +413,8 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
         if (h->persist_rows > 0 && ensure_persist(h, true)) { h->persist_rows = 0; return 1; }
     } else if (n == "persistent_delay_lora") {
         h->persist_delay_u = value < 0 ? -1 : (value > 256 ? 256 : value);
+    } else if (n == "prefill_small_blocks") {
+        h->prefill_small_blocks = value < 0 ? 0 : value;
     } else if (n == "prefill_ring4_blocks") {
         h->prefill_ring4_blocks = value < 0 ? 0 : value;
     } else if (n == "prefill_splitk_rows") {
@@ -985,7 +989,7 @@ static int run_layers(ctts_gpt* h, float* x, const RowMeta* meta, const float* r
     // (round 5: also with per-utterance adapters -- their low-rank terms come from the two lora.hip launches per layer and are added in the split GEMMs' epilogues)
     const bool pfs = prepack && (dt == CTTS_DTYPE_F32) && h->wsplit != nullptr && h->split_rows_min > 0 && (R >= h->split_rows_min);
     const float sp_scale = 1.0f / 64.0f;
-    const SplitGemmPolicy sp_pol = {h->prefill_pp_blocks, h->prefill_sk_rows, h->sk_scratch, h->sk_cap_floats, h->prefill_ring4_blocks};
+    const SplitGemmPolicy sp_pol = {h->prefill_pp_blocks, h->prefill_sk_rows, h->sk_scratch, h->sk_cap_floats, h->prefill_small_blocks, h->prefill_ring4_blocks};
     // decode above the split-K batch sizes: the residual stream travels between kernels as a packed B operand in the engine dtype + per-tile
     // sums of squares (EPI_RESID_XH -> PRO_XH, kernels.h); layer 0 still normalises the sampler's fp32 rows itself.  (Handing gate|up
     // the packed copy at batches <= 4 too was measured slower in fp16: batch 1 393 vs 381 us/step, 2 415 vs 403, 4 450 vs 443.)

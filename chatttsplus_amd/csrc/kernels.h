@@ -185,6 +185,7 @@ struct SplitGemmPolicy {
     int sk_rows;                // "prefill_splitk_rows": passes of <= this many rows slice the down projection's K four ways (0 = never)
     float* sk_scratch;          //   the slices' partial outputs [4][rows padded to 128][N] (an engine buffer for <= 2048 rows)
     size_t sk_cap_floats;
+    int small_blocks;           // "prefill_small_blocks": a launch of at most this many 128 x 128 blocks (K slices counted) runs on 64 x 64 blocks instead (0 = never)
     int ring4_blocks;           // "prefill_ring4_blocks": a 128 x 128 launch of at most this many blocks (one per CU anyway) keeps three k-tile stages in flight in a 4-stage LDS ring (0 = never)
 };
 int launch_prefill_split_gemm(int epi, const GemmArgs& a, const void* Wsplit, const void* Xhi, const void* Xlo, void* act_hi, void* act_lo,

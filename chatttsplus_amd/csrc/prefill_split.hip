@@ -194,7 +194,9 @@ __device__ __forceinline__ void sp_epilogue(f32x4 (&acc)[NT][NG], const SplitGem
 // RING = LDS stages of 32 KB.  2: two blocks per CU, the second block's MFMAs fill the first one's barrier / landing bubbles (long passes).  4: one block per CU with three
 // stages in flight, one barrier per k-tile -- for grids of at most one block per CU (short passes), where a k-tile took ~1 us of which 0.4 are MFMAs: with a ring of two the
 // copy of stage kt + 2 is issued only after stage kt is read and has one iteration to land.
-template <int EPI, int RING = SP_RING>
+// WT = n tiles and row groups per wave: 4 (128 x 128 blocks) or 2 (64 x 64 blocks, stages of 16 KB: four times the blocks for passes so short that 128 x 128 blocks leave most
+// CUs idle -- a CU pulls its block's panels at ~30 GB/s whatever the ring depth, the chip has 256 of them).
+template <int EPI, int RING = SP_RING, int WT = 4>
 __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void prefill_split_gemm_kernel(const SplitGemm p, const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -207,29 +209,30 @@ __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void prefill_split_gemm_ker
         bx = seq / rpx;
         by = (seq % rpx) * 8 + xcd;
     }
-    const int nt0 = bx * 8, g0 = by * 8;                   // first n tile / first 16-row group of the block
+    constexpr int BT = 2 * WT, STAGE = 4 * BT * 1024;      // tiles (= row groups) per block; bytes per stage
+    const int nt0 = bx * BT, g0 = by * BT;                 // first n tile / first 16-row group of the block
     const int ktiles = p.kt_per;                           // this block's k-tiles: all of them, or slice blockIdx.z (EPI_PART)
     const int kt_all = p.ktiles, kt0 = blockIdx.z * p.kt_per;
-    // fragment f of a stage: 0..7 Whi tiles, 8..15 Wlo tiles, 16..23 Xhi groups, 24..31 Xlo groups
+    // fragment f of a stage: BT Whi tiles, BT Wlo tiles, BT Xhi groups, BT Xlo groups (WT = 4: 0..7, 8..15, 16..23, 24..31)
     auto src = [&](int f, int kt) -> const char* {
-        const half_t* img = (f < 8) ? p.Whi : (f < 16) ? p.Wlo : (f < 24) ? p.Xhi : p.Xlo;
-        const int unit = (f < 16) ? nt0 + (f & 7) : g0 + (f & 7);
-        return (const char*)img + ((size_t)unit * kt_all + kt0 + kt) * ((f < 16) ? 2048 : 1024) + (unsigned)(lane * 16);
+        const half_t* img = (f < BT) ? p.Whi : (f < 2 * BT) ? p.Wlo : (f < 3 * BT) ? p.Xhi : p.Xlo;
+        const int unit = (f < 2 * BT) ? nt0 + (f & (BT - 1)) : g0 + (f & (BT - 1));
+        return (const char*)img + ((size_t)unit * kt_all + kt0 + kt) * ((f < 2 * BT) ? 2048 : 1024) + (unsigned)(lane * 16);
     };
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 #define SP_DMA(kt_, buf_)                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                     \
+    _Pragma("unroll") for (int i = 0; i < BT; ++i) {                                                                    \
         const int f = wave + 4 * i;                                                                                      \
-        __builtin_amdgcn_global_load_lds((gptr_t)src(f, (kt_)), (lptr_t)(lds + (buf_) * SP_STAGE + f * 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)src(f, (kt_)), (lptr_t)(lds + (buf_) * STAGE + f * 1024), 16, 0, 0);    \
     }
     // s_waitcnt immediate (gfx9): vmcnt[3:0] and [15:14] | expcnt[6:4] = 7 (none) | lgkmcnt[11:8] = 0; a bare s_barrier (no vmcnt(0) fence)
 #define SP_WAIT_BAR(n_) { __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15) | (((n_) >> 4) << 14)); __builtin_amdgcn_s_barrier(); }
-    f32x4 acc[4][4];                                       // [n tile][row group]
+    f32x4 acc[WT][WT];                                     // [n tile][row group]
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < WT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < WT; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     SP_DMA(0, 0)
     SP_DMA(1, 1)                                           // ktiles >= 2 (checked by the launcher)
     if (RING > 2 && ktiles > 2) SP_DMA(2, 2)
@@ -237,18 +240,18 @@ __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void prefill_split_gemm_ker
     for (int kt = 0; kt < ktiles; ++kt) {
         // stage kt has landed for every wave (a wave's 8 loads per stage retire in order: the later stages' may stay in flight), and every wave is done with the
         // slot the next copy overwrites (RING > 2: it held stage kt - 1, whose fragments were consumed before this barrier)
-        if (RING > 2 && kt + 2 < ktiles) SP_WAIT_BAR(16) else if (kt + 1 < ktiles) SP_WAIT_BAR(8) else SP_WAIT_BAR(0)
-        const char* cur = lds + cb * SP_STAGE;
-        half8 wh[4], wl[4], xh[4], xl[4];
+        if (RING > 2 && kt + 2 < ktiles) SP_WAIT_BAR(2 * BT) else if (kt + 1 < ktiles) SP_WAIT_BAR(BT) else SP_WAIT_BAR(0)      // (a wave copies BT fragments per stage)
+        const char* cur = lds + cb * STAGE;
+        half8 wh[WT], wl[WT], xh[WT], xl[WT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            wh[t] = *(const half8*)(cur + (wn * 4 + t) * 1024 + lane * 16);
-            wl[t] = *(const half8*)(cur + (8 + wn * 4 + t) * 1024 + lane * 16);
+        for (int t = 0; t < WT; ++t) {
+            wh[t] = *(const half8*)(cur + (wn * WT + t) * 1024 + lane * 16);
+            wl[t] = *(const half8*)(cur + (BT + wn * WT + t) * 1024 + lane * 16);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            xh[g] = *(const half8*)(cur + (16 + wr * 4 + g) * 1024 + lane * 16);
-            xl[g] = *(const half8*)(cur + (24 + wr * 4 + g) * 1024 + lane * 16);
+        for (int g = 0; g < WT; ++g) {
+            xh[g] = *(const half8*)(cur + (2 * BT + wr * WT + g) * 1024 + lane * 16);
+            xl[g] = *(const half8*)(cur + (3 * BT + wr * WT + g) * 1024 + lane * 16);
         }
         if (RING == 2) {                                   // two stages (64 KB: two blocks per CU): the stage just read is the one the next copy overwrites
             __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): this wave's fragments are in registers
@@ -260,9 +263,9 @@ __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void prefill_split_gemm_ker
             SP_DMA(kt + AHEAD, nb)
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < WT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < WT; ++g) {
                 // tails first, head product last: the small terms meet while the accumulator's low bits still see them
                 acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], xh[g], acc[t][g], 0, 0, 0);
                 acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xl[g], acc[t][g], 0, 0, 0);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void prefill_split_gemm_ker
     }
 #undef SP_DMA
 #undef SP_WAIT_BAR
-    sp_epilogue<EPI, 4, 4>(acc, p, a, lane, nt0 + wn * 4, g0 + wr * 4);
+    sp_epilogue<EPI, WT, WT>(acc, p, a, lane, nt0 + wn * WT, g0 + wr * WT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -628,9 +631,11 @@ static int sp_launch(SplitGemm& p, const GemmArgs& a, const SplitGemmPolicy& pol
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_pp_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SPB_STAGE));
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_pp_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SPB_STAGE));
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SP_STAGE));
+        CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SP_STAGE / 2));
         if (EPI == EPI_RESID) {
             CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI_PART>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_RING * SP_STAGE));
             CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI_PART, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SP_STAGE));
+            CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)prefill_split_gemm_kernel<EPI_PART, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SP_STAGE / 2));
         }
         configured = true;
     }
@@ -653,12 +658,17 @@ static int sp_launch(SplitGemm& p, const GemmArgs& a, const SplitGemmPolicy& pol
     // four ways over grid.z, the slices' shares parked in `pol.sk_scratch`, resid_combine_kernel adds them in slice order and the residual.  Another summation order
     // than the unsliced kernel's (the usual 1e-7); a.lora_delta never rides here (the o_proj products have K = 768).
     const size_t rows_pad = (size_t)((p.R + 127) / 128) * 128;
-    if (EPI == EPI_RESID && shape == 0 && pol.sk_rows > 0 && p.R <= pol.sk_rows && p.ktiles >= 64 && (p.ktiles & 3) == 0 && a.lora_delta == nullptr &&
-        pol.sk_scratch != nullptr && 4 * rows_pad * (size_t)(nt * 16) <= pol.sk_cap_floats) {
+    const bool sliced = EPI == EPI_RESID && shape == 0 && pol.sk_rows > 0 && p.R <= pol.sk_rows && p.ktiles >= 64 && (p.ktiles & 3) == 0 && a.lora_delta == nullptr &&
+                        pol.sk_scratch != nullptr && 4 * rows_pad * (size_t)(nt * 16) <= pol.sk_cap_floats;
+    // passes so short that even the sliced grids leave most CUs idle: 64 x 64 blocks (four times as many), 4-stage ring of 16 KB stages
+    const bool small = shape == 0 && pol.small_blocks > 0 && (sliced ? 4 : 1) * b_old <= pol.small_blocks;
+    const dim3 g64(nt / 4, (p.R + 63) / 64, sliced ? 4 : 1);
+    if (sliced) {
         GemmArgs ap = a;
         ap.part_out = pol.sk_scratch;
         p.kt_per = p.ktiles / 4; p.part_stride = rows_pad * (size_t)(nt * 16);
-        if (4 * b_old <= pol.ring4_blocks) hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI_PART, 4>), dim3(nt / 8, (p.R + 127) / 128, 4), dim3(256), 4 * SP_STAGE, s, p, ap);
+        if (small) hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI_PART, 4, 2>), g64, dim3(256), 4 * SP_STAGE / 2, s, p, ap);
+        else if (4 * b_old <= pol.ring4_blocks) hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI_PART, 4>), dim3(nt / 8, (p.R + 127) / 128, 4), dim3(256), 4 * SP_STAGE, s, p, ap);
         else hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI_PART>), dim3(nt / 8, (p.R + 127) / 128, 4), dim3(256), SP_RING * SP_STAGE, s, p, ap);
         CTTS_HIP_CHECK(hipGetLastError());
         const int n4 = p.R * nt * 4;                        // f32x4 elements of [R][N]
@@ -668,6 +678,7 @@ static int sp_launch(SplitGemm& p, const GemmArgs& a, const SplitGemmPolicy& pol
     }
     if (shape == 4) hipLaunchKernelGGL((prefill_split_gemm_pp_kernel<EPI, 4>), dim3(nt / 16, rb), dim3(512), 2 * SPB_STAGE, s, p, a);
     else if (shape == 3) hipLaunchKernelGGL((prefill_split_gemm_pp_kernel<EPI, 3>), dim3(nt / 12, rb), dim3(512), 2 * SPB_STAGE, s, p, a);
+    else if (small) hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI, 4, 2>), g64, dim3(256), 4 * SP_STAGE / 2, s, p, a);
     else if (b_old <= pol.ring4_blocks) hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI, 4>), dim3(nt / 8, (p.R + 127) / 128), dim3(256), 4 * SP_STAGE, s, p, a);      // at most one block per CU anyway
     else hipLaunchKernelGGL((prefill_split_gemm_kernel<EPI>), dim3(nt / 8, (p.R + 127) / 128), dim3(256), SP_RING * SP_STAGE, s, p, a);
     CTTS_HIP_CHECK(hipGetLastError());

@@ -93,6 +93,9 @@ void ctts_gpt_destroy(ctts_gpt* h);
  *   "prefill_splitk_rows" fp32 engines, prompt pass: passes of <= this many rows slice the down projection's K = 3072 four ways and add the slices in order (default
  *                         2048; 0 = never): 6 blocks per 128 rows otherwise walk 96 k-tiles each -- an 8 x 56-token pass 3.4 -> 2.4 ms.  Another summation order
  *                         than the unsliced kernel's (hidden rows move by ~1e-6; token ids unchanged on every golden)
+ *   "prefill_small_blocks" / "prefill_ring4_blocks"   fp32 engines, short prompt passes: a split GEMM of at most this many 128 x 128 blocks (K slices counted) runs on 64 x 64
+ *                         blocks (default 192: four times the blocks for grids that leave most CUs idle) / on a 4-stage LDS ring, one block per CU (default 256); 0 = never.
+ *                         Bit-identical to the other block shapes
  *   "attn_wide_blocks"    unsplit decode attention takes 8-wave blocks while rows x heads < this (default 512 on fp32 engines, 4096 on fp16 engines; 0 = 256, the limit until round 6)
  *   "decode_splits"       key splits of the decode attention (0 = policy)       "split_rows"  split-K down projection as launch slices up to this batch size (default 8)
  *   "down_splitk_rows"    packed-residual decode batches of >= this many rows slice the down projection's K inside the launch, last arriver combines (default 9; 0 = never)

@@ -100,8 +100,8 @@ def test_split_decode_rows_are_independent_of_the_batch_they_ride_in(gpt):
 
 @pytest.mark.parametrize("B,P,pad", [(24, 40, [(7 * i) % 36 for i in range(24)]), (7, 300, [(41 * i) % 200 for i in range(7)]), (40, 390, None)])
 def test_prompt_pass_block_shapes_agree_bitwise(gpt, B, P, pad):
-    """The prompt pass's split GEMMs (llama.py:619-621,666,737-739 over all prompt rows) have three block shapes: 128 x 128 (two blocks per CU on a 2-stage LDS ring, or one
-    per CU on a 4-stage ring when the grid does not fill the chip) and, for long passes,
+    """The prompt pass's split GEMMs (llama.py:619-621,666,737-739 over all prompt rows) have four block shapes: 64 x 64 (the shortest passes), 128 x 128 (two blocks per CU
+    on a 2-stage LDS ring, or one per CU on a 4-stage ring when the grid does not fill the chip) and, for long passes,
     256 rows x 256 or 192 features with two counter-phased wave groups (prefill_split_gemm_pp_kernel<EPI, 4 | 3>; option `prefill_pp_blocks`: 0 = never, -4 / -3 =
     always that shape, > 0 = by round count).  Every output element accumulates its k-tiles in the same order in all of them, so tokens AND hidden states must agree
     bit for bit -- at row counts that are no multiple of 256 (960, 2100: partial last blocks) and at the largest pass this engine holds (15600 rows)."""
@@ -113,8 +113,14 @@ def test_prompt_pass_block_shapes_agree_bitwise(gpt, B, P, pad):
         g.set_option("prefill_splitk_rows", 0)                  # (short passes slice the down projection's K: another summation order, its own test below)
         g.set_option("prefill_pp_blocks", 0)
         g.set_option("prefill_ring4_blocks", 0)
+        sm = g.get_option("prefill_small_blocks")
+        assert sm == 192, "the shortest passes run on 64 x 64 blocks by default"
+        g.set_option("prefill_small_blocks", 0)
         ref_ids, ref_h = _gen(g, B, P, 3, pad)
         outs = {}
+        g.set_option("prefill_small_blocks", 1 << 20)           # every 128 x 128 launch as four times as many 64 x 64 blocks
+        outs["64x64"] = _gen(g, B, P, 3, pad)
+        g.set_option("prefill_small_blocks", sm)
         g.set_option("prefill_ring4_blocks", 1 << 20)           # every 128 x 128 launch on the 4-stage ring
         outs["ring4"] = _gen(g, B, P, 3, pad)
         g.set_option("prefill_ring4_blocks", r4)
