@@ -78,8 +78,10 @@ struct ctts_gpt {
     int split_dec_rows = 9;                      // fp32 engines: decode batches of >= this many rows (packed-residual path, no per-utterance adapters) run their projections on the
                                                  // head / tail images: 3 fp16 MFMAs per product instead of 8 exact-f32 ones (skinny_gemm.hip dispatch_split); 0 = never.  "split_decode_rows"
     void *sp_x_hi = nullptr, *sp_x_lo = nullptr, *sp_act_hi = nullptr, *sp_act_lo = nullptr;   //   ... and of the prompt rows' operands
-    int split_rows_min = 384;                    //   prompt passes of at least this many rows use them (prompt pass ms old / split: 192 rows 2.0 / 3.0, 384 rows 3.1 / 3.0,
-                                                 //   768 rows 5.3 / 3.6, 1152 rows 7.5 / 3.7; diagnostic builds: CTTS_PREFILL_SPLIT, 0 = never)
+    int split_rows_min = 65;                     //   prompt passes of at least this many rows use them.  384 until the end of round 6 (prompt pass ms row kernels / split GEMMs then:
+                                                 //   192 rows 2.0 / 3.0, 384 rows 3.1 / 3.0, 768 rows 5.3 / 3.6); with 64 x 64 blocks and the sliced down projection of short
+                                                 //   passes (prefill_split.hip sp_launch) the split GEMMs win from the first pass that has more than one 64-row block:
+                                                 //   66 rows 1.48 / 1.22, 96: 1.52 / 1.23, 192: 2.13 / 1.31, 288: 2.58 / 1.39, 360: 3.24 / 1.60 (diagnostic builds: CTTS_PREFILL_SPLIT, 0 = never)
     std::vector<LayerW> lw;
     void* whead = nullptr;
     void* whead_text = nullptr;                  // refine-text head (21178 x H), packed like whead; optional
@@ -396,7 +398,9 @@ extern "C" int ctts_gpt_set_option(ctts_gpt* h, const char* name, int value) {
     if (!h || !name) { ctts_set_error("set_option: null argument"); return 1; }
     const std::string n(name);
     if (n == "prefill_split_rows") {             // prompt passes of >= this many rows use the head / tail fp16 split GEMMs (fp32 engines); 0 = never.  Before finalize.
-        if (h->finalized) { ctts_set_error("set_option(prefill_split_rows): set it before the weights are loaded"); return 1; }
+        // before finalize: also decides whether the images are built; afterwards the pass can be switched off (0: a checkpoint that leaves the fp16 range, see
+        // ctts_gpt_saturations) or moved while the images exist
+        if (h->finalized && value > 0 && !(h->split_ok && h->wsplit)) { ctts_set_error("set_option(prefill_split_rows): this engine holds no head / tail weight images (fp16 engine, a weight beyond the fp16 range, or the option was 0 at finalize)"); return 1; }
         h->split_rows_min = value < 0 ? 0 : value;
     } else if (n == "split_decode_rows") {       // fp32 engines: decode batches of >= this many rows multiply on the fp16 pipes with head / tail operands (0 = never; see split_dec_rows)
         if (!h->finalized) h->split_dec_rows = value < 0 ? 0 : value;      // before finalize: also decides whether the images are built

@@ -395,7 +395,7 @@ class GPT:
     @torch.no_grad()
     def _report_saturations(self, h, st, what: str) -> int:
         """fp16 stores of unbounded values saturate instead of overflowing to inf (fp16 engines: SwiGLU outputs, packed residual; fp32 engines:
-        only the SwiGLU head / tail images of a prompt pass over >= 384 rows, prefill_split.hip).  A non-zero count means the checkpoint drives
+        the SwiGLU head / tail images of a prompt pass over more than 64 rows, prefill_split.hip, and of decode batches of >= 9 rows).  A non-zero count means the checkpoint drives
         activations past the fp16 range: the result is finite but clipped -- say so."""
         nsat = C.c_int32(0)
         _lib.check(self._lib.ctts_gpt_saturations(h, C.byref(nsat), st), "saturations")
@@ -405,14 +405,15 @@ class GPT:
             if self.dtype_code == _lib.DTYPE_F16:
                 msg = f"use weight_dtype='fp32' for this checkpoint"
             else:
-                msg = ("the fp32 engine's long-prompt pass and its decode batches of >= 9 rows keep silu(gate) * up / 16 and the scaled residual rows as fp16 head / tail "
-                       "images; THIS call's values were clipped there.  The engine now keeps the exact fp32 decode kernels (split_decode_rows=0) for the following calls; "
-                       "construct the GPT with options={'prefill_split_rows': 0, 'split_decode_rows': 0} to keep them from the first call on for this checkpoint")
-                try:
-                    if self.get_option("split_decode_rows") > 0:
-                        self.set_option("split_decode_rows", 0)
-                except Exception:      # noqa: BLE001 (the warning below still tells the caller)
-                    pass
+                msg = ("the fp32 engine's prompt passes of more than 64 rows and its decode batches of >= 9 rows keep silu(gate) * up / 16 and the scaled residual rows as fp16 "
+                       "head / tail images; THIS call's values were clipped there.  The engine now keeps the exact fp32 kernels (split_decode_rows=0, prefill_split_rows=0) for "
+                       "the following calls; construct the GPT with options={'prefill_split_rows': 0, 'split_decode_rows': 0} to keep them from the first call on for this checkpoint")
+                for opt in ("split_decode_rows", "prefill_split_rows"):
+                    try:
+                        if self.get_option(opt) > 0:
+                            self.set_option(opt, 0)
+                    except Exception:      # noqa: BLE001 (the warning below still tells the caller)
+                        pass
             warnings.warn(f"hip GPT (weight_dtype {'fp16' if self.dtype_code == _lib.DTYPE_F16 else 'fp32'}): {n} fp16 stores saturated or were NaN "
                           f"during this {what}; {msg}", RuntimeWarning)
         return n

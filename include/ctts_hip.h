@@ -62,7 +62,7 @@ void ctts_gpt_destroy(ctts_gpt* h);
 
 /* Named engine options (the YAML's `kwargs.options` of the hip GPT; no counterpart in the reference -- the TensorRT path fixes such choices when
  * the engine is built, trt_models/llama_trt_model.py:25-81).  Explicit calls only: the product library reads no behaviour from the environment.
- *   "prefill_split_rows"  fp32 engines: prompt passes of >= this many rows use the 3-term fp16 split GEMMs (default 384; 0 = never; before finalize)
+ *   "prefill_split_rows"  fp32 engines: prompt passes of >= this many rows use the 3-term fp16 split GEMMs (default 65: every pass of more than 64 rows; 384 until round 6; 0 = never; before finalize)
  *   "split_decode_rows"   fp32 engines: decode batches of >= this many rows (packed-residual path, >= 9 rows, no per-utterance adapters) run their projections on the fp16 matrix
  *                         pipes with head / tail fp16 operands -- 3 MFMAs per product at fp32-level accuracy, the prompt pass's arithmetic -- instead of exact-f32 MFMA
  *                         (default 9; 0 = never.  Set to 0 BEFORE finalize and the engine builds no head / tail weight images unless the prompt pass needs them)
@@ -232,7 +232,7 @@ int ctts_gpt_progress(ctts_gpt* h, int32_t* steps_done, int32_t* all_finished, v
 
 /* fp16 engines store SwiGLU outputs and the packed residual copy as fp16: values beyond the fp16 range are SATURATED at +-65504 and
  * counted (the reference's .half() path would produce inf -> NaN silently on such a checkpoint, pipeline:37-41); `count` = saturated or NaN
- * stores since ctts_gpt_begin.  Synchronises the stream.  fp32 engines store fp32 everywhere EXCEPT in the prompt pass over >= 384 rows, whose
+ * stores since ctts_gpt_begin.  Synchronises the stream.  fp32 engines store fp32 everywhere EXCEPT in the prompt pass over >= 65 rows ("prefill_split_rows"), whose
  * split GEMMs keep silu(g) * u / 16 as fp16 head / tail images (prefill_split.hip): a value beyond +-65504 * 16 there is clamped and counted too
  * (the decode steps of an fp32 engine never count). */
 int ctts_gpt_saturations(ctts_gpt* h, int32_t* count, void* stream);

@@ -178,7 +178,7 @@ def test_fp16_overflow_saturates_and_is_reported(B):
         # range too.  The engine must say so and fall back to its exact fp32 decode kernels by itself: the second call below is clean and equals an engine that never used them.
         assert nsat32 > 0 and any("split_decode_rows" in w for w in warn32), (nsat32, warn32)
         g = GPT(LLAMA, max_batch=B, max_seq_len=64, weight_dtype="fp32")
-        gx = GPT(LLAMA, max_batch=B, max_seq_len=64, weight_dtype="fp32", options={"split_decode_rows": 0})
+        gx = GPT(LLAMA, max_batch=B, max_seq_len=64, weight_dtype="fp32", options={"split_decode_rows": 0, "prefill_split_rows": 0})
         try:
             res = []
             for eng, calls in ((g, 2), (gx, 1)):
@@ -191,7 +191,7 @@ def test_fp16_overflow_saturates_and_is_reported(B):
                                               min_new_token=6, logits_warpers=LW, logits_processors=LP, return_hidden=True, noise="device", seed=3))[-1]
                     res.append((o, eng.saturations))
             assert res[0][1] > 0 and res[1][1] == 0 and res[2][1] == 0, [r[1] for r in res]
-            assert g.get_option("split_decode_rows") == 0
+            assert g.get_option("split_decode_rows") == 0 and g.get_option("prefill_split_rows") == 0      # (the 120-row prompt pass runs on the images too since round 6's 65-row threshold)
             for b in range(B):
                 assert torch.equal(res[1][0].ids[b], res[2][0].ids[b]) and torch.equal(res[1][0].hiddens[b], res[2][0].hiddens[b]), b
             o32 = res[1][0]

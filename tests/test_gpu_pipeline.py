@@ -640,7 +640,7 @@ def test_per_utterance_lora_through_the_split_prompt_pass():
     rng = np.random.Generator(np.random.Philox(key=79))
     ads = [[(l, t, (rng.standard_normal((r, 768)) * 0.05).astype(np.float32), (rng.standard_normal((768, r)) * 0.05).astype(np.float32), 2.0)
             for l in range(6) for t in ("q_proj", "k_proj", "v_proj", "o_proj")] for r in (8, 16)]
-    B, T, N = 10, 48, 6                                                  # 480 prompt rows >= the split pass's 384-row threshold
+    B, T, N = 10, 48, 6                                                  # 480 prompt rows: the split pass (every pass of more than 64 rows since round 6; 384 before)
     ids, mask = synth.prompt_ids(B, T, cfg["num_text_tokens"], 31, pad_left=[(5 * b) % 11 for b in range(B)])
     slots = [(b % 3) - 1 for b in range(B)]                              # -1 (none), 0, 1
     lw = [type("P", (), dict(top_p=0.7, min_tokens_to_keep=3))(), type("K", (), dict(top_k=20))()]
@@ -649,7 +649,7 @@ def test_per_utterance_lora_through_the_split_prompt_pass():
         g = GPT(llama, max_batch=B, max_seq_len=T + N + 8, weight_dtype="fp32", options=opts)
         try:
             g.load_state_dict(sd)
-            assert g.get_option("prefill_split_rows") == (384 if name == "split" else 0)
+            assert g.get_option("prefill_split_rows") == (65 if name == "split" else 0)
             for i, ad in enumerate(ads):
                 g.load_adapter(i, ad)
             emb = g(torch.from_numpy(ids), torch.ones(B, T, dtype=torch.bool))

@@ -212,7 +212,7 @@ def test_continuous_batching_gives_every_utterance_its_sliced_result(gpt32, rows
     limits = [int(x) for x in rng.integers(2, N + 1, size=NU)]
     limits[5], limits[6] = 1, N
     if rows == 20:
-        limits[8:20] = [3] * 12          # 12 rows free at one snapshot: an admission of 12 x 39 = 468 prompt rows -> the split prompt path (>= 384 rows) on re-used KV lanes
+        limits[8:20] = [3] * 12          # 12 rows free at one snapshot: an admission of 12 x 39 = 468 prompt rows -> the split prompt path on re-used KV lanes
     uids = [1000 + 7 * u for u in range(NU)]
     ids, mask = synth.prompt_ids(NU, T, 21178, 83, pad_left=pads)
     emb = g(torch.from_numpy(ids), torch.ones(ids.shape[:2], dtype=torch.bool))

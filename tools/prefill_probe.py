@@ -15,9 +15,10 @@ from chatttsplus_amd.hip_models.gpt import GPT, sampler_cfg_from_objects    # no
 
 B, P = int(sys.argv[1]), int(sys.argv[2])
 wd = sys.argv[3] if len(sys.argv) > 3 else "fp16"
-optsets = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",")) for a in sys.argv[4:]] or [{}]
+init = dict((kv.split("=")[0], int(kv.split("=")[1])) for a in sys.argv[4:] if a.startswith("init:") for kv in a[5:].split(","))      # "init:name=value": options set before the weights load
+optsets = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",")) for a in sys.argv[4:] if not a.startswith("init:")] or [{}]
 dev = torch.device("cuda", 0)
-g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=B, max_seq_len=P + 40, weight_dtype=wd, device="cuda:0")
+g = GPT(dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, num_hidden_layers=20), max_batch=B, max_seq_len=P + 40, weight_dtype=wd, device="cuda:0", options=init or None)
 g.load_state_dict(synth.gpt_state_dict(synth.GPT_REAL, 1234))
 rngpad = [(7 * b) % max(1, P // 3) for b in range(B)]
 ids, mask = synth.prompt_ids(B, P, 21178, 5, pad_left=rngpad)
@@ -41,4 +42,4 @@ for rnd in range(2 if len(optsets) > 1 else 1):
             _lib.check(g._lib.ctts_gpt_prefill(g._h, emb.data_ptr(), st), "prefill")
             _lib.check(g._lib.ctts_gpt_sample(g._h, st), "sample")
             torch.cuda.synchronize()
-            print(f"B={B} P={P} {wd} {opts if opts else ''}: prompt pass {1e3 * (time.perf_counter() - t0):.3f} ms  first ids {out_ids[0, 0].tolist()} {out_ids[B - 1, 0].tolist()}", flush=True)
+            print(f"B={B} P={P} {wd} {dict(init, **opts) if (opts or init) else ''}: prompt pass {1e3 * (time.perf_counter() - t0):.3f} ms  first ids {out_ids[0, 0].tolist()} {out_ids[B - 1, 0].tolist()}", flush=True)
