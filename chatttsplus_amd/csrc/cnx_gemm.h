@@ -21,6 +21,16 @@
 #define CNX_RING 2
 #endif
 #define CNX_STAGE (32 * 1024)
+// A launch of at most this many 128 x 128 blocks runs as four times as many 64 x 64 blocks (round 6).  Vocoder call, ms, 128 x 128 only -> with the two limits below:
+// 1 x 48 tokens (a streaming window) 1.71 -> 0.85, 1 x 512: 1.79 -> 0.99, 2 x 272: 1.83 -> 1.09, 4 x 272: 2.05 -> 1.65, 8 x 272: 2.65 -> 2.6, 16 x 272 and up: unchanged.
+// The first pointwise GEMM (K = 512: 16 k-tiles) gains up to ~640 blocks, the second (K = 2048: 64 k-tiles per block, N = 512) only below ~128 -- at 160 blocks it
+// lost 2 %, at 320 7 % (profiles/r06_ab_prefill_pp_gemm.jsonl).
+#ifndef CNX_SMALL_BLOCKS_PW1
+#define CNX_SMALL_BLOCKS_PW1 768
+#endif
+#ifndef CNX_SMALL_BLOCKS_PW2
+#define CNX_SMALL_BLOCKS_PW2 128
+#endif
 enum { CNX_PW1 = 0, CNX_PW2 = 1 };
 
 struct CnxGemm {
@@ -46,82 +56,88 @@ __device__ inline void cnx_split4(const f32x4 v, half4& hi, half4& lo) {
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, CNX_RING == 2 ? 2 : 1) void cnx_gemm_kernel(const CnxGemm p) {
+// WT = n tiles and frame groups per wave: 4 (128 x 128 blocks) or 2 (64 x 64 blocks on a ring of four 16 KB stages: four times the blocks for the small batches of
+// a single request or a streaming window, whose 128 x 128 grids -- 20 to 80 blocks -- leave most CUs idle while a block walks up to 64 k-tiles; round 6, as
+// prefill_split.hip's short passes).  Every output element accumulates its K range in the same order in both shapes.
+template <int EPI, int RING = CNX_RING, int WT = 4>
+__global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void cnx_gemm_kernel(const CnxGemm p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int BT = 2 * WT, STAGE = 4 * BT * 1024;      // tiles (= frame groups) per block; bytes per stage
     const int z = blockIdx.z, M = p.Ms[z];
-    if ((int)blockIdx.y * 128 >= M) return;
+    if ((int)blockIdx.y * (16 * BT) >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wn = wave & 1;
-    const int nt0 = blockIdx.x * 8, g0 = blockIdx.y * 8;   // first n tile / first 16-frame group of the block
+    const int nt0 = blockIdx.x * BT, g0 = blockIdx.y * BT; // first n tile / first 16-frame group of the block
     const int ktiles = p.ktiles;
     const half_t *Xh = p.Xhi + (size_t)z * p.sX, *Xl = p.Xlo + (size_t)z * p.sX;
-    // fragment f of a stage: 0..7 Whi tiles, 8..15 Wlo tiles, 16..23 Xhi groups, 24..31 Xlo groups
+    // fragment f of a stage: BT Whi tiles, BT Wlo tiles, BT Xhi groups, BT Xlo groups
     auto src = [&](int f, int kt) -> const char* {
-        const half_t* img = (f < 8) ? p.Whi : (f < 16) ? p.Wlo : (f < 24) ? Xh : Xl;
-        const int unit = (f < 16) ? nt0 + (f & 7) : g0 + (f & 7);
+        const half_t* img = (f < BT) ? p.Whi : (f < 2 * BT) ? p.Wlo : (f < 3 * BT) ? Xh : Xl;
+        const int unit = (f < 2 * BT) ? nt0 + (f & (BT - 1)) : g0 + (f & (BT - 1));
         return (const char*)img + ((size_t)unit * ktiles + kt) * 1024 + (unsigned)(lane * 16);
     };
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 #define CNX_DMA(kt_, buf_)                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                      \
+    _Pragma("unroll") for (int i = 0; i < BT; ++i) {                                                                     \
         const int f = wave + 4 * i;                                                                                       \
-        __builtin_amdgcn_global_load_lds((gptr_t)src(f, (kt_)), (lptr_t)(lds + (buf_) * CNX_STAGE + f * 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)src(f, (kt_)), (lptr_t)(lds + (buf_) * STAGE + f * 1024), 16, 0, 0);     \
     }
 #define CNX_WAIT_BAR(n_) { __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15) | (((n_) >> 4) << 14)); __builtin_amdgcn_s_barrier(); }
-    f32x4 acc[4][4];                                       // [n tile][frame group]
+    f32x4 acc[WT][WT];                                     // [n tile][frame group]
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < WT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < WT; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     CNX_DMA(0, 0)
     CNX_DMA(1, 1)                                          // ktiles >= 2 (checked by the launcher)
+    if (RING > 2 && ktiles > 2) CNX_DMA(2, 2)              // a ring of four keeps three stages in flight and needs one barrier per k-tile
     int cb = 0;
     for (int kt = 0; kt < ktiles; ++kt) {
-        if (kt + 1 < ktiles) CNX_WAIT_BAR(8) else CNX_WAIT_BAR(0)
-        const char* cur = lds + cb * CNX_STAGE;
-        half8 wh[4], wl[4], xh[4], xl[4];
+        if (RING > 2 && kt + 2 < ktiles) CNX_WAIT_BAR(2 * BT) else if (kt + 1 < ktiles) CNX_WAIT_BAR(BT) else CNX_WAIT_BAR(0)      // (a wave copies BT fragments per stage)
+        const char* cur = lds + cb * STAGE;
+        half8 wh[WT], wl[WT], xh[WT], xl[WT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            wh[t] = *(const half8*)(cur + (wn * 4 + t) * 1024 + lane * 16);
-            wl[t] = *(const half8*)(cur + (8 + wn * 4 + t) * 1024 + lane * 16);
+        for (int t = 0; t < WT; ++t) {
+            wh[t] = *(const half8*)(cur + (wn * WT + t) * 1024 + lane * 16);
+            wl[t] = *(const half8*)(cur + (BT + wn * WT + t) * 1024 + lane * 16);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            xh[g] = *(const half8*)(cur + (16 + wr * 4 + g) * 1024 + lane * 16);
-            xl[g] = *(const half8*)(cur + (24 + wr * 4 + g) * 1024 + lane * 16);
+        for (int g = 0; g < WT; ++g) {
+            xh[g] = *(const half8*)(cur + (2 * BT + wr * WT + g) * 1024 + lane * 16);
+            xl[g] = *(const half8*)(cur + (3 * BT + wr * WT + g) * 1024 + lane * 16);
         }
-        if (CNX_RING == 2) {                               // two stages (64 KB: two blocks per CU): the stage just read is the one the next copy overwrites
+        if (RING == 2) {                                   // two stages (64 KB: two blocks per CU): the stage just read is the one the next copy overwrites
             __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): this wave's fragments are in registers
             __builtin_amdgcn_s_barrier();
         }
-        if (kt + 2 < ktiles) {
-            const int nb = (cb + 2 >= CNX_RING) ? cb + 2 - CNX_RING : cb + 2;
-            CNX_DMA(kt + 2, nb)
+        constexpr int AHEAD = RING == 2 ? 2 : 3;           // stages in flight
+        if (kt + AHEAD < ktiles) {
+            const int nb = (cb + AHEAD >= RING) ? cb + AHEAD - RING : cb + AHEAD;
+            CNX_DMA(kt + AHEAD, nb)
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < WT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < WT; ++g) {
                 acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], xh[g], acc[t][g], 0, 0, 0);
                 acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xl[g], acc[t][g], 0, 0, 0);
                 acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xh[g], acc[t][g], 0, 0, 0);
             }
-        cb = (cb + 1 == CNX_RING) ? 0 : cb + 1;
+        cb = (cb + 1 == RING) ? 0 : cb + 1;
     }
 #undef CNX_DMA
 #undef CNX_WAIT_BAR
     // C tile layout: lane = (iq = lane >> 4, n = lane & 15): frame n of the group, features 4 * iq + j of the n tile (j = register)
     const int iq = lane >> 4, nn = lane & 15;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int G = g0 + wr * 4 + g, frame = G * 16 + nn;
+    for (int g = 0; g < WT; ++g) {
+        const int G = g0 + wr * WT + g, frame = G * 16 + nn;
         if (frame >= M) continue;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int f0 = (nt0 + wn * 4 + t) * 16 + 4 * iq;          // first of this lane's 4 features
+        for (int t = 0; t < WT; ++t) {
+            const int f0 = (nt0 + wn * WT + t) * 16 + 4 * iq;         // first of this lane's 4 features
             const f32x4 b = *(const f32x4*)(p.bias + f0), c = acc[t][g];
             f32x4 v = {c[0] * (1.0f / CNX_WSCALE) + b[0], c[1] * (1.0f / CNX_WSCALE) + b[1], c[2] * (1.0f / CNX_WSCALE) + b[2], c[3] * (1.0f / CNX_WSCALE) + b[3]};
             if (EPI == CNX_PW1) {
@@ -145,10 +161,14 @@ static int launch_cnx_gemm_t(const CnxGemm& p, int Fmax, int nb, hipStream_t s) 
     static bool configured = false;
     if (!configured) {
         CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)cnx_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, CNX_RING * CNX_STAGE));
+        CTTS_HIP_CHECK(hipFuncSetAttribute((const void*)cnx_gemm_kernel<EPI, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CNX_STAGE / 2));
         configured = true;
     }
     if (p.N % 128 || p.ktiles < 2) { ctts_set_error("cnx_gemm: N=%d K=%d not supported", p.N, p.ktiles * 32); return 1; }
-    hipLaunchKernelGGL((cnx_gemm_kernel<EPI>), dim3(p.N / 128, (Fmax + 127) / 128, nb), dim3(256), CNX_RING * CNX_STAGE, s, p);
+    const int blocks = (p.N / 128) * ((Fmax + 127) / 128) * nb;
+    if (blocks <= (EPI == CNX_PW1 ? CNX_SMALL_BLOCKS_PW1 : CNX_SMALL_BLOCKS_PW2))          // grids that leave CUs idle: four times as many 64 x 64 blocks
+        hipLaunchKernelGGL((cnx_gemm_kernel<EPI, 4, 2>), dim3(p.N / 64, (Fmax + 63) / 64, nb), dim3(256), 4 * CNX_STAGE / 2, s, p);
+    else hipLaunchKernelGGL((cnx_gemm_kernel<EPI>), dim3(p.N / 128, (Fmax + 127) / 128, nb), dim3(256), CNX_RING * CNX_STAGE, s, p);
     CTTS_HIP_CHECK(hipGetLastError());
     return 0;
 }
